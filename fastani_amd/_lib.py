@@ -1,0 +1,18 @@
+"""Loader of the HIP product library.  Fails loudly: there is no CPU implementation behind fastani_amd."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libfastani_amd.so")
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("fastani_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib

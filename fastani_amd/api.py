@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference seams over the C-ABI (include/ani_abi.h), via ctypes.
+
+    Sketch(engine, params, genomes)        ≙ skch::Sketch::Sketch          (src/map/include/winSketch.hpp:109)
+    Sketch.map_query(genome)               ≙ skch::Map::Map + callback     (src/map/include/computeMap.hpp:93)
+    Sketch.compute_cgi(maps, total, qid)   ≙ cgi::computeCGI               (src/cgi/include/computeCoreIdentity.hpp:166)
+    Sketch.map_cgi_batch(genomes, first)   ≙ the query loop of src/cgi/core_genome_identity.cpp:81-106
+
+Everything here is plumbing: numpy arrays in, numpy record arrays out.  All compute happens in
+libfastani_amd.so (hand-written HIP kernels, gfx950); there is no Python or CPU fallback.
+"""
+import ctypes as C
+import numpy as np
+
+MINIMIZER_DT = np.dtype([("hash", "<u4"), ("seqId", "<i4"), ("wpos", "<i4")])
+MAPPING_DT = np.dtype([("queryLen", "<i4"), ("refStartPos", "<i4"), ("refEndPos", "<i4"), ("queryStartPos", "<i4"),
+                       ("queryEndPos", "<i4"), ("refSeqId", "<i4"), ("querySeqId", "<i4"), ("nucIdentity", "<f4"),
+                       ("nucIdentityUpperBound", "<f4"), ("sketchSize", "<i4"), ("conservedSketches", "<i4")])
+CGI_DT = np.dtype([("refGenomeId", "<i4"), ("qryGenomeId", "<i4"), ("countSeq", "<i4"),
+                   ("totalQueryFragments", "<i4"), ("identity", "<f4")])
+
+ANI_SEQ_HOST_ASCII = 0
+ANI_SEQ_DEVICE_PACKED2 = 1
+
+
+class AniError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ani error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("kmerSize", C.c_int32), ("windowSize", C.c_int32), ("fragLen", C.c_int32),
+                ("percentageIdentity", C.c_float)]
+
+
+class SeqBatch(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("nGenomes", C.c_int32), ("nContigs", C.c_int32),
+                ("genomeContigStart", C.c_void_p), ("contigOffset", C.c_void_p), ("contigLen", C.c_void_p),
+                ("data", C.c_void_p)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
+                                          "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
+                                          "l2Steps", "mappings", "cgiRows")] + \
+               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def _bind(lib):
+    vp = C.c_void_p
+    sig = {
+        "ani_init": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "ani_shutdown": (None, [vp]),
+        "ani_last_error": (C.c_char_p, []),
+        "ani_free": (None, [vp]),
+        "ani_device_free": (None, [vp, vp]),
+        "ani_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
+        "ani_reset_counters": (C.c_int, [vp]),
+        "ani_params_default": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int]),
+        "ani_recommended_window": (C.c_int, [C.c_int, C.c_int]),
+        "ani_min_hits_relaxed": (C.c_int, [C.c_int, C.c_int, C.c_float]),
+        "ani_identity": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "ani_sketch_build": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp)]),
+        "ani_sketch_destroy": (None, [vp]),
+        "ani_sketch_export": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_sketch_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "ani_sketch_records": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_sketch_from_records": (C.c_int, [vp, C.POINTER(Params), vp, C.c_size_t, vp, C.c_int32, vp, C.c_int32, C.POINTER(vp)]),
+        "ani_map_query": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+        "ani_query_sketch": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_compute_cgi": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_map_cgi_batch": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sorted(sig)
+
+
+ABI_SYMBOLS = None
+
+
+class HostGenomes:
+    """A batch of genomes in host memory: list of genomes, each a list of contigs (bytes / str / uint8 arrays).
+    Bytes are passed as read from FASTA; the library upper-cases them (commonFunc.hpp:56-66)."""
+
+    def __init__(self, genomes):
+        self.contig_start = [0]
+        lens, offs, parts = [], [], []
+        off = 0
+        for contigs in genomes:
+            for c in contigs:
+                if isinstance(c, str):
+                    c = c.encode()
+                a = np.frombuffer(bytes(c), dtype=np.uint8) if isinstance(c, (bytes, bytearray)) else np.ascontiguousarray(c, dtype=np.uint8)
+                parts.append(a)
+                lens.append(len(a))
+                offs.append(off)
+                off += len(a)
+            self.contig_start.append(len(lens))
+        self.data = np.concatenate(parts) if parts else np.zeros(1, dtype=np.uint8)
+        if len(self.data) == 0:
+            self.data = np.zeros(1, dtype=np.uint8)
+        self.gcs = np.asarray(self.contig_start, dtype=np.int32)
+        self.off = np.asarray(offs if offs else [0], dtype=np.int64)
+        self.len = np.asarray(lens if lens else [0], dtype=np.int32)
+        self.n_genomes = len(genomes)
+        self.n_contigs = len(lens)
+
+    def batch(self):
+        b = SeqBatch()
+        b.layout = ANI_SEQ_HOST_ASCII
+        b.nGenomes = self.n_genomes
+        b.nContigs = self.n_contigs
+        b.genomeContigStart = self.gcs.ctypes.data
+        b.contigOffset = self.off.ctypes.data
+        b.contigLen = self.len.ctypes.data
+        b.data = self.data.ctypes.data
+        return b
+
+
+class DeviceGenomes:
+    """Single-contig genomes of equal length, 2-bit packed, already resident in device memory at `dev_ptr`
+    (genome i at word offset i*ceil(len/16)) — the synthetic benchmark input."""
+
+    def __init__(self, dev_ptr, n_genomes, genome_len, first=0, count=None):
+        count = n_genomes - first if count is None else count
+        words = (genome_len + 15) // 16
+        self.gcs = np.arange(count + 1, dtype=np.int32)
+        self.off = (np.arange(first, first + count, dtype=np.int64) * words)
+        self.len = np.full(count, genome_len, dtype=np.int32)
+        self.dev_ptr = dev_ptr
+        self.n_genomes = count
+        self.n_contigs = count
+
+    def batch(self):
+        b = SeqBatch()
+        b.layout = ANI_SEQ_DEVICE_PACKED2
+        b.nGenomes = self.n_genomes
+        b.nContigs = self.n_contigs
+        b.genomeContigStart = self.gcs.ctypes.data
+        b.contigOffset = self.off.ctypes.data
+        b.contigLen = self.len.ctypes.data
+        b.data = self.dev_ptr
+        return b
+
+
+def _as_batch(g):
+    if isinstance(g, (HostGenomes, DeviceGenomes)):
+        return g
+    return HostGenomes(g)
+
+
+class Engine:
+    """One ani_ctx: one device, one host thread."""
+
+    def __init__(self, lib, device=0):
+        global ABI_SYMBOLS
+        self.lib = lib
+        ABI_SYMBOLS = _bind(lib)
+        h = C.c_void_p()
+        self._chk(lib.ani_init(device, C.byref(h)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AniError(rc, (self.lib.ani_last_error() or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ani_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def params(self, k=16, frag_len=3000):
+        p = Params()
+        self._chk(self.lib.ani_params_default(C.byref(p), k, frag_len))
+        return p
+
+    def counters(self):
+        c = Counters()
+        self._chk(self.lib.ani_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._chk(self.lib.ani_reset_counters(self.h))
+
+    def _take(self, ptr, n, dt):
+        if n == 0:
+            out = np.zeros(0, dtype=dt)
+        else:
+            out = np.frombuffer(C.string_at(ptr, n * dt.itemsize), dtype=dt).copy()
+        self.lib.ani_free(ptr)
+        return out
+
+    def query_sketch(self, params, genomes):
+        g = _as_batch(genomes)
+        b = g.batch()
+        hp, op, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.ani_query_sketch(self.h, C.byref(params), C.byref(b), C.byref(hp), C.byref(op), C.byref(n)))
+        offs = self._take(op, n.value + 1, np.dtype("<u8"))
+        hashes = self._take(hp, int(offs[-1]), np.dtype("<u4"))
+        return [hashes[int(offs[i]):int(offs[i + 1])] for i in range(n.value)]
+
+    def synth_packed(self, seed, first_genome, n_genomes, genome_len, dev_ptr):
+        self._chk(self.lib.ani_synth_packed(self.h, seed, first_genome, n_genomes, genome_len, dev_ptr))
+
+    def sketch_records(self, params, genomes, seq_id_base):
+        """-> (device pointer to 12-byte records, count); free with device_free."""
+        g = _as_batch(genomes)
+        b = g.batch()
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.ani_sketch_records(self.h, C.byref(params), C.byref(b), seq_id_base, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def device_free(self, ptr):
+        self.lib.ani_device_free(self.h, ptr)
+
+
+class Sketch:
+    def __init__(self, engine, params, genomes=None, records=None):
+        """Either `genomes` (≙ Sketch::Sketch over the reference files) or
+        records=(dev_ptr, n, contig_len[int32], genome_contig_start[int32]) for the multi-GPU staging path."""
+        self.e = engine
+        self.params = params
+        h = C.c_void_p()
+        if records is not None:
+            ptr, n, clen, gcs = records
+            clen = np.ascontiguousarray(clen, dtype=np.int32)
+            gcs = np.ascontiguousarray(gcs, dtype=np.int32)
+            engine._chk(engine.lib.ani_sketch_from_records(engine.h, C.byref(params), ptr, n, clen.ctypes.data, len(clen),
+                                                           gcs.ctypes.data, len(gcs) - 1, C.byref(h)))
+        else:
+            g = _as_batch(genomes)
+            b = g.batch()
+            engine._chk(engine.lib.ani_sketch_build(engine.h, C.byref(params), C.byref(b), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.e.lib.ani_sketch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def minimizers(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.e._chk(self.e.lib.ani_sketch_export(self.h, C.byref(p), C.byref(n)))
+        return self.e._take(p, n.value, MINIMIZER_DT)
+
+    def stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        d, f = C.c_int32(), C.c_int32()
+        self.e._chk(self.e.lib.ani_sketch_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(f)))
+        return dict(minimizers=a.value, unique=b.value, totalLength=c.value, contigs=d.value, genomes=f.value)
+
+    def map_query(self, genome):
+        """genome = list of contigs of ONE query genome -> (mappings, totalQueryFragments)"""
+        g = _as_batch([genome]) if not isinstance(genome, (HostGenomes, DeviceGenomes)) else genome
+        b = g.batch()
+        p, n, tot = C.c_void_p(), C.c_size_t(), C.c_uint64()
+        self.e._chk(self.e.lib.ani_map_query(self.e.h, self.h, C.byref(b), C.byref(p), C.byref(n), C.byref(tot)))
+        return self.e._take(p, n.value, MAPPING_DT), tot.value
+
+    def compute_cgi(self, mappings, total_fragments, query_id):
+        m = np.ascontiguousarray(mappings, dtype=MAPPING_DT)
+        p, n = C.c_void_p(), C.c_size_t()
+        self.e._chk(self.e.lib.ani_compute_cgi(self.e.h, self.h, m.ctypes.data if len(m) else None, len(m), total_fragments,
+                                               query_id, C.byref(p), C.byref(n)))
+        return self.e._take(p, n.value, CGI_DT)
+
+    def map_cgi_batch(self, genomes, first_query_id=0):
+        g = _as_batch(genomes)
+        b = g.batch()
+        p, n = C.c_void_p(), C.c_size_t()
+        self.e._chk(self.e.lib.ani_map_cgi_batch(self.e.h, self.h, C.byref(b), first_query_id, C.byref(p), C.byref(n)))
+        return self.e._take(p, n.value, CGI_DT)

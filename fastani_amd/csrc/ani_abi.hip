@@ -1,0 +1,972 @@
+// ani_abi.hip — C-ABI of the MI355X-native ANI engine (include/ani_abi.h): host orchestration of the HIP kernels.
+//
+// The three reference seams this file stands in for (paths relative to /root/reference):
+//   skch::Sketch::Sketch   src/map/include/winSketch.hpp:109      -> ani_sketch_build / ani_sketch_from_records
+//   skch::Map::Map         src/map/include/computeMap.hpp:93      -> ani_map_query
+//   cgi::computeCGI        src/cgi/include/computeCoreIdentity.hpp:166 -> ani_compute_cgi
+// plus the fused query loop of src/cgi/core_genome_identity.cpp:81-106 -> ani_map_cgi_batch.
+// There is no CPU code path behind these entry points: without a usable HIP device every call fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ani_abi.h"
+#include "host/stats.hpp"
+#include "kernels/common.hpp"
+#include "kernels/index.hpp"
+#include "kernels/l1.hpp"
+#include "kernels/l2.hpp"
+#include "kernels/reduce.hpp"
+#include "kernels/scan.hpp"
+#include "kernels/sketch.hpp"
+#include "kernels/synth.hpp"
+
+extern "C" int ani_sort_pairs_u32(const uint32_t *keysIn, uint32_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                                  size_t n, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE,       \
+                                      "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return rc_; } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr; size_t cap = 0;
+  int ensure(size_t bytes)
+  {
+    if (bytes <= cap) return ANI_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return fail(ANI_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    cap = want;
+    return ANI_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+inline unsigned grid_for(size_t n, unsigned block = 256, unsigned maxBlocks = 65535u * 8u)
+{
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > maxBlocks) g = maxBlocks;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+// =====================================================================================================
+struct ani_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  ani_counters_t counters;
+  // scalar device counters (array of 16 x u64)
+  DevBuf dCounters;
+  // workspaces reused across calls
+  DevBuf seqPacked, seqAscii, contigOff, contigLen, contigMode;
+  DevBuf tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
+  DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
+  DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
+  DevBuf candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
+  DevBuf ocFrag, ocSeq, ocStart, ocEnd;
+  DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
+  DevBuf bins, queryFragments, rows;
+};
+
+struct ani_sketch {
+  ani_ctx *ctx = nullptr;
+  ani_params_t params;
+  uint32_t n = 0;
+  int32_t nContigs = 0, nGenomes = 0;
+  uint64_t nUnique = 0, totalLen = 0;
+  std::vector<int32_t> contigLen, genomeContigStart;
+  // device arrays
+  uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
+  uint32_t *sHash = nullptr, *sIdx = nullptr, *bucketStart = nullptr;
+  int bucketShift = 0; uint32_t nBuckets = 0;
+  int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
+  uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr;
+  uint32_t totalBins = 0;
+  // LUTs
+  ani::stat::Luts luts;
+  int32_t *dMinHits = nullptr, *dMinShared = nullptr; uint32_t *dIdLUT = nullptr; int dLutMaxS = 0;
+};
+
+namespace {
+
+enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_N = 16 };
+
+unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
+
+int zero_counters(ani_ctx *c)
+{
+  HIP_TRY(hipMemsetAsync(c->dCounters.p, 0, CNT_N * 8, c->stream));
+  return ANI_OK;
+}
+int read_counters(ani_ctx *c, unsigned long long *host)
+{
+  HIP_TRY(hipMemcpyAsync(host, c->dCounters.p, CNT_N * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ANI_OK;
+}
+
+struct StageTimer {
+  ani_ctx *c; double *acc;
+  StageTimer(ani_ctx *c_, double *acc_) : c(c_), acc(acc_) { (void)hipEventRecord(c->ev0, c->stream); }
+  ~StageTimer()
+  {
+    (void)hipEventRecord(c->ev1, c->stream);
+    (void)hipEventSynchronize(c->ev1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    *acc += ms;
+  }
+};
+
+// device-wide exclusive scan of int32 counts (n < 2^31) -> uint32 offsets; the total comes back through *total.
+// Two device levels of 2048-element blocks; the (<= 512) level-2 block totals are finished on the host.
+int device_scan(ani_ctx *c, const int32_t *in, uint32_t *out, uint32_t n, uint64_t *total)
+{
+  using namespace ani;
+  *total = 0;
+  if (n == 0) return ANI_OK;
+  const uint32_t nb1 = (n + kScanPerBlock - 1) / kScanPerBlock;
+  const uint32_t nb2 = (nb1 + kScanPerBlock - 1) / kScanPerBlock;
+  TRY(c->scanTmpA.ensure((size_t)nb1 * 4)); TRY(c->scanTmpB.ensure((size_t)nb1 * 4)); TRY(c->scanTmpC.ensure((size_t)nb2 * 4)); TRY(c->scanTmpD.ensure((size_t)nb2 * 4));
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb1), dim3(kTPB), 0, c->stream, in, out, n, c->scanTmpA.as<int32_t>());
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb2), dim3(kTPB), 0, c->stream, (const int32_t *)c->scanTmpA.as<int32_t>(), c->scanTmpB.as<uint32_t>(), nb1,
+                     c->scanTmpC.as<int32_t>());
+  std::vector<int32_t> tot2(nb2);
+  HIP_TRY(hipMemcpyAsync(tot2.data(), c->scanTmpC.p, (size_t)nb2 * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  uint64_t run = 0;
+  std::vector<uint32_t> off2(nb2);
+  for (uint32_t i = 0; i < nb2; i++) { off2[i] = (uint32_t)run; run += (uint64_t)(uint32_t)tot2[i]; }
+  if (run > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "prefix sum exceeds 2^32 elements");
+  *total = run;
+  if (nb2 > 1) {
+    HIP_TRY(hipMemcpyAsync(c->scanTmpD.p, off2.data(), (size_t)nb2 * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scan_add, dim3((nb1 + 255) / 256), dim3(256), 0, c->stream, c->scanTmpB.as<uint32_t>(), nb1, (const uint32_t *)c->scanTmpD.as<uint32_t>());
+  }
+  if (nb1 > 1)
+    hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, c->stream, out, n, (const uint32_t *)c->scanTmpB.as<uint32_t>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return ANI_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// A batch of genomes resident on the device.
+// -----------------------------------------------------------------------------------------------------
+struct DeviceBatch {
+  int32_t nGenomes = 0, nContigs = 0;
+  std::vector<int32_t> genomeContigStart, contigLen;
+  std::vector<int64_t> contigOff;      // words (packed) or bytes (ascii), per contig, into its own buffer
+  std::vector<uint8_t> contigPacked;
+  const uint32_t *dPacked = nullptr; const uint8_t *dAscii = nullptr;
+  const int64_t *dContigOff = nullptr; const int32_t *dContigLen = nullptr; const uint8_t *dContigMode = nullptr;
+  uint64_t totalBases = 0;
+};
+
+int check_batch(const ani_seq_batch_t *b)
+{
+  if (!b || b->nGenomes < 0 || b->nContigs < 0 || (b->nContigs && (!b->genomeContigStart || !b->contigOffset || !b->contigLen)))
+    return fail(ANI_ERR_ARG, "invalid sequence batch");
+  if (b->nContigs && !b->data) return fail(ANI_ERR_ARG, "sequence batch without data");
+  if (b->layout != ANI_SEQ_HOST_ASCII && b->layout != ANI_SEQ_DEVICE_PACKED2) return fail(ANI_ERR_ARG, "unknown sequence layout %d", b->layout);
+  for (int32_t c = 0; c < b->nContigs; c++) if (b->contigLen[c] < 0) return fail(ANI_ERR_LIMIT, "contig %d has a negative length (>= 2^31 bases?)", c);
+  return ANI_OK;
+}
+
+// genomes [g0, g1) of `b` -> device (packs pure-ACGT contigs to 2 bits per base on the way)
+int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1, DeviceBatch *out)
+{
+  const int32_t c0 = b->genomeContigStart[g0], c1 = b->genomeContigStart[g1];
+  out->nGenomes = g1 - g0; out->nContigs = c1 - c0;
+  out->genomeContigStart.resize(out->nGenomes + 1);
+  for (int32_t g = g0; g <= g1; g++) out->genomeContigStart[g - g0] = b->genomeContigStart[g] - c0;
+  out->contigLen.assign(b->contigLen + c0, b->contigLen + c1);
+  out->contigOff.resize(out->nContigs); out->contigPacked.resize(out->nContigs);
+  out->totalBases = 0;
+  for (int32_t c = 0; c < out->nContigs; c++) out->totalBases += (uint64_t)out->contigLen[c];
+
+  if (b->layout == ANI_SEQ_DEVICE_PACKED2) {
+    for (int32_t c = 0; c < out->nContigs; c++) { out->contigOff[c] = b->contigOffset[c0 + c]; out->contigPacked[c] = 1; }
+    out->dPacked = (const uint32_t *)b->data; out->dAscii = nullptr;
+  } else {
+    static uint8_t code[256]; static bool init = false;
+    if (!init) { memset(code, 4, 256); code['A'] = code['a'] = 0; code['C'] = code['c'] = 1; code['G'] = code['g'] = 2; code['T'] = code['t'] = 3; init = true; }
+    const uint8_t *src = (const uint8_t *)b->data;
+    std::vector<uint32_t> packed; std::vector<uint8_t> ascii;
+    for (int32_t c = 0; c < out->nContigs; c++) {
+      const uint8_t *s = src + b->contigOffset[c0 + c];
+      const int32_t len = out->contigLen[c];
+      bool pure = true;
+      for (int32_t i = 0; i < len; i++) if (code[s[i]] > 3) { pure = false; break; }
+      out->contigPacked[c] = pure;
+      if (pure) {
+        out->contigOff[c] = (int64_t)packed.size();
+        const size_t nw = ((size_t)len + 15) / 16;
+        const size_t base = packed.size(); packed.resize(base + nw + 2, 0u);     // +2 words of slack for the 3-word fetch
+        for (int32_t i = 0; i < len; i++) packed[base + (i >> 4)] |= (uint32_t)code[s[i]] << (2 * (i & 15));
+      } else {
+        out->contigOff[c] = (int64_t)ascii.size();
+        ascii.insert(ascii.end(), s, s + len);
+        while (ascii.size() & 3) ascii.push_back(0);
+      }
+    }
+    TRY(ctx->seqPacked.ensure(packed.size() * 4 + 16)); TRY(ctx->seqAscii.ensure(ascii.size() + 16));
+    if (!packed.empty()) HIP_TRY(hipMemcpyAsync(ctx->seqPacked.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!ascii.empty()) HIP_TRY(hipMemcpyAsync(ctx->seqAscii.p, ascii.data(), ascii.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));    // host vectors die at scope exit
+    out->dPacked = ctx->seqPacked.as<uint32_t>(); out->dAscii = ctx->seqAscii.as<uint8_t>();
+  }
+  const size_t nc = (size_t)out->nContigs;
+  TRY(ctx->contigOff.ensure(nc * 8 + 8)); TRY(ctx->contigLen.ensure(nc * 4 + 4)); TRY(ctx->contigMode.ensure(nc + 4));
+  if (nc) {
+    HIP_TRY(hipMemcpyAsync(ctx->contigOff.p, out->contigOff.data(), nc * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->contigLen.p, out->contigLen.data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->contigMode.p, out->contigPacked.data(), nc, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  out->dContigOff = ctx->contigOff.as<int64_t>(); out->dContigLen = ctx->contigLen.as<int32_t>(); out->dContigMode = ctx->contigMode.as<uint8_t>();
+  return ANI_OK;
+}
+
+int check_params(const ani_params_t *p)
+{
+  if (!p) return fail(ANI_ERR_ARG, "null parameters");
+  if (p->kmerSize < 1 || p->kmerSize > 16) return fail(ANI_ERR_ARG, "kmerSize must be in 1..16 (hash_t is 32 bit, parseCmdArgs.hpp:142)");
+  if (p->windowSize < 1 || p->windowSize > ani::kTile - ani::kTPB) return fail(ANI_ERR_LIMIT, "windowSize %d outside 1..%d", p->windowSize, ani::kTile - ani::kTPB);
+  if (p->fragLen < 1 || p->fragLen <= 20) return fail(ANI_ERR_ARG, "fragLen must exceed 20 (bin width is fragLen-20, computeCoreIdentity.hpp:194)");
+  return ANI_OK;
+}
+
+}  // namespace
+
+namespace {
+using namespace ani;
+
+// -----------------------------------------------------------------------------------------------------
+// reference minimizer records of a device-resident batch (position order, global seqIds)
+// -----------------------------------------------------------------------------------------------------
+int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, int32_t seqIdBase, uint32_t **dRecords, size_t *nOut)
+{
+  const int k = p->kmerSize, w = p->windowSize;
+  std::vector<TileDesc> tiles;
+  const int stride = kTile - (w - 1);
+  uint64_t positions = 0;
+  for (int32_t c = 0; c < db.nContigs; c++) {
+    const int32_t len = db.contigLen[c];
+    if (len < w || len < k) continue;                       // winSketch.hpp:153
+    const int32_t nPos = len - k + 1;
+    positions += (uint64_t)nPos;
+    for (int64_t B = 0; B == 0 || B + (w - 1) < nPos; B += stride) tiles.push_back(TileDesc{c, (int32_t)B});
+  }
+  const size_t nT = tiles.size();
+  *dRecords = nullptr; *nOut = 0;
+  if (nT == 0) return ANI_OK;
+  if (nT > 0x7fffffffu) return fail(ANI_ERR_LIMIT, "too many tiles in one reference batch");
+  TRY(ctx->tiles.ensure(nT * sizeof(TileDesc))); TRY(ctx->tileMeta.ensure(nT * sizeof(TileMeta)));
+  TRY(ctx->tileCnt.ensure(nT * 4)); TRY(ctx->tileDrop.ensure(nT)); TRY(ctx->tileOff.ensure((nT + 1) * 4));
+  HIP_TRY(hipMemcpyAsync(ctx->tiles.p, tiles.data(), nT * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+  uint64_t cap = (uint64_t)((double)positions * 2.6 / (w + 1)) + 64 * nT + 4096;
+  if (cap > positions + nT) cap = positions + nT;
+  unsigned long long host[CNT_N];
+  for (int attempt = 0;; attempt++) {
+    if (cap > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "reference batch yields more than 2^32 minimizers; split the reference list");
+    TRY(ctx->poolHash.ensure(cap * 4)); TRY(ctx->poolWpos.ensure(cap * 4));
+    TRY(zero_counters(ctx));
+    {
+      StageTimer tm(ctx, &ctx->counters.msSketch);
+      hipLaunchKernelGGL(k_sketch_tiles, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff,
+                         db.dContigLen, db.dContigMode, ctx->tiles.as<TileDesc>(), k, w, ctx->poolHash.as<uint32_t>(),
+                         ctx->poolWpos.as<int32_t>(), (uint32_t)cap, cnt_ptr(ctx, CNT_POOL), ctx->tileMeta.as<TileMeta>());
+    }
+    HIP_TRY(hipGetLastError());
+    TRY(read_counters(ctx, host));
+    if (host[CNT_POOL] <= cap) break;
+    if (attempt > 2) return fail(ANI_ERR_INTERNAL, "minimizer pool did not converge");
+    cap = host[CNT_POOL];
+  }
+  StageTimer tm(ctx, &ctx->counters.msSketch);
+  hipLaunchKernelGGL(k_sketch_tile_counts, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, ctx->tiles.as<TileDesc>(),
+                     ctx->tileMeta.as<TileMeta>(), (int)nT, ctx->tileCnt.as<int32_t>(), ctx->tileDrop.as<uint8_t>());
+  uint64_t total = 0;
+  TRY(device_scan(ctx, ctx->tileCnt.as<int32_t>(), ctx->tileOff.as<uint32_t>(), (uint32_t)nT, &total));
+  if (total >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "reference batch yields >= 2^31 minimizers; split the reference list");
+  if (total == 0) return ANI_OK;
+  uint32_t *rec = nullptr;
+  HIP_TRY(hipMalloc((void **)&rec, total * 12));
+  hipLaunchKernelGGL(k_sketch_gather, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, ctx->tiles.as<TileDesc>(), ctx->tileMeta.as<TileMeta>(),
+                     ctx->tileDrop.as<uint8_t>(), ctx->tileOff.as<uint32_t>(), ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(),
+                     seqIdBase, rec);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *dRecords = rec; *nOut = (size_t)total;
+  return ANI_OK;
+}
+
+void free_sketch_device(ani_sketch *sk)
+{
+  void *ptrs[] = {sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->sIdx, sk->bucketStart, sk->contigFirstMin,
+                  sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
+  for (void *q : ptrs) if (q) (void)hipFree(q);
+}
+
+int upload_luts(ani_sketch *sk, int maxS)
+{
+  if (maxS <= sk->dLutMaxS) return ANI_OK;
+  int target = std::max(maxS, 512);
+  if (target > sk->params.fragLen) target = std::max(maxS, std::min(target, sk->params.fragLen));
+  sk->luts.extend(sk->params.kmerSize, sk->params.percentageIdentity, target);
+  if (sk->dMinHits) { (void)hipFree(sk->dMinHits); (void)hipFree(sk->dMinShared); (void)hipFree(sk->dIdLUT); sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr; }
+  const size_t n1 = (size_t)sk->luts.maxS + 1, n2 = sk->luts.idBits.size();
+  HIP_TRY(hipMalloc((void **)&sk->dMinHits, n1 * 4)); HIP_TRY(hipMalloc((void **)&sk->dMinShared, n1 * 4)); HIP_TRY(hipMalloc((void **)&sk->dIdLUT, n2 * 4 + 4));
+  HIP_TRY(hipMemcpy(sk->dMinHits, sk->luts.minHits.data(), n1 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(sk->dMinShared, sk->luts.minShared.data(), n1 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(sk->dIdLUT, sk->luts.idBits.data(), n2 * 4, hipMemcpyHostToDevice));
+  sk->dLutMaxS = sk->luts.maxS;
+  return ANI_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// index over device-resident records (≙ Sketch::index, winSketch.hpp:181-193)
+// -----------------------------------------------------------------------------------------------------
+int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, size_t n, const int32_t *contigLen, int32_t nContigs,
+                const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "index of %zu minimizers exceeds 2^31; split the reference list (results are independent per reference genome)", n);
+  ani_sketch *sk = new ani_sketch();
+  sk->ctx = ctx; sk->params = *p; sk->n = (uint32_t)n; sk->nContigs = nContigs; sk->nGenomes = nGenomes;
+  sk->contigLen.assign(contigLen, contigLen + nContigs);
+  sk->genomeContigStart.assign(genomeContigStart, genomeContigStart + nGenomes + 1);
+  for (int32_t c = 0; c < nContigs; c++) sk->totalLen += (uint64_t)contigLen[c];
+  auto bail = [&](int rc) { free_sketch_device(sk); delete sk; return rc; };
+#define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
+#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  const size_t n4 = (n ? n : 1) * 4;
+  SK_HIP(hipMalloc((void **)&sk->mHash, n4)); SK_HIP(hipMalloc((void **)&sk->mSeq, n4)); SK_HIP(hipMalloc((void **)&sk->mWpos, n4));
+  SK_HIP(hipMalloc((void **)&sk->prevSame, n4)); SK_HIP(hipMalloc((void **)&sk->nextSame, n4));
+  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->sIdx, n4));
+  {
+    StageTimer tm(ctx, &ctx->counters.msIndex);
+    uint32_t *tmpK = nullptr, *tmpV = nullptr;
+    SK_HIP(hipMalloc((void **)&tmpK, n4)); SK_HIP(hipMalloc((void **)&tmpV, n4));
+    if (n) {
+      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV);
+      int rc = ani_sort_pairs_u32(tmpK, sk->sHash, tmpV, sk->sIdx, n, ctx->stream);
+      if (rc != 0) { (void)hipFree(tmpK); (void)hipFree(tmpV); return bail(fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
+    }
+    (void)hipFree(tmpK); (void)hipFree(tmpV);
+    SK_TRY(zero_counters(ctx));
+    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, sk->sIdx, (uint32_t)n, sk->prevSame, sk->nextSame, cnt_ptr(ctx, CNT_UNIQ));
+    // bucket table over the top bits: about one bucket per entry, between 2^10 and 2^28 buckets
+    int bits = 10;
+    while (bits < 28 && (1ull << bits) < n) bits++;
+    sk->bucketShift = 32 - bits; sk->nBuckets = 1u << bits;
+    SK_HIP(hipMalloc((void **)&sk->bucketStart, ((size_t)sk->nBuckets + 1) * 4));
+    hipLaunchKernelGGL(k_index_buckets, dim3(grid_for((size_t)sk->nBuckets + 1)), dim3(256), 0, ctx->stream, sk->sHash, (uint32_t)n, sk->bucketShift, sk->nBuckets, sk->bucketStart);
+    SK_HIP(hipMalloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
+    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    SK_HIP(hipGetLastError());
+    unsigned long long host[CNT_N];
+    SK_TRY(read_counters(ctx, host));
+    sk->nUnique = host[CNT_UNIQ];
+  }
+  // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194)
+  std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);
+  std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1);
+  const int32_t binW = p->fragLen - 20;
+  uint64_t run = 0;
+  for (int32_t g = 0; g < nGenomes; g++) {
+    gBin[g] = (uint32_t)run;
+    for (int32_t c = genomeContigStart[g]; c < genomeContigStart[g + 1]; c++) {
+      cg[c] = g; binBase[c] = (uint32_t)run; run += (uint64_t)(contigLen[c] / binW) + 1;
+      if (run > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "reference set has more than 2^32 position bins"));
+    }
+  }
+  gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run;
+  sk->totalBins = (uint32_t)run;
+  SK_HIP(hipMalloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(hipMalloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
+  SK_HIP(hipMalloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4));
+  SK_HIP(hipMemcpy(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
+  SK_HIP(hipMemcpy(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice));
+  SK_HIP(hipMemcpy(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice));
+  SK_TRY(upload_luts(sk, 512));
+  ctx->counters.refMinimizers += n; ctx->counters.refUniqueHashes += sk->nUnique; ctx->counters.refBases += sk->totalLen;
+#undef SK_TRY
+#undef SK_HIP
+  *out = sk;
+  return ANI_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// query path for one device-resident sub-batch
+// -----------------------------------------------------------------------------------------------------
+struct QueryRun {
+  int32_t nFrag = 0, nCand = 0;
+  std::vector<int32_t> fragGenome, fragQSeq, genomeFragments;
+};
+
+int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *qr)
+{
+  const ani_params_t &p = sk->params;
+  const int k = p.kmerSize, w = p.windowSize, L = p.fragLen;
+  // ---- fragment table (computeMap.hpp:132-190) ----
+  std::vector<FragDesc> frags;
+  qr->fragGenome.clear(); qr->fragQSeq.clear(); qr->genomeFragments.assign(db.nGenomes, 0);
+  for (int32_t g = 0; g < db.nGenomes; g++) {
+    int32_t seqCounter = 0;
+    for (int32_t c = db.genomeContigStart[g]; c < db.genomeContigStart[g + 1]; c++) {
+      const int32_t len = db.contigLen[c];
+      if (len < w || len < k || len < L) continue;            // :138
+      const int32_t fc = len / L;                              // :152
+      for (int32_t i = 0; i < fc; i++) {
+        frags.push_back(FragDesc{c, i * L});
+        qr->fragGenome.push_back(g); qr->fragQSeq.push_back(seqCounter + i);
+      }
+      seqCounter += fc;
+    }
+    qr->genomeFragments[g] = seqCounter;
+  }
+  const size_t nF = frags.size();
+  qr->nFrag = (int32_t)nF; qr->nCand = 0;
+  ctx->counters.queryGenomes += (uint64_t)db.nGenomes; ctx->counters.queryFragments += nF; ctx->counters.queryBases += db.totalBases;
+  if (nF == 0) return ANI_OK;
+  if (nF > 0x3fffffffu) return fail(ANI_ERR_LIMIT, "too many fragments in one query batch");
+  TRY(ctx->frags.ensure(nF * sizeof(FragDesc))); TRY(ctx->fragOff.ensure(nF * 4)); TRY(ctx->fragS.ensure(nF * 4));
+  TRY(ctx->fragGenome.ensure(nF * 4)); TRY(ctx->fragQSeq.ensure(nF * 4));
+  HIP_TRY(hipMemcpyAsync(ctx->frags.p, frags.data(), nF * sizeof(FragDesc), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->fragGenome.p, qr->fragGenome.data(), nF * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->fragQSeq.p, qr->fragQSeq.data(), nF * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+  unsigned long long host[CNT_N];
+  // ---- fragment sketches ----
+  uint64_t qcap = (uint64_t)nF * (uint64_t)((2.6 * L) / (w + 1) + 32) + 1024;
+  for (int attempt = 0;; attempt++) {
+    if (qcap > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "query batch sketch exceeds 2^32 hashes");
+    TRY(ctx->qPool.ensure(qcap * 4));
+    TRY(zero_counters(ctx));
+    {
+      StageTimer tm(ctx, &ctx->counters.msFragSketch);
+      hipLaunchKernelGGL(k_fragment_sketch, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigMode,
+                         ctx->frags.as<FragDesc>(), L, k, w, ctx->qPool.as<uint32_t>(), (uint32_t)qcap, cnt_ptr(ctx, CNT_QPOOL),
+                         ctx->fragOff.as<uint32_t>(), ctx->fragS.as<int32_t>(), (int *)cnt_ptr(ctx, CNT_MAXS));
+    }
+    HIP_TRY(hipGetLastError());
+    TRY(read_counters(ctx, host));
+    if (host[CNT_QPOOL] <= qcap) break;
+    if (attempt > 2) return fail(ANI_ERR_INTERNAL, "query sketch pool did not converge");
+    qcap = host[CNT_QPOOL];
+  }
+  const int maxS = (int)(uint32_t)host[CNT_MAXS];
+  if (maxS >= 0x7fffffff) return fail(ANI_ERR_LIMIT, "a query fragment produced more than %d minimizers", kFragHashCap);
+  ctx->counters.querySketchHashes += host[CNT_QPOOL];
+  TRY(upload_luts(sk, maxS));
+
+  // ---- L1 ----
+  TRY(ctx->fragCandOff.ensure(nF * 4)); TRY(ctx->fragCandCnt.ensure(nF * 4)); TRY(ctx->fragCandCntClamped.ensure(nF * 4));
+  TRY(ctx->fragHits.ensure(nF * 4)); TRY(ctx->fragOrdOff.ensure((nF + 1) * 4));
+  uint64_t ccap = (uint64_t)nF * 8 + 4096;
+  for (int attempt = 0;; attempt++) {
+    if (ccap > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
+    TRY(ctx->candFrag.ensure(ccap * 4)); TRY(ctx->candSeq.ensure(ccap * 4)); TRY(ctx->candStart.ensure(ccap * 4)); TRY(ctx->candEnd.ensure(ccap * 4));
+    TRY(zero_counters(ctx));
+    L1Args a;
+    a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>(); a.nFrag = (int32_t)nF;
+    a.sHash = sk->sHash; a.sIdx = sk->sIdx; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.nIndex = sk->n;
+    a.mSeq = sk->mSeq; a.mWpos = sk->mWpos; a.minHitsLUT = sk->dMinHits; a.lutMaxS = sk->dLutMaxS; a.L = L;
+    a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
+    a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);
+    a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
+    a.sumHits = cnt_ptr(ctx, CNT_HITS);
+    {
+      StageTimer tm(ctx, &ctx->counters.msL1);
+      hipLaunchKernelGGL(k_l1, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
+      hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, ctx->fragCandCnt.as<int32_t>(),
+                         ctx->fragCandCntClamped.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG));
+    }
+    HIP_TRY(hipGetLastError());
+    TRY(read_counters(ctx, host));
+    if (host[CNT_CAND] <= ccap) break;
+    if (attempt > 2) return fail(ANI_ERR_INTERNAL, "candidate pool did not converge");
+    ccap = host[CNT_CAND];
+  }
+  if ((uint32_t)host[CNT_NEG] != 0)
+    return fail(ANI_ERR_LIMIT, "%u query fragment(s) exceed the L1 fast-path limits (sketch size > %d or seed hits > %d): "
+                               "low-complexity/repetitive input; run with the reference's -s sanity check semantics or split the reference list",
+                (uint32_t)host[CNT_NEG], kL1MaxS, kL1HitCap);
+  ctx->counters.seedHits += host[CNT_HITS];
+  uint64_t nCand = 0;
+  {
+    StageTimer tm(ctx, &ctx->counters.msL1);
+    TRY(device_scan(ctx, ctx->fragCandCntClamped.as<int32_t>(), ctx->fragOrdOff.as<uint32_t>(), (uint32_t)nF, &nCand));
+    if (nCand) {
+      TRY(ctx->ocFrag.ensure(nCand * 4)); TRY(ctx->ocSeq.ensure(nCand * 4)); TRY(ctx->ocStart.ensure(nCand * 4)); TRY(ctx->ocEnd.ensure(nCand * 4));
+      hipLaunchKernelGGL(k_l1_order, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, ctx->fragCandOff.as<uint32_t>(), ctx->fragCandCntClamped.as<int32_t>(),
+                         ctx->fragOrdOff.as<uint32_t>(), (int32_t)nF, ctx->candSeq.as<int32_t>(), ctx->candStart.as<int32_t>(), ctx->candEnd.as<int32_t>(),
+                         ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(), ctx->ocStart.as<int32_t>(), ctx->ocEnd.as<int32_t>());
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  qr->nCand = (int32_t)nCand;
+  ctx->counters.l1Candidates += nCand;
+  if (nCand == 0) return ANI_OK;
+
+  // ---- L2 ----
+  TRY(ctx->l2Best.ensure(nCand * 4)); TRY(ctx->l2First.ensure(nCand * 4)); TRY(ctx->l2Last.ensure(nCand * 4));
+  TRY(ctx->refStart.ensure(nCand * 4)); TRY(ctx->idBits.ensure(nCand * 4));
+  {
+    size_t lanes = std::min<size_t>(nCand, (size_t)1 << 18);
+    lanes = (lanes + kTPB - 1) / kTPB * kTPB;
+    const size_t wordsPerLane = (size_t)maxS + 1;
+    while (lanes > kTPB && lanes * wordsPerLane * 4 > ((size_t)3 << 30)) lanes = (lanes / 2 + kTPB - 1) / kTPB * kTPB;
+    TRY(ctx->l2Scratch.ensure(lanes * wordsPerLane * 4));
+    TRY(zero_counters(ctx));
+    L2Args a;
+    a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
+    a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.contigFirstMin = sk->contigFirstMin;
+    a.L = L; a.w = w; a.k = k; a.scratch = ctx->l2Scratch.as<uint32_t>(); a.laneStride = lanes;
+    a.outBest = ctx->l2Best.as<int32_t>(); a.outFirst = ctx->l2First.as<int32_t>(); a.outLast = ctx->l2Last.as<int32_t>();
+    a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS);
+    StageTimer tm(ctx, &ctx->counters.msL2);
+    for (size_t base = 0; base < nCand; base += lanes)
+      hipLaunchKernelGGL(k_l2, dim3((unsigned)(lanes / kTPB)), dim3(kTPB), 0, ctx->stream, a, (int32_t)base);
+    FinishArgs fa;
+    fa.nCand = (int32_t)nCand; fa.candFrag = a.candFrag; fa.candSeq = a.candSeq; fa.best = a.outBest; fa.firstPos = a.outFirst; fa.lastPos = a.outLast;
+    fa.fragS = a.fragS; fa.idLUT = sk->dIdLUT; fa.minShared = sk->dMinShared; fa.lutMaxS = sk->dLutMaxS;
+    fa.refStart = ctx->refStart.as<int32_t>(); fa.idBits = ctx->idBits.as<uint32_t>();
+    hipLaunchKernelGGL(k_finish_candidates, dim3(grid_for(nCand)), dim3(256), 0, ctx->stream, fa);
+    HIP_TRY(hipGetLastError());
+  }
+  TRY(read_counters(ctx, host));
+  ctx->counters.l2WindowEntries += host[CNT_ENTRIES]; ctx->counters.l2Steps += host[CNT_STEPS];
+  return ANI_OK;
+}
+
+// 1-way / 2-way / mean for the candidates produced by query_stages; rows appended to `rows`
+int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuery, int32_t firstQueryId, std::vector<ani_cgi_t> *rows)
+{
+  if (nQuery == 0) return ANI_OK;
+  const size_t binsPerQuery = sk->totalBins;
+  const size_t nBins = binsPerQuery * (size_t)nQuery;
+  TRY(ctx->bins.ensure((nBins ? nBins : 1) * 4)); TRY(ctx->queryFragments.ensure((size_t)nQuery * 4));
+  const size_t rowCap = (size_t)nQuery * (size_t)sk->nGenomes;
+  TRY(ctx->rows.ensure((rowCap ? rowCap : 1) * 20));
+  TRY(zero_counters(ctx));
+  hipError_t e1, e2;
+  {
+  StageTimer tm(ctx, &ctx->counters.msReduce);
+  e1 = hipMemsetAsync(ctx->bins.p, 0, (nBins ? nBins : 1) * 4, ctx->stream);
+  e2 = hipMemcpyAsync(ctx->queryFragments.p, qr.genomeFragments.data(), (size_t)nQuery * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (qr.nCand) {
+    OneWayArgs a;
+    a.nCand = qr.nCand; a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.refStart = ctx->refStart.as<int32_t>();
+    a.idBits = ctx->idBits.as<uint32_t>(); a.fragGenome = ctx->fragGenome.as<int32_t>(); a.contigGenome = sk->contigGenome;
+    a.contigBinBase = sk->contigBinBase; a.binWidth = sk->params.fragLen - 20; a.bins = ctx->bins.as<uint32_t>(); a.binsPerQuery = binsPerQuery;
+    hipLaunchKernelGGL(k_oneway_bins, dim3(grid_for((size_t)qr.nCand)), dim3(256), 0, ctx->stream, a);
+  }
+  PairArgs pa;
+  pa.nQuery = nQuery; pa.nRefGenomes = sk->nGenomes; pa.bins = ctx->bins.as<uint32_t>(); pa.binsPerQuery = binsPerQuery;
+  pa.genomeBinStart = sk->genomeBinStart; pa.queryFragments = ctx->queryFragments.as<int32_t>(); pa.firstQueryId = firstQueryId;
+  pa.rows = ctx->rows.as<uint32_t>(); pa.rowCap = (uint32_t)rowCap; pa.rowCount = cnt_ptr(ctx, CNT_ROWS);
+  hipLaunchKernelGGL(k_pair_reduce, dim3(grid_for(rowCap)), dim3(256), 0, ctx->stream, pa);
+  }
+  HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(hipGetLastError());
+  unsigned long long host[CNT_N];
+  TRY(read_counters(ctx, host));
+  const size_t m = (size_t)host[CNT_ROWS];
+  if (m > rowCap) return fail(ANI_ERR_INTERNAL, "row count overflow");
+  const size_t old = rows->size();
+  rows->resize(old + m);
+  if (m) HIP_TRY(hipMemcpy(rows->data() + old, ctx->rows.p, m * 20, hipMemcpyDeviceToHost));
+  std::sort(rows->begin() + old, rows->end(), [](const ani_cgi_t &x, const ani_cgi_t &y) {
+    return x.qryGenomeId != y.qryGenomeId ? x.qryGenomeId < y.qryGenomeId : x.refGenomeId < y.refGenomeId;
+  });
+  ctx->counters.cgiRows += m;
+  return ANI_OK;
+}
+
+template <class T> int to_host_malloc(const std::vector<T> &v, T **out, size_t *n)
+{
+  *n = v.size();
+  *out = (T *)malloc((v.size() ? v.size() : 1) * sizeof(T));
+  if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
+  if (!v.empty()) memcpy(*out, v.data(), v.size() * sizeof(T));
+  return ANI_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char *ani_last_error(void) { return g_err.c_str(); }
+void ani_free(void *p) { free(p); }
+void ani_device_free(ani_ctx *ctx, void *p) { (void)ctx; if (p) (void)hipFree(p); }
+
+int ani_init(int device, ani_ctx **out)
+{
+  if (!out) return fail(ANI_ERR_ARG, "null output");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(ANI_ERR_DEVICE, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(ANI_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+  HIP_TRY(hipSetDevice(device));
+  ani_ctx *c = new ani_ctx();
+  c->device = device;
+  memset(&c->counters, 0, sizeof c->counters);
+  HIP_TRY(hipStreamCreate(&c->stream));
+  HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+  int rc = c->dCounters.ensure(CNT_N * 8);
+  if (rc != ANI_OK) { delete c; return rc; }
+  *out = c;
+  return ANI_OK;
+}
+
+void ani_shutdown(ani_ctx *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->tiles, &c->tileMeta, &c->tileCnt,
+                    &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
+                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
+                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Best,
+                    &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
+  for (DevBuf *b : bufs) b->release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ani_get_counters(ani_ctx *c, ani_counters_t *out)
+{
+  if (!c || !out) return fail(ANI_ERR_ARG, "null argument");
+  *out = c->counters;
+  return ANI_OK;
+}
+int ani_reset_counters(ani_ctx *c)
+{
+  if (!c) return fail(ANI_ERR_ARG, "null argument");
+  memset(&c->counters, 0, sizeof c->counters);
+  return ANI_OK;
+}
+
+int ani_recommended_window(int k, int fragLen)
+{
+  // fixed arguments of the CLI: p_value 1e-3, alphabet 4, identity 80, reference size 5e6 (parseCmdArgs.hpp:118-127, :225-228)
+  return ani::stat::recommended_window_size(1e-03, k, 4, 80.0f, fragLen, 5000000);
+}
+int ani_params_default(ani_params_t *p, int kmerSize, int fragLen)
+{
+  if (!p) return fail(ANI_ERR_ARG, "null parameters");
+  p->kmerSize = kmerSize > 0 ? kmerSize : 16;
+  p->fragLen = fragLen > 0 ? fragLen : 3000;
+  p->percentageIdentity = 80.0f;
+  if (p->kmerSize > 16) return fail(ANI_ERR_ARG, "kmerSize must be <= 16");
+  p->windowSize = ani_recommended_window(p->kmerSize, p->fragLen);
+  return ANI_OK;
+}
+int ani_min_hits_relaxed(int s, int k, float identity) { return ani::stat::estimate_minimum_hits_relaxed(s, k, identity); }
+int ani_identity(int shared, int s, int k, float *nucIdentity, float *upperBound)
+{
+  if (s <= 0 || shared < 0 || shared > s || !nucIdentity) return fail(ANI_ERR_ARG, "invalid (shared, sketchSize)");
+  ani::stat::identity(shared, s, k, nucIdentity, upperBound);
+  return ANI_OK;
+}
+
+int ani_sketch_records(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, int32_t seqIdBase, void **devRecords, size_t *n)
+{
+  if (!ctx || !devRecords || !n) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_params(p)); TRY(check_batch(refs));
+  HIP_TRY(hipSetDevice(ctx->device));
+  DeviceBatch db;
+  TRY(upload_batch(ctx, refs, 0, refs->nGenomes, &db));
+  uint32_t *rec = nullptr;
+  TRY(sketch_records(ctx, p, db, seqIdBase, &rec, n));
+  *devRecords = rec;
+  return ANI_OK;
+}
+
+int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *devRecords, size_t n, const int32_t *contigLen, int32_t nContigs,
+                            const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  if (!ctx || !out || (n && !devRecords) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
+    return fail(ANI_ERR_ARG, "invalid argument");
+  TRY(check_params(p));
+  HIP_TRY(hipSetDevice(ctx->device));
+  return build_index(ctx, p, (const uint32_t *)devRecords, n, contigLen, nContigs, genomeContigStart, nGenomes, out);
+}
+
+int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, ani_sketch **out)
+{
+  if (!ctx || !out) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_params(p)); TRY(check_batch(refs));
+  HIP_TRY(hipSetDevice(ctx->device));
+  // references are sketched in slices of genomes so that the temporary pools stay small; records are appended
+  // in genome order, i.e. position order with global seqIds
+  std::vector<uint32_t *> parts; std::vector<size_t> partN;
+  size_t total = 0;
+  auto cleanup = [&]() { for (uint32_t *q : parts) if (q) (void)hipFree(q); };
+  int32_t g0 = 0;
+  while (g0 < refs->nGenomes) {
+    int32_t g1 = g0; uint64_t bases = 0;
+    while (g1 < refs->nGenomes && (g1 == g0 || bases < (1ull << 30))) {
+      for (int32_t c = refs->genomeContigStart[g1]; c < refs->genomeContigStart[g1 + 1]; c++) bases += (uint64_t)refs->contigLen[c];
+      g1++;
+    }
+    DeviceBatch db;
+    int rc = upload_batch(ctx, refs, g0, g1, &db);
+    uint32_t *rec = nullptr; size_t n = 0;
+    if (rc == ANI_OK) rc = sketch_records(ctx, p, db, refs->genomeContigStart[g0], &rec, &n);
+    if (rc != ANI_OK) { cleanup(); return rc; }
+    parts.push_back(rec); partN.push_back(n); total += n;
+    g0 = g1;
+  }
+  uint32_t *all = nullptr;
+  if (parts.size() == 1) { all = parts[0]; parts[0] = nullptr; }
+  else if (total) {
+    hipError_t e = hipMalloc((void **)&all, total * 12);
+    if (e != hipSuccess) { cleanup(); return fail(ANI_ERR_NOMEM, "hipMalloc(%zu) failed", total * 12); }
+    size_t o = 0;
+    for (size_t i = 0; i < parts.size(); i++) {
+      if (partN[i]) (void)hipMemcpyAsync(all + 3 * o, parts[i], partN[i] * 12, hipMemcpyDeviceToDevice, ctx->stream);
+      o += partN[i];
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  cleanup();
+  int rc = build_index(ctx, p, all, total, refs->contigLen, refs->nContigs, refs->genomeContigStart, refs->nGenomes, out);
+  if (all) (void)hipFree(all);
+  return rc;
+}
+
+void ani_sketch_destroy(ani_sketch *sk)
+{
+  if (!sk) return;
+  (void)hipSetDevice(sk->ctx->device);
+  free_sketch_device(sk);
+  delete sk;
+}
+
+int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n)
+{
+  if (!sk || !out || !n) return fail(ANI_ERR_ARG, "null argument");
+  ani_ctx *ctx = sk->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  *n = sk->n;
+  *out = (ani_minimizer_t *)malloc((sk->n ? (size_t)sk->n : 1) * sizeof(ani_minimizer_t));
+  if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
+  if (sk->n == 0) return ANI_OK;
+  uint32_t *tmp = nullptr;
+  HIP_TRY(hipMalloc((void **)&tmp, (size_t)sk->n * 12));
+  hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(sk->n)), dim3(256), 0, ctx->stream, sk->mHash, sk->mSeq, sk->mWpos, sk->n, tmp);
+  hipError_t e = hipMemcpyAsync(*out, tmp, (size_t)sk->n * 12, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(tmp);
+  HIP_TRY(e); HIP_TRY(e2);
+  return ANI_OK;
+}
+
+int ani_sketch_stats(const ani_sketch *sk, uint64_t *nMinimizers, uint64_t *nUnique, uint64_t *totalLength, int32_t *nContigs, int32_t *nGenomes)
+{
+  if (!sk) return fail(ANI_ERR_ARG, "null sketch");
+  if (nMinimizers) *nMinimizers = sk->n;
+  if (nUnique) *nUnique = sk->nUnique;
+  if (totalLength) *totalLength = sk->totalLen;
+  if (nContigs) *nContigs = sk->nContigs;
+  if (nGenomes) *nGenomes = sk->nGenomes;
+  return ANI_OK;
+}
+
+int ani_query_sketch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *query, uint32_t **hashes, uint64_t **offsets, size_t *nFragments)
+{
+  if (!ctx || !hashes || !offsets || !nFragments) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_params(p)); TRY(check_batch(query));
+  HIP_TRY(hipSetDevice(ctx->device));
+  // run the fragment-sketch stage against an empty index
+  ani_sketch *sk = nullptr;
+  int32_t gcs[1] = {0};
+  TRY(build_index(ctx, p, nullptr, 0, nullptr, 0, gcs, 0, &sk));
+  DeviceBatch db; QueryRun qr;
+  int rc = upload_batch(ctx, query, 0, query->nGenomes, &db);
+  if (rc == ANI_OK) rc = query_stages(ctx, sk, db, &qr);
+  if (rc == ANI_OK) {
+    const size_t nF = (size_t)qr.nFrag;
+    std::vector<uint32_t> off(nF); std::vector<int32_t> s(nF);
+    if (nF) {
+      (void)hipMemcpy(off.data(), ctx->fragOff.p, nF * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(s.data(), ctx->fragS.p, nF * 4, hipMemcpyDeviceToHost);
+    }
+    std::vector<uint64_t> offs(nF + 1, 0);
+    for (size_t f = 0; f < nF; f++) offs[f + 1] = offs[f] + (uint64_t)(s[f] > 0 ? s[f] : 0);
+    std::vector<uint32_t> h(offs[nF]);
+    for (size_t f = 0; f < nF; f++)
+      if (s[f] > 0) (void)hipMemcpy(h.data() + offs[f], ctx->qPool.as<uint32_t>() + off[f], (size_t)s[f] * 4, hipMemcpyDeviceToHost);
+    size_t dummy;
+    rc = to_host_malloc(h, hashes, &dummy);
+    if (rc == ANI_OK) rc = to_host_malloc(offs, offsets, &dummy);
+    *nFragments = nF;
+  }
+  ani_sketch_destroy(sk);
+  return rc;
+}
+
+int ani_map_query(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t *query, ani_mapping_t **out, size_t *n, uint64_t *totalQueryFragments)
+{
+  if (!ctx || !skc || !out || !n) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_batch(query));
+  if (query->nGenomes != 1) return fail(ANI_ERR_ARG, "ani_map_query maps exactly one query genome (Map::Map takes one queryno, computeMap.hpp:93)");
+  ani_sketch *sk = const_cast<ani_sketch *>(skc);
+  HIP_TRY(hipSetDevice(ctx->device));
+  DeviceBatch db; QueryRun qr;
+  TRY(upload_batch(ctx, query, 0, 1, &db));
+  TRY(query_stages(ctx, sk, db, &qr));
+  if (totalQueryFragments) *totalQueryFragments = (uint64_t)qr.genomeFragments[0];
+  std::vector<ani_mapping_t> maps;
+  if (qr.nCand) {
+    const size_t nC = (size_t)qr.nCand;
+    TRY(ctx->keepFlags.ensure(nC * 4)); TRY(ctx->keepOff.ensure((nC + 1) * 4));
+    hipLaunchKernelGGL(ani::k_keep_flags, dim3(grid_for(nC)), dim3(256), 0, ctx->stream, (int32_t)nC, ctx->idBits.as<uint32_t>(), ctx->keepFlags.as<int32_t>());
+    uint64_t nKeep = 0;
+    TRY(device_scan(ctx, ctx->keepFlags.as<int32_t>(), ctx->keepOff.as<uint32_t>(), (uint32_t)nC, &nKeep));
+    if (nKeep) {
+      TRY(ctx->mapOut.ensure(nKeep * 44));
+      hipLaunchKernelGGL(ani::k_emit_mappings, dim3(grid_for(nC)), dim3(256), 0, ctx->stream, (int32_t)nC, ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(),
+                         ctx->refStart.as<int32_t>(), ctx->idBits.as<uint32_t>(), ctx->l2Best.as<int32_t>(), ctx->fragS.as<int32_t>(),
+                         ctx->fragQSeq.as<int32_t>(), ctx->keepOff.as<uint32_t>(), sk->params.fragLen, ctx->mapOut.as<uint32_t>());
+      HIP_TRY(hipGetLastError());
+      maps.resize(nKeep);
+      HIP_TRY(hipMemcpy(maps.data(), ctx->mapOut.p, nKeep * 44, hipMemcpyDeviceToHost));
+      // nucIdentityUpperBound (computeMap.hpp:378-381) is a host scalar per (sketchSize, shared); memoised
+      std::unordered_map<uint64_t, float> memo;
+      for (auto &m : maps) {
+        const uint64_t key = ((uint64_t)(uint32_t)m.sketchSize << 32) | (uint32_t)m.conservedSketches;
+        auto it = memo.find(key);
+        if (it == memo.end()) {
+          float id, ub; ani::stat::identity(m.conservedSketches, m.sketchSize, sk->params.kmerSize, &id, &ub);
+          it = memo.emplace(key, ub).first;
+        }
+        m.nucIdentityUpperBound = it->second;
+      }
+    }
+  }
+  ctx->counters.mappings += maps.size();
+  return to_host_malloc(maps, out, n);
+}
+
+int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *skc, const ani_mapping_t *mappings, size_t n, uint64_t totalQueryFragments, int32_t queryFileNo,
+                    ani_cgi_t **out, size_t *m)
+{
+  if (!ctx || !skc || !out || !m || (n && !mappings)) return fail(ANI_ERR_ARG, "null argument");
+  ani_sketch *sk = const_cast<ani_sketch *>(skc);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "too many mappings");
+  // The device reducer expects mappings grouped by (fragment, reference contig): order them the way Map reports them
+  std::vector<uint32_t> ord(n);
+  for (size_t i = 0; i < n; i++) ord[i] = (uint32_t)i;
+  std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+    const ani_mapping_t &a = mappings[x], &b = mappings[y];
+    if (a.querySeqId != b.querySeqId) return a.querySeqId < b.querySeqId;
+    if (a.refSeqId != b.refSeqId) return a.refSeqId < b.refSeqId;
+    return a.refStartPos < b.refStartPos;
+  });
+  std::vector<int32_t> cFrag(n), cSeq(n), cStart(n), fragIds; std::vector<uint32_t> cBits(n);
+  // compress querySeqId -> dense fragment index (all of one genome)
+  int32_t lastQ = -1, f = -1;
+  for (size_t i = 0; i < n; i++) {
+    const ani_mapping_t &a = mappings[ord[i]];
+    if (a.refSeqId < 0 || a.refSeqId >= sk->nContigs) return fail(ANI_ERR_ARG, "mapping %zu refers to contig %d outside the sketch", i, a.refSeqId);
+    if (a.refStartPos < 0 || a.refStartPos > sk->contigLen[a.refSeqId]) return fail(ANI_ERR_ARG, "mapping %zu has refStartPos outside its contig", i);
+    if (a.querySeqId != lastQ || f < 0) { f++; lastQ = a.querySeqId; fragIds.push_back(a.querySeqId); }
+    cFrag[i] = f; cSeq[i] = a.refSeqId; cStart[i] = a.refStartPos; memcpy(&cBits[i], &a.nucIdentity, 4);
+    if (a.nucIdentity <= 0.0f) return fail(ANI_ERR_ARG, "mapping %zu has non-positive identity", i);
+  }
+  QueryRun qr; qr.nCand = (int32_t)n; qr.nFrag = f + 1; qr.genomeFragments.assign(1, (int32_t)totalQueryFragments);
+  const size_t nF = (size_t)(f + 1);
+  if (n) {
+    TRY(ctx->ocFrag.ensure(n * 4)); TRY(ctx->ocSeq.ensure(n * 4)); TRY(ctx->refStart.ensure(n * 4)); TRY(ctx->idBits.ensure(n * 4)); TRY(ctx->fragGenome.ensure(nF * 4));
+    HIP_TRY(hipMemcpy(ctx->ocFrag.p, cFrag.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->ocSeq.p, cSeq.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->refStart.p, cStart.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->idBits.p, cBits.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(ctx->fragGenome.p, 0, nF * 4));
+  }
+  std::vector<ani_cgi_t> rows;
+  TRY(reduce_stage(ctx, sk, qr, 1, queryFileNo, &rows));
+  return to_host_malloc(rows, out, m);
+}
+
+int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t *queries, int32_t firstQueryId, ani_cgi_t **out, size_t *m)
+{
+  if (!ctx || !skc || !out || !m) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_batch(queries));
+  ani_sketch *sk = const_cast<ani_sketch *>(skc);
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<ani_cgi_t> rows;
+  // sub-batches bounded by fragments (~2^18) and by the bin table (~2 GiB)
+  const int L = sk->params.fragLen;
+  int32_t g0 = 0;
+  while (g0 < queries->nGenomes) {
+    int32_t g1 = g0; uint64_t fr = 0;
+    const uint64_t maxQ = std::max<uint64_t>(1, ((uint64_t)2 << 30) / (4ull * std::max<uint32_t>(sk->totalBins, 1)));
+    while (g1 < queries->nGenomes && (g1 == g0 || (fr < (1u << 18) && (uint64_t)(g1 - g0) < maxQ))) {
+      for (int32_t c = queries->genomeContigStart[g1]; c < queries->genomeContigStart[g1 + 1]; c++) fr += (uint64_t)(queries->contigLen[c] / L);
+      g1++;
+    }
+    DeviceBatch db; QueryRun qr;
+    TRY(upload_batch(ctx, queries, g0, g1, &db));
+    TRY(query_stages(ctx, sk, db, &qr));
+    TRY(reduce_stage(ctx, sk, qr, g1 - g0, firstQueryId + g0, &rows));
+    g0 = g1;
+  }
+  return to_host_malloc(rows, out, m);
+}
+
+int ani_synth_packed(ani_ctx *ctx, uint64_t seed, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut)
+{
+  if (!ctx || !devOut || nGenomes < 0 || genomeLen <= 0 || firstGenomeId < 0) return fail(ANI_ERR_ARG, "invalid argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t words = (size_t)nGenomes * (((size_t)genomeLen + 15) / 16);
+  if (words == 0) return ANI_OK;
+  hipLaunchKernelGGL(ani::k_synth_packed, dim3(grid_for(words, 256, 65535)), dim3(256), 0, ctx->stream, seed, firstGenomeId, nGenomes, genomeLen, (uint32_t *)devOut);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ANI_OK;
+}
+
+}  // extern "C"
+

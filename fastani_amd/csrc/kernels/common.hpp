@@ -1,0 +1,156 @@
+// common.hpp — device primitives shared by the gfx950 kernels of the ANI hot path.
+//
+//  * k-mer hashing: MurmurHash3_x64_128(kmer, k, seed 42) low 32 bits, on two 64-bit words that hold the
+//    k-mer's ASCII bytes (reference: src/common/murmur3.h:226-303 via src/map/include/commonFunc.hpp:71-81).
+//  * workgroup scan / bitonic sort over LDS (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ani {
+
+constexpr int kWave = 64;
+constexpr int kTPB = 256;             // threads per workgroup for all cooperative kernels (4 waves)
+constexpr uint32_t kMurmurSeed = 42;  // commonFunc.hpp:32
+
+// ---------------------------------------------------------------------------------------------
+// MurmurHash3_x64_128 -> low 32 bits of h1
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+__host__ __device__ __forceinline__ uint64_t fmix64(uint64_t z)
+{
+  z ^= z >> 33; z *= 0xff51afd7ed558ccdULL;
+  z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL;
+  z ^= z >> 33;
+  return z;
+}
+
+// k == 16: exactly one body block, empty tail (murmur3.h:245-254, :290-298)
+__host__ __device__ __forceinline__ uint32_t murmur32_k16(uint64_t k1, uint64_t k2)
+{
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = kMurmurSeed, h2 = kMurmurSeed;
+  k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+  h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+  k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+  h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  h1 ^= 16; h2 ^= 16;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  return (uint32_t)(h1 + h2);
+}
+
+// k < 16: no body block; k1 = bytes 0..min(k,8)-1, k2 = bytes 8..k-1, bytes beyond k are zero (murmur3.h:265-285)
+__host__ __device__ __forceinline__ uint32_t murmur32_tail(uint64_t k1, uint64_t k2, int k)
+{
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = kMurmurSeed, h2 = kMurmurSeed;
+  if (k > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+  k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+  h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  return (uint32_t)(h1 + h2);
+}
+
+// ASCII byte of a 2-bit code (A=0 C=1 G=2 T=3) and of its complement
+__host__ __device__ __forceinline__ uint32_t code_to_ascii(uint32_t c) { return (0x54474341u >> (8 * c)) & 0xffu; }
+__host__ __device__ __forceinline__ uint32_t code_to_ascii_comp(uint32_t c) { return (0x41434754u >> (8 * c)) & 0xffu; }
+// complement of a raw byte: only A,C,G,T change (commonFunc.hpp:37-54)
+__host__ __device__ __forceinline__ uint32_t ascii_comp(uint32_t b)
+{
+  return b == 'A' ? 'T' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'T' ? 'A' : b;
+}
+// commonFunc.hpp:61-64
+__host__ __device__ __forceinline__ uint32_t ascii_upper(uint32_t b) { return (b > 96 && b < 123) ? b - 32 : b; }
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup primitives (256 threads = 4 waves of 64)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    int o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive scan of one int per thread across the workgroup; *total = sum over all threads.
+// `ws` = LDS scratch of at least 8 ints.  Contains barriers: every thread of the block must call it.
+__device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total)
+{
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  int incl = wave_incl_scan(v);
+  __syncthreads();                       // protect ws against a previous use
+  if (lane == kWave - 1) ws[wv] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kTPB / kWave; i++) { int x = ws[i]; if (i < wv) base += x; tot += x; }
+  *total = tot;
+  return base + incl - v;
+}
+
+// inclusive max-scan (used for "nearest predecessor with property" searches)
+__device__ __forceinline__ int block_incl_maxscan(int v, int *ws)
+{
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    int o = __shfl_up(v, d);
+    if (lane >= d) v = o > v ? o : v;
+  }
+  __syncthreads();
+  if (lane == kWave - 1) ws[wv] = v;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kTPB / kWave; i++) { int x = ws[i]; if (i < wv) v = x > v ? x : v; }
+  return v;
+}
+
+// In-place exclusive scan of an int array of n elements that lives in LDS or global memory, by the whole
+// workgroup, any n.  Returns the total.  `ws` = LDS scratch (>= 8 ints).
+__device__ inline int block_array_excl_scan(int *a, int n, int *ws)
+{
+  int carry = 0;
+  // each pass covers kTPB*8 consecutive elements; thread t owns 8 consecutive ones
+  for (int base = 0; base < n; base += kTPB * 8) {
+    int first = base + (int)threadIdx.x * 8;
+    int loc[8]; int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { int idx = first + j; int x = idx < n ? a[idx] : 0; loc[j] = sum; sum += x; }
+    int tot; int off = block_excl_scan(sum, ws, &tot);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { int idx = first + j; if (idx < n) a[idx] = carry + off + loc[j]; }
+    carry += tot;
+  }
+  __syncthreads();
+  return carry;
+}
+
+// Bitonic sort of n2 (power of two) keys, ascending, by the whole workgroup.  Works on LDS or global pointers.
+template <class K>
+__device__ inline void block_bitonic_sort(K *a, int n2)
+{
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (n2 >> 1); t += kTPB) {
+        int lo = 2 * t - (t & (stride - 1));          // index with the `stride` bit cleared
+        int hi = lo + stride;
+        bool up = ((lo & size) == 0);
+        K x = a[lo], y = a[hi];
+        if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__host__ __device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+}  // namespace ani

@@ -1,0 +1,168 @@
+// l1.hpp — L1 stage: seed lookup and candidate regions, one workgroup per query fragment.
+//
+// Restates skch::Map::doL1Mapping (src/map/include/computeMap.hpp:252-304: probe every unique fragment hash in the
+// lookup index and collect all (seqId,wpos) occurrences) and computeL1CandidateRegions (:313-354: sort the hits,
+// slide a run of `minimumHits` consecutive hits, keep runs that stay on one contig and span < fragLen, merge
+// overlapping candidates).  Stateless form, SURVEY.md App. A.3.
+//
+// Fast path (this kernel): s <= kL1MaxS and H <= kL1HitCap, everything in LDS: probe (bucket table + binary search in
+// the hash-sorted index), gather hits as 64-bit (seqId<<32 | wpos) keys, bitonic sort, flag valid runs, compact,
+// flag group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous
+// candidate" only needs the previous valid run), scan, emit.  Larger fragments are flagged (fragCandCnt = -1) and
+// taken by the overflow path.
+#pragma once
+#include "common.hpp"
+
+namespace ani {
+
+constexpr int kL1MaxS = 1024;
+constexpr int kL1HitCap = 4096;
+
+struct L1Args {
+  const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
+  const uint32_t *sHash; const uint32_t *sIdx; const uint32_t *bucketStart; int bucketShift; uint32_t nIndex;
+  const int32_t *mSeq; const int32_t *mWpos;
+  const int32_t *minHitsLUT; int32_t lutMaxS;
+  int L;
+  int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
+  uint32_t *fragCandOff; int32_t *fragCandCnt; int32_t *fragHits;
+  unsigned long long *sumHits;
+};
+
+// occurrences of hash h in the hash-sorted index: [first, first+cnt)
+__device__ __forceinline__ void l1_probe(const L1Args &a, uint32_t h, uint32_t &first, uint32_t &cnt)
+{
+  const uint32_t b = h >> a.bucketShift;
+  uint32_t lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
+  const uint32_t bhi = hi;
+  while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a.sHash[mid] < h) lo = mid + 1; else hi = mid; }
+  first = lo;
+  // upper bound inside the bucket (occurrence lists are short except for low-complexity repeats)
+  uint32_t e = lo;
+  if (e < bhi && a.sHash[e] == h) {
+    uint32_t l2 = e + 1, h2 = bhi;
+    while (l2 < h2) { uint32_t mid = l2 + ((h2 - l2) >> 1); if (a.sHash[mid] <= h) l2 = mid + 1; else h2 = mid; }
+    e = l2;
+  }
+  cnt = e - lo;
+}
+
+__device__ __forceinline__ int32_t hit_seq(uint64_t h) { return (int32_t)(h >> 32); }
+__device__ __forceinline__ int32_t hit_wpos(uint64_t h) { return (int32_t)(uint32_t)h; }
+
+// run starting at sorted hit a is a candidate (computeMap.hpp:332)
+__device__ __forceinline__ bool l1_valid(const uint64_t *hits, int a, int m, int L)
+{
+  const uint64_t x = hits[a], y = hits[a + m - 1];
+  return hit_seq(x) == hit_seq(y) && hit_wpos(y) - hit_wpos(x) < L;
+}
+// j-th valid run opens a new candidate (computeMap.hpp:342-350, negated)
+__device__ __forceinline__ bool l1_head(const uint64_t *hits, const int *V, int j, int m, int L)
+{
+  if (j == 0) return true;
+  const uint64_t x = hits[V[j]], px = hits[V[j - 1]];
+  int32_t start = hit_wpos(hits[V[j] + m - 1]) - L + 1; if (start < 0) start = 0;
+  return hit_seq(x) != hit_seq(px) || hit_wpos(px) < start;
+}
+
+__global__ __launch_bounds__(kTPB) void k_l1(L1Args a)
+{
+  __shared__ uint64_t hits[kL1HitCap];
+  __shared__ int V[kL1HitCap];
+  __shared__ int ws[16];
+  __shared__ unsigned long long sBase;
+  const int f = blockIdx.x;
+  const int t = threadIdx.x;
+  const int s = a.fragS[f];
+  if (s <= 0) {
+    if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; a.fragHits[f] = 0; }
+    return;
+  }
+  const uint32_t *q = a.qPool + a.fragOff[f];
+  int *pFirst = V, *pOff = V + kL1MaxS;            // probe results alias V (V is only written after the gather)
+
+  if (s > kL1MaxS) {                               // overflow path: only count the hits here
+    int c = 0;
+    for (int i = t; i < s; i += kTPB) { uint32_t fi, cn; l1_probe(a, q[i], fi, cn); c += (int)cn; }
+    int H; block_excl_scan(c, ws, &H);
+    if (t == 0) { a.fragCandCnt[f] = -1; a.fragCandOff[f] = 0; a.fragHits[f] = H; }
+    return;
+  }
+  for (int i = t; i < s; i += kTPB) { uint32_t fi, cn; l1_probe(a, q[i], fi, cn); pFirst[i] = (int)fi; pOff[i] = (int)cn; }
+  __syncthreads();
+  const int H = block_array_excl_scan(pOff, s, ws);
+  if (H > kL1HitCap) {
+    if (t == 0) { a.fragCandCnt[f] = -1; a.fragCandOff[f] = 0; a.fragHits[f] = H; }
+    return;
+  }
+  if (H == 0) {
+    if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; a.fragHits[f] = 0; }
+    return;
+  }
+  // gather (computeMap.hpp:283-299)
+  for (int i = t; i < s; i += kTPB) {
+    const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H, fi = pFirst[i];
+    for (int c = 0; c < e - o; c++) {
+      const uint32_t idx = a.sIdx[fi + c];
+      hits[o + c] = ((uint64_t)(uint32_t)a.mSeq[idx] << 32) | (uint32_t)a.mWpos[idx];
+    }
+  }
+  const int n2 = next_pow2(H);
+  for (int i = H + t; i < n2; i += kTPB) hits[i] = ~0ull;
+  block_bitonic_sort<uint64_t>(hits, n2);           // :320 (starts with a barrier: the gather is complete)
+
+  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1; if (m < 1) m = 1;      // :301, :316
+  const int nA = H - m + 1;
+  int nG = 0;
+  if (nA > 0) {
+    // valid runs, compacted in order
+    int per = (nA + kTPB - 1) / kTPB;
+    int lo = t * per, hi = lo + per < nA ? lo + per : nA;
+    int c = 0;
+    for (int x = lo; x < hi; x++) c += l1_valid(hits, x, m, a.L);
+    int nv; int r = block_excl_scan(c, ws, &nv);
+    for (int x = lo; x < hi; x++) if (l1_valid(hits, x, m, a.L)) V[r++] = x;
+    __syncthreads();
+    // candidate heads
+    per = (nv + kTPB - 1) / kTPB;
+    lo = t * per; hi = lo + per < nv ? lo + per : nv;
+    c = 0;
+    for (int j = lo; j < hi; j++) c += l1_head(hits, V, j, m, a.L);
+    int g = block_excl_scan(c, ws, &nG);
+    if (t == 0) sBase = nG ? atomicAdd(a.candCount, (unsigned long long)nG) : 0ull;
+    __syncthreads();
+    const unsigned long long base = sBase;
+    if (base + (unsigned long long)nG <= (unsigned long long)a.candCap) {
+      for (int j = lo; j < hi; j++) {
+        const bool head = l1_head(hits, V, j, m, a.L);
+        if (head) g++;
+        const unsigned long long slot = base + (unsigned long long)(g - 1);     // group of run j
+        if (head) {
+          int32_t start = hit_wpos(hits[V[j] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
+          a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[j]]); a.candStart[slot] = start;
+        }
+        if (j == nv - 1 || l1_head(hits, V, j + 1, m, a.L)) a.candEnd[slot] = hit_wpos(hits[V[j]]);   // :336,:347
+      }
+    }
+    if (t == 0) a.fragCandOff[f] = (uint32_t)base;
+  } else if (t == 0) a.fragCandOff[f] = 0;
+  if (t == 0) { a.fragCandCnt[f] = nG; a.fragHits[f] = H; atomicAdd(a.sumHits, (unsigned long long)H); }
+}
+
+// reorder candidates into the reference's callback order: fragment ascending, then (seqId, start) as produced
+__global__ void k_l1_order(const uint32_t *__restrict__ fragCandOff, const int32_t *__restrict__ fragCandCnt,
+                           const uint32_t *__restrict__ orderedOff, int32_t nFrag,
+                           const int32_t *__restrict__ inSeq, const int32_t *__restrict__ inStart, const int32_t *__restrict__ inEnd,
+                           int32_t *__restrict__ outFrag, int32_t *__restrict__ outSeq, int32_t *__restrict__ outStart,
+                           int32_t *__restrict__ outEnd)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nFrag) return;
+  const int n = fragCandCnt[f];
+  const uint32_t src = fragCandOff[f], dst = orderedOff[f];
+  for (int i = 0; i < n; i++) {
+    outFrag[dst + i] = f; outSeq[dst + i] = inSeq[src + i]; outStart[dst + i] = inStart[src + i]; outEnd[dst + i] = inEnd[src + i];
+  }
+}
+
+}  // namespace ani

@@ -1,0 +1,139 @@
+// reduce.hpp — identity estimate + filter per candidate (skch::Map::doL2Mapping, src/map/include/computeMap.hpp:363-410)
+// and the ANI reducer (cgi::computeCGI, src/cgi/include/computeCoreIdentity.hpp:166-298).
+//
+// Identity and the 90 % CI filter are pure functions of (shared, s); the host evaluates the reference's float
+// expressions once (host/stats.hpp) and uploads
+//   idLUT[lutOff(s) + shared] = nucIdentity (float bits),   minShared[s] = smallest `shared` that passes :384.
+//
+// Reducer without sorting.  Candidates arrive ordered by (fragment, seqId, start), so all mappings of one
+// (fragment, reference genome) pair are adjacent:
+//   1-way (computeCoreIdentity.hpp:214-231): the group's maximum under (nucIdentity, refSeqId, refStartPos);
+//   2-way (:237-254): atomicMax of the identity bits into a dense bin table [query genome][contig bin], bin =
+//          refStartPos / (fragLen-20) (:194) — identities are non-negative floats, so their bit patterns order like uints;
+//   mean  (:267-297): one lane per (query genome, reference genome) walks that genome's bins in (contig, bin) order
+//          and adds the non-empty ones sequentially in float — the same order the reference sums in.
+#pragma once
+#include "common.hpp"
+
+namespace ani {
+
+__host__ __device__ __forceinline__ uint32_t lut_off(int s) { return (uint32_t)(((int64_t)(s - 1) * (s + 2)) / 2); }
+
+struct FinishArgs {
+  int32_t nCand;
+  const int32_t *candFrag, *candSeq;
+  const int32_t *best, *firstPos, *lastPos;
+  const int32_t *fragS;
+  const uint32_t *idLUT; const int32_t *minShared; int32_t lutMaxS;
+  // outputs per candidate
+  int32_t *refStart;        // meanOptimalPos (computeMap.hpp:496)
+  uint32_t *idBits;         // nucIdentity bits, 0 if filtered out
+};
+
+__global__ void k_finish_candidates(FinishArgs a)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.nCand) return;
+  const int s = a.fragS[a.candFrag[c]];
+  const int b = a.best[c];
+  a.refStart[c] = (a.firstPos[c] + a.lastPos[c]) / 2;
+  uint32_t bits = 0;
+  if (b > 0 && s <= a.lutMaxS && b >= a.minShared[s]) bits = a.idLUT[lut_off(s) + b];
+  a.idBits[c] = bits;
+}
+
+struct OneWayArgs {
+  int32_t nCand;
+  const int32_t *candFrag, *candSeq, *refStart; const uint32_t *idBits;
+  const int32_t *fragGenome;        // fragment -> query genome index inside the batch
+  const int32_t *contigGenome;      // reference contig -> reference genome
+  const uint32_t *contigBinBase;    // reference contig -> first bin
+  int32_t binWidth;                 // fragLen - 20
+  uint32_t *bins; size_t binsPerQuery;
+};
+
+// one lane per candidate; the first candidate of each (fragment, genome) group resolves the group
+__global__ void k_oneway_bins(OneWayArgs a)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.nCand) return;
+  const int f = a.candFrag[c];
+  const int g = a.contigGenome[a.candSeq[c]];
+  if (c > 0 && a.candFrag[c - 1] == f && a.contigGenome[a.candSeq[c - 1]] == g) return;   // not a group head
+  uint32_t bBits = 0; int32_t bSeq = -1, bPos = -1;
+  for (int x = c; x < a.nCand && a.candFrag[x] == f && a.contigGenome[a.candSeq[x]] == g; x++) {
+    const uint32_t bits = a.idBits[x];
+    if (!bits) continue;
+    const int32_t sq = a.candSeq[x], ps = a.refStart[x];
+    // cgid_types.hpp:35-36 order, keep the last = the maximum
+    if (bits > bBits || (bits == bBits && (sq > bSeq || (sq == bSeq && ps > bPos)))) { bBits = bits; bSeq = sq; bPos = ps; }
+  }
+  if (bBits) {
+    const size_t bin = (size_t)a.fragGenome[f] * a.binsPerQuery + a.contigBinBase[bSeq] + (uint32_t)(bPos / a.binWidth);
+    atomicMax(&a.bins[bin], bBits);
+  }
+}
+
+struct PairArgs {
+  int32_t nQuery, nRefGenomes;
+  const uint32_t *bins; size_t binsPerQuery;
+  const uint32_t *genomeBinStart;      // [nRefGenomes+1] first bin of each reference genome
+  const int32_t *queryFragments;       // [nQuery] totalQueryFragments
+  int32_t firstQueryId;
+  // output rows (cgi::CGI_Results layout, 5 words), appended with an atomic counter
+  uint32_t *rows; uint32_t rowCap; unsigned long long *rowCount;
+};
+
+__global__ void k_pair_reduce(PairArgs a)
+{
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long long)a.nQuery * a.nRefGenomes) return;
+  const int qi = (int)(p / a.nRefGenomes), g = (int)(p % a.nRefGenomes);
+  const uint32_t *b = a.bins + (size_t)qi * a.binsPerQuery;
+  float sum = 0.0f; int cnt = 0;
+  for (uint32_t x = a.genomeBinStart[g]; x < a.genomeBinStart[g + 1]; x++) {
+    const uint32_t bits = b[x];
+    if (bits) { sum += __uint_as_float(bits); cnt++; }
+  }
+  if (cnt) {
+    const unsigned long long r = atomicAdd(a.rowCount, 1ull);
+    if (r < a.rowCap) {
+      uint32_t *row = a.rows + 5 * r;
+      row[0] = (uint32_t)g; row[1] = (uint32_t)(a.firstQueryId + qi); row[2] = (uint32_t)cnt;
+      row[3] = (uint32_t)a.queryFragments[qi]; row[4] = __float_as_uint(sum / cnt);
+    }
+  }
+}
+
+// mapping export for ani_map_query: compacted, candidate order preserved by a prior scan of the keep flags
+__global__ void k_emit_mappings(int32_t nCand, const int32_t *__restrict__ candFrag, const int32_t *__restrict__ candSeq,
+                                const int32_t *__restrict__ refStart, const uint32_t *__restrict__ idBits,
+                                const int32_t *__restrict__ best, const int32_t *__restrict__ fragS,
+                                const int32_t *__restrict__ fragQuerySeqId, const uint32_t *__restrict__ outOff, int L,
+                                uint32_t *__restrict__ out /* 11 words per mapping; upper bound filled on the host */)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nCand || !idBits[c]) return;
+  uint32_t *m = out + 11 * (size_t)outOff[c];
+  const int f = candFrag[c];
+  m[0] = (uint32_t)L; m[1] = (uint32_t)refStart[c]; m[2] = (uint32_t)(refStart[c] + L - 1); m[3] = 0; m[4] = (uint32_t)(L - 1);
+  m[5] = (uint32_t)candSeq[c]; m[6] = (uint32_t)fragQuerySeqId[f]; m[7] = idBits[c]; m[8] = 0;
+  m[9] = (uint32_t)fragS[f]; m[10] = (uint32_t)best[c];
+}
+
+__global__ void k_keep_flags(int32_t n, const uint32_t *__restrict__ idBits, int32_t *__restrict__ flags)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) flags[c] = idBits[c] != 0;
+}
+
+__global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out, unsigned int *__restrict__ nNeg)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = in[i];
+  out[i] = v > 0 ? v : 0;
+  if (v < 0) atomicAdd(nNeg, 1u);
+}
+
+}  // namespace ani

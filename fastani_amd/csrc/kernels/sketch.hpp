@@ -1,0 +1,358 @@
+// sketch.hpp — winnowed-minimizer kernels (reference sketch tiles + query fragment sketches).
+//
+// Restates skch::CommonFunc::addMinimizers (src/map/include/commonFunc.hpp:91-167) in stateless form
+// (SURVEY.md App. A.1/A.2):
+//   h(i)   = min(hashFwd(i), hashBwd(i)), position skipped iff hashFwd == hashBwd            (:126-134)
+//   P(i)   = rightmost non-skipped j in (i-w, i] minimising h(j)                             (:137-148)
+//   emit (h(P(i)), seqId, i-w+1) at every non-skipped i >= w-1 whose P(i) differs from P at the previous
+//   such position                                                                            (:152-161)
+//
+// Work decomposition: one workgroup (256 threads) per tile of kTile = 3072 consecutive k-mer start positions of
+// one contig; each thread owns kPer = 12 consecutive positions.  The thread packs its 27 bases into a 64-bit
+// register (2-bit codes), keeps the forward and reverse-complement k-mer as rolling 2x64-bit ASCII words and
+// hashes both strands per position.  Canonical hashes go to LDS as 64-bit keys (hash<<32 | reversed position,
+// so that `min` implements "smallest hash, rightmost on ties"); the w-wide window minimum is computed by
+// log2(w) doubling rounds over LDS.  Tiles overlap by w-1 positions.  Argmin positions are monotone in i, so
+// "P at the previous non-skipped position" is a max-scan.
+#pragma once
+#include "common.hpp"
+
+namespace ani {
+
+constexpr int kPer = 12;
+constexpr int kTile = kTPB * kPer;   // 3072 k-mer positions per tile
+constexpr uint64_t kSkipKey = ~0ull;
+
+struct TileDesc {          // one per tile, built on the host from contig lengths
+  int32_t contig;          // index into the batch's contig table
+  int32_t firstPos;        // B: first k-mer start position hashed by this tile
+};
+struct TileMeta {          // produced by k_sketch_tiles
+  uint32_t off;            // offset of this tile's records in the temporary pool
+  int32_t cnt;             // records emitted (the first one is provisional, see firstP)
+  int32_t firstP;          // absolute argmin position behind the first emitted record, -1 if none
+  int32_t lastP;           // absolute argmin position at the last non-skipped window of the tile, -1 if none
+};
+
+// ------------------------------------------------------------------------------------------------
+// Per-thread strand hashing of kPer consecutive positions.
+//   PACKED: seq = const uint32_t* (16 bases per word), off in words;  else seq = const uint8_t*, off in bytes.
+// key[j] = (canonical hash << 32) | (kTile-1-local) or kSkipKey (skipped / beyond the contig end)
+// ------------------------------------------------------------------------------------------------
+template <bool PACKED>
+__device__ __forceinline__ void hash_positions(const void *seq, int64_t off, int32_t len, int32_t i0, int local0,
+                                               int k, uint64_t (&key)[kPer])
+{
+  // ---- fetch the 27 bases [i0, i0+27) as ASCII on demand ----
+  uint64_t bits = 0;                  // PACKED: 2-bit codes of bases i0.. in bits 2j..2j+1
+  const uint8_t *bytes = nullptr;
+  if (PACKED) {
+    const uint32_t *wds = (const uint32_t *)seq + off;
+    const int32_t nWords = (len + 15) >> 4;
+    const int32_t w0 = i0 >> 4;
+    const int sh = (i0 & 15) * 2;
+    uint64_t a = w0 < nWords ? wds[w0] : 0u;
+    uint64_t b = w0 + 1 < nWords ? wds[w0 + 1] : 0u;
+    uint64_t c = w0 + 2 < nWords ? wds[w0 + 2] : 0u;
+    uint64_t lo = a | (b << 32);
+    bits = sh ? ((lo >> sh) | (c << (64 - sh))) : lo;
+  } else {
+    bytes = (const uint8_t *)seq + off;
+  }
+  auto fwd_byte = [&](int j) -> uint64_t {
+    if (PACKED) return code_to_ascii((uint32_t)(bits >> (2 * j)) & 3u);
+    int32_t p = i0 + j;
+    return p < len ? ascii_upper(bytes[p]) : 0u;
+  };
+  auto rc_byte = [&](int j) -> uint64_t {
+    if (PACKED) return code_to_ascii_comp((uint32_t)(bits >> (2 * j)) & 3u);
+    int32_t p = i0 + j;
+    return p < len ? ascii_comp(ascii_upper(bytes[p])) : 0u;
+  };
+
+  // forward 16-byte window F = S[i..i+16) ; reverse window R: byte j = comp(S[i+15-j])
+  uint64_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    flo |= fwd_byte(j) << (8 * j);
+    fhi |= fwd_byte(8 + j) << (8 * j);
+    rhi |= rc_byte(j) << (8 * (7 - j));
+    rlo |= rc_byte(8 + j) << (8 * (7 - j));
+  }
+  const bool k16 = (k == 16);
+  const uint64_t maskLo = k >= 8 ? ~0ull : ((1ull << (8 * k)) - 1);
+  const uint64_t maskHi = k16 ? ~0ull : (k > 8 ? ((1ull << (8 * (k - 8))) - 1) : 0ull);
+  const int rsh = 8 * (16 - k);       // the k-byte reverse complement is R shifted right by 16-k bytes
+  const int32_t nPos = len - k + 1;
+
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    uint32_t hf, hb;
+    if (k16) {
+      hf = murmur32_k16(flo, fhi);
+      hb = murmur32_k16(rlo, rhi);
+    } else {
+      uint64_t r1, r2;
+      if (rsh < 64) { r1 = (rlo >> rsh) | (rhi << (64 - rsh)); r2 = rhi >> rsh; }
+      else { r1 = rsh == 64 ? rhi : (rhi >> (rsh - 64)); r2 = 0; }
+      hf = murmur32_tail(flo & maskLo, fhi & maskHi, k);
+      hb = murmur32_tail(r1, r2, k);
+    }
+    const bool ok = (i0 + j < nPos) && (hf != hb);                      // commonFunc.hpp:131
+    const uint32_t h = hf < hb ? hf : hb;                               // :134
+    key[j] = ok ? (((uint64_t)h << 32) | (uint32_t)(kTile - 1 - (local0 + j))) : kSkipKey;
+    // roll to position i+1
+    const uint64_t nb = fwd_byte(16 + j), nc = rc_byte(16 + j);
+    flo = (flo >> 8) | (fhi << 56);
+    fhi = (fhi >> 8) | (nb << 56);
+    rhi = (rhi << 8) | (rlo >> 56);
+    rlo = (rlo << 8) | nc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile core: hashes + window minimum + emission flags.  All 256 threads of the workgroup call it.
+//   keys : LDS, kTile uint64
+//   ws   : LDS scratch, >= kTPB + 8 ints
+// Outputs per thread: em[j] (emit at own position j), W[j] (window-min key), and block-wide first/last P.
+// ------------------------------------------------------------------------------------------------
+template <bool PACKED>
+__device__ __forceinline__ void tile_winnow(const void *seq, int64_t off, int32_t len, int32_t B, int k, int w,
+                                            uint64_t *keys, int *ws,
+                                            uint64_t (&W)[kPer], bool (&em)[kPer], int &tileFirstP, int &tileLastP)
+{
+  const int t = threadIdx.x;
+  const int local0 = t * kPer;
+  const int32_t nPos = len - k + 1;
+  uint64_t key[kPer];
+  hash_positions<PACKED>(seq, off, len, B + local0, local0, k, key);
+  bool own_ok[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; j++) { keys[local0 + j] = key[j]; W[j] = key[j]; own_ok[j] = key[j] != kSkipKey; }
+
+  // ---- window minimum over (i-w, i] by doubling: after the loop W = min over the last p positions ----
+  int p = 1;
+  while (2 * p <= w) {
+    __syncthreads();
+    uint64_t r[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) { int q = local0 + j - p; r[j] = q >= 0 ? keys[q] : kSkipKey; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; j++) { W[j] = r[j] < W[j] ? r[j] : W[j]; keys[local0 + j] = W[j]; }
+    p <<= 1;
+  }
+  __syncthreads();
+  if (w > p) {
+    const int d = w - p;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) { int q = local0 + j - d; uint64_t r = q >= 0 ? keys[q] : kSkipKey; W[j] = r < W[j] ? r : W[j]; }
+  }
+
+  // ---- emission: argmin positions are monotone, so "previous P" is a running maximum ----
+  int P[kPer]; bool val[kPer];
+  int myMax = -1, myFirst = -1;
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int l = local0 + j;
+    val[j] = own_ok[j] && l >= w - 1 && (B + l) < nPos;
+    P[j] = val[j] ? (kTile - 1 - (int)(uint32_t)W[j]) : -1;
+    if (val[j]) { if (myFirst < 0) myFirst = P[j]; myMax = P[j]; }
+  }
+  int incl = block_incl_maxscan(myMax, ws);        // max P over threads 0..t
+  __syncthreads();
+  ws[8 + t] = incl;
+  __syncthreads();
+  int prev = t > 0 ? ws[8 + t - 1] : -1;           // max P over all earlier threads
+  const int lastAll = ws[8 + kTPB - 1];
+  // first valid P in the tile: the thread whose predecessor max is -1 and that has a valid position
+  __syncthreads();
+  if (t == 0) ws[0] = -1;
+  __syncthreads();
+  if (myFirst >= 0 && prev < 0) ws[0] = myFirst;   // exactly one thread satisfies this
+  __syncthreads();
+  const int firstAll = ws[0];
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    em[j] = val[j] && P[j] != prev;
+    if (val[j]) prev = P[j];
+  }
+  tileFirstP = firstAll >= 0 ? B + firstAll : -1;
+  tileLastP = lastAll >= 0 ? B + lastAll : -1;
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reference sketch, pass 1: one workgroup per tile; records go to a temporary pool in tile-arrival order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTPB) void k_sketch_tiles(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
+                                                       const int64_t *__restrict__ contigOff, const int32_t *__restrict__ contigLen,
+                                                       const uint8_t *__restrict__ contigMode /* 1 = 2-bit packed, 0 = raw bytes */,
+                                                       const TileDesc *__restrict__ tiles, int k, int w,
+                                                       uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos,
+                                                       uint32_t poolCap, unsigned long long *__restrict__ poolCount,
+                                                       TileMeta *__restrict__ meta)
+{
+  __shared__ uint64_t keys[kTile];
+  __shared__ int ws[kTPB + 16];
+  __shared__ unsigned long long sBase;
+  const TileDesc td = tiles[blockIdx.x];
+  const int64_t off = contigOff[td.contig];
+  const int32_t len = contigLen[td.contig];
+  uint64_t W[kPer]; bool em[kPer]; int firstP, lastP;
+  if (contigMode[td.contig]) tile_winnow<true>(packed, off, len, td.firstPos, k, w, keys, ws, W, em, firstP, lastP);
+  else tile_winnow<false>(ascii, off, len, td.firstPos, k, w, keys, ws, W, em, firstP, lastP);
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; j++) cnt += em[j];
+  int total; int rank = block_excl_scan(cnt, ws, &total);
+  if (threadIdx.x == 0) sBase = total ? atomicAdd(poolCount, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  const unsigned long long base = sBase;
+  if (base + (unsigned long long)total <= (unsigned long long)poolCap) {
+#pragma unroll
+    for (int j = 0; j < kPer; j++)
+      if (em[j]) {
+        poolHash[base + rank] = (uint32_t)(W[j] >> 32);
+        poolWpos[base + rank] = td.firstPos + (int)threadIdx.x * kPer + j - w + 1;     // currentWindowId, commonFunc.hpp:124
+        rank++;
+      }
+  }
+  if (threadIdx.x == 0) {
+    TileMeta m; m.off = (uint32_t)base; m.cnt = total; m.firstP = firstP; m.lastP = lastP;
+    meta[blockIdx.x] = m;
+  }
+}
+
+// pass 2: decide, per tile, whether its provisional first record repeats the argmin that the nearest earlier
+// non-empty tile of the same contig ended with (then it is not a new minimizer, commonFunc.hpp:155).
+__global__ void k_sketch_tile_counts(const TileDesc *__restrict__ tiles, const TileMeta *__restrict__ meta, int nTiles,
+                                     int32_t *__restrict__ outCnt /* [nTiles] */, uint8_t *__restrict__ dropFirst)
+{
+  int T = blockIdx.x * blockDim.x + threadIdx.x;
+  if (T >= nTiles) return;
+  const TileMeta m = meta[T];
+  int drop = 0;
+  if (m.cnt > 0) {
+    const int c = tiles[T].contig;
+    for (int U = T - 1; U >= 0 && tiles[U].contig == c; U--) {
+      const int lp = meta[U].lastP;
+      if (lp >= 0) { drop = (lp == m.firstP); break; }
+    }
+  }
+  dropFirst[T] = (uint8_t)drop;
+  outCnt[T] = m.cnt - drop;
+}
+
+// pass 3: gather the tile-ordered records into position order as 12-byte skch::MinimizerInfo records.
+__global__ __launch_bounds__(kTPB) void k_sketch_gather(const TileDesc *__restrict__ tiles, const TileMeta *__restrict__ meta,
+                                                        const uint8_t *__restrict__ dropFirst, const uint32_t *__restrict__ outOff,
+                                                        const uint32_t *__restrict__ poolHash, const int32_t *__restrict__ poolWpos,
+                                                        int32_t seqIdBase, uint32_t *__restrict__ records /* 3 words each */)
+{
+  const int T = blockIdx.x;
+  const TileMeta m = meta[T];
+  const int drop = dropFirst[T];
+  const int n = m.cnt - drop;
+  const size_t dst = outOff[T];
+  const int32_t seqId = seqIdBase + tiles[T].contig;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    const uint32_t src = m.off + drop + r;
+    uint32_t *rec = records + 3 * (dst + r);
+    rec[0] = poolHash[src]; rec[1] = (uint32_t)seqId; rec[2] = (uint32_t)poolWpos[src];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query fragments: one workgroup per fragment (computeMap.hpp:157-175 aliases bytes [i*L, i*L+L) of the
+// contig; :260 winnows them in isolation; :268-274 sort + unique by hash => sketch size s).
+// Sorted unique hashes go to a pool; per fragment (offset, s).
+// ------------------------------------------------------------------------------------------------
+struct FragDesc {
+  int32_t contig;     // contig index in the query batch
+  int32_t start;      // first base of the fragment inside the contig (i * fragLen)
+};
+
+constexpr int kFragHashCap = 4096;   // minimizers one fragment may produce before sort/unique (LDS staging)
+
+template <bool PACKED>
+__device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ seq, const int64_t *__restrict__ contigOff,
+                                                     const FragDesc *__restrict__ frags, int fragLen, int k, int w,
+                                                     uint32_t *__restrict__ pool, uint32_t poolCap,
+                                                     unsigned long long *__restrict__ poolCount,
+                                                     uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS,
+                                                     int *__restrict__ maxS,
+                                                     uint64_t *keys, uint32_t *hbuf, int *ws, unsigned long long *sBasePtr)
+{
+  const FragDesc fd = frags[blockIdx.x];
+  // The fragment is winnowed as a "virtual contig" that starts at base fd.start of the real contig and ends at
+  // fd.start + fragLen: tile_winnow only emits for windows that lie completely inside its first tile position
+  // onwards (local >= w-1) and for k-mers that end before the virtual end, i.e. in isolation from the
+  // neighbouring fragments.
+  const int64_t off = contigOff[fd.contig];
+  const int32_t vlen = fd.start + fragLen;
+  const int32_t nPos = fragLen - k + 1;
+  const int stride = kTile - (w - 1);
+  int produced = 0;
+  int prevLastP = -1;
+  bool overflow = false;
+  for (int32_t B = 0; B == 0 || B + (w - 1) < nPos; B += stride) {
+    uint64_t W[kPer]; bool em[kPer]; int firstP, lastP;
+    tile_winnow<PACKED>(seq, off, vlen, fd.start + B, k, w, keys, ws, W, em, firstP, lastP);
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) cnt += em[j];
+    int total; int rank = block_excl_scan(cnt, ws, &total);
+    const int drop = (total > 0 && prevLastP >= 0 && firstP == prevLastP) ? 1 : 0;   // commonFunc.hpp:155 across tiles
+#pragma unroll
+    for (int j = 0; j < kPer; j++)
+      if (em[j]) {
+        const int r = produced + rank - drop;
+        if (rank >= drop) { if (r < kFragHashCap) hbuf[r] = (uint32_t)(W[j] >> 32); }
+        rank++;
+      }
+    produced += total - drop;
+    if (produced > kFragHashCap) { overflow = true; produced = kFragHashCap; }
+    if (lastP >= 0) prevLastP = lastP;
+    __syncthreads();
+  }
+  // ---- sort + unique (computeMap.hpp:268-274) ----
+  const int n = produced;
+  const int n2 = next_pow2(n > 1 ? n : 1);
+  for (int i = n + threadIdx.x; i < n2; i += kTPB) hbuf[i] = 0xffffffffu;
+  block_bitonic_sort<uint32_t>(hbuf, n2);
+  const int per = (n + kTPB - 1) / kTPB;
+  const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  int cntU = 0;
+  for (int i = lo; i < hi; i++) cntU += (i == 0 || hbuf[i] != hbuf[i - 1]);
+  int s; int r = block_excl_scan(cntU, ws, &s);
+  if (threadIdx.x == 0) {
+    *sBasePtr = s ? atomicAdd(poolCount, (unsigned long long)s) : 0ull;
+    fragOff[blockIdx.x] = (uint32_t)*sBasePtr;
+    fragS[blockIdx.x] = overflow ? -1 : s;
+    atomicMax(maxS, overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+  }
+  __syncthreads();
+  const unsigned long long base = *sBasePtr;
+  if (base + (unsigned long long)s <= (unsigned long long)poolCap)
+    for (int i = lo; i < hi; i++)
+      if (i == 0 || hbuf[i] != hbuf[i - 1]) pool[base + r++] = hbuf[i];
+}
+
+__global__ __launch_bounds__(kTPB) void k_fragment_sketch(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
+                                                          const int64_t *__restrict__ contigOff, const uint8_t *__restrict__ contigMode,
+                                                          const FragDesc *__restrict__ frags, int fragLen, int k, int w,
+                                                          uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
+                                                          uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS, int *__restrict__ maxS)
+{
+  __shared__ uint64_t keys[kTile];
+  __shared__ uint32_t hbuf[kFragHashCap];
+  __shared__ int ws[kTPB + 16];
+  __shared__ unsigned long long sBase;
+  if (contigMode[frags[blockIdx.x].contig])
+    fragment_sketch_body<true>(packed, contigOff, frags, fragLen, k, w, pool, poolCap, poolCount, fragOff, fragS, maxS, keys, hbuf, ws, &sBase);
+  else
+    fragment_sketch_body<false>(ascii, contigOff, frags, fragLen, k, w, pool, poolCap, poolCount, fragOff, fragS, maxS, keys, hbuf, ws, &sBase);
+}
+
+}  // namespace ani

@@ -1,0 +1,164 @@
+/* ani_abi.h — C-ABI of the MI355X-native ANI engine (libfastani_amd.so).
+ *
+ * FastANI has no FFI/plugin interface; its seams are three C++ constructors/functions that
+ * core_genome_identity() calls (all paths relative to /root/reference):
+ *
+ *   skch::Sketch::Sketch(const Parameters&)                         src/map/include/winSketch.hpp:109
+ *   skch::Map::Map(param, sketch, totalQueryFragments&, queryno, callback)   src/map/include/computeMap.hpp:93
+ *   cgi::computeCGI(param, mapResults, mapper, sketch, totalQueryFragments, queryFileNo, fileName, out)
+ *                                                                   src/cgi/include/computeCoreIdentity.hpp:166
+ *
+ * Each entry point below replaces one of those seams (cited per function).  Plain pointers and sizes only;
+ * no C++ or torch types cross this boundary.  The library is implemented with hand-written HIP kernels for
+ * gfx950; there is no CPU fallback behind this ABI — every call fails with ANI_ERR_DEVICE if no GPU is usable.
+ *
+ * Conventions
+ *   - every function returns 0 (ANI_OK) or a negative ani_status; ani_last_error() gives the message.
+ *   - the caller owns all inputs; host outputs returned through `T **out` are allocated by the library and
+ *     released with ani_free(); device outputs are released with ani_device_free().
+ *   - one ani_ctx per device and per host thread (mirror of "one Sketch per OpenMP thread",
+ *     src/cgi/core_genome_identity.cpp:55-65); a context is not thread-safe.
+ *   - POD records are bit-identical to the reference structs (little-endian, 32-bit fields).
+ */
+#ifndef ANI_ABI_H
+#define ANI_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ANI_OK = 0,
+  ANI_ERR_ARG = -1,       /* invalid argument */
+  ANI_ERR_DEVICE = -2,    /* no usable GPU / HIP runtime error */
+  ANI_ERR_NOMEM = -3,     /* host or device allocation failed */
+  ANI_ERR_LIMIT = -4,     /* input exceeds a documented limit (e.g. contig >= 2^31 bases, base_types.hpp:15) */
+  ANI_ERR_INTERNAL = -5
+} ani_status;
+
+/* skch::MinimizerInfo — src/map/include/base_types.hpp:22-53 (12 bytes) */
+typedef struct { uint32_t hash; int32_t seqId; int32_t wpos; } ani_minimizer_t;
+
+/* skch::MappingResult — src/map/include/base_types.hpp:89-102 (44 bytes) */
+typedef struct {
+  int32_t queryLen, refStartPos, refEndPos, queryStartPos, queryEndPos, refSeqId, querySeqId;
+  float nucIdentity, nucIdentityUpperBound;
+  int32_t sketchSize, conservedSketches;
+} ani_mapping_t;
+
+/* cgi::CGI_Results — src/cgi/include/cgid_types.hpp:68-80 (20 bytes) */
+typedef struct { int32_t refGenomeId, qryGenomeId, countSeq, totalQueryFragments; float identity; } ani_cgi_t;
+
+/* The subset of skch::Parameters (src/map/include/map_parameters.hpp:22-41) that the hot path reads.
+ * ani_params_default() fills the reference's defaults (src/map/include/parseCmdArgs.hpp:118-130) and
+ * derives windowSize the way the CLI does (parseCmdArgs.hpp:225-228 -> Stat::recommendedWindowSize,
+ * src/map/include/map_stats.hpp:226-256). */
+typedef struct {
+  int32_t kmerSize;            /* 1..16 */
+  int32_t windowSize;          /* derived; 24 for k=16, fragLen=3000 */
+  int32_t fragLen;             /* Parameters::minReadLength */
+  float percentageIdentity;    /* 80 */
+} ani_params_t;
+
+/* A batch of genomes handed to the library.  Genome g owns contigs [genomeContigStart[g], genomeContigStart[g+1]);
+ * contig c has contigLen[c] bases.
+ *   layout ANI_SEQ_HOST_ASCII   : `data` is host memory, raw sequence bytes as read from FASTA (newlines removed);
+ *                                 contig c starts at byte contigOffset[c].  The library upper-cases a-z
+ *                                 (src/map/include/commonFunc.hpp:56-66) and leaves every other byte as is.
+ *   layout ANI_SEQ_DEVICE_PACKED2: `data` is DEVICE memory, 2-bit codes A=0 C=1 G=2 T=3, 16 bases per little-endian
+ *                                 uint32 (base j of a word in bits 2j..2j+1); contig c starts at WORD contigOffset[c]
+ *                                 (contigs are word-aligned).  Only valid for pure-ACGT data.
+ */
+typedef enum { ANI_SEQ_HOST_ASCII = 0, ANI_SEQ_DEVICE_PACKED2 = 1 } ani_seq_layout;
+typedef struct {
+  int32_t layout;
+  int32_t nGenomes;
+  int32_t nContigs;
+  const int32_t *genomeContigStart;   /* [nGenomes+1] host */
+  const int64_t *contigOffset;        /* [nContigs]   host; bytes (ASCII) or words (PACKED2) */
+  const int32_t *contigLen;           /* [nContigs]   host; bases */
+  const void *data;
+} ani_seq_batch_t;
+
+typedef struct ani_ctx ani_ctx;
+typedef struct ani_sketch ani_sketch;
+
+/* Run-time counters for the measurement contract: the algorithmic-byte figure of a run is
+ * computed from these, never estimated. */
+typedef struct {
+  uint64_t refBases, refMinimizers, refUniqueHashes;
+  uint64_t queryGenomes, queryFragments, queryBases, querySketchHashes;   /* Σ s over fragments */
+  uint64_t seedHits;          /* H_total */
+  uint64_t l1Candidates;
+  uint64_t l2WindowEntries;   /* Σ m_c over candidates */
+  uint64_t l2Steps;           /* Σ super-window placements evaluated */
+  uint64_t mappings;
+  uint64_t cgiRows;
+  double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
+} ani_counters_t;
+
+/* ---- life cycle ---- */
+int ani_init(int device, ani_ctx **out);
+void ani_shutdown(ani_ctx *ctx);
+const char *ani_last_error(void);
+void ani_free(void *hostPtr);
+void ani_device_free(ani_ctx *ctx, void *devPtr);
+int ani_get_counters(ani_ctx *ctx, ani_counters_t *out);
+int ani_reset_counters(ani_ctx *ctx);
+
+/* ---- host-side scalars: skch::Stat (src/map/include/map_stats.hpp) ---- */
+int ani_params_default(ani_params_t *p, int kmerSize, int fragLen);          /* parseCmdArgs.hpp:118-130,:225-228 */
+int ani_recommended_window(int kmerSize, int fragLen);                       /* map_stats.hpp:226-256 */
+int ani_min_hits_relaxed(int sketchSize, int kmerSize, float identity);      /* map_stats.hpp:142-167 */
+int ani_identity(int shared, int sketchSize, int kmerSize, float *nucIdentity, float *upperBound); /* computeMap.hpp:375-381 */
+
+/* ---- reference sketch: replaces skch::Sketch::Sketch (winSketch.hpp:109-115: build :124, index :181) ---- */
+int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, ani_sketch **out);
+void ani_sketch_destroy(ani_sketch *sk);
+/* position-ordered minimizerIndex (winSketch.hpp:93) copied to the host — for parity tests and staging */
+int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n);
+/* the numbers Sketch::sanityCheck needs (winSketch.hpp:298-318): Σ occurrences, #unique hashes, Σ contig length */
+int ani_sketch_stats(const ani_sketch *sk, uint64_t *nMinimizers, uint64_t *nUnique, uint64_t *totalLength,
+                     int32_t *nContigs, int32_t *nGenomes);
+
+/* Multi-GPU staging: rank r sketches its share of the reference genomes into device-resident
+ * 12-byte records with GLOBAL seqIds (seqIdBase = contigs before this shard), the caller all-gathers the
+ * records over RCCL (torch.distributed), and every rank builds the full index from the gathered records. */
+int ani_sketch_records(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, int32_t seqIdBase,
+                       void **devRecords, size_t *n);
+int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *devRecords, size_t n,
+                            const int32_t *contigLen, int32_t nContigs,
+                            const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out);
+
+/* ---- mapping: replaces skch::Map::Map + callback (computeMap.hpp:93-102, mapQuery :112) for ONE query genome.
+ * Mappings are returned in the reference's callback order (fragment, then candidate).  *totalQueryFragments is
+ * set (not accumulated). */
+int ani_map_query(ani_ctx *ctx, const ani_sketch *sk, const ani_seq_batch_t *query,
+                  ani_mapping_t **out, size_t *n, uint64_t *totalQueryFragments);
+/* fragment sketches of one query genome (computeMap.hpp:260-274): offsets[nFragments+1], concatenated sorted
+ * unique hashes — for parity tests */
+int ani_query_sketch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *query,
+                     uint32_t **hashes, uint64_t **offsets, size_t *nFragments);
+
+/* ---- reducer: replaces cgi::computeCGI (computeCoreIdentity.hpp:166-298) for one query genome ---- */
+int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *sk, const ani_mapping_t *mappings, size_t n,
+                    uint64_t totalQueryFragments, int32_t queryFileNo, ani_cgi_t **out, size_t *m);
+
+/* ---- fused many-to-many path: the query loop of core_genome_identity.cpp:81-106 for a whole batch of query
+ * genomes, device-resident end to end (Map + computeCGI per query; no mapping records leave the GPU).
+ * Row order: query id ascending, then refGenomeId ascending.  qryGenomeId = firstQueryId + index in batch. */
+int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *sk, const ani_seq_batch_t *queries, int32_t firstQueryId,
+                      ani_cgi_t **out, size_t *m);
+
+/* ---- synthetic genomes (benchmark input generator; DESIGN.md §Synthetic data) ----
+ * Writes nGenomes genomes of genomeLen bases, 2-bit packed, genome i at word offset i*ceil(genomeLen/16) of devOut
+ * (device memory, caller-allocated). */
+int ani_synth_packed(ani_ctx *ctx, uint64_t seed, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,14 @@
+/* TEST INFRASTRUCTURE ONLY — CPU stand-in for fastani_amd/csrc/sort_device.hip (rocPRIM radix sort) in the emu build. */
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <numeric>
+#include <vector>
+extern "C" int ani_sort_pairs_u32(const uint32_t *keysIn, uint32_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                                  size_t n, hipStream_t)
+{
+  std::vector<uint32_t> ord(n);
+  std::iota(ord.begin(), ord.end(), 0u);
+  std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return keysIn[a] < keysIn[b]; });
+  for (size_t i = 0; i < n; i++) { keysOut[i] = keysIn[ord[i]]; valsOut[i] = valsIn[ord[i]]; }
+  return 0;
+}

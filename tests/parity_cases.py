@@ -1,0 +1,156 @@
+"""Parity cases shared by the GPU tests (-m gpu, product library) and the CPU-emulation tests (not gpu, tests/emu build).
+Each case drives the engine through the C-ABI and compares with the CPU oracle (tests/orc.py) on the same inputs.
+Bars: minimizers, fragment sketches, mapping records (incl. float fields) and CGI rows BIT-EXACT."""
+import numpy as np
+
+import orc
+from fastani_amd.api import DeviceGenomes, Sketch
+
+
+def rng_genome(seed, n, alphabet=b"ACGT"):
+    r = np.random.default_rng(seed)
+    return np.frombuffer(alphabet, dtype=np.uint8)[r.integers(0, len(alphabet), n)]
+
+
+def mutate(g, rate, seed):
+    r = np.random.default_rng(seed)
+    g = g.copy()
+    m = r.random(len(g)) < rate
+    g[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, int(m.sum()))]
+    return g
+
+
+def messy_genome(seed, n):
+    """multi-contig genome with N runs, IUPAC codes, lower case, a too-short contig and a contig shorter than fragLen"""
+    g = orc.synth_genome(seed, 3, n)
+    g[1000:1300] = ord("N")
+    g[5000] = ord("R")
+    g[20000:26000] = np.frombuffer(g[20000:26000].tobytes().lower(), dtype=np.uint8)
+    g[26000:26010] = ord("n")
+    cut = [0, n // 2, n // 2 + 10, n // 2 + 30, n // 2 + 2000, n]
+    return [g[cut[i]:cut[i + 1]] for i in range(len(cut) - 1)]
+
+
+def check_sketch(engine, genomes, k=16, frag_len=3000):
+    p = engine.params(k, frag_len)
+    assert p.windowSize == orc.recommended_window(k, frag_len)
+    sk = Sketch(engine, p, genomes)
+    osk = orc.Sketch(genomes, k, p.windowSize)
+    got, exp = sk.minimizers(), osk.minimizers()
+    assert len(got) == len(exp), (len(got), len(exp))
+    assert np.array_equal(got, exp)
+    st = sk.stats()
+    assert st["minimizers"] == len(exp) and st["unique"] == osk.unique()
+    return p, sk, osk
+
+
+def check_queries(engine, p, sk, osk, queries, k=16, frag_len=3000):
+    all_rows = []
+    for qi, q in enumerate(queries):
+        fr = engine.query_sketch(p, [q])
+        exp_fr = []
+        for c in q:
+            c = orc.upper(c)
+            if len(c) < max(p.windowSize, k, frag_len):
+                continue
+            for i in range(len(c) // frag_len):
+                exp_fr.append(orc.fragment_sketch(c[i * frag_len:(i + 1) * frag_len], k, p.windowSize))
+        assert len(fr) == len(exp_fr)
+        for a, b in zip(fr, exp_fr):
+            assert np.array_equal(a, b)
+        maps, tot = sk.map_query(q)
+        omaps, otot = osk.map_genome(q, frag_len)
+        assert tot == otot
+        assert len(maps) == len(omaps), (len(maps), len(omaps))
+        assert np.array_equal(maps, omaps)
+        cg = sk.compute_cgi(maps, tot, qi)
+        ocg = osk.compute_cgi(omaps, otot, qi, frag_len)
+        assert np.array_equal(cg, ocg)
+        all_rows.append(ocg)
+    rows = sk.map_cgi_batch(queries, 0)
+    exp = np.concatenate(all_rows) if all_rows else np.zeros(0, dtype=rows.dtype)
+    assert np.array_equal(rows, exp)
+    return rows
+
+
+def case_synthetic_cluster(engine, n=120000):
+    genomes = [[orc.synth_genome(7, g, n)] for g in (0, 1, 4, 11, 16, 19, 20)]
+    p, sk, osk = check_sketch(engine, genomes)
+    rows = check_queries(engine, p, sk, osk, [genomes[0], genomes[3], genomes[6]])
+    assert len(rows) >= 8
+
+
+def case_messy(engine):
+    genomes = [messy_genome(5, 90000), [orc.synth_genome(5, 0, 60000)], [rng_genome(1, 10, b"ACGT")], messy_genome(5, 50000)]
+    p, sk, osk = check_sketch(engine, genomes)
+    check_queries(engine, p, sk, osk, [genomes[0], genomes[1], [b"NNNNNNNN" * 500], genomes[2]])
+
+
+def case_kmer12(engine):
+    genomes = [[orc.synth_genome(3, g, 50000)] for g in (0, 5, 12)]
+    p, sk, osk = check_sketch(engine, genomes, k=12)
+    check_queries(engine, p, sk, osk, [genomes[1]], k=12)
+
+
+def case_fraglen1000(engine):
+    genomes = [[orc.synth_genome(9, g, 40000)] for g in (0, 7)]
+    p, sk, osk = check_sketch(engine, genomes, frag_len=1000)
+    check_queries(engine, p, sk, osk, [genomes[0], genomes[1]], frag_len=1000)
+
+
+def case_tandem_repeats(engine):
+    """duplicate hashes inside one super-window (set semantics of the sliding map) and rightmost-tie winnowing"""
+    unit = rng_genome(4, 700)
+    rep = np.tile(unit, 30)                       # 21 kb of a 700-bp tandem repeat
+    noise = mutate(rep, 0.03, 8)
+    flank = rng_genome(6, 20000)
+    ref = np.concatenate([flank[:10000], rep, flank[10000:]])
+    qry = np.concatenate([flank[:10000], noise, flank[10000:]])
+    genomes = [[ref], [qry]]
+    p, sk, osk = check_sketch(engine, genomes)
+    check_queries(engine, p, sk, osk, [[qry], [ref]])
+
+
+def case_low_complexity(engine):
+    """the reference's repeat_* fixtures in miniature: A-runs separated by a T (tests/gen_tests_data.py:33-55)"""
+    def rep(na, n):
+        return np.frombuffer((b"A" * na + b"T") * (n // (na + 1) + 1), dtype=np.uint8)[:n]
+    genomes = [[rep(64, 3500)], [rep(128, 3300)]]      # stays inside the L1 fast-path limits (<= 4096 seed hits)
+    p, sk, osk = check_sketch(engine, genomes)
+    check_queries(engine, p, sk, osk, [[rep(128, 9000)], [rep(64, 6000)]])
+
+
+def case_empty_and_short(engine):
+    genomes = [[b"ACGT" * 3], [orc.synth_genome(2, 0, 30000)], [b""], [orc.synth_genome(2, 1, 2999)]]
+    p, sk, osk = check_sketch(engine, genomes)
+    check_queries(engine, p, sk, osk, [[b"ACGTACGT"], genomes[1], genomes[3], [b""]])
+
+
+def case_device_synth(engine, alloc):
+    """ani_synth_packed == oracle generator, and the DEVICE_PACKED2 input path == the host ASCII path"""
+    n, L = 4, 33333
+    words = (L + 15) // 16
+    buf, ptr = alloc(n * words * 4)
+    engine.synth_packed(13, 18, n, L, ptr)
+    host = np.asarray(buf.cpu() if hasattr(buf, "cpu") else buf).view(np.uint32)[:n * words].reshape(n, words)
+    for i in range(n):
+        g = orc.synth_genome(13, 18 + i, L)
+        code = np.zeros(256, dtype=np.uint32)
+        code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
+        c = np.zeros(words * 16, dtype=np.uint32)
+        c[:L] = code[g]
+        exp = (c.reshape(words, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint32)
+        assert np.array_equal(host[i], exp)
+    p = engine.params()
+    dg = DeviceGenomes(ptr, n, L)
+    sk_dev = Sketch(engine, p, dg)
+    genomes = [[orc.synth_genome(13, 18 + i, L)] for i in range(n)]
+    sk_host = Sketch(engine, p, genomes)
+    assert np.array_equal(sk_dev.minimizers(), sk_host.minimizers())
+    r1 = sk_dev.map_cgi_batch(dg, 0)
+    r2 = sk_host.map_cgi_batch(genomes, 0)
+    assert np.array_equal(r1, r2) and len(r1) >= n
+
+
+ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
+             case_empty_and_short]
