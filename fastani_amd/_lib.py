@@ -14,5 +14,11 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("fastani_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        try:
+            # PyTorch-ROCm bundles its own libamdhip64; when both live in one process torch must be imported first so that
+            # a single HIP runtime is shared (plumbing only — nothing here needs torch)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = ctypes.CDLL(LIB_PATH)
     return _lib

@@ -42,8 +42,8 @@ class SeqBatch(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
                                           "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
-                                          "l2Steps", "mappings", "cgiRows")] + \
-               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce")]
+                                          "l2Steps", "l2QueryHashes", "l2Launches", "mappings", "cgiRows")] + \
+               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -57,6 +57,7 @@ def _bind(lib):
         "ani_last_error": (C.c_char_p, []),
         "ani_free": (None, [vp]),
         "ani_device_free": (None, [vp, vp]),
+        "ani_device_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "ani_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
         "ani_reset_counters": (C.c_int, [vp]),
         "ani_params_default": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int]),
@@ -74,7 +75,7 @@ def _bind(lib):
         "ani_query_sketch": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_compute_cgi": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_map_cgi_batch": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
-        "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
+        "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -213,8 +214,8 @@ class Engine:
         hashes = self._take(hp, int(offs[-1]), np.dtype("<u4"))
         return [hashes[int(offs[i]):int(offs[i + 1])] for i in range(n.value)]
 
-    def synth_packed(self, seed, first_genome, n_genomes, genome_len, dev_ptr):
-        self._chk(self.lib.ani_synth_packed(self.h, seed, first_genome, n_genomes, genome_len, dev_ptr))
+    def synth_packed(self, seed, first_genome, n_genomes, genome_len, dev_ptr, variant=0):
+        self._chk(self.lib.ani_synth_packed(self.h, seed, variant, first_genome, n_genomes, genome_len, dev_ptr))
 
     def sketch_records(self, params, genomes, seq_id_base):
         """-> (device pointer to 12-byte records, count); free with device_free."""
@@ -226,6 +227,9 @@ class Engine:
 
     def device_free(self, ptr):
         self.lib.ani_device_free(self.h, ptr)
+
+    def device_copy(self, dst, src, nbytes):
+        self._chk(self.lib.ani_device_copy(self.h, dst, src, nbytes))
 
 
 class Sketch:

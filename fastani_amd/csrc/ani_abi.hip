@@ -83,7 +83,7 @@ inline unsigned grid_for(size_t n, unsigned block = 256, unsigned maxBlocks = 65
 struct ani_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   ani_counters_t counters;
   // scalar device counters (array of 16 x u64)
   DevBuf dCounters;
@@ -120,7 +120,7 @@ struct ani_sketch {
 namespace {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_N = 16 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_N = 16 };
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
@@ -136,14 +136,18 @@ int read_counters(ani_ctx *c, unsigned long long *host)
   return ANI_OK;
 }
 
+// HIP-event bracket on the launch stream; `slot` selects an event pair so that timers can nest
 struct StageTimer {
-  ani_ctx *c; double *acc;
-  StageTimer(ani_ctx *c_, double *acc_) : c(c_), acc(acc_) { (void)hipEventRecord(c->ev0, c->stream); }
+  ani_ctx *c; double *acc; hipEvent_t a, b;
+  StageTimer(ani_ctx *c_, double *acc_, int slot = 0) : c(c_), acc(acc_), a(slot ? c_->ev2 : c_->ev0), b(slot ? c_->ev3 : c_->ev1)
+  {
+    (void)hipEventRecord(a, c->stream);
+  }
   ~StageTimer()
   {
-    (void)hipEventRecord(c->ev1, c->stream);
-    (void)hipEventSynchronize(c->ev1);
-    float ms = 0; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    (void)hipEventRecord(b, c->stream);
+    (void)hipEventSynchronize(b);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
     *acc += ms;
   }
 };
@@ -558,10 +562,15 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.contigFirstMin = sk->contigFirstMin;
     a.L = L; a.w = w; a.k = k; a.scratch = ctx->l2Scratch.as<uint32_t>(); a.laneStride = lanes;
     a.outBest = ctx->l2Best.as<int32_t>(); a.outFirst = ctx->l2First.as<int32_t>(); a.outLast = ctx->l2Last.as<int32_t>();
-    a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS);
+    a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS); a.sumQ = cnt_ptr(ctx, CNT_SUMQ);
     StageTimer tm(ctx, &ctx->counters.msL2);
-    for (size_t base = 0; base < nCand; base += lanes)
-      hipLaunchKernelGGL(k_l2, dim3((unsigned)(lanes / kTPB)), dim3(kTPB), 0, ctx->stream, a, (int32_t)base);
+    {
+      StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
+      for (size_t base = 0; base < nCand; base += lanes) {
+        hipLaunchKernelGGL(k_l2, dim3((unsigned)(lanes / kTPB)), dim3(kTPB), 0, ctx->stream, a, (int32_t)base);
+        ctx->counters.l2Launches++;
+      }
+    }
     FinishArgs fa;
     fa.nCand = (int32_t)nCand; fa.candFrag = a.candFrag; fa.candSeq = a.candSeq; fa.best = a.outBest; fa.firstPos = a.outFirst; fa.lastPos = a.outLast;
     fa.fragS = a.fragS; fa.idLUT = sk->dIdLUT; fa.minShared = sk->dMinShared; fa.lutMaxS = sk->dLutMaxS;
@@ -570,7 +579,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     HIP_TRY(hipGetLastError());
   }
   TRY(read_counters(ctx, host));
-  ctx->counters.l2WindowEntries += host[CNT_ENTRIES]; ctx->counters.l2Steps += host[CNT_STEPS];
+  ctx->counters.l2WindowEntries += host[CNT_ENTRIES]; ctx->counters.l2Steps += host[CNT_STEPS]; ctx->counters.l2QueryHashes += host[CNT_SUMQ];
   return ANI_OK;
 }
 
@@ -649,7 +658,7 @@ int ani_init(int device, ani_ctx **out)
   c->device = device;
   memset(&c->counters, 0, sizeof c->counters);
   HIP_TRY(hipStreamCreate(&c->stream));
-  HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1)); HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
   int rc = c->dCounters.ensure(CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }
   *out = c;
@@ -668,8 +677,18 @@ void ani_shutdown(ani_ctx *c)
   for (DevBuf *b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->ev3) (void)hipEventDestroy(c->ev3);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+int ani_device_copy(ani_ctx *c, void *dst, const void *src, size_t bytes)
+{
+  if (!c || (bytes && (!dst || !src))) return fail(ANI_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  if (bytes) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+  return ANI_OK;
 }
 
 int ani_get_counters(ani_ctx *c, ani_counters_t *out)
@@ -956,13 +975,13 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t
   return to_host_malloc(rows, out, m);
 }
 
-int ani_synth_packed(ani_ctx *ctx, uint64_t seed, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut)
+int ani_synth_packed(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut)
 {
   if (!ctx || !devOut || nGenomes < 0 || genomeLen <= 0 || firstGenomeId < 0) return fail(ANI_ERR_ARG, "invalid argument");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t words = (size_t)nGenomes * (((size_t)genomeLen + 15) / 16);
   if (words == 0) return ANI_OK;
-  hipLaunchKernelGGL(ani::k_synth_packed, dim3(grid_for(words, 256, 65535)), dim3(256), 0, ctx->stream, seed, firstGenomeId, nGenomes, genomeLen, (uint32_t *)devOut);
+  hipLaunchKernelGGL(ani::k_synth_packed, dim3(grid_for(words, 256, 65535)), dim3(256), 0, ctx->stream, seed, variant, firstGenomeId, nGenomes, genomeLen, (uint32_t *)devOut);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return ANI_OK;

@@ -175,14 +175,14 @@ struct L2Args {
   uint32_t *scratch; size_t laneStride;
   // outputs
   int32_t *outBest, *outFirst, *outLast;
-  unsigned long long *sumEntries, *sumSteps;
+  unsigned long long *sumEntries, *sumSteps, *sumQ;
 };
 
 __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, int32_t candBase)
 {
   const int32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   const int32_t c = candBase + lane;
-  unsigned long long e = 0, st = 0;
+  unsigned long long e = 0, st = 0, sq = 0;
   if (c < a.nCand && (size_t)lane < a.laneStride) {
     const int32_t f = a.candFrag[c];
     const int32_t seq = a.candSeq[c];
@@ -191,12 +191,12 @@ __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, int32_t candBase)
                               a.contigFirstMin[seq], a.contigFirstMin[seq + 1], a.candStart[c], a.candEnd[c],
                               a.L, a.w, a.k, state);
     a.outBest[c] = r.best; a.outFirst[c] = r.firstPos; a.outLast[c] = r.lastPos;
-    e = (unsigned long long)r.entries; st = (unsigned long long)r.steps;
+    e = (unsigned long long)r.entries; st = (unsigned long long)r.steps; sq = (unsigned long long)a.fragS[f];
   }
   // counters for the algorithmic-byte figure: one atomic per wave
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { e += __shfl_down(e, d); st += __shfl_down(st, d); }
-  if ((threadIdx.x & 63) == 0 && (e | st)) { atomicAdd(a.sumEntries, e); atomicAdd(a.sumSteps, st); }
+  for (int d = 32; d > 0; d >>= 1) { e += __shfl_down(e, d); st += __shfl_down(st, d); sq += __shfl_down(sq, d); }
+  if ((threadIdx.x & 63) == 0 && (e | st | sq)) { atomicAdd(a.sumEntries, e); atomicAdd(a.sumSteps, st); atomicAdd(a.sumQ, sq); }
 }
 
 }  // namespace ani

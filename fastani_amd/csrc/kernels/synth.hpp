@@ -2,7 +2,8 @@
 // Clustered population after SURVEY.md §8d: genome g belongs to cluster g/20; member m = g%20 is the cluster's
 // ancestor with i.i.d. substitutions at rate kRatePermille[m]/1000.  Counter-based (splitmix64 finaliser), so any
 // base of any genome is a pure function of (seed, genome, position); oracle/ani_oracle.c:orc_synth_genome computes
-// the same function on the CPU (tests compare them byte for byte).
+// the same function on the CPU (tests compare them byte for byte).  `variant` re-draws the substitutions of every
+// member while keeping the cluster ancestors: variant v of genome g is an independent descendant with the same rate.
 #pragma once
 #include "common.hpp"
 
@@ -33,7 +34,7 @@ __host__ __device__ __forceinline__ uint32_t synth_base(uint64_t keyAnc, uint64_
   return b;
 }
 
-__global__ void k_synth_packed(uint64_t seed, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, uint32_t *__restrict__ out)
+__global__ void k_synth_packed(uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, uint32_t *__restrict__ out)
 {
   const int32_t wordsPerGenome = (genomeLen + 15) >> 4;
   const long long total = (long long)nGenomes * wordsPerGenome;
@@ -42,7 +43,7 @@ __global__ void k_synth_packed(uint64_t seed, int32_t firstGenomeId, int32_t nGe
     const int32_t gi = (int32_t)(i / wordsPerGenome), wi = (int32_t)(i % wordsPerGenome);
     const int32_t g = firstGenomeId + gi;
     const uint64_t keyAnc = sm64_fin(root + 2 * (uint64_t)(g / 20));
-    const uint64_t keyMut = sm64_fin(root + 2 * (uint64_t)g + 1);
+    const uint64_t keyMut = sm64_fin(root + 2 * (uint64_t)g + 1) ^ sm64_fin(variant);   // variant 0 leaves the key unchanged
     const uint32_t thr = (uint32_t)(((uint64_t)synth_rate_permille(g % 20) * 16777216ULL + 500ULL) / 1000ULL);
     uint32_t word = 0;
     for (int j = 0; j < 16; j++) {

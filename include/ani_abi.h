@@ -95,9 +95,12 @@ typedef struct {
   uint64_t l1Candidates;
   uint64_t l2WindowEntries;   /* Σ m_c over candidates */
   uint64_t l2Steps;           /* Σ super-window placements evaluated */
+  uint64_t l2QueryHashes;     /* Σ s over candidates (each candidate reads its fragment sketch once) */
+  uint64_t l2Launches;        /* launches of the L2 kernel */
   uint64_t mappings;
   uint64_t cgiRows;
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
+  double msL2Kernel;          /* HIP-event time of the L2 kernel launches alone (on the launch stream) */
 } ani_counters_t;
 
 /* ---- life cycle ---- */
@@ -106,6 +109,8 @@ void ani_shutdown(ani_ctx *ctx);
 const char *ani_last_error(void);
 void ani_free(void *hostPtr);
 void ani_device_free(ani_ctx *ctx, void *devPtr);
+/* copy between device buffers of this context (used by the host side to stage records into communication buffers) */
+int ani_device_copy(ani_ctx *ctx, void *dst, const void *src, size_t bytes);
 int ani_get_counters(ani_ctx *ctx, ani_counters_t *out);
 int ani_reset_counters(ani_ctx *ctx);
 
@@ -155,8 +160,8 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *sk, const ani_seq_batch_t 
 
 /* ---- synthetic genomes (benchmark input generator; DESIGN.md §Synthetic data) ----
  * Writes nGenomes genomes of genomeLen bases, 2-bit packed, genome i at word offset i*ceil(genomeLen/16) of devOut
- * (device memory, caller-allocated). */
-int ani_synth_packed(ani_ctx *ctx, uint64_t seed, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut);
+ * (device memory, caller-allocated).  `variant` re-draws the substitutions with the cluster ancestors kept (0 = base set). */
+int ani_synth_packed(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut);
 
 #ifdef __cplusplus
 }

@@ -131,10 +131,10 @@ def case_device_synth(engine, alloc):
     n, L = 4, 33333
     words = (L + 15) // 16
     buf, ptr = alloc(n * words * 4)
-    engine.synth_packed(13, 18, n, L, ptr)
+    engine.synth_packed(13, 18, n, L, ptr, variant=3)
     host = np.asarray(buf.cpu() if hasattr(buf, "cpu") else buf).view(np.uint32)[:n * words].reshape(n, words)
     for i in range(n):
-        g = orc.synth_genome(13, 18 + i, L)
+        g = orc.synth_genome(13, 18 + i, L, variant=3)
         code = np.zeros(256, dtype=np.uint32)
         code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
         c = np.zeros(words * 16, dtype=np.uint32)
@@ -144,7 +144,7 @@ def case_device_synth(engine, alloc):
     p = engine.params()
     dg = DeviceGenomes(ptr, n, L)
     sk_dev = Sketch(engine, p, dg)
-    genomes = [[orc.synth_genome(13, 18 + i, L)] for i in range(n)]
+    genomes = [[orc.synth_genome(13, 18 + i, L, variant=3)] for i in range(n)]
     sk_host = Sketch(engine, p, genomes)
     assert np.array_equal(sk_dev.minimizers(), sk_host.minimizers())
     r1 = sk_dev.map_cgi_batch(dg, 0)
