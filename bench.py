@@ -199,17 +199,28 @@ def main():
     if rank == 0:
         pairs = NG * NG * world
         value = pairs * args.steps / dt
-        # roofline of the dominant kernel: algorithmic bytes / HIP-event time of its launches (timed region only)
+        # roofline of the dominant kernel: algorithmic bytes / HIP-event time of its launches, timed region only
         l2_bytes = 12.0 * c["l2WindowEntries"] + 4.0 * c["l2QueryHashes"]
-        l2_s = c["msL2Kernel"] / 1e3
-        achieved = l2_bytes / l2_s / 1e9 if l2_s > 0 else 0.0
-        launches = max(1, c["l2Launches"])
-        roof = {"bound": "hbm", "kernel": "ani::k_l2", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        cand = {
+            "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate"),
+            "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate"),
+            "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
+            "ani::k_l1": (c["msL1"], 4.0 * c["querySketchHashes"] + 8.0 * c["seedHits"], "4 B x fragment sketch hashes + 8 B x seed hits"),
+            "ani::k_sketch_tiles": (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"], "G/4 packed bases + 12 B x minimizers"),
+            "ani::k_fragment_sketch": (c["msFragSketch"], c["queryBases"] / 4.0 + 4.0 * c["querySketchHashes"], "G/4 packed bases + 4 B x sketch hashes"),
+        }
+        dom = max(cand, key=lambda k: cand[k][0])
+        ms, nbytes, what = cand[dom]
+        achieved = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": round(l2_bytes / launches, 1), "launches": int(launches),
-                "avg_launch_ms": round(c["msL2Kernel"] / launches, 4),
-                "note": "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, summed over the "
-                        "candidates of a launch; HBM PMC traffic: see profiles/"}
+                "algorithmic_bytes": what, "kernel_ms_per_step": round(ms / args.steps, 3),
+                "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in cand.items()},
+                "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()}}
+        if dom == "ani::k_l2_sim":
+            launches = max(1, c["l2Launches"])
+            roof.update({"launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
+                         "algorithmic_bytes_per_launch": round(nbytes / launches, 1)})
         stages = {k: round(c[k] / args.steps, 3) for k in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce")}
         out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -220,7 +231,8 @@ def main():
                "rows_last_step": int(len(rows)),
                "stage_ms_per_step_rank0": stages,
                "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
-                                                                              "l2WindowEntries", "l2Steps", "cgiRows")},
+                                                                              "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
+                                                                              "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows")},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, e, p)

@@ -95,6 +95,7 @@ struct ani_ctx {
   DevBuf candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
+  DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList;
   DevBuf bins, queryFragments, rows;
 };
 
@@ -107,7 +108,7 @@ struct ani_sketch {
   std::vector<int32_t> contigLen, genomeContigStart;
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
-  uint32_t *sHash = nullptr, *sIdx = nullptr, *bucketStart = nullptr;
+  uint32_t *sHash = nullptr, *sIdx = nullptr, *bucketStart = nullptr, *mWposF = nullptr;
   int bucketShift = 0; uint32_t nBuckets = 0;
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
   uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr;
@@ -120,7 +121,7 @@ struct ani_sketch {
 namespace {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_N = 16 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_N = 16 };
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
@@ -340,7 +341,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 
 void free_sketch_device(ani_sketch *sk)
 {
-  void *ptrs[] = {sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->sIdx, sk->bucketStart, sk->contigFirstMin,
+  void *ptrs[] = {sk->mWposF, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->sIdx, sk->bucketStart, sk->contigFirstMin,
                   sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
   for (void *q : ptrs) if (q) (void)hipFree(q);
 }
@@ -379,7 +380,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   const size_t n4 = (n ? n : 1) * 4;
   SK_HIP(hipMalloc((void **)&sk->mHash, n4)); SK_HIP(hipMalloc((void **)&sk->mSeq, n4)); SK_HIP(hipMalloc((void **)&sk->mWpos, n4));
   SK_HIP(hipMalloc((void **)&sk->prevSame, n4)); SK_HIP(hipMalloc((void **)&sk->nextSame, n4));
-  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->sIdx, n4));
+  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->sIdx, n4)); SK_HIP(hipMalloc((void **)&sk->mWposF, n4));
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
     uint32_t *tmpK = nullptr, *tmpV = nullptr;
@@ -391,7 +392,8 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     }
     (void)hipFree(tmpK); (void)hipFree(tmpV);
     SK_TRY(zero_counters(ctx));
-    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, sk->sIdx, (uint32_t)n, sk->prevSame, sk->nextSame, cnt_ptr(ctx, CNT_UNIQ));
+    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, sk->sIdx, (uint32_t)n, sk->prevSame, sk->nextSame, sk->mSeq, sk->mWpos,
+                              (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
     // bucket table over the top bits: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
     while (bits < 28 && (1ull << bits) < n) bits++;
@@ -550,27 +552,77 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   TRY(ctx->l2Best.ensure(nCand * 4)); TRY(ctx->l2First.ensure(nCand * 4)); TRY(ctx->l2Last.ensure(nCand * 4));
   TRY(ctx->refStart.ensure(nCand * 4)); TRY(ctx->idBits.ensure(nCand * 4));
   {
-    size_t lanes = std::min<size_t>(nCand, (size_t)1 << 18);
-    lanes = (lanes + kTPB - 1) / kTPB * kTPB;
-    const size_t wordsPerLane = (size_t)maxS + 1;
-    while (lanes > kTPB && lanes * wordsPerLane * 4 > ((size_t)3 << 30)) lanes = (lanes / 2 + kTPB - 1) / kTPB * kTPB;
-    TRY(ctx->l2Scratch.ensure(lanes * wordsPerLane * 4));
+    StageTimer tm(ctx, &ctx->counters.msL2);
     TRY(zero_counters(ctx));
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.contigFirstMin = sk->contigFirstMin;
-    a.L = L; a.w = w; a.k = k; a.scratch = ctx->l2Scratch.as<uint32_t>(); a.laneStride = lanes;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mWposF = sk->mWposF; a.contigFirstMin = sk->contigFirstMin;
+    a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
     a.outBest = ctx->l2Best.as<int32_t>(); a.outFirst = ctx->l2First.as<int32_t>(); a.outLast = ctx->l2Last.as<int32_t>();
     a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS); a.sumQ = cnt_ptr(ctx, CNT_SUMQ);
-    StageTimer tm(ctx, &ctx->counters.msL2);
-    {
-      StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
-      for (size_t base = 0; base < nCand; base += lanes) {
-        hipLaunchKernelGGL(k_l2, dim3((unsigned)(lanes / kTPB)), dim3(kTPB), 0, ctx->stream, a, (int32_t)base);
+
+    // ordered candidate offset per fragment on the host: chunk [c0,c1) -> fragment range
+    std::vector<uint32_t> ordOff(nF);
+    HIP_TRY(hipMemcpyAsync(ordOff.data(), ctx->fragOrdOff.p, nF * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+    const size_t CH = (size_t)1 << 18;       // candidates per chunk: <= 2^18 * 16384 code words, inside the uint32 scan
+    TRY(ctx->l2Ranges.ensure(CH * sizeof(L2Range))); TRY(ctx->l2CodeCount.ensure(CH * 4)); TRY(ctx->l2CodeOff.ensure(CH * 4));
+    TRY(ctx->l2SlowFlag.ensure(CH * 4)); TRY(ctx->l2SlowList.ensure(nCand * 4));
+    HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream));
+    for (size_t c0 = 0; c0 < nCand; c0 += CH) {
+      const size_t c1 = std::min<size_t>(nCand, c0 + CH);
+      const size_t n = c1 - c0;
+      L2FastArgs fa;
+      fa.g = a; fa.c0 = (int32_t)c0; fa.c1 = (int32_t)c1;
+      fa.ranges = ctx->l2Ranges.as<L2Range>(); fa.codeCount = ctx->l2CodeCount.as<int32_t>(); fa.codeOff = ctx->l2CodeOff.as<uint32_t>();
+      fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag.as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.nFrag = (int32_t)nF;
+      // fragments that own candidates c0 and c1-1 (ordOff is non-decreasing; fragments without candidates repeat a value)
+      const int32_t fA = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)c0) - ordOff.begin()) - 1;
+      const int32_t fB = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)(c1 - 1)) - ordOff.begin()) - 1;
+      fa.fragBase = fA;
+      { const char *ev = getenv("ANI_L2_PATH"); fa.allowFast = !(ev && !strcmp(ev, "general")); }
+      {
+        StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
+        hipLaunchKernelGGL(k_l2_ranges, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);
+      }
+      uint64_t nCodes = 0;
+      TRY(device_scan(ctx, fa.codeCount, ctx->l2CodeOff.as<uint32_t>(), (uint32_t)n, &nCodes));
+      TRY(ctx->l2Codes.ensure((nCodes + 64) * 2));
+      fa.codes = ctx->l2Codes.as<uint32_t>();
+      if (nCodes) {
+        {
+          StageTimer tk(ctx, &ctx->counters.msL2Codes, 1);
+          hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)(fB - fA + 1)), dim3(kTPB), 0, ctx->stream, fa);
+        }
+        {
+          StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
+          hipLaunchKernelGGL(k_l2_sim, dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa);
+        }
         ctx->counters.l2Launches++;
       }
+      // whatever did not qualify (or overflowed a gap counter) is appended to the sub-batch's list for the general kernel
+      hipLaunchKernelGGL(k_l2_collect_slow, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag,
+                         ctx->l2SlowList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG), cnt_ptr(ctx, CNT_REASON));
+      HIP_TRY(hipGetLastError());
     }
+    unsigned long long nSlow64 = 0;
+    HIP_TRY(hipMemcpyAsync(&nSlow64, cnt_ptr(ctx, CNT_NEG), 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t nSlowTotal = (size_t)(uint32_t)nSlow64;
+    if (nSlowTotal) {
+      size_t lanes = (std::min<size_t>(nSlowTotal, (size_t)1 << 17) + kTPB - 1) / kTPB * kTPB;
+      const size_t wordsPerLane = (size_t)maxS + 1;
+      while (lanes > kTPB && lanes * wordsPerLane * 4 > ((size_t)2 << 30)) lanes = (lanes / 2 + kTPB - 1) / kTPB * kTPB;
+      TRY(ctx->l2Scratch.ensure(lanes * wordsPerLane * 4));
+      L2Args sa = a; sa.scratch = ctx->l2Scratch.as<uint32_t>(); sa.laneStride = lanes;
+      StageTimer tk(ctx, &ctx->counters.msL2Slow, 1);
+      for (size_t base = 0; base < nSlowTotal; base += lanes)
+        hipLaunchKernelGGL(k_l2, dim3((unsigned)(lanes / kTPB)), dim3(kTPB), 0, ctx->stream, sa, (const int32_t *)ctx->l2SlowList.as<int32_t>(), (int32_t)nSlowTotal, (int32_t)base);
+      HIP_TRY(hipGetLastError());
+    }
+    ctx->counters.l2SlowCandidates += nSlowTotal; ctx->counters.l2FastCandidates += nCand - nSlowTotal;
     FinishArgs fa;
     fa.nCand = (int32_t)nCand; fa.candFrag = a.candFrag; fa.candSeq = a.candSeq; fa.best = a.outBest; fa.firstPos = a.outFirst; fa.lastPos = a.outLast;
     fa.fragS = a.fragS; fa.idLUT = sk->dIdLUT; fa.minShared = sk->dMinShared; fa.lutMaxS = sk->dLutMaxS;
@@ -580,6 +632,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   }
   TRY(read_counters(ctx, host));
   ctx->counters.l2WindowEntries += host[CNT_ENTRIES]; ctx->counters.l2Steps += host[CNT_STEPS]; ctx->counters.l2QueryHashes += host[CNT_SUMQ];
+  ctx->counters.l2SlowLimit += host[CNT_REASON + 1]; ctx->counters.l2SlowDup += host[CNT_REASON + 2]; ctx->counters.l2SlowOverflow += host[CNT_REASON + 3];
   return ANI_OK;
 }
 
@@ -672,7 +725,7 @@ void ani_shutdown(ani_ctx *c)
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->tiles, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
                     &c->fragGenome, &c->fragQSeq, &c->qPool, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
-                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Best,
+                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -34,8 +34,15 @@ __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *
 }
 
 // after the stable sort by hash: same-hash neighbours and the unique-hash count
+// also: mWposF[idx] = wpos | nearDup << 31.  nearDup(j) = some same-hash entry j' of the same contig can share a super-window
+// with j.  All entries of a window except its first lie within cmw = countMinimizerWindows positions; the first entry
+// (MIIteratorL2 keeps the minimizer that is active at the window start) may trail by less than the gap to its successor.
+// So for j' < j: possible iff wpos[j] - wpos[j'] <= cmw + (wpos[j'+1] - wpos[j']).  Entries without the flag behave as a
+// plain set member in the L2 fast path; flagged ones consult prevSame/nextSame there.
 __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint32_t *__restrict__ sIdx, uint32_t n,
                               int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame,
+                              const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos, int32_t cmw,
+                              uint32_t *__restrict__ mWposF,
                               unsigned long long *__restrict__ nUnique)
 {
   unsigned long long uniq = 0;
@@ -45,6 +52,16 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint32_t
     const bool sameNext = r + 1 < n && sHash[r + 1] == h;
     prevSame[idx] = samePrev ? (int32_t)sIdx[r - 1] : -1;
     nextSame[idx] = sameNext ? (int32_t)sIdx[r + 1] : -1;
+    bool near = false;
+    if (samePrev) {
+      const uint32_t p = sIdx[r - 1];                    // p < idx (stable sort)
+      near |= mSeq[p] == mSeq[idx] && mWpos[idx] - mWpos[p] <= cmw + (mWpos[p + 1] - mWpos[p]);
+    }
+    if (sameNext) {
+      const uint32_t q = sIdx[r + 1];                    // q > idx
+      near |= mSeq[q] == mSeq[idx] && mWpos[q] - mWpos[idx] <= cmw + (mWpos[idx + 1] - mWpos[idx]);
+    }
+    mWposF[idx] = (uint32_t)mWpos[idx] | (near ? 0x80000000u : 0u);
     uniq += !samePrev;
   }
 #pragma unroll

@@ -159,7 +159,26 @@ __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel: one lane per candidate.
+// Kernels.
+//
+// General kernel (k_l2): one lane per candidate, everything on the fly (rank lookups by binary search in global
+// memory, state words in a lane-interleaved global scratch array).  Any sketch size, any region length.  It is the
+// safety net: candidates are routed here through `list`.
+//
+// Fast path (k_l2_ranges -> k_l2_codes -> k_l2_sim), taken when s <= kL2FastMaxS and the candidate's index range is
+// <= kL2FastMaxEntries long:
+//   k_l2_ranges  one lane per candidate: the three searchIndex() calls of computeMap.hpp:424-436
+//   k_l2_codes   one workgroup per fragment: the fragment sketch sits in LDS; every reference minimizer of every
+//                candidate range is ranked against it once and stored as one 16-bit entry
+//                  bit 0 = hash is a query hash, bits 1..9 = gap (or rank-1), bit 10 = a same-hash neighbour may share
+//                  a super-window with this entry (nearDup, precomputed at index build), bits 11..15 = wpos - previous
+//                  wpos (31 = escape: read the index)
+//   k_l2_sim     one lane per candidate: the sliding simulation over those entries.  State in LDS: 5-bit gap counters +
+//                1-bit presence flags, word-interleaved over the wave so that lanes never collide on a bank.  Entries are
+//                streamed by two monotone cursors through registers (16 entries + 8 prefetched per cursor); refills are
+//                issued at wave-uniform points every 8 steps so that their latency never sits on a step's critical path.
+//                Entries flagged nearDup consult prevSame/nextSame (exact set semantics, slidingMap.hpp:150-154,:178).
+//                A gap counter that would exceed 31 sends the candidate to k_l2.
 // ------------------------------------------------------------------------------------------------
 struct L2Args {
   // candidates (SoA)
@@ -169,21 +188,23 @@ struct L2Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS;
   // reference index, position order
   const uint32_t *mHash; const int32_t *mWpos; const int32_t *prevSame; const int32_t *nextSame;
+  const uint32_t *mWposF;          // wpos | nearDup << 31
   const int32_t *contigFirstMin;   // [nContigs+1]
   int L, w, k;
-  // lane-interleaved scratch: (maxS+1) words per lane
+  // lane-interleaved scratch of the general kernel: (maxS+1) words per lane
   uint32_t *scratch; size_t laneStride;
   // outputs
   int32_t *outBest, *outFirst, *outLast;
   unsigned long long *sumEntries, *sumSteps, *sumQ;
 };
 
-__global__ __launch_bounds__(kTPB) void k_l2(L2Args a, int32_t candBase)
+__global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__restrict__ list, int32_t listCount, int32_t listBase)
 {
   const int32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-  const int32_t c = candBase + lane;
+  const int32_t li = listBase + lane;
   unsigned long long e = 0, st = 0, sq = 0;
-  if (c < a.nCand && (size_t)lane < a.laneStride) {
+  if (li < listCount && (size_t)lane < a.laneStride) {
+    const int32_t c = list ? list[li] : li;
     const int32_t f = a.candFrag[c];
     const int32_t seq = a.candSeq[c];
     L2State state; state.w = a.scratch + lane; state.stride = a.laneStride;
@@ -197,6 +218,226 @@ __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, int32_t candBase)
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { e += __shfl_down(e, d); st += __shfl_down(st, d); sq += __shfl_down(sq, d); }
   if ((threadIdx.x & 63) == 0 && (e | st | sq)) { atomicAdd(a.sumEntries, e); atomicAdd(a.sumSteps, st); atomicAdd(a.sumQ, sq); }
+}
+
+// ---------------------------------------------------------------- fast path
+constexpr int kL2FastMaxS = 319;
+constexpr int kL2FastMaxEntries = 16384;
+constexpr int kL2CntBits = 5, kL2CntPerWord = 6;              // six 5-bit gap counters per word (sorted-sketch spacings are
+constexpr uint32_t kL2CntMax = (1u << kL2CntBits) - 1;        //  uneven: the widest gap routinely holds 10-15 reference hashes)
+constexpr int kL2NibWords = (kL2FastMaxS + 1 + kL2CntPerWord - 1) / kL2CntPerWord;   // 54 words (gaps 0..319)
+constexpr int kL2BitWords = (kL2FastMaxS + 1 + 31) / 32;      // 10 words of presence bits (ranks 1..319)
+constexpr int kL2WordsPerLane = kL2NibWords + kL2BitWords;    // 64 words = 256 B per lane, 16 KiB per wave
+constexpr int kL2SimTPB = 128;                                // 32 KiB LDS per workgroup -> 5 workgroups = 10 waves per CU
+
+struct L2Range { int32_t beg0, end0, last, wposBeg0; };
+
+struct L2FastArgs {
+  L2Args g;
+  int32_t c0, c1;                  // candidate chunk [c0, c1)
+  L2Range *ranges;                 // [c1-c0]
+  int32_t *codeCount;              // [c1-c0] 16-bit entries per candidate rounded up to 8, 0 = not on the fast path
+  const uint32_t *codeOff;         // [c1-c0] exclusive scan of codeCount (in entries)
+  uint32_t *codes;
+  int32_t *slowFlag;               // [c1-c0] 1 = take the general kernel
+  const uint32_t *fragCandOff;     // ordered candidate offset per fragment [nFrag]
+  int32_t nFrag, fragBase;         // first fragment of the chunk
+  int32_t allowFast;               // 0: route everything to the general kernel (test knob ANI_L2_PATH=general)
+};
+
+__global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
+{
+  const int32_t c = a.c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.c1) return;
+  const int32_t i = c - a.c0;
+  const int32_t seq = a.g.candSeq[c];
+  const int32_t cLo = a.g.contigFirstMin[seq], cHi = a.g.contigFirstMin[seq + 1];
+  const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
+  L2Range r;
+  r.beg0 = lower_bound_wpos(a.g.mWpos, cLo, cHi, a.g.candStart[c]);
+  r.wposBeg0 = a.g.mWpos[r.beg0];
+  r.end0 = lower_bound_wpos(a.g.mWpos, cLo, cHi, r.wposBeg0 + cmw);
+  r.last = lower_bound_wpos(a.g.mWpos, cLo, cHi, a.g.candEnd[c] + a.g.L);
+  a.ranges[i] = r;
+  const int32_t m = r.last - r.beg0;
+  const int32_t s = a.g.fragS[a.g.candFrag[c]];
+  const bool fast = a.allowFast && s >= 1 && s <= kL2FastMaxS && m >= 1 && m <= kL2FastMaxEntries;
+  a.codeCount[i] = fast ? ((m + 7) & ~7) : 0;      // 16-bit entries, padded to 16-byte blocks
+  a.slowFlag[i] = fast ? 0 : 1;
+}
+
+constexpr uint32_t kL2DupBit = 1u << 10;
+constexpr uint32_t kL2DwEscape = 31u;
+
+__global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
+{
+  __shared__ uint32_t qs[kL2FastMaxS + 1];
+  const int32_t f = a.fragBase + blockIdx.x;
+  const int32_t s = a.g.fragS[f];
+  int32_t cA = (int32_t)a.fragCandOff[f], cB = (f + 1 < a.nFrag) ? (int32_t)a.fragCandOff[f + 1] : a.g.nCand;
+  if (cA < a.c0) cA = a.c0;
+  if (cB > a.c1) cB = a.c1;
+  if (cA >= cB || s < 1 || s > kL2FastMaxS) return;
+  const uint32_t *q = a.g.qPool + a.g.fragOff[f];
+  for (int i = threadIdx.x; i < s; i += kTPB) qs[i] = q[i];
+  __syncthreads();
+  for (int32_t c = cA; c < cB; c++) {
+    const int32_t i = c - a.c0;
+    if (a.codeCount[i] == 0) continue;
+    const L2Range r = a.ranges[i];
+    uint16_t *out = (uint16_t *)a.codes + a.codeOff[i];
+    for (int32_t j = r.beg0 + (int32_t)threadIdx.x; j < r.last; j += kTPB) {
+      const uint32_t wf = a.g.mWposF[j];
+      uint32_t dw = 0;
+      if (j > r.beg0) dw = (wf & 0x7fffffffu) - (a.g.mWposF[j - 1] & 0x7fffffffu);
+      if (dw > kL2DwEscape) dw = kL2DwEscape;
+      out[j - r.beg0] = (uint16_t)(q_rank(qs, s, a.g.mHash[j]) | ((wf >> 31) ? kL2DupBit : 0u) | (dw << 11));
+    }
+  }
+}
+
+// One monotone cursor over a candidate's 16-bit entries: A0|A1 hold entries [8b, 8b+16), B (entries [8b+16, 8b+24)) is in
+// flight.  get() only touches A0/A1; sync() is called at wave-uniform points at most 8 consumed entries apart.
+struct L2Stream {
+  const uint4 *p; int b; uint4 A0, A1, B;
+  __device__ __forceinline__ void init(const uint4 *p_) { p = p_; b = 0; A0 = p[0]; A1 = p[1]; B = p[2]; }
+  __device__ __forceinline__ void sync(int j)
+  {
+    if (j - 8 * b >= 8) { A0 = A1; A1 = B; b++; B = p[b + 2]; }
+  }
+  __device__ __forceinline__ uint32_t get(int j) const
+  {
+    const int o = j - 8 * b;                       // 0..15
+    const uint4 blk = (o & 8) ? A1 : A0;
+    const int d = (o >> 1) & 3;
+    const uint32_t wd = d == 0 ? blk.x : d == 1 ? blk.y : d == 2 ? blk.z : blk.w;
+    return (o & 1) ? (wd >> 16) : (wd & 0xffffu);
+  }
+};
+
+__global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
+{
+  __shared__ uint32_t lds[(kL2SimTPB / kWave) * kL2WordsPerLane * kWave];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  uint32_t *S = lds + wv * (kL2WordsPerLane * kWave) + lane;         // word x of this lane: S[x * kWave]
+  const int32_t c = a.c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long cntE = 0, cntS = 0, cntQ = 0;
+  if (c < a.c1 && a.slowFlag[c - a.c0] == 0) {
+    const int32_t i = c - a.c0;
+    const L2Range r = a.ranges[i];
+    const int32_t f = a.g.candFrag[c];
+    const int s = a.g.fragS[f];
+    const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
+    const int m = r.last - r.beg0;
+#pragma unroll
+    for (int x = 0; x < kL2WordsPerLane; x++) S[x * kWave] = 0u;
+    int iStar = s, cStar = 0, shared = 0;
+    bool ovf = false;
+    auto nib = [&](int g) -> int { const int wq = g / kL2CntPerWord; return (int)((S[wq * kWave] >> ((g - wq * kL2CntPerWord) * kL2CntBits)) & kL2CntMax); };
+    auto bit = [&](int x) -> int { return (int)((S[(kL2NibWords + (x >> 5)) * kWave] >> (x & 31)) & 1u); };
+    auto insert = [&](uint32_t code) {
+      const int idx = (int)((code >> 1) & 0x1ffu);
+      if (code & 1u) {
+        const int x = idx + 1;
+        S[(kL2NibWords + (x >> 5)) * kWave] |= 1u << (x & 31);
+        if (x <= iStar) shared++;
+      } else {
+        const int wq = idx / kL2CntPerWord, sh = (idx - wq * kL2CntPerWord) * kL2CntBits;
+        const uint32_t wd = S[wq * kWave];
+        if (((wd >> sh) & kL2CntMax) == kL2CntMax) { ovf = true; return; }
+        S[wq * kWave] = wd + (1u << sh);
+        if (idx < iStar) {
+          cStar++;
+          if (iStar + cStar > s) { shared -= bit(iStar); iStar--; cStar -= nib(iStar); }
+        }
+      }
+    };
+    auto erase = [&](uint32_t code) {
+      const int idx = (int)((code >> 1) & 0x1ffu);
+      if (code & 1u) {
+        const int x = idx + 1;
+        S[(kL2NibWords + (x >> 5)) * kWave] &= ~(1u << (x & 31));
+        if (x <= iStar) shared--;
+      } else {
+        const int wq = idx / kL2CntPerWord;
+        S[wq * kWave] -= 1u << ((idx - wq * kL2CntPerWord) * kL2CntBits);
+        if (idx < iStar) cStar--;
+        if (iStar < s) {
+          const int ng = nib(iStar);
+          if (iStar + 1 + cStar + ng <= s) { cStar += ng; iStar++; shared += bit(iStar); }
+        }
+      }
+    };
+    // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
+    auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
+      const uint32_t dw = code >> 11;
+      return dw == kL2DwEscape ? (int32_t)(a.g.mWposF[r.beg0 + j] & 0x7fffffffu) : prev + (int32_t)dw;
+    };
+    const uint4 *base = (const uint4 *)((const uint16_t *)a.codes + a.codeOff[i]);
+    L2Stream cb, ce;
+    cb.init(base); ce.init(base);
+    // first super-window: entries [0, end0-beg0)  (computeMap.hpp:448)
+    int end = r.end0 - r.beg0, beg = 0;
+    int32_t wEnd = r.wposBeg0;                       // becomes wpos of entry `end`
+    for (int j = 0; j < end; j++) {
+      if ((j & 7) == 0) ce.sync(j);
+      const uint32_t cd = ce.get(j);
+      if (j > 0) wEnd = next_wpos(wEnd, cd, j);
+      if (!(cd & kL2DupBit) || a.g.prevSame[r.beg0 + j] < r.beg0) insert(cd);
+    }
+    uint32_t codeEnd = 0;
+    if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
+    int32_t wBeg = r.wposBeg0, pos = r.wposBeg0;
+    uint32_t codeBeg = cb.get(0);
+    uint32_t codeBegNext = (1 < m) ? cb.get(1) : 0u;
+    int32_t wBegNext = (1 < m) ? next_wpos(wBeg, codeBegNext, 1) : wBeg;
+    int best = 0; int32_t firstPos = 0, lastPos = 0; int steps = 0;
+    bool advB = false, advE = false; uint32_t delCode = 0, insCode = 0;
+    while (end < m && !ovf) {                        // computeMap.hpp:455
+      if ((steps & 7) == 0) { cb.sync(beg + 1); ce.sync(end); }
+      if (advB) {                                    // delete_ref(prev_beg): entry beg-1; still present iff a later same-hash entry was inserted
+        bool eff = true;
+        if (delCode & kL2DupBit) { const int32_t nx = a.g.nextSame[r.beg0 + beg - 1]; eff = !(nx >= 0 && nx < r.beg0 + (advE ? end - 1 : end)); }
+        if (eff) erase(delCode);
+      }
+      if (advE) {                                    // insert_ref(prev_end): entry end-1; new iff no same-hash entry in [beg, end-1)
+        if (!(insCode & kL2DupBit) || a.g.prevSame[r.beg0 + end - 1] < r.beg0 + beg) insert(insCode);
+      }
+      if (shared > best) { best = shared; firstPos = wBeg; lastPos = wBeg; }
+      else if (shared == best) lastPos = wBeg;
+      steps++;
+      // MIIteratorL2::next
+      const int32_t d1 = wBegNext - pos, d2 = wEnd - (pos + cmw - 1);
+      const int32_t adv = d1 < d2 ? d1 : d2;
+      pos += adv;
+      advB = (adv == d1); advE = (adv == d2);
+      if (advB) {
+        delCode = codeBeg; beg++; wBeg = wBegNext; codeBeg = codeBegNext;
+        if (beg + 1 < m) { codeBegNext = cb.get(beg + 1); wBegNext = next_wpos(wBeg, codeBegNext, beg + 1); }
+      }
+      if (advE) {
+        insCode = codeEnd; end++;
+        if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
+      }
+    }
+    if (ovf) a.slowFlag[i] = 3;
+    else {
+      a.g.outBest[c] = best; a.g.outFirst[c] = firstPos; a.g.outLast[c] = lastPos;
+      cntE = (unsigned long long)m; cntS = (unsigned long long)steps; cntQ = (unsigned long long)s;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { cntE += __shfl_down(cntE, d); cntS += __shfl_down(cntS, d); cntQ += __shfl_down(cntQ, d); }
+  if (lane == 0 && (cntE | cntS | cntQ)) { atomicAdd(a.g.sumEntries, cntE); atomicAdd(a.g.sumSteps, cntS); atomicAdd(a.g.sumQ, cntQ); }
+}
+
+// candidates of the chunk that must take the general kernel -> list (order irrelevant)
+// slowFlag: 1 = outside the fast-path limits, 3 = gap counter overflow
+__global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t *__restrict__ list,
+                                  unsigned int *__restrict__ count, unsigned long long *__restrict__ reasons /* [4] */)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && slowFlag[i]) { list[atomicAdd(count, 1u)] = c0 + i; atomicAdd(&reasons[slowFlag[i] & 3], 1ull); }
 }
 
 }  // namespace ani

@@ -96,11 +96,15 @@ typedef struct {
   uint64_t l2WindowEntries;   /* Σ m_c over candidates */
   uint64_t l2Steps;           /* Σ super-window placements evaluated */
   uint64_t l2QueryHashes;     /* Σ s over candidates (each candidate reads its fragment sketch once) */
-  uint64_t l2Launches;        /* launches of the L2 kernel */
+  uint64_t l2Launches;        /* launches of the dominant L2 kernel (ani::k_l2_sim) */
+  uint64_t l2FastCandidates;  /* candidates finished by the LDS fast path */
+  uint64_t l2SlowCandidates;  /* candidates routed to the general kernel (ani::k_l2) */
+  uint64_t l2SlowLimit, l2SlowDup, l2SlowOverflow;   /* ... by reason: size limits / same-hash neighbour or wide gap / counter overflow */
   uint64_t mappings;
   uint64_t cgiRows;
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
-  double msL2Kernel;          /* HIP-event time of the L2 kernel launches alone (on the launch stream) */
+  double msL2Kernel;          /* HIP-event time of the ani::k_l2_sim launches alone (on the launch stream) */
+  double msL2Ranges, msL2Codes, msL2Slow;   /* ani::k_l2_ranges, ani::k_l2_codes, ani::k_l2 */
 } ani_counters_t;
 
 /* ---- life cycle ---- */

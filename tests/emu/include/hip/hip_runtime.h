@@ -32,6 +32,8 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct emu_uint3 { unsigned x, y, z; };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 
 namespace hipemu {
 extern emu_uint3 g_threadIdx, g_blockIdx;
