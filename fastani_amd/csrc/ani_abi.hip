@@ -109,6 +109,7 @@ struct ani_sketch {
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
   uint32_t *sHash = nullptr, *sIdx = nullptr, *bucketStart = nullptr, *mWposF = nullptr;
+  uint64_t *sSW = nullptr;
   int bucketShift = 0; uint32_t nBuckets = 0;
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
   uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr;
@@ -341,7 +342,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 
 void free_sketch_device(ani_sketch *sk)
 {
-  void *ptrs[] = {sk->mWposF, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->sIdx, sk->bucketStart, sk->contigFirstMin,
+  void *ptrs[] = {sk->sSW, sk->mWposF, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->sIdx, sk->bucketStart, sk->contigFirstMin,
                   sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
   for (void *q : ptrs) if (q) (void)hipFree(q);
 }
@@ -380,7 +381,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   const size_t n4 = (n ? n : 1) * 4;
   SK_HIP(hipMalloc((void **)&sk->mHash, n4)); SK_HIP(hipMalloc((void **)&sk->mSeq, n4)); SK_HIP(hipMalloc((void **)&sk->mWpos, n4));
   SK_HIP(hipMalloc((void **)&sk->prevSame, n4)); SK_HIP(hipMalloc((void **)&sk->nextSame, n4));
-  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->sIdx, n4)); SK_HIP(hipMalloc((void **)&sk->mWposF, n4));
+  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->sIdx, n4)); SK_HIP(hipMalloc((void **)&sk->mWposF, n4)); SK_HIP(hipMalloc((void **)&sk->sSW, 2 * n4));
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
     uint32_t *tmpK = nullptr, *tmpV = nullptr;
@@ -394,6 +395,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     SK_TRY(zero_counters(ctx));
     if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, sk->sIdx, (uint32_t)n, sk->prevSame, sk->nextSame, sk->mSeq, sk->mWpos,
                               (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
+    if (n) hipLaunchKernelGGL(k_index_payload, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sIdx, sk->mSeq, sk->mWpos, (uint32_t)n, sk->sSW);
     // bucket table over the top bits: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
     while (bits < 28 && (1ull << bits) < n) bits++;
@@ -509,8 +511,8 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     TRY(zero_counters(ctx));
     L1Args a;
     a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>(); a.nFrag = (int32_t)nF;
-    a.sHash = sk->sHash; a.sIdx = sk->sIdx; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.nIndex = sk->n;
-    a.mSeq = sk->mSeq; a.mWpos = sk->mWpos; a.minHitsLUT = sk->dMinHits; a.lutMaxS = sk->dLutMaxS; a.L = L;
+    a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.nIndex = sk->n;
+    a.minHitsLUT = sk->dMinHits; a.lutMaxS = sk->dLutMaxS; a.L = L;
     a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
     a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
@@ -582,7 +584,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
       const int32_t fA = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)c0) - ordOff.begin()) - 1;
       const int32_t fB = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)(c1 - 1)) - ordOff.begin()) - 1;
       fa.fragBase = fA;
-      { const char *ev = getenv("ANI_L2_PATH"); fa.allowFast = !(ev && !strcmp(ev, "general")); }
+      { const char *ev = getenv("ANI_L2_PATH"); fa.allowFast = (ev && !strcmp(ev, "general")) ? 0 : (ev && !strcmp(ev, "classB")) ? 2 : 1; }
       {
         StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
         hipLaunchKernelGGL(k_l2_ranges, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);
@@ -598,7 +600,8 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
-          hipLaunchKernelGGL(k_l2_sim, dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa);
         }
         ctx->counters.l2Launches++;
       }

@@ -69,6 +69,17 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint32_t
   if ((threadIdx.x & 63) == 0 && uniq) atomicAdd(nUnique, uniq);
 }
 
+// hash-ordered payload for the L1 gather: sSW[r] = (seqId << 32) | wpos of the r-th entry in hash order, so that the
+// occurrence list of one hash is one contiguous run of 8-byte words
+__global__ void k_index_payload(const uint32_t *__restrict__ sIdx, const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
+                                uint32_t n, uint64_t *__restrict__ sSW)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const uint32_t idx = sIdx[r];
+    sSW[r] = ((uint64_t)(uint32_t)mSeq[idx] << 32) | (uint32_t)mWpos[idx];
+  }
+}
+
 // bucketStart[b] = first r with (sHash[r] >> shift) >= b, for b = 0..nBuckets (inclusive)
 __global__ void k_index_buckets(const uint32_t *__restrict__ sHash, uint32_t n, int shift, uint32_t nBuckets,
                                 uint32_t *__restrict__ bucketStart)

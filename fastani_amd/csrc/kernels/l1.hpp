@@ -20,8 +20,7 @@ constexpr int kL1HitCap = 4096;
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
-  const uint32_t *sHash; const uint32_t *sIdx; const uint32_t *bucketStart; int bucketShift; uint32_t nIndex;
-  const int32_t *mSeq; const int32_t *mWpos;
+  const uint32_t *sHash; const uint64_t *sSW; const uint32_t *bucketStart; int bucketShift; uint32_t nIndex;
   const int32_t *minHitsLUT; int32_t lutMaxS;
   int L;
   int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
@@ -102,10 +101,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a)
   // gather (computeMap.hpp:283-299)
   for (int i = t; i < s; i += kTPB) {
     const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H, fi = pFirst[i];
-    for (int c = 0; c < e - o; c++) {
-      const uint32_t idx = a.sIdx[fi + c];
-      hits[o + c] = ((uint64_t)(uint32_t)a.mSeq[idx] << 32) | (uint32_t)a.mWpos[idx];
-    }
+    for (int c = 0; c < e - o; c++) hits[o + c] = a.sSW[fi + c];
   }
   const int n2 = next_pow2(H);
   for (int i = H + t; i < n2; i += kTPB) hits[i] = ~0ull;

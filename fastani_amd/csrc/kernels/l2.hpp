@@ -173,12 +173,12 @@ __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
 //                  bit 0 = hash is a query hash, bits 1..9 = gap (or rank-1), bit 10 = a same-hash neighbour may share
 //                  a super-window with this entry (nearDup, precomputed at index build), bits 11..15 = wpos - previous
 //                  wpos (31 = escape: read the index)
-//   k_l2_sim     one lane per candidate: the sliding simulation over those entries.  State in LDS: 5-bit gap counters +
+//   k_l2_sim     one lane per candidate: the sliding simulation over those entries.  State in LDS: 5- or 6-bit gap counters +
 //                1-bit presence flags, word-interleaved over the wave so that lanes never collide on a bank.  Entries are
 //                streamed by two monotone cursors through registers (16 entries + 8 prefetched per cursor); refills are
 //                issued at wave-uniform points every 8 steps so that their latency never sits on a step's critical path.
 //                Entries flagged nearDup consult prevSame/nextSame (exact set semantics, slidingMap.hpp:150-154,:178).
-//                A gap counter that would exceed 31 sends the candidate to k_l2.
+//                A class-A counter that would exceed 31 re-runs the candidate in class B, a class-B counter past 63 sends it to k_l2.
 // ------------------------------------------------------------------------------------------------
 struct L2Args {
   // candidates (SoA)
@@ -223,12 +223,25 @@ __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__restrict
 // ---------------------------------------------------------------- fast path
 constexpr int kL2FastMaxS = 319;
 constexpr int kL2FastMaxEntries = 16384;
-constexpr int kL2CntBits = 5, kL2CntPerWord = 6;              // six 5-bit gap counters per word (sorted-sketch spacings are
-constexpr uint32_t kL2CntMax = (1u << kL2CntBits) - 1;        //  uneven: the widest gap routinely holds 10-15 reference hashes)
-constexpr int kL2NibWords = (kL2FastMaxS + 1 + kL2CntPerWord - 1) / kL2CntPerWord;   // 54 words (gaps 0..319)
-constexpr int kL2BitWords = (kL2FastMaxS + 1 + 31) / 32;      // 10 words of presence bits (ranks 1..319)
-constexpr int kL2WordsPerLane = kL2NibWords + kL2BitWords;    // 64 words = 256 B per lane, 16 KiB per wave
-constexpr int kL2SimTPB = 128;                                // 32 KiB LDS per workgroup -> 5 workgroups = 10 waves per CU
+// LDS state geometry of the simulation kernel, two variants:
+//   class A  s <= 255, six 5-bit gap counters per word: 43 + 8 = 51 words = 204 B per lane -> 12 waves per CU
+//   class B  s <= 319, five 6-bit gap counters per word: 64 + 10 = 74 words = 296 B per lane -> 8 waves per CU
+// (sorted-sketch spacings are uneven: the widest gap of a window routinely holds 10-15 reference hashes, so 4 bits are
+//  not enough; a class-A candidate whose counter would pass 31 is re-run in class B, one that would pass 63 in k_l2)
+template <int MAXS, int BITS, int PER>
+struct L2Geom {
+  static constexpr int kMaxS = MAXS, kBits = BITS, kPer = PER;
+  static constexpr uint32_t kCntMax = (1u << BITS) - 1;
+  static constexpr int kCntWords = (MAXS + 1 + PER - 1) / PER;
+  static constexpr int kBitWords = (MAXS + 1 + 31) / 32;
+  static constexpr int kWords = kCntWords + kBitWords;
+  static constexpr int kDivMul = PER == 6 ? 171 : 205;        // idx / PER == (idx * kDivMul) >> 10 for idx <= 319
+  static_assert(PER == 5 || PER == 6, "division constant");
+  static_assert(BITS * PER <= 32, "counters per word");
+};
+using L2GeomA = L2Geom<255, 5, 6>;
+using L2GeomB = L2Geom<319, 6, 5>;
+constexpr int kL2SimTPB = 128;
 
 struct L2Range { int32_t beg0, end0, last, wposBeg0; };
 
@@ -242,7 +255,7 @@ struct L2FastArgs {
   int32_t *slowFlag;               // [c1-c0] 1 = take the general kernel
   const uint32_t *fragCandOff;     // ordered candidate offset per fragment [nFrag]
   int32_t nFrag, fragBase;         // first fragment of the chunk
-  int32_t allowFast;               // 0: route everything to the general kernel (test knob ANI_L2_PATH=general)
+  int32_t allowFast;               // test knob ANI_L2_PATH: 0 = everything to the general kernel, 2 = everything to class B
 };
 
 __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
   const int32_t s = a.g.fragS[a.g.candFrag[c]];
   const bool fast = a.allowFast && s >= 1 && s <= kL2FastMaxS && m >= 1 && m <= kL2FastMaxEntries;
   a.codeCount[i] = fast ? ((m + 7) & ~7) : 0;      // 16-bit entries, padded to 16-byte blocks
-  a.slowFlag[i] = fast ? 0 : 1;
+  a.slowFlag[i] = fast ? ((s <= L2GeomA::kMaxS && a.allowFast != 2) ? 0 : 4) : 1;
 }
 
 constexpr uint32_t kL2DupBit = 1u << 10;
@@ -301,9 +314,16 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 struct L2Stream {
   const uint4 *p; int b; uint4 A0, A1, B;
   __device__ __forceinline__ void init(const uint4 *p_) { p = p_; b = 0; A0 = p[0]; A1 = p[1]; B = p[2]; }
+  // Branch-free on purpose: the refill is issued by every lane at the same (wave-uniform) point, outside divergent
+  // control flow, so that the compiler keeps it in flight until B is first read — at the next sync(), 8 steps later.
+  // (Inside an `if` the load result would have to be merged at the join and s_waitcnt vmcnt(0) lands right behind it.)
   __device__ __forceinline__ void sync(int j)
   {
-    if (j - 8 * b >= 8) { A0 = A1; A1 = B; b++; B = p[b + 2]; }
+    const bool sh = (j - 8 * b >= 8);
+    A0.x = sh ? A1.x : A0.x; A0.y = sh ? A1.y : A0.y; A0.z = sh ? A1.z : A0.z; A0.w = sh ? A1.w : A0.w;
+    A1.x = sh ? B.x : A1.x; A1.y = sh ? B.y : A1.y; A1.z = sh ? B.z : A1.z; A1.w = sh ? B.w : A1.w;
+    b += sh ? 1 : 0;
+    B = p[b + 2];
   }
   __device__ __forceinline__ uint32_t get(int j) const
   {
@@ -315,59 +335,71 @@ struct L2Stream {
   }
 };
 
+// One window event, written without control flow (selects only).  SIGN = +1: the entry enters the window
+// (slidingMap.hpp:137-161 + :231-254), SIGN = -1: it leaves (:167-211 + :261-284).  All LDS reads are issued up front
+// (the entry's own word, the gap counter and the presence bit next to the pivot), the own-word hazard is patched in
+// registers, one write goes back.  `on` = false turns the whole event into a no-op (inactive lane / ineffective event).
+struct L2Regs { int s, iStar, cStar, shared; int ovf; };
+
+template <class G, int SIGN>
+__device__ __forceinline__ void l2_apply(uint32_t *S, L2Regs &r, uint32_t code, bool on)
+{
+  const int isQ = (int)(code & 1u);
+  const int idx = (int)((code >> 1) & 0x1ffu);
+  const int x = idx + 1;                                             // rank of a query hash
+  // pivot-adjacent cells: j = iStar-1 for an insertion, iStar for a deletion; need n[j] and b[j+1]
+  int j = r.iStar - (SIGN > 0 ? 1 : 0); j = j < 0 ? 0 : j;
+  int jb = j + 1; jb = jb > G::kMaxS ? G::kMaxS : jb;
+  const int wOwnN = (idx * G::kDivMul) >> 10, shOwnN = (idx - wOwnN * G::kPer) * G::kBits;
+  const int wOwn = isQ ? G::kCntWords + (x >> 5) : wOwnN;
+  const int wJ = (j * G::kDivMul) >> 10, shJ = (j - wJ * G::kPer) * G::kBits;
+  const uint32_t own = S[wOwn * kWave];
+  const uint32_t cj = S[wJ * kWave];
+  const uint32_t bj = S[(G::kCntWords + (jb >> 5)) * kWave];
+  const uint32_t delta = isQ ? (1u << (x & 31)) : (1u << shOwnN);
+  const int full = (SIGN > 0) & (isQ ^ 1) & (int)(((own >> shOwnN) & G::kCntMax) == G::kCntMax);
+  r.ovf |= on ? full : 0;
+  const bool act = on && !full;
+  S[wOwn * kWave] = act ? (SIGN > 0 ? own + delta : own - delta) : own;
+  int cntj = (int)((cj >> shJ) & G::kCntMax);
+  cntj += ((isQ ^ 1) & (int)(idx == j)) ? SIGN : 0;                  // the event itself changed n[j]
+  int bitj = (int)((bj >> (jb & 31)) & 1u);
+  bitj = (isQ & (int)(x == jb)) ? (SIGN > 0 ? 1 : 0) : bitj;         // ... or b[j+1]
+  const int below = (isQ ^ 1) & (int)(idx < r.iStar);
+  int iStar = r.iStar, cStar = r.cStar, shared = r.shared;
+  shared += (isQ & (int)(x <= iStar)) ? SIGN : 0;
+  cStar += below ? SIGN : 0;
+  if (SIGN > 0) {
+    const int mv = below & (int)(iStar + cStar > r.s);               // q_iStar leaves the s smallest
+    shared -= mv ? bitj : 0; iStar -= mv; cStar -= mv ? cntj : 0;
+  } else {
+    const int mv = (isQ ^ 1) & (int)(iStar < r.s) & (int)(iStar + 1 + cStar + cntj <= r.s);   // q_{iStar+1} joins them
+    cStar += mv ? cntj : 0; iStar += mv; shared += mv ? bitj : 0;
+  }
+  r.iStar = act ? iStar : r.iStar; r.cStar = act ? cStar : r.cStar; r.shared = act ? shared : r.shared;
+}
+
+// slowFlag protocol: 0 = class A, 4 = class B (s in 256..319), 5 = class A overflowed -> class B,
+//                    1 = outside every fast-path limit, 3 = class B overflowed -> general kernel
+template <class G>
 __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
 {
-  __shared__ uint32_t lds[(kL2SimTPB / kWave) * kL2WordsPerLane * kWave];
+  __shared__ uint32_t lds[(kL2SimTPB / kWave) * G::kWords * kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  uint32_t *S = lds + wv * (kL2WordsPerLane * kWave) + lane;         // word x of this lane: S[x * kWave]
+  uint32_t *S = lds + wv * (G::kWords * kWave) + lane;               // word x of this lane: S[x * kWave]
   const int32_t c = a.c0 + blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long cntE = 0, cntS = 0, cntQ = 0;
-  if (c < a.c1 && a.slowFlag[c - a.c0] == 0) {
+  const int myFlag = c < a.c1 ? a.slowFlag[c - a.c0] : 1;
+  const bool mine = (G::kMaxS == 255) ? (myFlag == 0) : (myFlag == 4 || myFlag == 5);
+  if (mine) {
     const int32_t i = c - a.c0;
     const L2Range r = a.ranges[i];
     const int32_t f = a.g.candFrag[c];
-    const int s = a.g.fragS[f];
     const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
     const int m = r.last - r.beg0;
 #pragma unroll
-    for (int x = 0; x < kL2WordsPerLane; x++) S[x * kWave] = 0u;
-    int iStar = s, cStar = 0, shared = 0;
-    bool ovf = false;
-    auto nib = [&](int g) -> int { const int wq = g / kL2CntPerWord; return (int)((S[wq * kWave] >> ((g - wq * kL2CntPerWord) * kL2CntBits)) & kL2CntMax); };
-    auto bit = [&](int x) -> int { return (int)((S[(kL2NibWords + (x >> 5)) * kWave] >> (x & 31)) & 1u); };
-    auto insert = [&](uint32_t code) {
-      const int idx = (int)((code >> 1) & 0x1ffu);
-      if (code & 1u) {
-        const int x = idx + 1;
-        S[(kL2NibWords + (x >> 5)) * kWave] |= 1u << (x & 31);
-        if (x <= iStar) shared++;
-      } else {
-        const int wq = idx / kL2CntPerWord, sh = (idx - wq * kL2CntPerWord) * kL2CntBits;
-        const uint32_t wd = S[wq * kWave];
-        if (((wd >> sh) & kL2CntMax) == kL2CntMax) { ovf = true; return; }
-        S[wq * kWave] = wd + (1u << sh);
-        if (idx < iStar) {
-          cStar++;
-          if (iStar + cStar > s) { shared -= bit(iStar); iStar--; cStar -= nib(iStar); }
-        }
-      }
-    };
-    auto erase = [&](uint32_t code) {
-      const int idx = (int)((code >> 1) & 0x1ffu);
-      if (code & 1u) {
-        const int x = idx + 1;
-        S[(kL2NibWords + (x >> 5)) * kWave] &= ~(1u << (x & 31));
-        if (x <= iStar) shared--;
-      } else {
-        const int wq = idx / kL2CntPerWord;
-        S[wq * kWave] -= 1u << ((idx - wq * kL2CntPerWord) * kL2CntBits);
-        if (idx < iStar) cStar--;
-        if (iStar < s) {
-          const int ng = nib(iStar);
-          if (iStar + 1 + cStar + ng <= s) { cStar += ng; iStar++; shared += bit(iStar); }
-        }
-      }
-    };
+    for (int x = 0; x < G::kWords; x++) S[x * kWave] = 0u;
+    L2Regs R; R.s = a.g.fragS[f]; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = 0;
     // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
     auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
       const uint32_t dw = code >> 11;
@@ -383,7 +415,9 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
       if ((j & 7) == 0) ce.sync(j);
       const uint32_t cd = ce.get(j);
       if (j > 0) wEnd = next_wpos(wEnd, cd, j);
-      if (!(cd & kL2DupBit) || a.g.prevSame[r.beg0 + j] < r.beg0) insert(cd);
+      bool eff = true;
+      if (cd & kL2DupBit) eff = a.g.prevSame[r.beg0 + j] < r.beg0;
+      l2_apply<G, +1>(S, R, cd, eff);
     }
     uint32_t codeEnd = 0;
     if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
@@ -393,18 +427,22 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
     int32_t wBegNext = (1 < m) ? next_wpos(wBeg, codeBegNext, 1) : wBeg;
     int best = 0; int32_t firstPos = 0, lastPos = 0; int steps = 0;
     bool advB = false, advE = false; uint32_t delCode = 0, insCode = 0;
-    while (end < m && !ovf) {                        // computeMap.hpp:455
+    while (end < m && !R.ovf) {                      // computeMap.hpp:455
       if ((steps & 7) == 0) { cb.sync(beg + 1); ce.sync(end); }
-      if (advB) {                                    // delete_ref(prev_beg): entry beg-1; still present iff a later same-hash entry was inserted
-        bool eff = true;
-        if (delCode & kL2DupBit) { const int32_t nx = a.g.nextSame[r.beg0 + beg - 1]; eff = !(nx >= 0 && nx < r.beg0 + (advE ? end - 1 : end)); }
-        if (eff) erase(delCode);
+      {                                              // delete_ref(prev_beg): entry beg-1; stays iff a later same-hash entry was inserted
+        bool eff = advB;
+        if (advB && (delCode & kL2DupBit)) { const int32_t nx = a.g.nextSame[r.beg0 + beg - 1]; eff = !(nx >= 0 && nx < r.beg0 + (advE ? end - 1 : end)); }
+        l2_apply<G, -1>(S, R, delCode, eff);
       }
-      if (advE) {                                    // insert_ref(prev_end): entry end-1; new iff no same-hash entry in [beg, end-1)
-        if (!(insCode & kL2DupBit) || a.g.prevSame[r.beg0 + end - 1] < r.beg0 + beg) insert(insCode);
+      {                                              // insert_ref(prev_end): entry end-1; new iff no same-hash entry in [beg, end-1)
+        bool eff = advE;
+        if (advE && (insCode & kL2DupBit)) eff = a.g.prevSame[r.beg0 + end - 1] < r.beg0 + beg;
+        l2_apply<G, +1>(S, R, insCode, eff);
       }
-      if (shared > best) { best = shared; firstPos = wBeg; lastPos = wBeg; }
-      else if (shared == best) lastPos = wBeg;
+      const bool better = R.shared > best, tie = R.shared == best;
+      best = better ? R.shared : best;
+      firstPos = better ? wBeg : firstPos;
+      lastPos = (better || tie) ? wBeg : lastPos;
       steps++;
       // MIIteratorL2::next
       const int32_t d1 = wBegNext - pos, d2 = wEnd - (pos + cmw - 1);
@@ -420,10 +458,11 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
         if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
       }
     }
-    if (ovf) a.slowFlag[i] = 3;
+    if (R.ovf) a.slowFlag[i] = (G::kMaxS == 255) ? 5 : 3;
     else {
+      a.slowFlag[i] = 0;
       a.g.outBest[c] = best; a.g.outFirst[c] = firstPos; a.g.outLast[c] = lastPos;
-      cntE = (unsigned long long)m; cntS = (unsigned long long)steps; cntQ = (unsigned long long)s;
+      cntE = (unsigned long long)m; cntS = (unsigned long long)steps; cntQ = (unsigned long long)R.s;
     }
   }
 #pragma unroll
@@ -432,7 +471,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
 }
 
 // candidates of the chunk that must take the general kernel -> list (order irrelevant)
-// slowFlag: 1 = outside the fast-path limits, 3 = gap counter overflow
+// after both simulation classes ran: slowFlag 1 = outside the fast-path limits, 3 = gap counter overflow, 0 = done
 __global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t *__restrict__ list,
                                   unsigned int *__restrict__ count, unsigned long long *__restrict__ reasons /* [4] */)
 {
