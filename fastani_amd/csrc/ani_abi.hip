@@ -85,6 +85,7 @@ struct ani_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   ani_counters_t counters;
+  double candPerFrag = 12.0;      // running estimate that sizes the L1 candidate pool
   // scalar device counters (array of 16 x u64)
   DevBuf dCounters;
   // workspaces reused across calls
@@ -92,10 +93,10 @@ struct ani_ctx {
   DevBuf tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
-  DevBuf candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
+  DevBuf probeFirst, probeCnt, l1LargeList, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
-  DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList;
+  DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList, l2ClassList;
   DevBuf bins, queryFragments, rows;
 };
 
@@ -122,7 +123,7 @@ struct ani_sketch {
 namespace {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_N = 16 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_N = 16 };
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
@@ -504,11 +505,16 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   // ---- L1 ----
   TRY(ctx->fragCandOff.ensure(nF * 4)); TRY(ctx->fragCandCnt.ensure(nF * 4)); TRY(ctx->fragCandCntClamped.ensure(nF * 4));
   TRY(ctx->fragHits.ensure(nF * 4)); TRY(ctx->fragOrdOff.ensure((nF + 1) * 4));
-  uint64_t ccap = (uint64_t)nF * 8 + 4096;
+  TRY(ctx->probeFirst.ensure((host[CNT_QPOOL] + 1) * 4)); TRY(ctx->probeCnt.ensure((host[CNT_QPOOL] + 1) * 4));
+  uint64_t ccap = (uint64_t)((double)nF * ctx->candPerFrag) + 4096;
+  TRY(ctx->l1LargeList.ensure(nF * 4));
+  unsigned nLarge = 0;
+  unsigned long long hitsTotal = 0;
   for (int attempt = 0;; attempt++) {
     if (ccap > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
     TRY(ctx->candFrag.ensure(ccap * 4)); TRY(ctx->candSeq.ensure(ccap * 4)); TRY(ctx->candStart.ensure(ccap * 4)); TRY(ctx->candEnd.ensure(ccap * 4));
-    TRY(zero_counters(ctx));
+    if (attempt == 0) TRY(zero_counters(ctx));
+    else { HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CAND), 0, 8, ctx->stream)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
     L1Args a;
     a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>(); a.nFrag = (int32_t)nF;
     a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.nIndex = sk->n;
@@ -517,23 +523,35 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
+    a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
+    a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_CLASSB);
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
-      hipLaunchKernelGGL(k_l1, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
+      if (attempt == 0) hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
+      hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
+      if (attempt == 0) {
+        unsigned long long nl = 0;
+        HIP_TRY(hipMemcpyAsync(&nl, cnt_ptr(ctx, CNT_CLASSB), 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        nLarge = (unsigned)nl;
+      }
+      if (nLarge) hipLaunchKernelGGL((k_l1<kL1HitCapSmall, kL1HitCapMax>), dim3(nLarge), dim3(kTPB), 0, ctx->stream, a);
       hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, ctx->fragCandCnt.as<int32_t>(),
                          ctx->fragCandCntClamped.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG));
     }
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
+    if (attempt == 0) hitsTotal = host[CNT_HITS];
     if (host[CNT_CAND] <= ccap) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "candidate pool did not converge");
     ccap = host[CNT_CAND];
   }
+  ctx->candPerFrag = std::max(ctx->candPerFrag, 1.25 * (double)host[CNT_CAND] / (double)nF);   // size the pool right next time
   if ((uint32_t)host[CNT_NEG] != 0)
-    return fail(ANI_ERR_LIMIT, "%u query fragment(s) exceed the L1 fast-path limits (sketch size > %d or seed hits > %d): "
+    return fail(ANI_ERR_LIMIT, "%u query fragment(s) exceed the L1 LDS limits (sketch size > %d or seed hits > %d): "
                                "low-complexity/repetitive input; run with the reference's -s sanity check semantics or split the reference list",
-                (uint32_t)host[CNT_NEG], kL1MaxS, kL1HitCap);
-  ctx->counters.seedHits += host[CNT_HITS];
+                (uint32_t)host[CNT_NEG], kL1MaxS, kL1HitCapMax);
+  ctx->counters.seedHits += hitsTotal;
   uint64_t nCand = 0;
   {
     StageTimer tm(ctx, &ctx->counters.msL1);
@@ -569,9 +587,9 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     HIP_TRY(hipMemcpyAsync(ordOff.data(), ctx->fragOrdOff.p, nF * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
 
-    const size_t CH = (size_t)1 << 18;       // candidates per chunk: <= 2^18 * 16384 code words, inside the uint32 scan
+    const size_t CH = (size_t)1 << 20;       // candidates per chunk (a chunk whose code entries exceed 2^32 is rejected by the scan)
     TRY(ctx->l2Ranges.ensure(CH * sizeof(L2Range))); TRY(ctx->l2CodeCount.ensure(CH * 4)); TRY(ctx->l2CodeOff.ensure(CH * 4));
-    TRY(ctx->l2SlowFlag.ensure(CH * 4)); TRY(ctx->l2SlowList.ensure(nCand * 4));
+    TRY(ctx->l2SlowFlag.ensure(CH * 4)); TRY(ctx->l2SlowList.ensure(nCand * 4)); TRY(ctx->l2ClassList.ensure(CH * 4));
     HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream));
     for (size_t c0 = 0; c0 < nCand; c0 += CH) {
       const size_t c1 = std::min<size_t>(nCand, c0 + CH);
@@ -600,8 +618,13 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)nullptr, (const unsigned int *)nullptr);
+          // the few class-B candidates (s in 256..319) are compacted first so that they fill whole waves
+          HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CLASSB), 0, 8, ctx->stream));
+          hipLaunchKernelGGL(k_l2_collect_class, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag, 4,
+                             ctx->l2ClassList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
+          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)ctx->l2ClassList.as<int32_t>(),
+                             (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
         }
         ctx->counters.l2Launches++;
       }
@@ -727,8 +750,8 @@ void ani_shutdown(ani_ctx *c)
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->tiles, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
-                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
-                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2Best,
+                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
+                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -5,18 +5,20 @@
 // slide a run of `minimumHits` consecutive hits, keep runs that stay on one contig and span < fragLen, merge
 // overlapping candidates).  Stateless form, SURVEY.md App. A.3.
 //
-// Fast path (this kernel): s <= kL1MaxS and H <= kL1HitCap, everything in LDS: probe (bucket table + binary search in
-// the hash-sorted index), gather hits as 64-bit (seqId<<32 | wpos) keys, bitonic sort, flag valid runs, compact,
-// flag group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous
-// candidate" only needs the previous valid run), scan, emit.  Larger fragments are flagged (fragCandCnt = -1) and
-// taken by the overflow path.
+// Two passes.  k_l1_probe: one lane per sketch hash, bucket table + binary search in the hash-sorted index, no LDS, so the
+// dependent loads are hidden by occupancy.  k_l1<HLO,HCAP>: one workgroup per fragment with HLO < H <= HCAP seed hits,
+// everything in LDS: gather the hit runs as 64-bit (seqId<<32 | wpos) keys, bitonic sort, flag valid runs, compact, flag
+// group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous candidate" only needs
+// the previous valid run), scan, emit.  Two LDS classes (<= 2048 hits: 6 workgroups per CU; <= 8192 hits).  Larger
+// fragments are flagged (fragCandCnt = -1): overflow path.
 #pragma once
 #include "common.hpp"
 
 namespace ani {
 
-constexpr int kL1MaxS = 1024;
-constexpr int kL1HitCap = 4096;
+constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS classes accept
+constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 8 KiB scratch -> 6 workgroups per CU
+constexpr int kL1HitCapMax = 8192;      // class L: 64 KiB + 32 KiB -> 1 workgroup per CU (rare: > 2048 seed hits in one fragment)
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
@@ -25,6 +27,8 @@ struct L1Args {
   int L;
   int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
   uint32_t *fragCandOff; int32_t *fragCandCnt; int32_t *fragHits;
+  uint32_t *probeFirst, *probeCnt;      // per sketch hash (aligned with qPool): occurrence run in the hash-sorted index
+  int32_t *largeList; unsigned int *largeCount;   // fragments with kL1HitCapSmall < H <= kL1HitCapMax
   unsigned long long *sumHits;
 };
 
@@ -64,43 +68,60 @@ __device__ __forceinline__ bool l1_head(const uint64_t *hits, const int *V, int 
   return hit_seq(x) != hit_seq(px) || hit_wpos(px) < start;
 }
 
+// Pass 1: probes only.  No LDS, one lane per query hash: the dependent loads of a probe (bucket table -> hash-sorted index)
+// are covered by occupancy instead of stalling the LDS-heavy sort kernel.  Writes (first, cnt) per sketch hash and H per fragment.
+__global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
+{
+  __shared__ int ws[16];
+  const int f = blockIdx.x;
+  const int s = a.fragS[f];
+  if (s <= 0) { if (threadIdx.x == 0) a.fragHits[f] = 0; return; }
+  const uint32_t off = a.fragOff[f];
+  int c = 0;
+  for (int i = threadIdx.x; i < s; i += kTPB) {
+    uint32_t fi, cn; l1_probe(a, a.qPool[off + i], fi, cn);
+    a.probeFirst[off + i] = fi; a.probeCnt[off + i] = cn;
+    c += (int)cn;
+  }
+  int H; block_excl_scan(c, ws, &H);
+  if (threadIdx.x == 0) {
+    a.fragHits[f] = H;
+    if (H) atomicAdd(a.sumHits, (unsigned long long)H);
+    // fragments of the large LDS class are listed so that its 96 KiB workgroups are only launched for them
+    if (H > kL1HitCapSmall && H <= kL1HitCapMax && s <= kL1MaxS) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
+  }
+}
+
+// Pass 2: gather + sort + candidate regions for the fragments whose hit count is in (HLO, HCAP]; everything in LDS.
+template <int HLO, int HCAP>
 __global__ __launch_bounds__(kTPB) void k_l1(L1Args a)
 {
-  __shared__ uint64_t hits[kL1HitCap];
-  __shared__ int V[kL1HitCap];
+  __shared__ uint64_t hits[HCAP];
+  __shared__ int V[HCAP];
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
-  const int f = blockIdx.x;
+  const int f = HLO == 0 ? (int)blockIdx.x : a.largeList[blockIdx.x];
   const int t = threadIdx.x;
   const int s = a.fragS[f];
-  if (s <= 0) {
-    if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; a.fragHits[f] = 0; }
+  const int H = a.fragHits[f];
+  if (HLO == 0 && (s <= 0 || H == 0)) {
+    if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; }
     return;
   }
-  const uint32_t *q = a.qPool + a.fragOff[f];
-  int *pFirst = V, *pOff = V + kL1MaxS;            // probe results alias V (V is only written after the gather)
-
-  if (s > kL1MaxS) {                               // overflow path: only count the hits here
-    int c = 0;
-    for (int i = t; i < s; i += kTPB) { uint32_t fi, cn; l1_probe(a, q[i], fi, cn); c += (int)cn; }
-    int H; block_excl_scan(c, ws, &H);
-    if (t == 0) { a.fragCandCnt[f] = -1; a.fragCandOff[f] = 0; a.fragHits[f] = H; }
+  if (HLO == 0 && (s > kL1MaxS || H > kL1HitCapMax)) {            // beyond every LDS class: overflow path
+    if (t == 0) { a.fragCandCnt[f] = -1; a.fragCandOff[f] = 0; }
     return;
   }
-  for (int i = t; i < s; i += kTPB) { uint32_t fi, cn; l1_probe(a, q[i], fi, cn); pFirst[i] = (int)fi; pOff[i] = (int)cn; }
+  if (H <= HLO || H > HCAP || s <= 0 || s > kL1MaxS) return;     // another class handles it
+  const uint32_t off = a.fragOff[f];
+  int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)
+  for (int i = t; i < s; i += kTPB) pOff[i] = (int)a.probeCnt[off + i];
   __syncthreads();
-  const int H = block_array_excl_scan(pOff, s, ws);
-  if (H > kL1HitCap) {
-    if (t == 0) { a.fragCandCnt[f] = -1; a.fragCandOff[f] = 0; a.fragHits[f] = H; }
-    return;
-  }
-  if (H == 0) {
-    if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; a.fragHits[f] = 0; }
-    return;
-  }
+  block_array_excl_scan(pOff, s, ws);
   // gather (computeMap.hpp:283-299)
   for (int i = t; i < s; i += kTPB) {
-    const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H, fi = pFirst[i];
+    const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H;
+    const uint32_t fi = a.probeFirst[off + i];
     for (int c = 0; c < e - o; c++) hits[o + c] = a.sSW[fi + c];
   }
   const int n2 = next_pow2(H);
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a)
     }
     if (t == 0) a.fragCandOff[f] = (uint32_t)base;
   } else if (t == 0) a.fragCandOff[f] = 0;
-  if (t == 0) { a.fragCandCnt[f] = nG; a.fragHits[f] = H; atomicAdd(a.sumHits, (unsigned long long)H); }
+  if (t == 0) a.fragCandCnt[f] = nG;
 }
 
 // reorder candidates into the reference's callback order: fragment ascending, then (seqId, start) as produced

@@ -173,12 +173,12 @@ __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
 //                  bit 0 = hash is a query hash, bits 1..9 = gap (or rank-1), bit 10 = a same-hash neighbour may share
 //                  a super-window with this entry (nearDup, precomputed at index build), bits 11..15 = wpos - previous
 //                  wpos (31 = escape: read the index)
-//   k_l2_sim     one lane per candidate: the sliding simulation over those entries.  State in LDS: 5- or 6-bit gap counters +
-//                1-bit presence flags, word-interleaved over the wave so that lanes never collide on a bank.  Entries are
-//                streamed by two monotone cursors through registers (16 entries + 8 prefetched per cursor); refills are
+//   k_l2_sim     one lane per candidate: the sliding simulation over those entries.  State in LDS: one byte per sketch rank (7-bit gap
+//                counter + presence bit), word-interleaved over the wave so that lanes never collide on a bank.  Entries are
+//                streamed by two monotone cursors through 16-entry LDS rings (+ 8 entries prefetched in registers per cursor); refills are
 //                issued at wave-uniform points every 8 steps so that their latency never sits on a step's critical path.
 //                Entries flagged nearDup consult prevSame/nextSame (exact set semantics, slidingMap.hpp:150-154,:178).
-//                A class-A counter that would exceed 31 re-runs the candidate in class B, a class-B counter past 63 sends it to k_l2.
+//                A gap counter that would pass 127 sends the candidate to k_l2.
 // ------------------------------------------------------------------------------------------------
 struct L2Args {
   // candidates (SoA)
@@ -223,24 +223,23 @@ __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__restrict
 // ---------------------------------------------------------------- fast path
 constexpr int kL2FastMaxS = 319;
 constexpr int kL2FastMaxEntries = 16384;
-// LDS state geometry of the simulation kernel, two variants:
-//   class A  s <= 255, six 5-bit gap counters per word: 43 + 8 = 51 words = 204 B per lane -> 12 waves per CU
-//   class B  s <= 319, five 6-bit gap counters per word: 64 + 10 = 74 words = 296 B per lane -> 8 waves per CU
-// (sorted-sketch spacings are uneven: the widest gap of a window routinely holds 10-15 reference hashes, so 4 bits are
-//  not enough; a class-A candidate whose counter would pass 31 is re-run in class B, one that would pass 63 in k_l2)
-template <int MAXS, int BITS, int PER>
+// LDS state of the simulation kernel: one 8-bit field per index g = 0..MAXS,
+//     field[g] = n[g] << 1 | b[g+1]        (7-bit gap counter + presence bit of the query hash that closes the gap)
+// so an event with code index idx — query hash of rank idx+1 or non-query hash of gap idx — touches exactly field[idx], and the
+// pivot logic, which needs n[j] together with b[j+1], reads exactly field[j].  Four fields per word, words interleaved over the
+// wave (byte address = ((g>>2)*64 + lane)*4 + (g&3)): every per-lane index hits bank = lane.
+//   class A  s <= 255: 64 words + 16-entry cursor rings (16 words) = 320 B per lane -> 20 KiB per wave, 8 waves per CU
+//   class B  s <= 319: 80 words + rings                            = 384 B per lane -> 24 KiB per wave, 6 waves per CU
+// A counter that would pass 127 sends the candidate to the general kernel.
+template <int MAXS>
 struct L2Geom {
-  static constexpr int kMaxS = MAXS, kBits = BITS, kPer = PER;
-  static constexpr uint32_t kCntMax = (1u << BITS) - 1;
-  static constexpr int kCntWords = (MAXS + 1 + PER - 1) / PER;
-  static constexpr int kBitWords = (MAXS + 1 + 31) / 32;
-  static constexpr int kWords = kCntWords + kBitWords;
-  static constexpr int kDivMul = PER == 6 ? 171 : 205;        // idx / PER == (idx * kDivMul) >> 10 for idx <= 319
-  static_assert(PER == 5 || PER == 6, "division constant");
-  static_assert(BITS * PER <= 32, "counters per word");
+  static constexpr int kMaxS = MAXS;
+  static constexpr int kStateWords = (MAXS + 1 + 3) / 4;
+  static constexpr int kRingWords = 16;                     // 2 cursors x 16 entries x 16 bit
+  static constexpr int kWords = kStateWords + kRingWords;
 };
-using L2GeomA = L2Geom<255, 5, 6>;
-using L2GeomB = L2Geom<319, 6, 5>;
+using L2GeomA = L2Geom<255>;
+using L2GeomB = L2Geom<319>;
 constexpr int kL2SimTPB = 128;
 
 struct L2Range { int32_t beg0, end0, last, wposBeg0; };
@@ -309,88 +308,92 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   }
 }
 
-// One monotone cursor over a candidate's 16-bit entries: A0|A1 hold entries [8b, 8b+16), B (entries [8b+16, 8b+24)) is in
-// flight.  get() only touches A0/A1; sync() is called at wave-uniform points at most 8 consumed entries apart.
+// One monotone cursor over a candidate's 16-bit entries.  Entries [8b, 8b+16) sit in a 16-entry LDS ring (entry j at ring
+// slot j & 15, lane-interleaved dwords => conflict-free ds_read_u16), block b+2 is in flight in registers.  sync() is called
+// at wave-uniform points at most 8 consumed entries apart; its global load is unconditional and outside divergent control
+// flow on purpose, so that it stays in flight until the next sync() instead of being waited for at a branch join.
 struct L2Stream {
-  const uint4 *p; int b; uint4 A0, A1, B;
-  __device__ __forceinline__ void init(const uint4 *p_) { p = p_; b = 0; A0 = p[0]; A1 = p[1]; B = p[2]; }
-  // Branch-free on purpose: the refill is issued by every lane at the same (wave-uniform) point, outside divergent
-  // control flow, so that the compiler keeps it in flight until B is first read — at the next sync(), 8 steps later.
-  // (Inside an `if` the load result would have to be merged at the join and s_waitcnt vmcnt(0) lands right behind it.)
+  const uint4 *p; int b; uint4 B;
+  uint32_t *ring;                // this lane's dword 0 of the cursor's ring: dword d at ring[d * kWave]
+  __device__ __forceinline__ void put(int blk, const uint4 v)
+  {
+    uint32_t *r = ring + ((blk & 1) * 4) * kWave;
+    r[0] = v.x; r[kWave] = v.y; r[2 * kWave] = v.z; r[3 * kWave] = v.w;
+  }
+  __device__ __forceinline__ void init(const uint4 *p_, uint32_t *ring_)
+  {
+    p = p_; ring = ring_; b = 0;
+    put(0, p[0]); put(1, p[1]); B = p[2];
+  }
   __device__ __forceinline__ void sync(int j)
   {
-    const bool sh = (j - 8 * b >= 8);
-    A0.x = sh ? A1.x : A0.x; A0.y = sh ? A1.y : A0.y; A0.z = sh ? A1.z : A0.z; A0.w = sh ? A1.w : A0.w;
-    A1.x = sh ? B.x : A1.x; A1.y = sh ? B.y : A1.y; A1.z = sh ? B.z : A1.z; A1.w = sh ? B.w : A1.w;
-    b += sh ? 1 : 0;
+    if (j - 8 * b >= 8) { put(b, B); b++; }      // block b is consumed: block b+2 takes its ring slot
     B = p[b + 2];
   }
   __device__ __forceinline__ uint32_t get(int j) const
   {
-    const int o = j - 8 * b;                       // 0..15
-    const uint4 blk = (o & 8) ? A1 : A0;
-    const int d = (o >> 1) & 3;
-    const uint32_t wd = d == 0 ? blk.x : d == 1 ? blk.y : d == 2 ? blk.z : blk.w;
-    return (o & 1) ? (wd >> 16) : (wd & 0xffffu);
+    const int e = j & 15;
+    const uint16_t *h = (const uint16_t *)(ring + (e >> 1) * kWave);
+    return h[e & 1];
   }
 };
 
 // One window event, written without control flow (selects only).  SIGN = +1: the entry enters the window
-// (slidingMap.hpp:137-161 + :231-254), SIGN = -1: it leaves (:167-211 + :261-284).  All LDS reads are issued up front
-// (the entry's own word, the gap counter and the presence bit next to the pivot), the own-word hazard is patched in
-// registers, one write goes back.  `on` = false turns the whole event into a no-op (inactive lane / ineffective event).
+// (slidingMap.hpp:137-161 + :231-254), SIGN = -1: it leaves (:167-211 + :261-284).  Both LDS reads (the entry's own field and
+// the field next to the pivot) are issued up front; `on` = false turns the event into a no-op.
 struct L2Regs { int s, iStar, cStar, shared; int ovf; };
 
-template <class G, int SIGN>
-__device__ __forceinline__ void l2_apply(uint32_t *S, L2Regs &r, uint32_t code, bool on)
+template <int SIGN>
+__device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, bool on)
 {
   const int isQ = (int)(code & 1u);
   const int idx = (int)((code >> 1) & 0x1ffu);
-  const int x = idx + 1;                                             // rank of a query hash
-  // pivot-adjacent cells: j = iStar-1 for an insertion, iStar for a deletion; need n[j] and b[j+1]
-  int j = r.iStar - (SIGN > 0 ? 1 : 0); j = j < 0 ? 0 : j;
-  int jb = j + 1; jb = jb > G::kMaxS ? G::kMaxS : jb;
-  const int wOwnN = (idx * G::kDivMul) >> 10, shOwnN = (idx - wOwnN * G::kPer) * G::kBits;
-  const int wOwn = isQ ? G::kCntWords + (x >> 5) : wOwnN;
-  const int wJ = (j * G::kDivMul) >> 10, shJ = (j - wJ * G::kPer) * G::kBits;
-  const uint32_t own = S[wOwn * kWave];
-  const uint32_t cj = S[wJ * kWave];
-  const uint32_t bj = S[(G::kCntWords + (jb >> 5)) * kWave];
-  const uint32_t delta = isQ ? (1u << (x & 31)) : (1u << shOwnN);
-  const int full = (SIGN > 0) & (isQ ^ 1) & (int)(((own >> shOwnN) & G::kCntMax) == G::kCntMax);
+  int j = r.iStar - (SIGN > 0 ? 1 : 0); j = j < 0 ? 0 : j;          // pivot-adjacent field: n[j], b[j+1]
+  uint8_t *pOwn = F + ((idx >> 2) << 8) + (idx & 3);
+  const uint8_t *pJ = F + ((j >> 2) << 8) + (j & 3);
+  const int own = *pOwn;
+  int fj = *pJ;
+  const int delta = 2 - isQ;                                         // counter lives in bits 1..7, presence in bit 0
+  const int full = (SIGN > 0) & (isQ ^ 1) & (int)(own >= 254);
   r.ovf |= on ? full : 0;
-  const bool act = on && !full;
-  S[wOwn * kWave] = act ? (SIGN > 0 ? own + delta : own - delta) : own;
-  int cntj = (int)((cj >> shJ) & G::kCntMax);
-  cntj += ((isQ ^ 1) & (int)(idx == j)) ? SIGN : 0;                  // the event itself changed n[j]
-  int bitj = (int)((bj >> (jb & 31)) & 1u);
-  bitj = (isQ & (int)(x == jb)) ? (SIGN > 0 ? 1 : 0) : bitj;         // ... or b[j+1]
-  const int below = (isQ ^ 1) & (int)(idx < r.iStar);
-  int iStar = r.iStar, cStar = r.cStar, shared = r.shared;
-  shared += (isQ & (int)(x <= iStar)) ? SIGN : 0;
-  cStar += below ? SIGN : 0;
+  const int act = (int)on & (full ^ 1);
+  *pOwn = (uint8_t)(own + (act ? SIGN * delta : 0));
+  fj += (idx == j) ? SIGN * delta : 0;                               // the event itself changed field[j]
+  const int cntj = fj >> 1, bitj = fj & 1;
+  const int lt = (int)(idx < r.iStar);                               // rank idx+1 <= iStar  <=>  gap idx < iStar
+  const int qOn = act & isQ, nOn = act & (isQ ^ 1);
+  r.shared += (qOn & lt) ? SIGN : 0;
+  r.cStar += (nOn & lt) ? SIGN : 0;
   if (SIGN > 0) {
-    const int mv = below & (int)(iStar + cStar > r.s);               // q_iStar leaves the s smallest
-    shared -= mv ? bitj : 0; iStar -= mv; cStar -= mv ? cntj : 0;
+    const int mv = nOn & lt & (int)(r.iStar + r.cStar > r.s);        // q_iStar leaves the s smallest
+    r.shared -= mv ? bitj : 0; r.iStar -= mv; r.cStar -= mv ? cntj : 0;
   } else {
-    const int mv = (isQ ^ 1) & (int)(iStar < r.s) & (int)(iStar + 1 + cStar + cntj <= r.s);   // q_{iStar+1} joins them
-    cStar += mv ? cntj : 0; iStar += mv; shared += mv ? bitj : 0;
+    const int mv = nOn & (int)(r.iStar < r.s) & (int)(r.iStar + 1 + r.cStar + cntj <= r.s);   // q_{iStar+1} joins them
+    r.cStar += mv ? cntj : 0; r.iStar += mv; r.shared += mv ? bitj : 0;
   }
-  r.iStar = act ? iStar : r.iStar; r.cStar = act ? cStar : r.cStar; r.shared = act ? shared : r.shared;
 }
 
-// slowFlag protocol: 0 = class A, 4 = class B (s in 256..319), 5 = class A overflowed -> class B,
-//                    1 = outside every fast-path limit, 3 = class B overflowed -> general kernel
+// slowFlag protocol: 0 = class A, 4 = class B (s in 256..319), 1 = outside every fast-path limit,
+//                    3 = a gap counter overflowed -> general kernel
+// `list` (optional): candidate ids to run, densely packed so that the few class-B candidates fill whole waves instead of
+// leaving one busy lane in every wave; *listCount is read on the device (no host round trip).
 template <class G>
-__global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
+__global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_t *__restrict__ list, const unsigned int *__restrict__ listCount)
 {
   __shared__ uint32_t lds[(kL2SimTPB / kWave) * G::kWords * kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   uint32_t *S = lds + wv * (G::kWords * kWave) + lane;               // word x of this lane: S[x * kWave]
-  const int32_t c = a.c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  uint8_t *F = (uint8_t *)S;                                          // field g: F[((g >> 2) << 8) + (g & 3)]
+  const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t c = a.c0 + slot;
+  if (list) {
+    const unsigned int n = *listCount;
+    if ((unsigned int)(blockIdx.x * blockDim.x) >= n) return;         // whole workgroup beyond the list
+    c = (unsigned int)slot < n ? list[slot] : a.c1;
+  }
   unsigned long long cntE = 0, cntS = 0, cntQ = 0;
   const int myFlag = c < a.c1 ? a.slowFlag[c - a.c0] : 1;
-  const bool mine = (G::kMaxS == 255) ? (myFlag == 0) : (myFlag == 4 || myFlag == 5);
+  const bool mine = (G::kMaxS == 255) ? (myFlag == 0) : (myFlag == 4);
   if (mine) {
     const int32_t i = c - a.c0;
     const L2Range r = a.ranges[i];
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
     const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
     const int m = r.last - r.beg0;
 #pragma unroll
-    for (int x = 0; x < G::kWords; x++) S[x * kWave] = 0u;
+    for (int x = 0; x < G::kStateWords; x++) S[x * kWave] = 0u;
     L2Regs R; R.s = a.g.fragS[f]; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = 0;
     // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
     auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
@@ -407,7 +410,8 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
     };
     const uint4 *base = (const uint4 *)((const uint16_t *)a.codes + a.codeOff[i]);
     L2Stream cb, ce;
-    cb.init(base); ce.init(base);
+    cb.init(base, S + G::kStateWords * kWave);
+    ce.init(base, S + (G::kStateWords + 8) * kWave);
     // first super-window: entries [0, end0-beg0)  (computeMap.hpp:448)
     int end = r.end0 - r.beg0, beg = 0;
     int32_t wEnd = r.wposBeg0;                       // becomes wpos of entry `end`
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
       if (j > 0) wEnd = next_wpos(wEnd, cd, j);
       bool eff = true;
       if (cd & kL2DupBit) eff = a.g.prevSame[r.beg0 + j] < r.beg0;
-      l2_apply<G, +1>(S, R, cd, eff);
+      l2_apply<+1>(F, R, cd, eff);
     }
     uint32_t codeEnd = 0;
     if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
@@ -432,12 +436,12 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
       {                                              // delete_ref(prev_beg): entry beg-1; stays iff a later same-hash entry was inserted
         bool eff = advB;
         if (advB && (delCode & kL2DupBit)) { const int32_t nx = a.g.nextSame[r.beg0 + beg - 1]; eff = !(nx >= 0 && nx < r.beg0 + (advE ? end - 1 : end)); }
-        l2_apply<G, -1>(S, R, delCode, eff);
+        l2_apply<-1>(F, R, delCode, eff);
       }
       {                                              // insert_ref(prev_end): entry end-1; new iff no same-hash entry in [beg, end-1)
         bool eff = advE;
         if (advE && (insCode & kL2DupBit)) eff = a.g.prevSame[r.beg0 + end - 1] < r.beg0 + beg;
-        l2_apply<G, +1>(S, R, insCode, eff);
+        l2_apply<+1>(F, R, insCode, eff);
       }
       const bool better = R.shared > best, tie = R.shared == best;
       best = better ? R.shared : best;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a)
         if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
       }
     }
-    if (R.ovf) a.slowFlag[i] = (G::kMaxS == 255) ? 5 : 3;
+    if (R.ovf) a.slowFlag[i] = 3;
     else {
       a.slowFlag[i] = 0;
       a.g.outBest[c] = best; a.g.outFirst[c] = firstPos; a.g.outLast[c] = lastPos;
@@ -477,6 +481,14 @@ __global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restri
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && slowFlag[i]) { list[atomicAdd(count, 1u)] = c0 + i; atomicAdd(&reasons[slowFlag[i] & 3], 1ull); }
+}
+
+// class-B candidates of the chunk (slowFlag == 4) -> dense list
+__global__ void k_l2_collect_class(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t flag, int32_t *__restrict__ list,
+                                   unsigned int *__restrict__ count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && slowFlag[i] == flag) list[atomicAdd(count, 1u)] = c0 + i;
 }
 
 }  // namespace ani
