@@ -29,8 +29,8 @@
 #include "kernels/sketch.hpp"
 #include "kernels/synth.hpp"
 
-extern "C" int ani_sort_pairs_u32(const uint32_t *keysIn, uint32_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
-                                  size_t n, hipStream_t stream);
+extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
+                                      size_t n, hipStream_t stream);
 
 namespace {
 
@@ -93,7 +93,7 @@ struct ani_ctx {
   DevBuf tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
-  DevBuf probeFirst, probeCnt, l1LargeList, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
+  DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
   DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList, l2ClassList;
@@ -109,7 +109,7 @@ struct ani_sketch {
   std::vector<int32_t> contigLen, genomeContigStart;
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
-  uint32_t *sHash = nullptr, *sIdx = nullptr, *bucketStart = nullptr, *mWposF = nullptr;
+  uint32_t *sHash = nullptr, *bucketStart = nullptr, *mWposF = nullptr;
   uint64_t *sSW = nullptr;
   int bucketShift = 0; uint32_t nBuckets = 0;
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
@@ -123,7 +123,7 @@ struct ani_sketch {
 namespace {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_N = 16 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_N = 24 };
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
@@ -343,7 +343,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 
 void free_sketch_device(ani_sketch *sk)
 {
-  void *ptrs[] = {sk->sSW, sk->mWposF, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->sIdx, sk->bucketStart, sk->contigFirstMin,
+  void *ptrs[] = {sk->sSW, sk->mWposF, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->bucketStart, sk->contigFirstMin,
                   sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
   for (void *q : ptrs) if (q) (void)hipFree(q);
 }
@@ -382,29 +382,29 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   const size_t n4 = (n ? n : 1) * 4;
   SK_HIP(hipMalloc((void **)&sk->mHash, n4)); SK_HIP(hipMalloc((void **)&sk->mSeq, n4)); SK_HIP(hipMalloc((void **)&sk->mWpos, n4));
   SK_HIP(hipMalloc((void **)&sk->prevSame, n4)); SK_HIP(hipMalloc((void **)&sk->nextSame, n4));
-  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->sIdx, n4)); SK_HIP(hipMalloc((void **)&sk->mWposF, n4)); SK_HIP(hipMalloc((void **)&sk->sSW, 2 * n4));
+  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->mWposF, n4)); SK_HIP(hipMalloc((void **)&sk->sSW, 2 * n4));
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
-    uint32_t *tmpK = nullptr, *tmpV = nullptr;
-    SK_HIP(hipMalloc((void **)&tmpK, n4)); SK_HIP(hipMalloc((void **)&tmpV, n4));
+    uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
+    SK_HIP(hipMalloc((void **)&tmpK, n4)); SK_HIP(hipMalloc((void **)&tmpV, 2 * n4));
     if (n) {
-      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV);
-      int rc = ani_sort_pairs_u32(tmpK, sk->sHash, tmpV, sk->sIdx, n, ctx->stream);
+      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, sk->mWposF,
+                         sk->prevSame, sk->nextSame, tmpK, tmpV);
+      int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, ctx->stream);
       if (rc != 0) { (void)hipFree(tmpK); (void)hipFree(tmpV); return bail(fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
     }
     (void)hipFree(tmpK); (void)hipFree(tmpV);
     SK_TRY(zero_counters(ctx));
-    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, sk->sIdx, (uint32_t)n, sk->prevSame, sk->nextSame, sk->mSeq, sk->mWpos,
-                              (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
-    if (n) hipLaunchKernelGGL(k_index_payload, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sIdx, sk->mSeq, sk->mWpos, (uint32_t)n, sk->sSW);
+    SK_HIP(hipMalloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
+    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
+                              (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
     // bucket table over the top bits: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
     while (bits < 28 && (1ull << bits) < n) bits++;
     sk->bucketShift = 32 - bits; sk->nBuckets = 1u << bits;
     SK_HIP(hipMalloc((void **)&sk->bucketStart, ((size_t)sk->nBuckets + 1) * 4));
     hipLaunchKernelGGL(k_index_buckets, dim3(grid_for((size_t)sk->nBuckets + 1)), dim3(256), 0, ctx->stream, sk->sHash, (uint32_t)n, sk->bucketShift, sk->nBuckets, sk->bucketStart);
-    SK_HIP(hipMalloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
-    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
     SK_HIP(hipGetLastError());
     unsigned long long host[CNT_N];
     SK_TRY(read_counters(ctx, host));
@@ -507,8 +507,8 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   TRY(ctx->fragHits.ensure(nF * 4)); TRY(ctx->fragOrdOff.ensure((nF + 1) * 4));
   TRY(ctx->probeFirst.ensure((host[CNT_QPOOL] + 1) * 4)); TRY(ctx->probeCnt.ensure((host[CNT_QPOOL] + 1) * 4));
   uint64_t ccap = (uint64_t)((double)nF * ctx->candPerFrag) + 4096;
-  TRY(ctx->l1LargeList.ensure(nF * 4));
-  unsigned nLarge = 0;
+  TRY(ctx->l1LargeList.ensure(nF * 4)); TRY(ctx->l1MidList.ensure(nF * 4));
+  unsigned nLarge = 0, nMid = 0;
   unsigned long long hitsTotal = 0;
   for (int attempt = 0;; attempt++) {
     if (ccap > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
@@ -524,18 +524,20 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
-    a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_CLASSB);
+    a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTL);
+    a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
       if (attempt == 0) hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
-      hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
+      hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr);
       if (attempt == 0) {
-        unsigned long long nl = 0;
-        HIP_TRY(hipMemcpyAsync(&nl, cnt_ptr(ctx, CNT_CLASSB), 8, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long nl[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(nl, cnt_ptr(ctx, CNT_LISTM), 16, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        nLarge = (unsigned)nl;
+        nMid = (unsigned)nl[0]; nLarge = (unsigned)nl[1];
       }
-      if (nLarge) hipLaunchKernelGGL((k_l1<kL1HitCapSmall, kL1HitCapMax>), dim3(nLarge), dim3(kTPB), 0, ctx->stream, a);
+      if (nMid) hipLaunchKernelGGL((k_l1<kL1HitCapSmall, kL1HitCapMid>), dim3(nMid), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.midList);
+      if (nLarge) hipLaunchKernelGGL((k_l1<kL1HitCapMid, kL1HitCapMax>), dim3(nLarge), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.largeList);
       hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, ctx->fragCandCnt.as<int32_t>(),
                          ctx->fragCandCntClamped.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG));
     }
@@ -750,7 +752,7 @@ void ani_shutdown(ani_ctx *c)
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->tiles, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
-                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
+                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();

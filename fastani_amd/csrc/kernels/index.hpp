@@ -3,25 +3,27 @@
 // Replaces skch::Sketch::index (src/map/include/winSketch.hpp:181-193: unordered_map<hash, vector<{seqId,wpos}>>)
 // and skch::Sketch::searchIndex (:259-270) by flat device arrays:
 //   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n]      + contigFirstMin[nContigs+1]
-//   hash order    (≙ minimizerPosLookupIndex)  sHash[n] (sorted), sIdx[n] (rank in position order; stable, so every
-//                                              hash's occurrence list stays in (seqId,wpos) order like :186-190)
+//   hash order    (≙ minimizerPosLookupIndex)  sHash[n] (sorted), sSW[n] = seqId<<32|wpos carried through the stable sort, so
+//                                              every hash's occurrence list is one contiguous run in (seqId,wpos) order (:186-190)
 //   bucket table  bucketStart[2^bits + 1]      lower bounds of the top `bits` hash bits inside sHash
-//   same-hash links (for the L2 set semantics) prevSame[n], nextSame[n]: neighbouring occurrence of the same hash in
-//                                              position order, -1 if none
+//   same-hash links (for the L2 set semantics) prevSame[n], nextSame[n]: neighbouring NEAR occurrence of the same hash in
+//                                              position order (one that can share a super-window), -1 otherwise
 #pragma once
 #include "common.hpp"
 
 namespace ani {
 
-// records: 12-byte (hash, seqId, wpos) triples in position order
+// records: 12-byte (hash, seqId, wpos) triples in position order -> SoA + sort input (key = hash, value = seqId<<32 | wpos)
 __global__ void k_index_split(const uint32_t *__restrict__ records, uint32_t n,
                               uint32_t *__restrict__ mHash, int32_t *__restrict__ mSeq, int32_t *__restrict__ mWpos,
-                              uint32_t *__restrict__ keyOut, uint32_t *__restrict__ valOut)
+                              uint32_t *__restrict__ mWposF, int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame,
+                              uint32_t *__restrict__ keyOut, uint64_t *__restrict__ valOut)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t h = records[3 * (size_t)i];
-    mHash[i] = h; mSeq[i] = (int32_t)records[3 * (size_t)i + 1]; mWpos[i] = (int32_t)records[3 * (size_t)i + 2];
-    keyOut[i] = h; valOut[i] = i;
+    const uint32_t h = records[3 * (size_t)i], sq = records[3 * (size_t)i + 1], wp = records[3 * (size_t)i + 2];
+    mHash[i] = h; mSeq[i] = (int32_t)sq; mWpos[i] = (int32_t)wp;
+    mWposF[i] = wp; prevSame[i] = -1; nextSame[i] = -1;          // links/flags are only written for near duplicates (rare)
+    keyOut[i] = h; valOut[i] = ((uint64_t)sq << 32) | wp;
   }
 }
 
@@ -33,51 +35,43 @@ __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *
   }
 }
 
-// after the stable sort by hash: same-hash neighbours and the unique-hash count
-// also: mWposF[idx] = wpos | nearDup << 31.  nearDup(j) = some same-hash entry j' of the same contig can share a super-window
-// with j.  All entries of a window except its first lie within cmw = countMinimizerWindows positions; the first entry
-// (MIIteratorL2 keeps the minimizer that is active at the window start) may trail by less than the gap to its successor.
-// So for j' < j: possible iff wpos[j] - wpos[j'] <= cmw + (wpos[j'+1] - wpos[j']).  Entries without the flag behave as a
-// plain set member in the L2 fast path; flagged ones consult prevSame/nextSame there.
-__global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint32_t *__restrict__ sIdx, uint32_t n,
-                              int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame,
-                              const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos, int32_t cmw,
-                              uint32_t *__restrict__ mWposF,
+// After the stable sort by hash (sHash[r], sSW[r] = seqId<<32|wpos; equal hashes stay in position order): unique-hash count
+// and, for NEAR duplicates only, the same-hash links and the nearDup flag (bit 31 of mWposF).
+//   nearDup: two same-hash entries j' < j of one contig can share a super-window.  All entries of a window except its first
+//   lie within cmw = countMinimizerWindows positions; the first entry (MIIteratorL2 keeps the minimizer that is active at the
+//   window start) may trail by less than the gap to its successor: possible iff wpos[j] - wpos[j'] <= cmw + (wpos[j'+1] - wpos[j']).
+// Entries without the flag behave as plain set members in L2; prevSame/nextSame of non-near pairs stay -1, which is equivalent
+// for every consumer (they are only ever compared against the bounds of one window).
+__global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t *__restrict__ sSW, uint32_t n,
+                              const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin, int32_t cmw,
+                              int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame, uint32_t *__restrict__ mWposF,
                               unsigned long long *__restrict__ nUnique)
 {
   unsigned long long uniq = 0;
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-    const uint32_t h = sHash[r], idx = sIdx[r];
-    const bool samePrev = r > 0 && sHash[r - 1] == h;
-    const bool sameNext = r + 1 < n && sHash[r + 1] == h;
-    prevSame[idx] = samePrev ? (int32_t)sIdx[r - 1] : -1;
-    nextSame[idx] = sameNext ? (int32_t)sIdx[r + 1] : -1;
-    bool near = false;
-    if (samePrev) {
-      const uint32_t p = sIdx[r - 1];                    // p < idx (stable sort)
-      near |= mSeq[p] == mSeq[idx] && mWpos[idx] - mWpos[p] <= cmw + (mWpos[p + 1] - mWpos[p]);
-    }
-    if (sameNext) {
-      const uint32_t q = sIdx[r + 1];                    // q > idx
-      near |= mSeq[q] == mSeq[idx] && mWpos[q] - mWpos[idx] <= cmw + (mWpos[idx + 1] - mWpos[idx]);
-    }
-    mWposF[idx] = (uint32_t)mWpos[idx] | (near ? 0x80000000u : 0u);
+    const bool samePrev = r > 0 && sHash[r - 1] == sHash[r];
     uniq += !samePrev;
+    if (!samePrev) continue;
+    const uint64_t a = sSW[r - 1], b = sSW[r];                   // a is positionally before b
+    if ((a >> 32) != (b >> 32)) continue;                        // different contigs never share a window
+    const int32_t seq = (int32_t)(a >> 32), wa = (int32_t)(uint32_t)a, wb = (int32_t)(uint32_t)b;
+    if (wb - wa > cmw + 65536) continue;                         // cheap reject before the searches
+    // positional indices: binary search on wpos inside the contig's slice
+    int32_t lo = contigFirstMin[seq], hi = contigFirstMin[seq + 1];
+    const int32_t cHi = hi;
+    while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wa) lo = mid + 1; else hi = mid; }
+    const int32_t ia = lo;
+    const int32_t gap = (ia + 1 < cHi) ? mWpos[ia + 1] - wa : 0;
+    if (wb - wa > cmw + gap) continue;
+    hi = cHi;
+    while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wb) lo = mid + 1; else hi = mid; }
+    const int32_t ib = lo;
+    nextSame[ia] = ib; prevSame[ib] = ia;
+    atomicOr(&mWposF[ia], 0x80000000u); atomicOr(&mWposF[ib], 0x80000000u);
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) uniq += __shfl_down(uniq, d);
   if ((threadIdx.x & 63) == 0 && uniq) atomicAdd(nUnique, uniq);
-}
-
-// hash-ordered payload for the L1 gather: sSW[r] = (seqId << 32) | wpos of the r-th entry in hash order, so that the
-// occurrence list of one hash is one contiguous run of 8-byte words
-__global__ void k_index_payload(const uint32_t *__restrict__ sIdx, const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
-                                uint32_t n, uint64_t *__restrict__ sSW)
-{
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-    const uint32_t idx = sIdx[r];
-    sSW[r] = ((uint64_t)(uint32_t)mSeq[idx] << 32) | (uint32_t)mWpos[idx];
-  }
 }
 
 // bucketStart[b] = first r with (sHash[r] >> shift) >= b, for b = 0..nBuckets (inclusive)

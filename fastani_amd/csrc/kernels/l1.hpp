@@ -9,7 +9,7 @@
 // dependent loads are hidden by occupancy.  k_l1<HLO,HCAP>: one workgroup per fragment with HLO < H <= HCAP seed hits,
 // everything in LDS: gather the hit runs as 64-bit (seqId<<32 | wpos) keys, bitonic sort, flag valid runs, compact, flag
 // group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous candidate" only needs
-// the previous valid run), scan, emit.  Two LDS classes (<= 2048 hits: 6 workgroups per CU; <= 8192 hits).  Larger
+// the previous valid run), scan, emit.  Three LDS classes (<= 2048 hits: 6 workgroups per CU; <= 4096; <= 8192), the larger two driven by fragment lists.  Larger
 // fragments are flagged (fragCandCnt = -1): overflow path.
 #pragma once
 #include "common.hpp"
@@ -18,7 +18,8 @@ namespace ani {
 
 constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS classes accept
 constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 8 KiB scratch -> 6 workgroups per CU
-constexpr int kL1HitCapMax = 8192;      // class L: 64 KiB + 32 KiB -> 1 workgroup per CU (rare: > 2048 seed hits in one fragment)
+constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgroups per CU
+constexpr int kL1HitCapMax = 8192;      // class L: 64 KiB + 32 KiB -> 1 workgroup per CU (rare)
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
@@ -28,7 +29,8 @@ struct L1Args {
   int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
   uint32_t *fragCandOff; int32_t *fragCandCnt; int32_t *fragHits;
   uint32_t *probeFirst, *probeCnt;      // per sketch hash (aligned with qPool): occurrence run in the hash-sorted index
-  int32_t *largeList; unsigned int *largeCount;   // fragments with kL1HitCapSmall < H <= kL1HitCapMax
+  int32_t *midList; unsigned int *midCount;       // fragments with kL1HitCapSmall < H <= kL1HitCapMid
+  int32_t *largeList; unsigned int *largeCount;   // fragments with kL1HitCapMid < H <= kL1HitCapMax
   unsigned long long *sumHits;
 };
 
@@ -87,20 +89,23 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
   if (threadIdx.x == 0) {
     a.fragHits[f] = H;
     if (H) atomicAdd(a.sumHits, (unsigned long long)H);
-    // fragments of the large LDS class are listed so that its 96 KiB workgroups are only launched for them
-    if (H > kL1HitCapSmall && H <= kL1HitCapMax && s <= kL1MaxS) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
+    // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
+    if (s <= kL1MaxS) {
+      if (H > kL1HitCapSmall && H <= kL1HitCapMid) a.midList[atomicAdd(a.midCount, 1u)] = f;
+      else if (H > kL1HitCapMid && H <= kL1HitCapMax) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
+    }
   }
 }
 
 // Pass 2: gather + sort + candidate regions for the fragments whose hit count is in (HLO, HCAP]; everything in LDS.
 template <int HLO, int HCAP>
-__global__ __launch_bounds__(kTPB) void k_l1(L1Args a)
+__global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict__ list)
 {
   __shared__ uint64_t hits[HCAP];
   __shared__ int V[HCAP];
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
-  const int f = HLO == 0 ? (int)blockIdx.x : a.largeList[blockIdx.x];
+  const int f = list ? list[blockIdx.x] : (int)blockIdx.x;
   const int t = threadIdx.x;
   const int s = a.fragS[f];
   const int H = a.fragHits[f];

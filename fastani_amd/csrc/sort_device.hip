@@ -1,4 +1,4 @@
-// sort_device.hip — the one library call on the path: a stable LSD radix sort of (hash, position-rank) pairs that
+// sort_device.hip — the one library call on the path: a stable LSD radix sort of (hash, seqId<<32|wpos) pairs that
 // orders the reference minimizers by hash (≙ filling minimizerPosLookupIndex, src/map/include/winSketch.hpp:181-193).
 // rocPRIM's device radix sort is used as plumbing; everything else on the path is hand-written.
 #include <cstring>
@@ -6,8 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 
-extern "C" int ani_sort_pairs_u32(const uint32_t *keysIn, uint32_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
-                                  size_t n, hipStream_t stream)
+extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
+                                      size_t n, hipStream_t stream)
 {
   if (n == 0) return 0;
   size_t tmpBytes = 0;

@@ -3,8 +3,8 @@
 #include <algorithm>
 #include <numeric>
 #include <vector>
-extern "C" int ani_sort_pairs_u32(const uint32_t *keysIn, uint32_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
-                                  size_t n, hipStream_t)
+extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
+                                      size_t n, hipStream_t)
 {
   std::vector<uint32_t> ord(n);
   std::iota(ord.begin(), ord.end(), 0u);
