@@ -29,6 +29,7 @@
 #include "kernels/sketch.hpp"
 #include "kernels/synth.hpp"
 
+extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, hipStream_t stream);
 extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
                                       size_t n, hipStream_t stream);
 
@@ -93,7 +94,7 @@ struct ani_ctx {
   DevBuf tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
-  DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
+  DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
   DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList, l2ClassList;
@@ -123,7 +124,7 @@ struct ani_sketch {
 namespace {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_N = 24 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_N = 24 };
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
@@ -507,8 +508,9 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   TRY(ctx->fragHits.ensure(nF * 4)); TRY(ctx->fragOrdOff.ensure((nF + 1) * 4));
   TRY(ctx->probeFirst.ensure((host[CNT_QPOOL] + 1) * 4)); TRY(ctx->probeCnt.ensure((host[CNT_QPOOL] + 1) * 4));
   uint64_t ccap = (uint64_t)((double)nF * ctx->candPerFrag) + 4096;
-  TRY(ctx->l1LargeList.ensure(nF * 4)); TRY(ctx->l1MidList.ensure(nF * 4));
-  unsigned nLarge = 0, nMid = 0;
+  TRY(ctx->l1LargeList.ensure(nF * 4)); TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
+  unsigned nLarge = 0, nMid = 0, nBig = 0;
+  std::vector<int32_t> bigFrags, bigS, bigH;
   unsigned long long hitsTotal = 0;
   for (int attempt = 0;; attempt++) {
     if (ccap > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
@@ -526,18 +528,36 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
     a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTL);
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
+    a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
       if (attempt == 0) hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
       hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr);
       if (attempt == 0) {
-        unsigned long long nl[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(nl, cnt_ptr(ctx, CNT_LISTM), 16, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long nl[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(nl, cnt_ptr(ctx, CNT_LISTM), 24, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        nMid = (unsigned)nl[0]; nLarge = (unsigned)nl[1];
+        nMid = (unsigned)nl[0]; nLarge = (unsigned)nl[1]; nBig = (unsigned)nl[2];
+        if (nBig) {
+          bigFrags.resize(nBig); bigS.resize(nBig); bigH.resize(nBig);
+          HIP_TRY(hipMemcpy(bigFrags.data(), ctx->l1BigList.p, (size_t)nBig * 4, hipMemcpyDeviceToHost));
+          for (unsigned i = 0; i < nBig; i++) {
+            HIP_TRY(hipMemcpy(&bigS[i], ctx->fragS.as<int32_t>() + bigFrags[i], 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&bigH[i], ctx->fragHits.as<int32_t>() + bigFrags[i], 4, hipMemcpyDeviceToHost));
+          }
+        }
       }
       if (nMid) hipLaunchKernelGGL((k_l1<kL1HitCapSmall, kL1HitCapMid>), dim3(nMid), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.midList);
       if (nLarge) hipLaunchKernelGGL((k_l1<kL1HitCapMid, kL1HitCapMax>), dim3(nLarge), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.largeList);
+      for (unsigned i = 0; i < nBig; i++) {          // oversized fragments: global-memory path, one at a time
+        const size_t H = (size_t)bigH[i], sz = (size_t)bigS[i];
+        if (H == 0) { int32_t z = 0; HIP_TRY(hipMemcpyAsync(ctx->fragCandCnt.as<int32_t>() + bigFrags[i], &z, 4, hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); continue; }
+        TRY(ctx->l1BigHitsA.ensure(H * 8)); TRY(ctx->l1BigHitsB.ensure(H * 8)); TRY(ctx->l1BigV.ensure(std::max(H, sz) * 4 + 16));
+        hipLaunchKernelGGL(k_l1_big_gather, dim3(1), dim3(kTPB), 0, ctx->stream, a, bigFrags[i], ctx->l1BigV.as<int>(), ctx->l1BigHitsA.as<uint64_t>());
+        int rc = ani_sort_keys_u64(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), H, ctx->stream);
+        if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of seed hits failed (%d)", rc);
+        hipLaunchKernelGGL(k_l1_big_candidates, dim3(1), dim3(kTPB), 0, ctx->stream, a, bigFrags[i], (const uint64_t *)ctx->l1BigHitsB.as<uint64_t>(), ctx->l1BigV.as<int>());
+      }
       hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, ctx->fragCandCnt.as<int32_t>(),
                          ctx->fragCandCntClamped.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG));
     }
@@ -752,7 +772,7 @@ void ani_shutdown(ani_ctx *c)
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->tiles, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
-                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
+                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();

@@ -10,7 +10,7 @@
 // everything in LDS: gather the hit runs as 64-bit (seqId<<32 | wpos) keys, bitonic sort, flag valid runs, compact, flag
 // group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous candidate" only needs
 // the previous valid run), scan, emit.  Three LDS classes (<= 2048 hits: 6 workgroups per CU; <= 4096; <= 8192), the larger two driven by fragment lists.  Larger
-// fragments are flagged (fragCandCnt = -1): overflow path.
+// fragments take k_l1_big_gather -> device radix sort -> k_l1_big_candidates over global memory.
 #pragma once
 #include "common.hpp"
 
@@ -31,6 +31,7 @@ struct L1Args {
   uint32_t *probeFirst, *probeCnt;      // per sketch hash (aligned with qPool): occurrence run in the hash-sorted index
   int32_t *midList; unsigned int *midCount;       // fragments with kL1HitCapSmall < H <= kL1HitCapMid
   int32_t *largeList; unsigned int *largeCount;   // fragments with kL1HitCapMid < H <= kL1HitCapMax
+  int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
   unsigned long long *sumHits;
 };
 
@@ -70,6 +71,49 @@ __device__ __forceinline__ bool l1_head(const uint64_t *hits, const int *V, int 
   return hit_seq(x) != hit_seq(px) || hit_wpos(px) < start;
 }
 
+// Sorted hits -> candidate regions of one fragment (computeMap.hpp:313-354).  hits/V may live in LDS or in global memory.
+__device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, const uint64_t *hits, int *V, int *ws,
+                                          unsigned long long *sBasePtr)
+{
+  const int t = threadIdx.x;
+  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1; if (m < 1) m = 1;      // :301, :316
+  const int nA = H - m + 1;
+  int nG = 0;
+  if (nA > 0) {
+    // valid runs, compacted in order
+    int per = (nA + kTPB - 1) / kTPB;
+    int lo = t * per, hi = lo + per < nA ? lo + per : nA;
+    int c = 0;
+    for (int x = lo; x < hi; x++) c += l1_valid(hits, x, m, a.L);
+    int nv; int r = block_excl_scan(c, ws, &nv);
+    for (int x = lo; x < hi; x++) if (l1_valid(hits, x, m, a.L)) V[r++] = x;
+    __syncthreads();
+    // candidate heads
+    per = (nv + kTPB - 1) / kTPB;
+    lo = t * per; hi = lo + per < nv ? lo + per : nv;
+    c = 0;
+    for (int j = lo; j < hi; j++) c += l1_head(hits, V, j, m, a.L);
+    int g = block_excl_scan(c, ws, &nG);
+    if (t == 0) *sBasePtr = nG ? atomicAdd(a.candCount, (unsigned long long)nG) : 0ull;
+    __syncthreads();
+    const unsigned long long base = *sBasePtr;
+    if (base + (unsigned long long)nG <= (unsigned long long)a.candCap) {
+      for (int j = lo; j < hi; j++) {
+        const bool head = l1_head(hits, V, j, m, a.L);
+        if (head) g++;
+        const unsigned long long slot = base + (unsigned long long)(g - 1);     // group of run j
+        if (head) {
+          int32_t start = hit_wpos(hits[V[j] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
+          a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[j]]); a.candStart[slot] = start;
+        }
+        if (j == nv - 1 || l1_head(hits, V, j + 1, m, a.L)) a.candEnd[slot] = hit_wpos(hits[V[j]]);   // :336,:347
+      }
+    }
+    if (t == 0) a.fragCandOff[f] = (uint32_t)base;
+  } else if (t == 0) a.fragCandOff[f] = 0;
+  if (t == 0) a.fragCandCnt[f] = nG;
+}
+
 // Pass 1: probes only.  No LDS, one lane per query hash: the dependent loads of a probe (bucket table -> hash-sorted index)
 // are covered by occupancy instead of stalling the LDS-heavy sort kernel.  Writes (first, cnt) per sketch hash and H per fragment.
 __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
@@ -90,10 +134,10 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
     a.fragHits[f] = H;
     if (H) atomicAdd(a.sumHits, (unsigned long long)H);
     // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
-    if (s <= kL1MaxS) {
+    if (s <= kL1MaxS && H <= kL1HitCapMax) {
       if (H > kL1HitCapSmall && H <= kL1HitCapMid) a.midList[atomicAdd(a.midCount, 1u)] = f;
-      else if (H > kL1HitCapMid && H <= kL1HitCapMax) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
-    }
+      else if (H > kL1HitCapMid) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
+    } else a.bigList[atomicAdd(a.bigCount, 1u)] = f;           // beyond every LDS class: global-memory path
   }
 }
 
@@ -113,10 +157,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
     if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; }
     return;
   }
-  if (HLO == 0 && (s > kL1MaxS || H > kL1HitCapMax)) {            // beyond every LDS class: overflow path
-    if (t == 0) { a.fragCandCnt[f] = -1; a.fragCandOff[f] = 0; }
-    return;
-  }
+  if (HLO == 0 && (s > kL1MaxS || H > kL1HitCapMax)) return;       // beyond every LDS class: k_l1_big_* below
   if (H <= HLO || H > HCAP || s <= 0 || s > kL1MaxS) return;     // another class handles it
   const uint32_t off = a.fragOff[f];
   int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)
@@ -133,42 +174,32 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   for (int i = H + t; i < n2; i += kTPB) hits[i] = ~0ull;
   block_bitonic_sort<uint64_t>(hits, n2);           // :320 (starts with a barrier: the gather is complete)
 
-  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1; if (m < 1) m = 1;      // :301, :316
-  const int nA = H - m + 1;
-  int nG = 0;
-  if (nA > 0) {
-    // valid runs, compacted in order
-    int per = (nA + kTPB - 1) / kTPB;
-    int lo = t * per, hi = lo + per < nA ? lo + per : nA;
-    int c = 0;
-    for (int x = lo; x < hi; x++) c += l1_valid(hits, x, m, a.L);
-    int nv; int r = block_excl_scan(c, ws, &nv);
-    for (int x = lo; x < hi; x++) if (l1_valid(hits, x, m, a.L)) V[r++] = x;
-    __syncthreads();
-    // candidate heads
-    per = (nv + kTPB - 1) / kTPB;
-    lo = t * per; hi = lo + per < nv ? lo + per : nv;
-    c = 0;
-    for (int j = lo; j < hi; j++) c += l1_head(hits, V, j, m, a.L);
-    int g = block_excl_scan(c, ws, &nG);
-    if (t == 0) sBase = nG ? atomicAdd(a.candCount, (unsigned long long)nG) : 0ull;
-    __syncthreads();
-    const unsigned long long base = sBase;
-    if (base + (unsigned long long)nG <= (unsigned long long)a.candCap) {
-      for (int j = lo; j < hi; j++) {
-        const bool head = l1_head(hits, V, j, m, a.L);
-        if (head) g++;
-        const unsigned long long slot = base + (unsigned long long)(g - 1);     // group of run j
-        if (head) {
-          int32_t start = hit_wpos(hits[V[j] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
-          a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[j]]); a.candStart[slot] = start;
-        }
-        if (j == nv - 1 || l1_head(hits, V, j + 1, m, a.L)) a.candEnd[slot] = hit_wpos(hits[V[j]]);   // :336,:347
-      }
-    }
-    if (t == 0) a.fragCandOff[f] = (uint32_t)base;
-  } else if (t == 0) a.fragCandOff[f] = 0;
-  if (t == 0) a.fragCandCnt[f] = nG;
+  l1_emit_candidates(a, f, s, H, hits, V, ws, &sBase);
+}
+
+// Fragments beyond the LDS classes (low-complexity / highly repetitive references): same algorithm over global memory,
+// one workgroup per fragment, the sort done by the device radix sort between the two kernels.
+__global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, int f, int *__restrict__ offTmp, uint64_t *__restrict__ hitsOut)
+{
+  __shared__ int ws[16];
+  const int s = a.fragS[f];
+  const int H = a.fragHits[f];
+  const uint32_t off = a.fragOff[f];
+  for (int i = threadIdx.x; i < s; i += kTPB) offTmp[i] = (int)a.probeCnt[off + i];
+  __syncthreads();
+  block_array_excl_scan(offTmp, s, ws);
+  for (int i = threadIdx.x; i < s; i += kTPB) {
+    const int o = offTmp[i], e = (i + 1 < s) ? offTmp[i + 1] : H;
+    const uint32_t fi = a.probeFirst[off + i];
+    for (int c = 0; c < e - o; c++) hitsOut[o + c] = a.sSW[fi + c];
+  }
+}
+
+__global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, int f, const uint64_t *__restrict__ hitsSorted, int *__restrict__ V)
+{
+  __shared__ int ws[16];
+  __shared__ unsigned long long sBase;
+  l1_emit_candidates(a, f, a.fragS[f], a.fragHits[f], hitsSorted, V, ws, &sBase);
 }
 
 // reorder candidates into the reference's callback order: fragment ascending, then (seqId, start) as produced

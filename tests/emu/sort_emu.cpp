@@ -12,3 +12,11 @@ extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut,
   for (size_t i = 0; i < n; i++) { keysOut[i] = keysIn[ord[i]]; valsOut[i] = valsIn[ord[i]]; }
   return 0;
 }
+
+extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, hipStream_t)
+{
+  std::vector<uint64_t> v(keysIn, keysIn + n);
+  std::sort(v.begin(), v.end());
+  for (size_t i = 0; i < n; i++) keysOut[i] = v[i];
+  return 0;
+}

@@ -120,6 +120,19 @@ def case_low_complexity(engine):
     check_queries(engine, p, sk, osk, [[rep(128, 9000)], [rep(64, 6000)]])
 
 
+def case_low_complexity_big(engine):
+    """thousands of seed hits per fragment (> every LDS class): L1 global-memory path, L2 ranges beyond the fast-path limit.
+    The reference's own repeat tests (tests/fastani_tests.cpp:302-416) guard such inputs with -s; without it they still map."""
+    def rep(na, n):
+        return np.frombuffer((b"A" * na + b"T") * (n // (na + 1) + 1), dtype=np.uint8)[:n]
+    genomes = [[rep(64, 40000)], [rep(128, 21000)], [orc.synth_genome(2, 0, 9000)]]
+    p, sk, osk = check_sketch(engine, genomes)
+    engine.reset_counters()
+    check_queries(engine, p, sk, osk, [[rep(128, 6000)], [np.full(3000, ord("A"), dtype=np.uint8)], genomes[2]])
+    c = engine.counters()
+    assert c["l2SlowCandidates"] > 0          # candidate ranges longer than 16384 entries went through the general kernel
+
+
 def case_empty_and_short(engine):
     genomes = [[b"ACGT" * 3], [orc.synth_genome(2, 0, 30000)], [b""], [orc.synth_genome(2, 1, 2999)]]
     p, sk, osk = check_sketch(engine, genomes)
@@ -153,4 +166,4 @@ def case_device_synth(engine, alloc):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_empty_and_short]
+             case_low_complexity_big, case_empty_and_short]
