@@ -202,7 +202,8 @@ def main():
         # roofline of the dominant kernel: algorithmic bytes / HIP-event time of its launches, timed region only
         l2_bytes = 12.0 * c["l2WindowEntries"] + 4.0 * c["l2QueryHashes"]
         cand = {
-            "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate"),
+            "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes - (12.0 * c["l2WindowEntriesB"] + 4.0 * c["l2QueryHashesB"]),
+                              "class-A launches (k_l2_sim<L2Geom<255>>): 12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per class-A candidate"),
             "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate"),
             "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
             "ani::k_l1": (c["msL1"], 4.0 * c["querySketchHashes"] + 8.0 * c["seedHits"], "4 B x fragment sketch hashes + 8 B x seed hits"),
@@ -217,6 +218,17 @@ def main():
                 "algorithmic_bytes": what, "kernel_ms_per_step": round(ms / args.steps, 3),
                 "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in cand.items()},
                 "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()}}
+        # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
+        # + WRITE_SIZE, per launch; profiles/r01e_pmc_traffic.json) — only quoted when it is this default workload
+        try:
+            if NG == 1000 and L == 5_000_000 and world == 1:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")))
+                key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
+                if key in tj["kernels"]:
+                    roof["traffic"] = tj["kernels"][key]["hbm_bytes_per_launch_corrected"]
+                    roof["traffic_source"] = "profiles/r01e_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         if dom == "ani::k_l2_sim":
             launches = max(1, c["l2Launches"])
             roof.update({"launches": int(launches), "avg_launch_ms": round(ms / launches, 4),

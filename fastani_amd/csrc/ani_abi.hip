@@ -124,7 +124,7 @@ struct ani_sketch {
 namespace {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_N = 24 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_ENTRIES_B = 19, CNT_SUMQ_B = 20, CNT_STEPS_B = 21, CNT_N = 24 };
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
@@ -641,11 +641,16 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
           hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)nullptr, (const unsigned int *)nullptr);
+        }
+        {
+          StageTimer tk(ctx, &ctx->counters.msL2SimB, 1);
           // the few class-B candidates (s in 256..319) are compacted first so that they fill whole waves
           HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CLASSB), 0, 8, ctx->stream));
           hipLaunchKernelGGL(k_l2_collect_class, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag, 4,
                              ctx->l2ClassList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
-          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)ctx->l2ClassList.as<int32_t>(),
+          L2FastArgs fb = fa;       // class B accumulates its algorithmic-byte counters separately
+          fb.g.sumEntries = cnt_ptr(ctx, CNT_ENTRIES_B); fb.g.sumQ = cnt_ptr(ctx, CNT_SUMQ_B); fb.g.sumSteps = cnt_ptr(ctx, CNT_STEPS_B);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fb, (const int32_t *)ctx->l2ClassList.as<int32_t>(),
                              (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
         }
         ctx->counters.l2Launches++;
@@ -679,7 +684,9 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     HIP_TRY(hipGetLastError());
   }
   TRY(read_counters(ctx, host));
-  ctx->counters.l2WindowEntries += host[CNT_ENTRIES]; ctx->counters.l2Steps += host[CNT_STEPS]; ctx->counters.l2QueryHashes += host[CNT_SUMQ];
+  ctx->counters.l2WindowEntries += host[CNT_ENTRIES] + host[CNT_ENTRIES_B]; ctx->counters.l2Steps += host[CNT_STEPS] + host[CNT_STEPS_B];
+  ctx->counters.l2QueryHashes += host[CNT_SUMQ] + host[CNT_SUMQ_B];
+  ctx->counters.l2WindowEntriesB += host[CNT_ENTRIES_B]; ctx->counters.l2QueryHashesB += host[CNT_SUMQ_B];
   ctx->counters.l2SlowLimit += host[CNT_REASON + 1]; ctx->counters.l2SlowDup += host[CNT_REASON + 2]; ctx->counters.l2SlowOverflow += host[CNT_REASON + 3];
   return ANI_OK;
 }

@@ -96,6 +96,7 @@ typedef struct {
   uint64_t l2WindowEntries;   /* Σ m_c over candidates */
   uint64_t l2Steps;           /* Σ super-window placements evaluated */
   uint64_t l2QueryHashes;     /* Σ s over candidates (each candidate reads its fragment sketch once) */
+  uint64_t l2WindowEntriesB, l2QueryHashesB;   /* the share of the two sums above handled by the class-B simulation launches */
   uint64_t l2Launches;        /* launches of the dominant L2 kernel (ani::k_l2_sim) */
   uint64_t l2FastCandidates;  /* candidates finished by the LDS fast path */
   uint64_t l2SlowCandidates;  /* candidates routed to the general kernel (ani::k_l2) */
@@ -103,8 +104,9 @@ typedef struct {
   uint64_t mappings;
   uint64_t cgiRows;
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
-  double msL2Kernel;          /* HIP-event time of the ani::k_l2_sim launches alone (on the launch stream) */
+  double msL2Kernel;          /* HIP-event time of the class-A ani::k_l2_sim launches alone (on the launch stream) */
   double msL2Ranges, msL2Codes, msL2Slow;   /* ani::k_l2_ranges, ani::k_l2_codes, ani::k_l2 */
+  double msL2SimB;            /* class-B simulation launches (ani::k_l2_sim<L2Geom<319>> + its list compaction) */
 } ani_counters_t;
 
 /* ---- life cycle ---- */
