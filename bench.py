@@ -161,6 +161,7 @@ def main():
             cl = counts.tolist()
             mx = max(cl)
             mine = torch.zeros(mx * 3, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()                          # the library copies on its own stream
             if n:
                 e.device_copy(mine.data_ptr(), ptr, n * 12)
                 e.device_free(ptr)
