@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -45,6 +47,46 @@ int fail(int code, const char *fmt, ...)
   return code;
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Caching device allocator: hipMalloc/hipFree of multi-GB arrays cost milliseconds each and a many-to-many run builds and
+// drops the same-sized index arrays over and over; freed blocks are kept and handed out again (best fit within 25 %).
+// On allocation failure the cache is dropped and the request retried.
+// -----------------------------------------------------------------------------------------------------
+struct DevicePool {
+  std::mutex mu;
+  std::unordered_map<void *, size_t> live;
+  std::multimap<size_t, void *> cache;
+  size_t cachedBytes = 0;
+  hipError_t alloc(void **out, size_t bytes)
+  {
+    if (bytes == 0) bytes = 1;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.lower_bound(bytes);
+    if (it != cache.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
+      *out = it->second; live[*out] = it->first; cachedBytes -= it->first; cache.erase(it);
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) { trim_locked(); (void)hipGetLastError(); e = hipMalloc(out, bytes); }
+    if (e == hipSuccess) live[*out] = bytes;
+    return e;
+  }
+  void release(void *p)
+  {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = live.find(p);
+    if (it == live.end()) { (void)hipFree(p); return; }
+    cache.emplace(it->second, p); cachedBytes += it->second; live.erase(it);
+  }
+  void trim_locked() { for (auto &kv : cache) (void)hipFree(kv.second); cache.clear(); cachedBytes = 0; }
+  void trim() { std::lock_guard<std::mutex> g(mu); trim_locked(); }
+};
+DevicePool g_pools[64];          // one per device ordinal (one process normally drives one GPU)
+inline DevicePool &cur_pool() { int d = 0; (void)hipGetDevice(&d); return g_pools[(d < 0 || d >= 64) ? 0 : d]; }
+inline hipError_t pool_malloc(void **p, size_t bytes) { return cur_pool().alloc(p, bytes); }
+inline void pool_free(void *p) { cur_pool().release(p); }
+
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t e_ = (expr);                                                                             \
@@ -59,14 +101,14 @@ struct DevBuf {
   int ensure(size_t bytes)
   {
     if (bytes <= cap) return ANI_OK;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (p) { pool_free(p); p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = pool_malloc(&p, want);
     if (e != hipSuccess) { p = nullptr; return fail(ANI_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
     cap = want;
     return ANI_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) pool_free(p); p = nullptr; cap = 0; }
   template <class T> T *as() const { return (T *)p; }
 };
 
@@ -91,13 +133,13 @@ struct ani_ctx {
   DevBuf dCounters;
   // workspaces reused across calls
   DevBuf seqPacked, seqAscii, contigOff, contigLen, contigMode;
-  DevBuf tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
+  DevBuf unitStart, unitAux, tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
   DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
-  DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList, l2ClassList;
+  DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList, l2ClassList, l2Order, l2LenHist;
   DevBuf bins, queryFragments, rows;
 };
 
@@ -286,23 +328,31 @@ using namespace ani;
 int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, int32_t seqIdBase, uint32_t **dRecords, size_t *nOut)
 {
   const int k = p->kmerSize, w = p->windowSize;
-  std::vector<TileDesc> tiles;
+  // per-contig tile prefix; the 1.6 M tile descriptors of a 1000-genome batch are expanded on the device
+  std::vector<uint32_t> tileStart((size_t)db.nContigs + 1, 0);
   const int stride = kTile - (w - 1);
-  uint64_t positions = 0;
+  uint64_t positions = 0, nT64 = 0;
   for (int32_t c = 0; c < db.nContigs; c++) {
+    tileStart[c] = (uint32_t)nT64;
     const int32_t len = db.contigLen[c];
     if (len < w || len < k) continue;                       // winSketch.hpp:153
     const int32_t nPos = len - k + 1;
     positions += (uint64_t)nPos;
-    for (int64_t B = 0; B == 0 || B + (w - 1) < nPos; B += stride) tiles.push_back(TileDesc{c, (int32_t)B});
+    uint64_t cnt = 1;                                       // tiles B = 0, stride, ... while B + (w-1) < nPos
+    if (nPos > w - 1) cnt = ((uint64_t)(nPos - (w - 1)) + stride - 1) / stride;
+    nT64 += cnt;
+    if (nT64 > 0x7fffffffull) return fail(ANI_ERR_LIMIT, "too many tiles in one reference batch");
   }
-  const size_t nT = tiles.size();
+  tileStart[db.nContigs] = (uint32_t)nT64;
+  const size_t nT = (size_t)nT64;
   *dRecords = nullptr; *nOut = 0;
   if (nT == 0) return ANI_OK;
-  if (nT > 0x7fffffffu) return fail(ANI_ERR_LIMIT, "too many tiles in one reference batch");
   TRY(ctx->tiles.ensure(nT * sizeof(TileDesc))); TRY(ctx->tileMeta.ensure(nT * sizeof(TileMeta)));
   TRY(ctx->tileCnt.ensure(nT * 4)); TRY(ctx->tileDrop.ensure(nT)); TRY(ctx->tileOff.ensure((nT + 1) * 4));
-  HIP_TRY(hipMemcpyAsync(ctx->tiles.p, tiles.data(), nT * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+  TRY(ctx->unitStart.ensure(tileStart.size() * 4));
+  HIP_TRY(hipMemcpyAsync(ctx->unitStart.p, tileStart.data(), tileStart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_expand_tiles, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), db.nContigs, (uint32_t)nT, stride,
+                     ctx->tiles.as<TileDesc>());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
 
   uint64_t cap = (uint64_t)((double)positions * 2.6 / (w + 1)) + 64 * nT + 4096;
@@ -332,7 +382,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
   if (total >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "reference batch yields >= 2^31 minimizers; split the reference list");
   if (total == 0) return ANI_OK;
   uint32_t *rec = nullptr;
-  HIP_TRY(hipMalloc((void **)&rec, total * 12));
+  HIP_TRY(pool_malloc((void **)&rec, total * 12));
   hipLaunchKernelGGL(k_sketch_gather, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, ctx->tiles.as<TileDesc>(), ctx->tileMeta.as<TileMeta>(),
                      ctx->tileDrop.as<uint8_t>(), ctx->tileOff.as<uint32_t>(), ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(),
                      seqIdBase, rec);
@@ -346,7 +396,7 @@ void free_sketch_device(ani_sketch *sk)
 {
   void *ptrs[] = {sk->sSW, sk->mWposF, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->bucketStart, sk->contigFirstMin,
                   sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
-  for (void *q : ptrs) if (q) (void)hipFree(q);
+  for (void *q : ptrs) if (q) pool_free(q);
 }
 
 int upload_luts(ani_sketch *sk, int maxS)
@@ -355,9 +405,9 @@ int upload_luts(ani_sketch *sk, int maxS)
   int target = std::max(maxS, 512);
   if (target > sk->params.fragLen) target = std::max(maxS, std::min(target, sk->params.fragLen));
   sk->luts.extend(sk->params.kmerSize, sk->params.percentageIdentity, target);
-  if (sk->dMinHits) { (void)hipFree(sk->dMinHits); (void)hipFree(sk->dMinShared); (void)hipFree(sk->dIdLUT); sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr; }
+  if (sk->dMinHits) { pool_free(sk->dMinHits); pool_free(sk->dMinShared); pool_free(sk->dIdLUT); sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr; }
   const size_t n1 = (size_t)sk->luts.maxS + 1, n2 = sk->luts.idBits.size();
-  HIP_TRY(hipMalloc((void **)&sk->dMinHits, n1 * 4)); HIP_TRY(hipMalloc((void **)&sk->dMinShared, n1 * 4)); HIP_TRY(hipMalloc((void **)&sk->dIdLUT, n2 * 4 + 4));
+  HIP_TRY(pool_malloc((void **)&sk->dMinHits, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dMinShared, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dIdLUT, n2 * 4 + 4));
   HIP_TRY(hipMemcpy(sk->dMinHits, sk->luts.minHits.data(), n1 * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(sk->dMinShared, sk->luts.minShared.data(), n1 * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(sk->dIdLUT, sk->luts.idBits.data(), n2 * 4, hipMemcpyHostToDevice));
@@ -381,22 +431,22 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
 #define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
 #define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const size_t n4 = (n ? n : 1) * 4;
-  SK_HIP(hipMalloc((void **)&sk->mHash, n4)); SK_HIP(hipMalloc((void **)&sk->mSeq, n4)); SK_HIP(hipMalloc((void **)&sk->mWpos, n4));
-  SK_HIP(hipMalloc((void **)&sk->prevSame, n4)); SK_HIP(hipMalloc((void **)&sk->nextSame, n4));
-  SK_HIP(hipMalloc((void **)&sk->sHash, n4)); SK_HIP(hipMalloc((void **)&sk->mWposF, n4)); SK_HIP(hipMalloc((void **)&sk->sSW, 2 * n4));
+  SK_HIP(pool_malloc((void **)&sk->mHash, n4)); SK_HIP(pool_malloc((void **)&sk->mSeq, n4)); SK_HIP(pool_malloc((void **)&sk->mWpos, n4));
+  SK_HIP(pool_malloc((void **)&sk->prevSame, n4)); SK_HIP(pool_malloc((void **)&sk->nextSame, n4));
+  SK_HIP(pool_malloc((void **)&sk->sHash, n4)); SK_HIP(pool_malloc((void **)&sk->mWposF, n4)); SK_HIP(pool_malloc((void **)&sk->sSW, 2 * n4));
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
     uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
-    SK_HIP(hipMalloc((void **)&tmpK, n4)); SK_HIP(hipMalloc((void **)&tmpV, 2 * n4));
+    SK_HIP(pool_malloc((void **)&tmpK, n4)); SK_HIP(pool_malloc((void **)&tmpV, 2 * n4));
     if (n) {
       hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, sk->mWposF,
                          sk->prevSame, sk->nextSame, tmpK, tmpV);
       int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, ctx->stream);
-      if (rc != 0) { (void)hipFree(tmpK); (void)hipFree(tmpV); return bail(fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
+      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
     }
-    (void)hipFree(tmpK); (void)hipFree(tmpV);
+    pool_free(tmpK); pool_free(tmpV);
     SK_TRY(zero_counters(ctx));
-    SK_HIP(hipMalloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
+    SK_HIP(pool_malloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
     hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
     if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
                               (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
@@ -404,7 +454,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     int bits = 10;
     while (bits < 28 && (1ull << bits) < n) bits++;
     sk->bucketShift = 32 - bits; sk->nBuckets = 1u << bits;
-    SK_HIP(hipMalloc((void **)&sk->bucketStart, ((size_t)sk->nBuckets + 1) * 4));
+    SK_HIP(pool_malloc((void **)&sk->bucketStart, ((size_t)sk->nBuckets + 1) * 4));
     hipLaunchKernelGGL(k_index_buckets, dim3(grid_for((size_t)sk->nBuckets + 1)), dim3(256), 0, ctx->stream, sk->sHash, (uint32_t)n, sk->bucketShift, sk->nBuckets, sk->bucketStart);
     SK_HIP(hipGetLastError());
     unsigned long long host[CNT_N];
@@ -425,8 +475,8 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   }
   gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run;
   sk->totalBins = (uint32_t)run;
-  SK_HIP(hipMalloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(hipMalloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
-  SK_HIP(hipMalloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4));
+  SK_HIP(pool_malloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
+  SK_HIP(pool_malloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4));
   SK_HIP(hipMemcpy(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
   SK_HIP(hipMemcpy(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice));
   SK_HIP(hipMemcpy(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice));
@@ -443,7 +493,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
 // -----------------------------------------------------------------------------------------------------
 struct QueryRun {
   int32_t nFrag = 0, nCand = 0;
-  std::vector<int32_t> fragGenome, fragQSeq, genomeFragments;
+  std::vector<int32_t> genomeFragments;
 };
 
 int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *qr)
@@ -451,33 +501,41 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   const ani_params_t &p = sk->params;
   const int k = p.kmerSize, w = p.windowSize, L = p.fragLen;
   // ---- fragment table (computeMap.hpp:132-190) ----
-  std::vector<FragDesc> frags;
-  qr->fragGenome.clear(); qr->fragQSeq.clear(); qr->genomeFragments.assign(db.nGenomes, 0);
+  // per-contig fragment prefix; fragment descriptors are expanded on the device
+  std::vector<uint32_t> fragStart((size_t)db.nContigs + 1, 0);
+  std::vector<int32_t> cGenome((size_t)db.nContigs + 1, 0), cQBase((size_t)db.nContigs + 1, 0);
+  qr->genomeFragments.assign(db.nGenomes, 0);
+  uint64_t nF64 = 0;
   for (int32_t g = 0; g < db.nGenomes; g++) {
     int32_t seqCounter = 0;
     for (int32_t c = db.genomeContigStart[g]; c < db.genomeContigStart[g + 1]; c++) {
+      fragStart[c] = (uint32_t)nF64; cGenome[c] = g; cQBase[c] = seqCounter;
       const int32_t len = db.contigLen[c];
       if (len < w || len < k || len < L) continue;            // :138
       const int32_t fc = len / L;                              // :152
-      for (int32_t i = 0; i < fc; i++) {
-        frags.push_back(FragDesc{c, i * L});
-        qr->fragGenome.push_back(g); qr->fragQSeq.push_back(seqCounter + i);
-      }
-      seqCounter += fc;
+      seqCounter += fc; nF64 += (uint64_t)fc;
+      if (nF64 > 0x3fffffffull) return fail(ANI_ERR_LIMIT, "too many fragments in one query batch");
     }
     qr->genomeFragments[g] = seqCounter;
   }
-  const size_t nF = frags.size();
+  fragStart[db.nContigs] = (uint32_t)nF64;
+  const size_t nF = (size_t)nF64;
   qr->nFrag = (int32_t)nF; qr->nCand = 0;
   ctx->counters.queryGenomes += (uint64_t)db.nGenomes; ctx->counters.queryFragments += nF; ctx->counters.queryBases += db.totalBases;
   if (nF == 0) return ANI_OK;
-  if (nF > 0x3fffffffu) return fail(ANI_ERR_LIMIT, "too many fragments in one query batch");
   TRY(ctx->frags.ensure(nF * sizeof(FragDesc))); TRY(ctx->fragOff.ensure(nF * 4)); TRY(ctx->fragS.ensure(nF * 4));
   TRY(ctx->fragGenome.ensure(nF * 4)); TRY(ctx->fragQSeq.ensure(nF * 4));
-  HIP_TRY(hipMemcpyAsync(ctx->frags.p, frags.data(), nF * sizeof(FragDesc), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->fragGenome.p, qr->fragGenome.data(), nF * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->fragQSeq.p, qr->fragQSeq.data(), nF * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  {
+    const size_t nc1 = (size_t)db.nContigs + 1;
+    TRY(ctx->unitStart.ensure(nc1 * 4)); TRY(ctx->unitAux.ensure(nc1 * 8));
+    HIP_TRY(hipMemcpyAsync(ctx->unitStart.p, fragStart.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->unitAux.p, cGenome.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->unitAux.as<int32_t>() + nc1, cQBase.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_expand_frags, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), (const int32_t *)ctx->unitAux.as<int32_t>(),
+                       (const int32_t *)(ctx->unitAux.as<int32_t>() + nc1), db.nContigs, (uint32_t)nF, L, ctx->frags.as<FragDesc>(), ctx->fragGenome.as<int32_t>(),
+                       ctx->fragQSeq.as<int32_t>());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
 
   unsigned long long host[CNT_N];
   // ---- fragment sketches ----
@@ -609,12 +667,14 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     HIP_TRY(hipMemcpyAsync(ordOff.data(), ctx->fragOrdOff.p, nF * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
 
-    const size_t CH = (size_t)1 << 20;       // candidates per chunk (a chunk whose code entries exceed 2^32 is rejected by the scan)
+    const size_t CH = (size_t)1 << 21;       // candidates per chunk (a chunk whose code entries exceed 2^32 is rejected by the scan)
     TRY(ctx->l2Ranges.ensure(CH * sizeof(L2Range))); TRY(ctx->l2CodeCount.ensure(CH * 4)); TRY(ctx->l2CodeOff.ensure(CH * 4));
     TRY(ctx->l2SlowFlag.ensure(CH * 4)); TRY(ctx->l2SlowList.ensure(nCand * 4)); TRY(ctx->l2ClassList.ensure(CH * 4));
+    TRY(ctx->l2Order.ensure(CH * 4)); TRY(ctx->l2LenHist.ensure((kL2LenBuckets + 4) * 4));
     HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream));
-    for (size_t c0 = 0; c0 < nCand; c0 += CH) {
-      const size_t c1 = std::min<size_t>(nCand, c0 + CH);
+    size_t chunk = CH;
+    for (size_t c0 = 0; c0 < nCand;) {
+      const size_t c1 = std::min<size_t>(nCand, c0 + chunk);
       const size_t n = c1 - c0;
       L2FastArgs fa;
       fa.g = a; fa.c0 = (int32_t)c0; fa.c1 = (int32_t)c1;
@@ -630,17 +690,33 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
         hipLaunchKernelGGL(k_l2_ranges, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);
       }
       uint64_t nCodes = 0;
-      TRY(device_scan(ctx, fa.codeCount, ctx->l2CodeOff.as<uint32_t>(), (uint32_t)n, &nCodes));
+      {
+        const int rc = device_scan(ctx, fa.codeCount, ctx->l2CodeOff.as<uint32_t>(), (uint32_t)n, &nCodes);
+        if (rc == ANI_ERR_LIMIT && chunk > 4096) { chunk /= 2; continue; }     // very long candidate ranges: smaller chunk, same candidates again
+        TRY(rc);
+      }
       TRY(ctx->l2Codes.ensure((nCodes + 64) * 2));
       fa.codes = ctx->l2Codes.as<uint32_t>();
       if (nCodes) {
+        {
+          // order the chunk's candidates by code-stream length (longest first) for the simulation
+          StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
+          unsigned int nn = (unsigned int)n;
+          HIP_TRY(hipMemsetAsync(ctx->l2LenHist.p, 0, kL2LenBuckets * 4, ctx->stream));
+          HIP_TRY(hipMemcpyAsync(ctx->l2LenHist.as<unsigned int>() + kL2LenBuckets, &nn, 4, hipMemcpyHostToDevice, ctx->stream));
+          hipLaunchKernelGGL(k_l2_len_hist, dim3(grid_for(n, kTPB, 2048)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)n, ctx->l2LenHist.as<unsigned int>());
+          hipLaunchKernelGGL(k_l2_len_scan, dim3(1), dim3(kTPB), 0, ctx->stream, ctx->l2LenHist.as<unsigned int>());
+          hipLaunchKernelGGL(k_l2_len_scatter, dim3(grid_for(n, kTPB)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)c0, (int32_t)n,
+                             ctx->l2LenHist.as<unsigned int>(), ctx->l2Order.as<int32_t>());
+        }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Codes, 1);
           hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)(fB - fA + 1)), dim3(kTPB), 0, ctx->stream, fa);
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)nullptr, (const unsigned int *)nullptr);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)ctx->l2Order.as<int32_t>(),
+                             (const unsigned int *)ctx->l2LenHist.as<unsigned int>() + kL2LenBuckets);
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2SimB, 1);
@@ -659,6 +735,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
       hipLaunchKernelGGL(k_l2_collect_slow, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag,
                          ctx->l2SlowList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG), cnt_ptr(ctx, CNT_REASON));
       HIP_TRY(hipGetLastError());
+      c0 = c1;
     }
     unsigned long long nSlow64 = 0;
     HIP_TRY(hipMemcpyAsync(&nSlow64, cnt_ptr(ctx, CNT_NEG), 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -752,7 +829,7 @@ extern "C" {
 
 const char *ani_last_error(void) { return g_err.c_str(); }
 void ani_free(void *p) { free(p); }
-void ani_device_free(ani_ctx *ctx, void *p) { (void)ctx; if (p) (void)hipFree(p); }
+void ani_device_free(ani_ctx *ctx, void *p) { (void)ctx; if (p) pool_free(p); }
 
 int ani_init(int device, ani_ctx **out)
 {
@@ -777,10 +854,10 @@ void ani_shutdown(ani_ctx *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->tiles, &c->tileMeta, &c->tileCnt,
+  DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->unitStart, &c->unitAux, &c->tiles, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
                     &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
-                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Best,
+                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Order, &c->l2LenHist, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -789,6 +866,7 @@ void ani_shutdown(ani_ctx *c)
   if (c->ev3) (void)hipEventDestroy(c->ev3);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  cur_pool().trim();
 }
 
 int ani_device_copy(ani_ctx *c, void *dst, const void *src, size_t bytes)
@@ -867,7 +945,7 @@ int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
   // in genome order, i.e. position order with global seqIds
   std::vector<uint32_t *> parts; std::vector<size_t> partN;
   size_t total = 0;
-  auto cleanup = [&]() { for (uint32_t *q : parts) if (q) (void)hipFree(q); };
+  auto cleanup = [&]() { for (uint32_t *q : parts) if (q) pool_free(q); };
   int32_t g0 = 0;
   while (g0 < refs->nGenomes) {
     int32_t g1 = g0; uint64_t bases = 0;
@@ -886,7 +964,7 @@ int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
   uint32_t *all = nullptr;
   if (parts.size() == 1) { all = parts[0]; parts[0] = nullptr; }
   else if (total) {
-    hipError_t e = hipMalloc((void **)&all, total * 12);
+    hipError_t e = pool_malloc((void **)&all, total * 12);
     if (e != hipSuccess) { cleanup(); return fail(ANI_ERR_NOMEM, "hipMalloc(%zu) failed", total * 12); }
     size_t o = 0;
     for (size_t i = 0; i < parts.size(); i++) {
@@ -897,7 +975,7 @@ int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
   }
   cleanup();
   int rc = build_index(ctx, p, all, total, refs->contigLen, refs->nContigs, refs->genomeContigStart, refs->nGenomes, out);
-  if (all) (void)hipFree(all);
+  if (all) pool_free(all);
   return rc;
 }
 
@@ -919,11 +997,11 @@ int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n)
   if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
   if (sk->n == 0) return ANI_OK;
   uint32_t *tmp = nullptr;
-  HIP_TRY(hipMalloc((void **)&tmp, (size_t)sk->n * 12));
+  HIP_TRY(pool_malloc((void **)&tmp, (size_t)sk->n * 12));
   hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(sk->n)), dim3(256), 0, ctx->stream, sk->mHash, sk->mSeq, sk->mWpos, sk->n, tmp);
   hipError_t e = hipMemcpyAsync(*out, tmp, (size_t)sk->n * 12, hipMemcpyDeviceToHost, ctx->stream);
   hipError_t e2 = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(tmp);
+  pool_free(tmp);
   HIP_TRY(e); HIP_TRY(e2);
   return ANI_OK;
 }

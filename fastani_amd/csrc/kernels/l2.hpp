@@ -483,6 +483,46 @@ __global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restri
   if (i < n && slowFlag[i]) { list[atomicAdd(count, 1u)] = c0 + i; atomicAdd(&reasons[slowFlag[i] & 3], 1ull); }
 }
 
+// Candidates of a chunk ordered by the length of their code stream (counting sort on codeCount / 16): the 64 lanes of a wave
+// then run about the same number of steps instead of waiting for the longest of 64 random candidates.
+constexpr int kL2LenBuckets = 1024;      // codeCount <= 16384 -> bucket = codeCount >> 4
+__global__ __launch_bounds__(kTPB) void k_l2_len_hist(const int32_t *__restrict__ codeCount, int32_t n, unsigned int *__restrict__ hist)
+{
+  __shared__ unsigned int h[kL2LenBuckets];
+  for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) h[i] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * kTPB + threadIdx.x; i < n; i += gridDim.x * kTPB) {
+    int b = codeCount[i] >> 4; b = b >= kL2LenBuckets ? kL2LenBuckets - 1 : b;
+    atomicAdd(&h[kL2LenBuckets - 1 - b], 1u);                  // longest first
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+__global__ __launch_bounds__(kTPB) void k_l2_len_scan(unsigned int *__restrict__ hist)     // one workgroup: exclusive scan in place
+{
+  __shared__ int ws[16];
+  block_array_excl_scan((int *)hist, kL2LenBuckets, ws);
+}
+__global__ __launch_bounds__(kTPB) void k_l2_len_scatter(const int32_t *__restrict__ codeCount, int32_t c0, int32_t n,
+                                                         unsigned int *__restrict__ cursor, int32_t *__restrict__ order)
+{
+  // one global atomic per (workgroup, bucket): ranks inside the workgroup come from LDS atomics
+  __shared__ unsigned int cnt[kL2LenBuckets], base[kL2LenBuckets];
+  for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) cnt[i] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * kTPB + threadIdx.x;
+  int b = 0; unsigned int r = 0;
+  if (i < n) {
+    b = codeCount[i] >> 4; b = b >= kL2LenBuckets ? kL2LenBuckets - 1 : b;
+    b = kL2LenBuckets - 1 - b;
+    r = atomicAdd(&cnt[b], 1u);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < kL2LenBuckets; j += kTPB) if (cnt[j]) base[j] = atomicAdd(&cursor[j], cnt[j]);
+  __syncthreads();
+  if (i < n) order[base[b] + r] = c0 + i;
+}
+
 // class-B candidates of the chunk (slowFlag == 4) -> dense list
 __global__ void k_l2_collect_class(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t flag, int32_t *__restrict__ list,
                                    unsigned int *__restrict__ count)

@@ -224,6 +224,23 @@ __global__ __launch_bounds__(kTPB) void k_sketch_tiles(const uint32_t *__restric
   }
 }
 
+// Tile / fragment tables are expanded on the device from per-contig prefix arrays (a 1000-genome batch has 1.6 M of each):
+//   unit u belongs to the contig c with start[c] <= u < start[c+1];  its offset inside the contig is (u - start[c]) * step
+__device__ __forceinline__ int32_t owner_of(const uint32_t *__restrict__ start, int32_t nContigs, uint32_t u)
+{
+  int32_t lo = 0, hi = nContigs;                      // last c with start[c] <= u  (start[] is non-decreasing, start[nContigs] = total)
+  while (hi - lo > 1) { int32_t mid = (lo + hi) >> 1; if (start[mid] <= u) lo = mid; else hi = mid; }
+  return lo;
+}
+
+__global__ void k_expand_tiles(const uint32_t *__restrict__ tileStart, int32_t nContigs, uint32_t nTiles, int32_t stride, TileDesc *__restrict__ tiles)
+{
+  const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+  if (T >= nTiles) return;
+  const int32_t c = owner_of(tileStart, nContigs, T);
+  tiles[T] = TileDesc{c, (int32_t)((T - tileStart[c]) * (uint32_t)stride)};
+}
+
 // pass 2: decide, per tile, whether its provisional first record repeats the argmin that the nearest earlier
 // non-empty tile of the same contig ended with (then it is not a new minimizer, commonFunc.hpp:155).
 __global__ void k_sketch_tile_counts(const TileDesc *__restrict__ tiles, const TileMeta *__restrict__ meta, int nTiles,
@@ -272,6 +289,19 @@ struct FragDesc {
   int32_t contig;     // contig index in the query batch
   int32_t start;      // first base of the fragment inside the contig (i * fragLen)
 };
+
+__global__ void k_expand_frags(const uint32_t *__restrict__ fragStart, const int32_t *__restrict__ contigGenomeLocal,
+                               const int32_t *__restrict__ contigQSeqBase, int32_t nContigs, uint32_t nFrags, int32_t fragLen,
+                               FragDesc *__restrict__ frags, int32_t *__restrict__ fragGenome, int32_t *__restrict__ fragQSeq)
+{
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nFrags) return;
+  const int32_t c = owner_of(fragStart, nContigs, f);
+  const int32_t i = (int32_t)(f - fragStart[c]);
+  frags[f] = FragDesc{c, i * fragLen};
+  fragGenome[f] = contigGenomeLocal[c];
+  fragQSeq[f] = contigQSeqBase[c] + i;            // running fragment id inside the query genome (computeMap.hpp:175,:188)
+}
 
 constexpr int kFragHashCap = 4096;   // minimizers one fragment may produce before sort/unique (LDS staging)
 
