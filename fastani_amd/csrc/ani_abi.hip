@@ -170,15 +170,21 @@ enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4,
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
+static_assert(CNT_N == ani::kStatStripeWords, "counter block size");
 int zero_counters(ani_ctx *c)
 {
-  HIP_TRY(hipMemsetAsync(c->dCounters.p, 0, CNT_N * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(c->dCounters.p, 0, (size_t)ani::kStatStripes * CNT_N * 8, c->stream));
   return ANI_OK;
 }
+// cursors live in stripe 0; statistics are spread over all stripes (kernels: stat_slot()) and summed here
 int read_counters(ani_ctx *c, unsigned long long *host)
 {
-  HIP_TRY(hipMemcpyAsync(host, c->dCounters.p, CNT_N * 8, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long all[ani::kStatStripes * CNT_N];
+  HIP_TRY(hipMemcpyAsync(all, c->dCounters.p, sizeof all, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < CNT_N; i++) host[i] = all[i];
+  for (int s = 1; s < ani::kStatStripes; s++)
+    for (int i = 0; i < CNT_N; i++) host[i] += all[s * CNT_N + i];
   return ANI_OK;
 }
 
@@ -448,7 +454,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     SK_TRY(zero_counters(ctx));
     SK_HIP(pool_malloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
     hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
-    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
+    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
                               (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
     // bucket table over the top bits: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
@@ -844,7 +850,7 @@ int ani_init(int device, ani_ctx **out)
   memset(&c->counters, 0, sizeof c->counters);
   HIP_TRY(hipStreamCreate(&c->stream));
   HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1)); HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
-  int rc = c->dCounters.ensure(CNT_N * 8);
+  int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }
   *out = c;
   return ANI_OK;

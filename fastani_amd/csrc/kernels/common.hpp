@@ -13,6 +13,12 @@ constexpr int kWave = 64;
 constexpr int kTPB = 256;             // threads per workgroup for all cooperative kernels (4 waves)
 constexpr uint32_t kMurmurSeed = 42;  // commonFunc.hpp:32
 
+// Statistics counters (sums only, never cursors) are striped over kStatStripes copies of the counter block so that the
+// per-wave atomics of a large grid do not serialise on one address; the host adds the stripes up.
+constexpr int kStatStripes = 32;
+constexpr int kStatStripeWords = 24;   // 64-bit words per stripe (= number of counters)
+__device__ __forceinline__ unsigned long long *stat_slot(unsigned long long *base) { return base + (blockIdx.x & (kStatStripes - 1)) * kStatStripeWords; }
+
 // ---------------------------------------------------------------------------------------------
 // MurmurHash3_x64_128 -> low 32 bits of h1
 // ---------------------------------------------------------------------------------------------

@@ -69,9 +69,17 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t
     nextSame[ia] = ib; prevSame[ib] = ia;
     atomicOr(&mWposF[ia], 0x80000000u); atomicOr(&mWposF[ib], 0x80000000u);
   }
+  // one atomic per workgroup (the grid is small: a grid-stride loop covers the index)
+  __shared__ unsigned long long part[8];
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) uniq += __shfl_down(uniq, d);
-  if ((threadIdx.x & 63) == 0 && uniq) atomicAdd(nUnique, uniq);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = uniq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (unsigned w = 0; w < (blockDim.x >> 6); w++) t += part[w];
+    if (t) atomicAdd(nUnique, t);
+  }
 }
 
 // bucketStart[b] = first r with (sHash[r] >> shift) >= b, for b = 0..nBuckets (inclusive)

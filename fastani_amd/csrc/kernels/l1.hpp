@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
   int H; block_excl_scan(c, ws, &H);
   if (threadIdx.x == 0) {
     a.fragHits[f] = H;
-    if (H) atomicAdd(a.sumHits, (unsigned long long)H);
+    if (H) atomicAdd(stat_slot(a.sumHits), (unsigned long long)H);
     // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
     if (s <= kL1MaxS && H <= kL1HitCapMax) {
       if (H > kL1HitCapSmall && H <= kL1HitCapMid) a.midList[atomicAdd(a.midCount, 1u)] = f;

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__restrict
   // counters for the algorithmic-byte figure: one atomic per wave
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { e += __shfl_down(e, d); st += __shfl_down(st, d); sq += __shfl_down(sq, d); }
-  if ((threadIdx.x & 63) == 0 && (e | st | sq)) { atomicAdd(a.sumEntries, e); atomicAdd(a.sumSteps, st); atomicAdd(a.sumQ, sq); }
+  if ((threadIdx.x & 63) == 0 && (e | st | sq)) { atomicAdd(stat_slot(a.sumEntries), e); atomicAdd(stat_slot(a.sumSteps), st); atomicAdd(stat_slot(a.sumQ), sq); }
 }
 
 // ---------------------------------------------------------------- fast path
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { cntE += __shfl_down(cntE, d); cntS += __shfl_down(cntS, d); cntQ += __shfl_down(cntQ, d); }
-  if (lane == 0 && (cntE | cntS | cntQ)) { atomicAdd(a.g.sumEntries, cntE); atomicAdd(a.g.sumSteps, cntS); atomicAdd(a.g.sumQ, cntQ); }
+  if (lane == 0 && (cntE | cntS | cntQ)) { atomicAdd(stat_slot(a.g.sumEntries), cntE); atomicAdd(stat_slot(a.g.sumSteps), cntS); atomicAdd(stat_slot(a.g.sumQ), cntQ); }
 }
 
 // candidates of the chunk that must take the general kernel -> list (order irrelevant)
