@@ -31,9 +31,9 @@
 #include "kernels/sketch.hpp"
 #include "kernels/synth.hpp"
 
-extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, hipStream_t stream);
+extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
 extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
-                                      size_t n, hipStream_t stream);
+                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
 
 namespace {
 
@@ -133,7 +133,7 @@ struct ani_ctx {
   DevBuf dCounters;
   // workspaces reused across calls
   DevBuf seqPacked, seqAscii, contigOff, contigLen, contigMode;
-  DevBuf unitStart, unitAux, tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
+  DevBuf sortTmp, unitStart, unitAux, tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
   DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
@@ -447,7 +447,9 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     if (n) {
       hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, sk->mWposF,
                          sk->prevSame, sk->nextSame, tmpK, tmpV);
-      int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, ctx->stream);
+      size_t tb = 0;
+      int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, nullptr, &tb, ctx->stream);
+      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 16); if (rc == ANI_OK) rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, ctx->sortTmp.p, &tb, ctx->stream); }
       if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
     }
     pool_free(tmpK); pool_free(tmpV);
@@ -618,7 +620,9 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
         if (H == 0) { int32_t z = 0; HIP_TRY(hipMemcpyAsync(ctx->fragCandCnt.as<int32_t>() + bigFrags[i], &z, 4, hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); continue; }
         TRY(ctx->l1BigHitsA.ensure(H * 8)); TRY(ctx->l1BigHitsB.ensure(H * 8)); TRY(ctx->l1BigV.ensure(std::max(H, sz) * 4 + 16));
         hipLaunchKernelGGL(k_l1_big_gather, dim3(1), dim3(kTPB), 0, ctx->stream, a, bigFrags[i], ctx->l1BigV.as<int>(), ctx->l1BigHitsA.as<uint64_t>());
-        int rc = ani_sort_keys_u64(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), H, ctx->stream);
+        size_t tb = 0;
+        int rc = ani_sort_keys_u64(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), H, nullptr, &tb, ctx->stream);
+        if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 16)); rc = ani_sort_keys_u64(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), H, ctx->sortTmp.p, &tb, ctx->stream); }
         if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of seed hits failed (%d)", rc);
         hipLaunchKernelGGL(k_l1_big_candidates, dim3(1), dim3(kTPB), 0, ctx->stream, a, bigFrags[i], (const uint64_t *)ctx->l1BigHitsB.as<uint64_t>(), ctx->l1BigV.as<int>());
       }
@@ -781,9 +785,8 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuer
   const size_t binsPerQuery = sk->totalBins;
   const size_t nBins = binsPerQuery * (size_t)nQuery;
   TRY(ctx->bins.ensure((nBins ? nBins : 1) * 4)); TRY(ctx->queryFragments.ensure((size_t)nQuery * 4));
-  const size_t rowCap = (size_t)nQuery * (size_t)sk->nGenomes;
-  TRY(ctx->rows.ensure((rowCap ? rowCap : 1) * 20));
-  TRY(zero_counters(ctx));
+  const size_t nPairs = (size_t)nQuery * (size_t)sk->nGenomes;
+  TRY(ctx->rows.ensure((nPairs ? nPairs : 1) * 8));
   hipError_t e1, e2;
   {
   StageTimer tm(ctx, &ctx->counters.msReduce);
@@ -798,21 +801,26 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuer
   }
   PairArgs pa;
   pa.nQuery = nQuery; pa.nRefGenomes = sk->nGenomes; pa.bins = ctx->bins.as<uint32_t>(); pa.binsPerQuery = binsPerQuery;
-  pa.genomeBinStart = sk->genomeBinStart; pa.queryFragments = ctx->queryFragments.as<int32_t>(); pa.firstQueryId = firstQueryId;
-  pa.rows = ctx->rows.as<uint32_t>(); pa.rowCap = (uint32_t)rowCap; pa.rowCount = cnt_ptr(ctx, CNT_ROWS);
-  hipLaunchKernelGGL(k_pair_reduce, dim3(grid_for(rowCap)), dim3(256), 0, ctx->stream, pa);
+  pa.genomeBinStart = sk->genomeBinStart; pa.pairCount = ctx->rows.as<uint32_t>(); pa.pairIdentity = ctx->rows.as<uint32_t>() + nPairs;
+  if (nPairs) hipLaunchKernelGGL(k_pair_reduce, dim3(grid_for(nPairs)), dim3(256), 0, ctx->stream, pa);
   }
   HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(hipGetLastError());
-  unsigned long long host[CNT_N];
-  TRY(read_counters(ctx, host));
-  const size_t m = (size_t)host[CNT_ROWS];
-  if (m > rowCap) return fail(ANI_ERR_INTERNAL, "row count overflow");
+  std::vector<uint32_t> dense(2 * nPairs);
+  if (nPairs) { HIP_TRY(hipMemcpyAsync(dense.data(), ctx->rows.p, nPairs * 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
+  size_t m = 0;
+  for (size_t p = 0; p < nPairs; p++) m += dense[p] != 0;
   const size_t old = rows->size();
   rows->resize(old + m);
-  if (m) HIP_TRY(hipMemcpy(rows->data() + old, ctx->rows.p, m * 20, hipMemcpyDeviceToHost));
-  std::sort(rows->begin() + old, rows->end(), [](const ani_cgi_t &x, const ani_cgi_t &y) {
-    return x.qryGenomeId != y.qryGenomeId ? x.qryGenomeId < y.qryGenomeId : x.refGenomeId < y.refGenomeId;
-  });
+  ani_cgi_t *out = rows->data() + old;
+  for (int32_t qi = 0; qi < nQuery; qi++)                           // query ascending, reference ascending
+    for (int32_t g = 0; g < sk->nGenomes; g++) {
+      const size_t p = (size_t)qi * (size_t)sk->nGenomes + (size_t)g;
+      if (!dense[p]) continue;
+      ani_cgi_t r; r.refGenomeId = g; r.qryGenomeId = firstQueryId + qi; r.countSeq = (int32_t)dense[p];
+      r.totalQueryFragments = qr.genomeFragments[qi];
+      memcpy(&r.identity, &dense[nPairs + p], 4);
+      *out++ = r;
+    }
   ctx->counters.cgiRows += m;
   return ANI_OK;
 }
@@ -860,7 +868,7 @@ void ani_shutdown(ani_ctx *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->unitStart, &c->unitAux, &c->tiles, &c->tileMeta, &c->tileCnt,
+  DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
                     &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Order, &c->l2LenHist, &c->l2Best,

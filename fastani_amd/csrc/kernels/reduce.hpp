@@ -78,10 +78,9 @@ struct PairArgs {
   int32_t nQuery, nRefGenomes;
   const uint32_t *bins; size_t binsPerQuery;
   const uint32_t *genomeBinStart;      // [nRefGenomes+1] first bin of each reference genome
-  const int32_t *queryFragments;       // [nQuery] totalQueryFragments
-  int32_t firstQueryId;
-  // output rows (cgi::CGI_Results layout, 5 words), appended with an atomic counter
-  uint32_t *rows; uint32_t rowCap; unsigned long long *rowCount;
+  // dense output [nQuery][nRefGenomes]: (countSeq, identity bits); countSeq == 0 = no row.  Dense and atomics-free, so the host
+  // reads the rows back already in (query, reference) order.
+  uint32_t *pairCount; uint32_t *pairIdentity;
 };
 
 __global__ void k_pair_reduce(PairArgs a)
@@ -95,14 +94,8 @@ __global__ void k_pair_reduce(PairArgs a)
     const uint32_t bits = b[x];
     if (bits) { sum += __uint_as_float(bits); cnt++; }
   }
-  if (cnt) {
-    const unsigned long long r = atomicAdd(a.rowCount, 1ull);
-    if (r < a.rowCap) {
-      uint32_t *row = a.rows + 5 * r;
-      row[0] = (uint32_t)g; row[1] = (uint32_t)(a.firstQueryId + qi); row[2] = (uint32_t)cnt;
-      row[3] = (uint32_t)a.queryFragments[qi]; row[4] = __float_as_uint(sum / cnt);
-    }
-  }
+  a.pairCount[p] = (uint32_t)cnt;
+  a.pairIdentity[p] = cnt ? __float_as_uint(sum / cnt) : 0u;
 }
 
 // mapping export for ani_map_query: compacted, candidate order preserved by a prior scan of the keep flags

@@ -4,8 +4,9 @@
 #include <numeric>
 #include <vector>
 extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
-                                      size_t n, hipStream_t)
+                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t)
 {
+  if (!tmp) { *tmpBytes = 16; return 0; }
   std::vector<uint32_t> ord(n);
   std::iota(ord.begin(), ord.end(), 0u);
   std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return keysIn[a] < keysIn[b]; });
@@ -13,8 +14,9 @@ extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut,
   return 0;
 }
 
-extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, hipStream_t)
+extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, void *tmp, size_t *tmpBytes, hipStream_t)
 {
+  if (!tmp) { *tmpBytes = 16; return 0; }
   std::vector<uint64_t> v(keysIn, keysIn + n);
   std::sort(v.begin(), v.end());
   for (size_t i = 0; i < n; i++) keysOut[i] = v[i];
