@@ -167,3 +167,48 @@ def case_device_synth(engine, alloc):
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
              case_low_complexity_big, case_empty_and_short]
+
+
+def fuzz(engine, seed, seconds=None, iterations=None):
+    """random genomes (alphabets with N / IUPAC / lower case, tandem repeats, A-rich), random contig splits, k in {8..16},
+    fragLen in {500..3000}: sketch, fragment sketches, mappings and CGI rows all bit-exact against the oracle"""
+    import time
+    rng = np.random.default_rng(seed)
+
+    def rand_genome(n):
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            return rng_genome(int(rng.integers(1e9)), n)
+        if kind == 1:
+            return orc.synth_genome(int(rng.integers(100)), int(rng.integers(0, 40)), n)
+        if kind == 2:
+            unit = rng_genome(int(rng.integers(1e9)), int(rng.integers(5, 400)))
+            return np.tile(unit, n // len(unit) + 1)[:n].copy()
+        if kind == 3:
+            return rng_genome(int(rng.integers(1e9)), n, b"ACGTN")
+        if kind == 4:
+            return rng_genome(int(rng.integers(1e9)), n, b"AAAAAAAT")
+        return rng_genome(int(rng.integers(1e9)), n, b"acgtACGTRYKM")
+
+    def contigs(g):
+        nc = int(rng.integers(1, 4))
+        cuts = [0] + sorted(rng.integers(0, len(g) + 1, nc - 1).tolist()) + [len(g)]
+        return [g[cuts[i]:cuts[i + 1]] for i in range(nc)]
+
+    t0, it = time.time(), 0
+    while (seconds is not None and time.time() - t0 < seconds) or (iterations is not None and it < iterations):
+        it += 1
+        k = int(rng.choice([16, 16, 16, 12, 14, 8]))
+        L = int(rng.choice([3000, 3000, 1000, 500, 2000]))
+        base = rand_genome(int(rng.integers(L, 12 * L)))
+        genomes = []
+        for _ in range(int(rng.integers(1, 5))):
+            if rng.random() < 0.6:
+                g = mutate(base, float(rng.choice([0, 0.01, 0.05, 0.1, 0.2])), int(rng.integers(1e9)))
+            else:
+                g = rand_genome(int(rng.integers(10, 10 * L)))
+            genomes.append(contigs(g))
+        qs = [genomes[int(rng.integers(len(genomes)))] for _ in range(2)] + [contigs(mutate(base, 0.03, int(rng.integers(1e9))))]
+        p, sk, osk = check_sketch(engine, genomes, k=k, frag_len=L)
+        check_queries(engine, p, sk, osk, qs, k=k, frag_len=L)
+    return it

@@ -20,3 +20,7 @@ def test_device_synth(emu_engine):
         a = np.zeros(nbytes // 4 + 4, dtype=np.uint32)
         return a, a.ctypes.data
     pc.case_device_synth(emu_engine, alloc)
+
+
+def test_fuzz(emu_engine):
+    assert pc.fuzz(emu_engine, seed=7, iterations=12) == 12

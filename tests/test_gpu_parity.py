@@ -78,3 +78,7 @@ def test_full_size_properties(gpu_engine):
     r = byq[(5, 0)]
     assert (int(r["countSeq"]), int(r["totalQueryFragments"])) == (int(o["countSeq"]), int(o["totalQueryFragments"]))
     assert r["identity"] == o["identity"]
+
+
+def test_fuzz(gpu_engine):
+    assert pc.fuzz(gpu_engine, seed=11, iterations=150) == 150
