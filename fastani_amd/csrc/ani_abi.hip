@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <atomic>
+#include <thread>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -111,6 +114,20 @@ struct DevBuf {
   void release() { if (p) pool_free(p); p = nullptr; cap = 0; }
   template <class T> T *as() const { return (T *)p; }
 };
+
+// host-side parallel loop for the ingest path (ANI_HOST_THREADS overrides the thread count; small jobs stay serial)
+template <class F>
+void parallel_for(size_t n, uint64_t work, F f)
+{
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 32) nt = 32;
+  if (const char *ev = getenv("ANI_HOST_THREADS")) { int v = atoi(ev); if (v >= 1) nt = (unsigned)v; }
+  if (nt > n) nt = (unsigned)n;
+  if (nt <= 1 || work < (1u << 22)) { for (size_t i = 0; i < n; i++) f(i); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
+  for (auto &x : th) x.join();
+}
 
 inline unsigned grid_for(size_t n, unsigned block = 256, unsigned maxBlocks = 65535u * 8u)
 {
@@ -275,27 +292,50 @@ int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1,
     for (int32_t c = 0; c < out->nContigs; c++) { out->contigOff[c] = b->contigOffset[c0 + c]; out->contigPacked[c] = 1; }
     out->dPacked = (const uint32_t *)b->data; out->dAscii = nullptr;
   } else {
-    static uint8_t code[256]; static bool init = false;
-    if (!init) { memset(code, 4, 256); code['A'] = code['a'] = 0; code['C'] = code['c'] = 1; code['G'] = code['g'] = 2; code['T'] = code['t'] = 3; init = true; }
+    // Ingest: classify every contig (pure ACGT -> 2 bits per base, anything else -> raw bytes) and pack, on host threads
+    // (contigs are split into segments of <= 4 Mbases so that one long chromosome still spreads over the threads).
+    static const std::array<uint8_t, 256> code = [] {
+      std::array<uint8_t, 256> t; t.fill(4);
+      t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
+      return t;
+    }();
     const uint8_t *src = (const uint8_t *)b->data;
-    std::vector<uint32_t> packed; std::vector<uint8_t> ascii;
-    for (int32_t c = 0; c < out->nContigs; c++) {
-      const uint8_t *s = src + b->contigOffset[c0 + c];
+    const int32_t nC = out->nContigs;
+    struct Seg { int32_t c; int32_t lo, hi; };
+    std::vector<Seg> segs;
+    const int32_t kSeg = 1 << 22;                       // multiple of 16: segments pack whole words
+    for (int32_t c = 0; c < nC; c++)
+      for (int32_t lo = 0; lo < out->contigLen[c] || lo == 0; lo += kSeg) { segs.push_back(Seg{c, lo, std::min(out->contigLen[c], lo + kSeg)}); if (out->contigLen[c] == 0) break; }
+    std::vector<uint8_t> segImpure(segs.size(), 0);
+    parallel_for(segs.size(), out->totalBases, [&](size_t i) {
+      const Seg &sg = segs[i];
+      const uint8_t *sp = src + b->contigOffset[c0 + sg.c];
+      uint8_t bad = 0;
+      for (int32_t x = sg.lo; x < sg.hi; x++) bad |= (uint8_t)(code[sp[x]] >> 2);
+      segImpure[i] = bad;
+    });
+    std::vector<uint8_t> impure(nC, 0);
+    for (size_t i = 0; i < segs.size(); i++) impure[segs[i].c] |= segImpure[i];
+    size_t nWords = 0, nBytes = 0;
+    for (int32_t c = 0; c < nC; c++) {
       const int32_t len = out->contigLen[c];
-      bool pure = true;
-      for (int32_t i = 0; i < len; i++) if (code[s[i]] > 3) { pure = false; break; }
-      out->contigPacked[c] = pure;
-      if (pure) {
-        out->contigOff[c] = (int64_t)packed.size();
-        const size_t nw = ((size_t)len + 15) / 16;
-        const size_t base = packed.size(); packed.resize(base + nw + 2, 0u);     // +2 words of slack for the 3-word fetch
-        for (int32_t i = 0; i < len; i++) packed[base + (i >> 4)] |= (uint32_t)code[s[i]] << (2 * (i & 15));
-      } else {
-        out->contigOff[c] = (int64_t)ascii.size();
-        ascii.insert(ascii.end(), s, s + len);
-        while (ascii.size() & 3) ascii.push_back(0);
-      }
+      out->contigPacked[c] = !impure[c];
+      if (!impure[c]) { out->contigOff[c] = (int64_t)nWords; nWords += ((size_t)len + 15) / 16 + 2; }   // +2 words of slack for the 3-word fetch
+      else { out->contigOff[c] = (int64_t)nBytes; nBytes += ((size_t)len + 3) & ~(size_t)3; }
     }
+    std::vector<uint32_t> packed(nWords, 0u); std::vector<uint8_t> ascii(nBytes, 0);
+    parallel_for(segs.size(), out->totalBases, [&](size_t i) {
+      const Seg &sg = segs[i];
+      const uint8_t *sp = src + b->contigOffset[c0 + sg.c];
+      if (!impure[sg.c]) {
+        uint32_t *dst = packed.data() + out->contigOff[sg.c];
+        for (int32_t x = sg.lo; x < sg.hi; x += 16) {
+          uint32_t wd = 0; const int32_t e = std::min(sg.hi, x + 16);
+          for (int32_t y = x; y < e; y++) wd |= (uint32_t)code[sp[y]] << (2 * (y & 15));
+          dst[x >> 4] = wd;
+        }
+      } else memcpy(ascii.data() + out->contigOff[sg.c] + sg.lo, sp + sg.lo, (size_t)(sg.hi - sg.lo));
+    });
     TRY(ctx->seqPacked.ensure(packed.size() * 4 + 16)); TRY(ctx->seqAscii.ensure(ascii.size() + 16));
     if (!packed.empty()) HIP_TRY(hipMemcpyAsync(ctx->seqPacked.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ascii.empty()) HIP_TRY(hipMemcpyAsync(ctx->seqAscii.p, ascii.data(), ascii.size(), hipMemcpyHostToDevice, ctx->stream));

@@ -10,6 +10,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -182,22 +184,46 @@ struct SeqReader {
 
 struct Genome { std::vector<std::string> names; std::vector<int32_t> lens; };
 
+struct FileData { std::vector<uint8_t> data; Genome g; };
+
+FileData readFile(const std::string &path)
+{
+  FileData fd;
+  SeqReader rd(path);
+  Record r;
+  while (rd.next(r)) {
+    if (r.seq.size() >= 0x7fffffffull) { std::cerr << "ERROR, contig of " << r.seq.size() << " bases in " << path << " exceeds the 2^31 limit of offset_t" << std::endl; exit(1); }
+    fd.data.insert(fd.data.end(), r.seq.begin(), r.seq.end());
+    fd.g.names.push_back(r.name); fd.g.lens.push_back((int32_t)r.seq.size());
+  }
+  return fd;
+}
+
+// gz + FASTA parsing is the wall-clock floor of a run once the kernels are fast: files are parsed on `threads` host threads
+// (this is what -t buys here; the reference uses it to split the references over OpenMP threads)
+std::vector<FileData> readFiles(const std::vector<std::string> &paths, int threads)
+{
+  std::vector<FileData> out(paths.size());
+  std::atomic<size_t> next{0};
+  const int nt = std::max(1, std::min<int>(threads, (int)paths.size()));
+  auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < paths.size();) out[i] = readFile(paths[i]); };
+  if (nt == 1) work();
+  else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto &x : th) x.join(); }
+  return out;
+}
+
 struct HostBatch {
   std::vector<uint8_t> data; std::vector<int64_t> off; std::vector<int32_t> len, gcs{0};
   std::vector<Genome> meta;
-  void add(const std::string &path)
+  void add(FileData &&fd)
   {
-    SeqReader rd(path);
-    Record r; Genome g;
-    while (rd.next(r)) {
-      if (r.seq.size() >= 0x7fffffffull) { std::cerr << "ERROR, contig of " << r.seq.size() << " bases in " << path << " exceeds the 2^31 limit of offset_t" << std::endl; exit(1); }
-      off.push_back((int64_t)data.size()); len.push_back((int32_t)r.seq.size());
-      data.insert(data.end(), r.seq.begin(), r.seq.end());
-      g.names.push_back(r.name); g.lens.push_back((int32_t)r.seq.size());
-    }
+    int64_t o = (int64_t)data.size();
+    for (int32_t l : fd.g.lens) { off.push_back(o); len.push_back(l); o += l; }
+    data.insert(data.end(), fd.data.begin(), fd.data.end());
     gcs.push_back((int32_t)len.size());
-    meta.push_back(std::move(g));
+    meta.push_back(std::move(fd.g));
   }
+  void add(const std::string &path) { add(readFile(path)); }
   ani_seq_batch_t batch() const
   {
     static const uint8_t dummy = 0;
@@ -241,7 +267,7 @@ int main(int argc, char **argv)
 
   // ---- queries are read once (the reference re-reads them in every thread) ----
   HostBatch Q;
-  for (auto &f : o.queries) Q.add(f);
+  { auto files = readFiles(o.queries, o.threads); for (auto &fd : files) Q.add(std::move(fd)); }
   ani_seq_batch_t qb = Q.batch();
 
   // ---- reference splits: one sketch, unless -s asks for the reference's per-split sanity check ----
@@ -254,7 +280,8 @@ int main(int argc, char **argv)
     for (int j = 0; j < (int)o.refs.size(); j++) if (nSplits == 1 || j % nSplits == sp) refIdx.push_back(j);   // computeCoreIdentity.hpp:467-472
     if (refIdx.empty()) continue;                                       // more threads than references: an empty split maps nothing
     HostBatch R;
-    for (int j : refIdx) R.add(o.refs[j]);
+    { std::vector<std::string> paths; for (int j : refIdx) paths.push_back(o.refs[j]);
+      auto files = readFiles(paths, o.threads); for (auto &fd : files) R.add(std::move(fd)); }
     ani_seq_batch_t rb = R.batch();
     ani_sketch *sk = nullptr;
     if (ani_sketch_build(ctx, &ap, &rb, &sk)) die("ani_sketch_build");
