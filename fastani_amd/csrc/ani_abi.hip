@@ -842,7 +842,7 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuer
   PairArgs pa;
   pa.nQuery = nQuery; pa.nRefGenomes = sk->nGenomes; pa.bins = ctx->bins.as<uint32_t>(); pa.binsPerQuery = binsPerQuery;
   pa.genomeBinStart = sk->genomeBinStart; pa.pairCount = ctx->rows.as<uint32_t>(); pa.pairIdentity = ctx->rows.as<uint32_t>() + nPairs;
-  if (nPairs) hipLaunchKernelGGL(k_pair_reduce, dim3(grid_for(nPairs)), dim3(256), 0, ctx->stream, pa);
+  if (nPairs) hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, ctx->stream, pa);   // one wave per pair
   }
   HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(hipGetLastError());
   std::vector<uint32_t> dense(2 * nPairs);

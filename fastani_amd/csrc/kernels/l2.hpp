@@ -279,11 +279,13 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
 }
 
 constexpr uint32_t kL2DupBit = 1u << 10;
+constexpr int kL2RankShift = 23, kL2RankBuckets = 512;
 constexpr uint32_t kL2DwEscape = 31u;
 
 __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
   __shared__ uint32_t qs[kL2FastMaxS + 1];
+  __shared__ uint16_t st[kL2RankBuckets + 2];
   const int32_t f = a.fragBase + blockIdx.x;
   const int32_t s = a.g.fragS[f];
   int32_t cA = (int32_t)a.fragCandOff[f], cB = (f + 1 < a.nFrag) ? (int32_t)a.fragCandOff[f + 1] : a.g.nCand;
@@ -292,6 +294,12 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   if (cA >= cB || s < 1 || s > kL2FastMaxS) return;
   const uint32_t *q = a.g.qPool + a.g.fragOff[f];
   for (int i = threadIdx.x; i < s; i += kTPB) qs[i] = q[i];
+  // hashes are uniform, so the top 9 bits bracket a rank to ~s/512 sketch entries: st[b] = #{q < b << 23}
+  for (int i = threadIdx.x; i <= s; i += kTPB) {
+    const int b0 = i > 0 ? (int)(q[i - 1] >> kL2RankShift) + 1 : 0;
+    const int b1 = i < s ? (int)(q[i] >> kL2RankShift) : kL2RankBuckets;
+    for (int b = b0; b <= b1; b++) st[b] = (uint16_t)i;
+  }
   __syncthreads();
   for (int32_t c = cA; c < cB; c++) {
     const int32_t i = c - a.c0;
@@ -303,7 +311,11 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
       uint32_t dw = 0;
       if (j > r.beg0) dw = (wf & 0x7fffffffu) - (a.g.mWposF[j - 1] & 0x7fffffffu);
       if (dw > kL2DwEscape) dw = kL2DwEscape;
-      out[j - r.beg0] = (uint16_t)(q_rank(qs, s, a.g.mHash[j]) | ((wf >> 31) ? kL2DupBit : 0u) | (dw << 11));
+      const uint32_t h = a.g.mHash[j];
+      int lo = st[h >> kL2RankShift], hi = st[(h >> kL2RankShift) + 1];
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h) lo = mid + 1; else hi = mid; }
+      const uint32_t rk = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h);          // == q_rank(qs, s, h)
+      out[j - r.beg0] = (uint16_t)(rk | ((wf >> 31) ? kL2DupBit : 0u) | (dw << 11));
     }
   }
 }
@@ -338,39 +350,42 @@ struct L2Stream {
   }
 };
 
-// One window event, written without control flow (selects only).  SIGN = +1: the entry enters the window
-// (slidingMap.hpp:137-161 + :231-254), SIGN = -1: it leaves (:167-211 + :261-284).  Both LDS reads (the entry's own field and
-// the field next to the pivot) are issued up front; `on` = false turns the event into a no-op.
-struct L2Regs { int s, iStar, cStar, shared; int ovf; };
+// One window event, written without control flow (selects only).  INS: the entry enters the window (slidingMap.hpp:137-161
+// + :231-254), otherwise it leaves (:167-211 + :261-284).  Both LDS reads (the entry's own field and the field next to the
+// pivot) are issued up front; `on` = false turns the event into a no-op.  Field g of this lane sits at F[g << 6]
+// (byte-interleaved over the wave: one shift to address it; the only bank conflicts are between the four lanes of a dword
+// column whose g differ by a multiple of 4 — the LDS pipe has an order of magnitude of slack under the VALU work of a step).
+struct L2Regs { int s, iStar, cStar, shared; bool ovf; };
 
-template <int SIGN>
-__device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, bool on)
+__device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, bool INS, bool on)
 {
-  const int isQ = (int)(code & 1u);
+  const bool isQ = (code & 1u) != 0;
   const int idx = (int)((code >> 1) & 0x1ffu);
-  int j = r.iStar - (SIGN > 0 ? 1 : 0); j = j < 0 ? 0 : j;          // pivot-adjacent field: n[j], b[j+1]
-  uint8_t *pOwn = F + ((idx >> 2) << 8) + (idx & 3);
-  const uint8_t *pJ = F + ((j >> 2) << 8) + (j & 3);
+  const int sg = INS ? 1 : -1;
+  int j = r.iStar - (INS ? 1 : 0); j = j < 0 ? 0 : j;               // pivot-adjacent field: n[j], b[j+1]
+  uint8_t *pOwn = F + (idx << 6);
   const int own = *pOwn;
-  int fj = *pJ;
-  const int delta = 2 - isQ;                                         // counter lives in bits 1..7, presence in bit 0
-  const int full = (SIGN > 0) & (isQ ^ 1) & (int)(own >= 254);
-  r.ovf |= on ? full : 0;
-  const int act = (int)on & (full ^ 1);
-  *pOwn = (uint8_t)(own + (act ? SIGN * delta : 0));
-  fj += (idx == j) ? SIGN * delta : 0;                               // the event itself changed field[j]
-  const int cntj = fj >> 1, bitj = fj & 1;
-  const int lt = (int)(idx < r.iStar);                               // rank idx+1 <= iStar  <=>  gap idx < iStar
-  const int qOn = act & isQ, nOn = act & (isQ ^ 1);
-  r.shared += (qOn & lt) ? SIGN : 0;
-  r.cStar += (nOn & lt) ? SIGN : 0;
-  if (SIGN > 0) {
-    const int mv = nOn & lt & (int)(r.iStar + r.cStar > r.s);        // q_iStar leaves the s smallest
-    r.shared -= mv ? bitj : 0; r.iStar -= mv; r.cStar -= mv ? cntj : 0;
-  } else {
-    const int mv = nOn & (int)(r.iStar < r.s) & (int)(r.iStar + 1 + r.cStar + cntj <= r.s);   // q_{iStar+1} joins them
-    r.cStar += mv ? cntj : 0; r.iStar += mv; r.shared += mv ? bitj : 0;
-  }
+  int fj = F[j << 6];
+  const int delta = isQ ? 1 : 2;                                     // counter lives in bits 1..7, presence in bit 0
+  const bool full = INS && !isQ && own >= 254;
+  r.ovf = r.ovf || (on && full);
+  const bool act = on && !full;
+  const int d = act ? (INS ? delta : -delta) : 0;
+  *pOwn = (uint8_t)(own + d);
+  fj += (idx == j) ? d : 0;                                          // the event itself changed field[j]
+  const int cntj = fj >> 1;
+  const bool lt = idx < r.iStar;                                     // rank idx+1 <= iStar  <=>  gap idx < iStar
+  const int t = (act && lt) ? sg : 0;
+  r.shared += isQ ? t : 0;
+  r.cStar += isQ ? 0 : t;
+  // insert: q_iStar leaves the s smallest;  delete: q_{iStar+1} joins them
+  const bool cond = INS ? (lt && r.iStar + r.cStar > r.s) : (r.iStar < r.s && r.iStar + 1 + r.cStar + cntj <= r.s);
+  const bool mv = act && !isQ && cond;
+  const int mone = mv ? sg : 0;                                      // insert: -1 on everything, delete: +1
+  const int cm = mv ? cntj : 0;
+  r.iStar -= mone;
+  r.shared -= (fj & 1) ? mone : 0;
+  r.cStar -= INS ? cm : -cm;
 }
 
 // slowFlag protocol: 0 = class A, 4 = class B (s in 256..319), 1 = outside every fast-path limit,
@@ -382,8 +397,9 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
 {
   __shared__ uint32_t lds[(kL2SimTPB / kWave) * G::kWords * kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-  uint32_t *S = lds + wv * (G::kWords * kWave) + lane;               // word x of this lane: S[x * kWave]
-  uint8_t *F = (uint8_t *)S;                                          // field g: F[((g >> 2) << 8) + (g & 3)]
+  uint32_t *W = lds + wv * (G::kWords * kWave);                       // this wave's LDS
+  uint8_t *F = (uint8_t *)W + lane;                                   // field g of this lane: F[g << 6]
+  uint32_t *S = W + lane;                                             // dword x of this lane: S[x * kWave] (cursor rings)
   const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   int32_t c = a.c0 + slot;
   if (list) {
@@ -391,6 +407,9 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
     if ((unsigned int)(blockIdx.x * blockDim.x) >= n) return;         // whole workgroup beyond the list
     c = (unsigned int)slot < n ? list[slot] : a.c1;
   }
+  // four lanes share each state dword, so the whole wave clears the state, whether or not a lane has a candidate
+#pragma unroll
+  for (int x = 0; x < G::kStateWords; x++) S[x * kWave] = 0u;
   unsigned long long cntE = 0, cntS = 0, cntQ = 0;
   const int myFlag = c < a.c1 ? a.slowFlag[c - a.c0] : 1;
   const bool mine = (G::kMaxS == 255) ? (myFlag == 0) : (myFlag == 4);
@@ -400,9 +419,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
     const int32_t f = a.g.candFrag[c];
     const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
     const int m = r.last - r.beg0;
-#pragma unroll
-    for (int x = 0; x < G::kStateWords; x++) S[x * kWave] = 0u;
-    L2Regs R; R.s = a.g.fragS[f]; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = 0;
+    L2Regs R; R.s = a.g.fragS[f]; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = false;
     // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
     auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
       const uint32_t dw = code >> 11;
@@ -421,45 +438,57 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
       if (j > 0) wEnd = next_wpos(wEnd, cd, j);
       bool eff = true;
       if (cd & kL2DupBit) eff = a.g.prevSame[r.beg0 + j] < r.beg0;
-      l2_apply<+1>(F, R, cd, eff);
+      l2_apply(F, R, cd, true, eff);
     }
     uint32_t codeEnd = 0;
     if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
-    int32_t wBeg = r.wposBeg0, pos = r.wposBeg0;
+    int32_t wBeg = r.wposBeg0;
     uint32_t codeBeg = cb.get(0);
     uint32_t codeBegNext = (1 < m) ? cb.get(1) : 0u;
     int32_t wBegNext = (1 < m) ? next_wpos(wBeg, codeBegNext, 1) : wBeg;
     int best = 0; int32_t firstPos = 0, lastPos = 0; int steps = 0;
-    bool advB = false, advE = false; uint32_t delCode = 0, insCode = 0;
-    while (end < m && !R.ovf) {                      // computeMap.hpp:455
-      if ((steps & 7) == 0) { cb.sync(beg + 1); ce.sync(end); }
-      {                                              // delete_ref(prev_beg): entry beg-1; stays iff a later same-hash entry was inserted
-        bool eff = advB;
-        if (advB && (delCode & kL2DupBit)) { const int32_t nx = a.g.nextSame[r.beg0 + beg - 1]; eff = !(nx >= 0 && nx < r.beg0 + (advE ? end - 1 : end)); }
-        l2_apply<-1>(F, R, delCode, eff);
-      }
-      {                                              // insert_ref(prev_end): entry end-1; new iff no same-hash entry in [beg, end-1)
-        bool eff = advE;
-        if (advE && (insCode & kL2DupBit)) eff = a.g.prevSame[r.beg0 + end - 1] < r.beg0 + beg;
-        l2_apply<+1>(F, R, insCode, eff);
-      }
-      const bool better = R.shared > best, tie = R.shared == best;
-      best = better ? R.shared : best;
-      firstPos = better ? wBeg : firstPos;
-      lastPos = (better || tie) ? wBeg : lastPos;
-      steps++;
-      // MIIteratorL2::next
-      const int32_t d1 = wBegNext - pos, d2 = wEnd - (pos + cmw - 1);
-      const int32_t adv = d1 < d2 ? d1 : d2;
-      pos += adv;
-      advB = (adv == d1); advE = (adv == d2);
-      if (advB) {
-        delCode = codeBeg; beg++; wBeg = wBegNext; codeBeg = codeBegNext;
-        if (beg + 1 < m) { codeBegNext = cb.get(beg + 1); wBegNext = next_wpos(wBeg, codeBegNext, beg + 1); }
-      }
-      if (advE) {
-        insCode = codeEnd; end++;
-        if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
+    // Event-driven form of the loop at computeMap.hpp:455-481.  A step of the reference advances MIIteratorL2 to the nearer of
+    //   pB = wpos[beg+1]            (the first entry leaves:  delete_ref(beg),  beg++)
+    //   pE = wpos[end] - cmw + 1    (entry `end` fits:        insert_ref(end),  end++)
+    // applies the delete and/or the insert and evaluates the window; the loop ends, unevaluated, with the insert that takes
+    // `end` to the end of the range.  Nearly every step carries one event only, so one pass of this loop is ONE event: apply it,
+    // advance its cursor, evaluate unless the insert of the same position (pB == pE: delete first, as the reference does) is
+    // still to come.  wpos is strictly increasing inside a contig, so after such a delete the next event is that insert.
+    if (end < m) {
+      best = R.shared; firstPos = R.shared > 0 ? wBeg : 0; lastPos = wBeg; steps = 1;     // first pass of :455, no events
+      const int32_t cmw1 = cmw - 1;
+      int b1 = 1;                                    // beg + 1
+      const uint32_t *ringB = S + G::kStateWords * kWave;
+      for (int it = 0; !R.ovf; it++) {
+        if ((it & 7) == 0) { cb.sync(b1); ce.sync(end); }
+        const int32_t pE = wEnd - cmw1;
+        const bool del = wBegNext <= pE;
+        if (!del && end + 1 >= m) break;
+        const bool more = del && wBegNext == pE;     // the insert of this step follows
+        const uint32_t code = del ? codeBeg : codeEnd;
+        bool eff = true;
+        if (code & kL2DupBit) {
+          if (del) {                                 // stays iff a later same-hash entry is already in the window
+            const int32_t nx = a.g.nextSame[r.beg0 + b1 - 1];
+            eff = !(nx >= 0 && nx < r.beg0 + end);
+          } else eff = a.g.prevSame[r.beg0 + end] < r.beg0 + b1 - 1;       // new iff no same-hash entry in [beg, end)
+        }
+        l2_apply(F, R, code, !del, eff);
+        // advance the event's cursor: fetch entry beg+2 resp. end+1 (both inside the range, see above)
+        const int jf = (del ? b1 : end) + 1;
+        const uint16_t *h = (const uint16_t *)(ringB + (del ? 0 : 8 * kWave) + ((jf & 15) >> 1) * kWave);
+        const uint32_t cf = h[jf & 1];
+        const int32_t wf = next_wpos(del ? wBegNext : wEnd, cf, jf);
+        codeBeg = del ? codeBegNext : codeBeg; wBeg = del ? wBegNext : wBeg;
+        codeBegNext = del ? cf : codeBegNext; wBegNext = del ? wf : wBegNext;
+        codeEnd = del ? codeEnd : cf; wEnd = del ? wEnd : wf;
+        b1 += del ? 1 : 0; end += del ? 0 : 1;
+        // evaluate (:468-476)
+        const bool better = !more && R.shared > best, tieOrBetter = !more && R.shared >= best;
+        best = better ? R.shared : best;
+        firstPos = better ? wBeg : firstPos;
+        lastPos = tieOrBetter ? wBeg : lastPos;
+        steps += more ? 0 : 1;
       }
     }
     if (R.ovf) a.slowFlag[i] = 3;

@@ -137,6 +137,8 @@ template <class T> static inline T __shfl_xor(T v, int m, int width = 64) {
   T r = emu_unbits<T>(all[lane ^ m]);
   (void)width; hipemu::wave_done(); return r;
 }
+// v_readlane_b32: value of (wave-uniform) lane l
+static inline int __builtin_amdgcn_readlane(int v, int l) { return __shfl(v, l); }
 static inline unsigned long long __ballot(int pred) {
   uint64_t mask; const uint64_t *all = hipemu::wave_gather(pred ? 1 : 0, &mask);
   unsigned long long r = 0;
@@ -151,6 +153,7 @@ static inline int __all(int pred) {
   hipemu::wave_done(); return r;
 }
 
+static inline int __mul24(int a, int b) { return a * b; }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
