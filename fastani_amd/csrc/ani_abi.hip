@@ -631,6 +631,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
+    a.filterShift = 1; while (a.filterShift < 30 && (1 << a.filterShift) < 2 * L) a.filterShift++;
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
     a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTL);
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);

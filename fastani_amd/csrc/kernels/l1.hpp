@@ -20,6 +20,8 @@ constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS cl
 constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 8 KiB scratch -> 6 workgroups per CU
 constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgroups per CU
 constexpr int kL1HitCapMax = 8192;      // class L: 64 KiB + 32 KiB -> 1 workgroup per CU (rare)
+constexpr int kL1FilterMinHits = 300;   // below this the sort is cheaper than the noise filter
+template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 14 : HCAP == 4096 ? 15 : 16; }   // log2(8 * HCAP) occupancy counters per tiling
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
@@ -33,6 +35,7 @@ struct L1Args {
   int32_t *largeList; unsigned int *largeCount;   // fragments with kL1HitCapMid < H <= kL1HitCapMax
   int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
   unsigned long long *sumHits;
+  int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
 };
 
 // occurrences of hash h in the hash-sorted index: [first, first+cnt)
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   __shared__ int V[HCAP];
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
+  __shared__ int sKeep;
   const int f = list ? list[blockIdx.x] : (int)blockIdx.x;
   const int t = threadIdx.x;
   const int s = a.fragS[f];
@@ -170,11 +174,54 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
     const uint32_t fi = a.probeFirst[off + i];
     for (int c = 0; c < e - o; c++) hits[o + c] = a.sSW[fi + c];
   }
-  const int n2 = next_pow2(H);
-  for (int i = H + t; i < n2; i += kTPB) hits[i] = ~0ull;
+  // Noise filter.  Minimizer hashes are minima over w k-mers, so they crowd the low end of the 32-bit range and most seed hits of
+  // a fragment against a large reference set are chance collisions: isolated hits (measured on 1000 x 5 Mbp: ~1300 hits per
+  // fragment, ~700 of them alone in their 4-kb neighbourhood).  With minimumHits m >= 2 a hit without another hit of the same
+  // contig within < fragLen is in no valid run (computeMap.hpp:326-336), and a run that becomes consecutive once it is gone
+  // spans it, i.e. would have been such a neighbour: dropping those hits leaves every candidate unchanged and shortens the sort.
+  // "Has a neighbour" is tested conservatively with two offset tilings of width W >= 2 fragLen (two points closer than W/2 share a
+  // tile in one of them) hashed into 2-bit occupancy counters: a collision only keeps a hit that could have been dropped.
+  int n = H;
+  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;
+  if (m >= 2 && H > kL1FilterMinHits) {
+    constexpr int NBW = HCAP / 4;                    // words per bit array; V holds {seenA, twiceA, seenB, twiceB}
+    uint32_t *bits = (uint32_t *)V;
+    __syncthreads();                                 // the gather is complete
+    for (int i = t; i < HCAP; i += kTPB) bits[i] = 0u;
+    if (t == 0) sKeep = 0;
+    __syncthreads();
+    constexpr int PER = HCAP / kTPB;
+    uint64_t hv[PER]; uint32_t ia[PER], ib[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int x = t + j * kTPB;
+      if (x < H) {
+        hv[j] = hits[x];
+        const uint32_t wpos = (uint32_t)hv[j], sq = (uint32_t)(hv[j] >> 32);
+        ia[j] = ((sq * 0x9E3779B1u + (wpos >> a.filterShift)) * 0x85EBCA77u) >> (32 - kL1FilterBits<HCAP>());
+        ib[j] = ((sq * 0xC2B2AE3Du + ((wpos + (1u << (a.filterShift - 1))) >> a.filterShift)) * 0x27D4EB2Fu) >> (32 - kL1FilterBits<HCAP>());
+        const uint32_t ba = 1u << (ia[j] & 31), bb = 1u << (ib[j] & 31);
+        if (atomicOr(&bits[ia[j] >> 5], ba) & ba) atomicOr(&bits[NBW + (ia[j] >> 5)], ba);
+        if (atomicOr(&bits[2 * NBW + (ib[j] >> 5)], bb) & bb) atomicOr(&bits[3 * NBW + (ib[j] >> 5)], bb);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const int x = t + j * kTPB;
+      if (x < H) {
+        const bool keep = ((bits[NBW + (ia[j] >> 5)] >> (ia[j] & 31)) | (bits[3 * NBW + (ib[j] >> 5)] >> (ib[j] & 31))) & 1u;
+        if (keep) hits[atomicAdd(&sKeep, 1)] = hv[j];      // every lane has read its hits: compaction in place, order irrelevant
+      }
+    }
+    __syncthreads();
+    n = sKeep;
+  }
+  const int n2 = next_pow2(n);
+  for (int i = n + t; i < n2; i += kTPB) hits[i] = ~0ull;
   block_bitonic_sort<uint64_t>(hits, n2);           // :320 (starts with a barrier: the gather is complete)
 
-  l1_emit_candidates(a, f, s, H, hits, V, ws, &sBase);
+  l1_emit_candidates(a, f, s, n, hits, V, ws, &sBase);
 }
 
 // Fragments beyond the LDS classes (low-complexity / highly repetitive references): same algorithm over global memory,

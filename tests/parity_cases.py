@@ -133,6 +133,15 @@ def case_low_complexity_big(engine):
     assert c["l2SlowCandidates"] > 0          # candidate ranges longer than 16384 entries went through the general kernel
 
 
+def case_sparse_hits(engine):
+    """few, scattered seed hits per reference (10-20 % divergence, 60 references): most hits are isolated and the L1 noise
+    filter drops them before the sort; the candidates must not change"""
+    base = rng_genome(22, 6000)
+    genomes = [[np.concatenate([rng_genome(1500 + i, 800), mutate(base, 0.2 if i % 3 else 0.1, 2500 + i), rng_genome(3500 + i, 800)])] for i in range(60)]
+    p, sk, osk = check_sketch(engine, genomes)
+    check_queries(engine, p, sk, osk, [[base], genomes[3]])
+
+
 def case_empty_and_short(engine):
     genomes = [[b"ACGT" * 3], [orc.synth_genome(2, 0, 30000)], [b""], [orc.synth_genome(2, 1, 2999)]]
     p, sk, osk = check_sketch(engine, genomes)
@@ -166,7 +175,7 @@ def case_device_synth(engine, alloc):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_empty_and_short]
+             case_low_complexity_big, case_sparse_hits, case_empty_and_short]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):
