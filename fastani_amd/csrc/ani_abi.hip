@@ -143,7 +143,12 @@ inline unsigned grid_for(size_t n, unsigned block = 256, unsigned maxBlocks = 65
 struct ani_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  // stage timers: event pairs are recorded as the launches go out and read back lazily (flush_timers), never by blocking the host
+  std::vector<hipEvent_t> timerEvents; size_t timerUsed = 0;
+  struct PendingTimer { size_t a, b; double *acc; };
+  std::vector<PendingTimer> timerPending;
   ani_counters_t counters;
   double candPerFrag = 12.0;      // running estimate that sizes the L1 candidate pool
   // scalar device counters (array of 16 x u64)
@@ -206,18 +211,35 @@ int read_counters(ani_ctx *c, unsigned long long *host)
 }
 
 // HIP-event bracket on the launch stream; `slot` selects an event pair so that timers can nest
+// HIP-event stage timer.  Both events are recorded on the stream the timed launches go to; the elapsed time is added to *acc when
+// the timers are flushed (at a point where the host waits for the device anyway), so timing never serialises host and device.
+void flush_timers(ani_ctx *c)
+{
+  if (c->timerPending.empty()) { c->timerUsed = 0; return; }
+  for (const auto &p : c->timerPending) {
+    (void)hipEventSynchronize(c->timerEvents[p.b]);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->timerEvents[p.a], c->timerEvents[p.b]) == hipSuccess) *p.acc += ms;
+  }
+  c->timerPending.clear(); c->timerUsed = 0;
+}
+size_t timer_event(ani_ctx *c)
+{
+  if (c->timerUsed == c->timerEvents.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); c->timerEvents.push_back(e); }
+  return c->timerUsed++;
+}
 struct StageTimer {
-  ani_ctx *c; double *acc; hipEvent_t a, b;
-  StageTimer(ani_ctx *c_, double *acc_, int slot = 0) : c(c_), acc(acc_), a(slot ? c_->ev2 : c_->ev0), b(slot ? c_->ev3 : c_->ev1)
+  ani_ctx *c; double *acc; size_t a; hipStream_t st;
+  StageTimer(ani_ctx *c_, double *acc_, int /*slot*/ = 0, hipStream_t stream = nullptr) : c(c_), acc(acc_), st(stream ? stream : c_->stream)
   {
-    (void)hipEventRecord(a, c->stream);
+    a = timer_event(c);
+    (void)hipEventRecord(c->timerEvents[a], st);
   }
   ~StageTimer()
   {
-    (void)hipEventRecord(b, c->stream);
-    (void)hipEventSynchronize(b);
-    float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-    *acc += ms;
+    const size_t b = timer_event(c);
+    (void)hipEventRecord(c->timerEvents[b], st);
+    c->timerPending.push_back({a, b, acc});
   }
 };
 
@@ -244,6 +266,7 @@ int device_scan(ani_ctx *c, const int32_t *in, uint32_t *out, uint32_t n, uint64
   *total = run;
   if (nb2 > 1) {
     HIP_TRY(hipMemcpyAsync(c->scanTmpD.p, off2.data(), (size_t)nb2 * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));     // off2 dies at scope exit
     hipLaunchKernelGGL(k_scan_add, dim3((nb1 + 255) / 256), dim3(256), 0, c->stream, c->scanTmpB.as<uint32_t>(), nb1, (const uint32_t *)c->scanTmpD.as<uint32_t>());
   }
   if (nb1 > 1)
@@ -498,12 +521,13 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
     if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
                               (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
-    // bucket table over the top bits: about one bucket per entry, between 2^10 and 2^28 buckets
+    // bucket table over the top bits of the (density-flattened) bucket key: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
     while (bits < 28 && (1ull << bits) < n) bits++;
     sk->bucketShift = 32 - bits; sk->nBuckets = 1u << bits;
     SK_HIP(pool_malloc((void **)&sk->bucketStart, ((size_t)sk->nBuckets + 1) * 4));
-    hipLaunchKernelGGL(k_index_buckets, dim3(grid_for((size_t)sk->nBuckets + 1)), dim3(256), 0, ctx->stream, sk->sHash, (uint32_t)n, sk->bucketShift, sk->nBuckets, sk->bucketStart);
+    if (n) hipLaunchKernelGGL(k_index_buckets, dim3(grid_for(n, 256, 65535)), dim3(256), 0, ctx->stream, sk->sHash, (uint32_t)n, sk->bucketShift, p->windowSize, sk->nBuckets, sk->bucketStart);
+    else SK_HIP(hipMemsetAsync(sk->bucketStart, 0, ((size_t)sk->nBuckets + 1) * 4, ctx->stream));
     SK_HIP(hipGetLastError());
     unsigned long long host[CNT_N];
     SK_TRY(read_counters(ctx, host));
@@ -546,6 +570,7 @@ struct QueryRun {
 
 int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *qr)
 {
+  if (ctx->timerPending.size() > 4096) flush_timers(ctx);      // no stage timer is open here
   const ani_params_t &p = sk->params;
   const int k = p.kmerSize, w = p.windowSize, L = p.fragLen;
   // ---- fragment table (computeMap.hpp:132-190) ----
@@ -625,7 +650,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     else { HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CAND), 0, 8, ctx->stream)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
     L1Args a;
     a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>(); a.nFrag = (int32_t)nF;
-    a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.nIndex = sk->n;
+    a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.bucketW = sk->params.windowSize; a.nIndex = sk->n;
     a.minHitsLUT = sk->dMinHits; a.lutMaxS = sk->dLutMaxS; a.L = L;
     a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
     a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);
@@ -752,9 +777,8 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
         {
           // order the chunk's candidates by code-stream length (longest first) for the simulation
           StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
-          unsigned int nn = (unsigned int)n;
           HIP_TRY(hipMemsetAsync(ctx->l2LenHist.p, 0, kL2LenBuckets * 4, ctx->stream));
-          HIP_TRY(hipMemcpyAsync(ctx->l2LenHist.as<unsigned int>() + kL2LenBuckets, &nn, 4, hipMemcpyHostToDevice, ctx->stream));
+          HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->l2LenHist.as<unsigned int>() + kL2LenBuckets), (int)n, 1, ctx->stream));   // list length for the simulation launch
           hipLaunchKernelGGL(k_l2_len_hist, dim3(grid_for(n, kTPB, 2048)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)n, ctx->l2LenHist.as<unsigned int>());
           hipLaunchKernelGGL(k_l2_len_scan, dim3(1), dim3(kTPB), 0, ctx->stream, ctx->l2LenHist.as<unsigned int>());
           hipLaunchKernelGGL(k_l2_len_scatter, dim3(grid_for(n, kTPB)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)c0, (int32_t)n,
@@ -764,22 +788,27 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
           StageTimer tk(ctx, &ctx->counters.msL2Codes, 1);
           hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)(fB - fA + 1)), dim3(kTPB), 0, ctx->stream, fa);
         }
+        // The few class-B candidates (s in 256..319) are compacted so that they fill whole waves; their launch is bound by the
+        // serial length of one lane, not by throughput, so it goes to the side stream and runs underneath the class-A launch.
+        HIP_TRY(hipEventRecord(ctx->evFork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+        {
+          StageTimer tk(ctx, &ctx->counters.msL2SimB, 1, ctx->stream2);
+          HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CLASSB), 0, 8, ctx->stream2));
+          hipLaunchKernelGGL(k_l2_collect_class, dim3(grid_for(n)), dim3(256), 0, ctx->stream2, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag, 4,
+                             ctx->l2ClassList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
+          L2FastArgs fb = fa;       // class B accumulates its algorithmic-byte counters separately
+          fb.g.sumEntries = cnt_ptr(ctx, CNT_ENTRIES_B); fb.g.sumQ = cnt_ptr(ctx, CNT_SUMQ_B); fb.g.sumSteps = cnt_ptr(ctx, CNT_STEPS_B);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream2, fb, (const int32_t *)ctx->l2ClassList.as<int32_t>(),
+                             (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
+        }
+        HIP_TRY(hipEventRecord(ctx->evJoin, ctx->stream2));
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
           hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)ctx->l2Order.as<int32_t>(),
                              (const unsigned int *)ctx->l2LenHist.as<unsigned int>() + kL2LenBuckets);
         }
-        {
-          StageTimer tk(ctx, &ctx->counters.msL2SimB, 1);
-          // the few class-B candidates (s in 256..319) are compacted first so that they fill whole waves
-          HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CLASSB), 0, 8, ctx->stream));
-          hipLaunchKernelGGL(k_l2_collect_class, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag, 4,
-                             ctx->l2ClassList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
-          L2FastArgs fb = fa;       // class B accumulates its algorithmic-byte counters separately
-          fb.g.sumEntries = cnt_ptr(ctx, CNT_ENTRIES_B); fb.g.sumQ = cnt_ptr(ctx, CNT_SUMQ_B); fb.g.sumSteps = cnt_ptr(ctx, CNT_STEPS_B);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fb, (const int32_t *)ctx->l2ClassList.as<int32_t>(),
-                             (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
-        }
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
         ctx->counters.l2Launches++;
       }
       // whatever did not qualify (or overflowed a gap counter) is appended to the sub-batch's list for the general kernel
@@ -898,7 +927,8 @@ int ani_init(int device, ani_ctx **out)
   c->device = device;
   memset(&c->counters, 0, sizeof c->counters);
   HIP_TRY(hipStreamCreate(&c->stream));
-  HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1)); HIP_TRY(hipEventCreate(&c->ev2)); HIP_TRY(hipEventCreate(&c->ev3));
+  HIP_TRY(hipStreamCreate(&c->stream2));
+  HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
   int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }
   *out = c;
@@ -915,10 +945,10 @@ void ani_shutdown(ani_ctx *c)
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Order, &c->l2LenHist, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->ev2) (void)hipEventDestroy(c->ev2);
-  if (c->ev3) (void)hipEventDestroy(c->ev3);
+  for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
+  if (c->evFork) (void)hipEventDestroy(c->evFork);
+  if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   cur_pool().trim();
@@ -935,12 +965,14 @@ int ani_device_copy(ani_ctx *c, void *dst, const void *src, size_t bytes)
 int ani_get_counters(ani_ctx *c, ani_counters_t *out)
 {
   if (!c || !out) return fail(ANI_ERR_ARG, "null argument");
+  flush_timers(c);
   *out = c->counters;
   return ANI_OK;
 }
 int ani_reset_counters(ani_ctx *c)
 {
   if (!c) return fail(ANI_ERR_ARG, "null argument");
+  flush_timers(c);
   memset(&c->counters, 0, sizeof c->counters);
   return ANI_OK;
 }

@@ -5,7 +5,7 @@
 //   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n]      + contigFirstMin[nContigs+1]
 //   hash order    (≙ minimizerPosLookupIndex)  sHash[n] (sorted), sSW[n] = seqId<<32|wpos carried through the stable sort, so
 //                                              every hash's occurrence list is one contiguous run in (seqId,wpos) order (:186-190)
-//   bucket table  bucketStart[2^bits + 1]      lower bounds of the top `bits` hash bits inside sHash
+//   bucket table  bucketStart[2^bits + 1]      lower bounds of the top `bits` bits of bucket_key(hash) inside sHash
 //   same-hash links (for the L2 set semantics) prevSame[n], nextSame[n]: neighbouring NEAR occurrence of the same hash in
 //                                              position order (one that can share a super-window), -1 otherwise
 #pragma once
@@ -82,19 +82,31 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t
   }
 }
 
-// bucketStart[b] = first r with (sHash[r] >> shift) >= b, for b = 0..nBuckets (inclusive)
-__global__ void k_index_buckets(const uint32_t *__restrict__ sHash, uint32_t n, int shift, uint32_t nBuckets,
+// Bucket key of a hash.  Minimizer hashes are minima over w k-mer hashes, so their density falls off like w (1 - v)^(w-1) over
+// the 32-bit range v = h / 2^32: buckets cut from the top bits of h would hold dozens of entries at the low end and none at the
+// high end.  The key is the CDF instead, ~ 2^32 (1 - (1 - v)^w) in 32-bit fixed point (square-and-multiply on the high halves
+// of the products): non-decreasing in h — every step is a floor of a product of non-decreasing factors — so a bucket is still
+// a contiguous run of the hash-sorted index, and close to uniformly filled.
+__host__ __device__ __forceinline__ uint32_t bucket_key(uint32_t h, int w)
+{
+  uint32_t p = ~h, r = 0xffffffffu;
+  for (int e = w; e; e >>= 1) {
+    if (e & 1) r = (uint32_t)(((uint64_t)r * p) >> 32);
+    p = (uint32_t)(((uint64_t)p * p) >> 32);
+  }
+  return ~r;
+}
+
+// bucketStart[b] = first r with (bucket_key(sHash[r]) >> shift) >= b, for b = 0..nBuckets (inclusive).  Entry-driven: entry r
+// fills the buckets between its predecessor's and its own (about one per entry), the last entry also the tail.  n >= 1.
+__global__ void k_index_buckets(const uint32_t *__restrict__ sHash, uint32_t n, int shift, int w, uint32_t nBuckets,
                                 uint32_t *__restrict__ bucketStart)
 {
-  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= nBuckets; b += gridDim.x * blockDim.x) {
-    uint32_t lo = 0, hi = n;
-    if (b == nBuckets) lo = n;
-    else
-      while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((sHash[mid] >> shift) < b) lo = mid + 1; else hi = mid;
-      }
-    bucketStart[b] = lo;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const int64_t k1 = (int64_t)(bucket_key(sHash[r], w) >> shift);
+    const int64_t k0 = r ? (int64_t)(bucket_key(sHash[r - 1], w) >> shift) : -1;
+    for (int64_t b = k0 + 1; b <= k1; b++) bucketStart[b] = r;
+    if (r == n - 1) for (int64_t b = k1 + 1; b <= (int64_t)nBuckets; b++) bucketStart[b] = n;
   }
 }
 

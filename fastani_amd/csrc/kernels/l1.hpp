@@ -13,6 +13,7 @@
 // fragments take k_l1_big_gather -> device radix sort -> k_l1_big_candidates over global memory.
 #pragma once
 #include "common.hpp"
+#include "index.hpp"
 
 namespace ani {
 
@@ -25,7 +26,7 @@ template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return H
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
-  const uint32_t *sHash; const uint64_t *sSW; const uint32_t *bucketStart; int bucketShift; uint32_t nIndex;
+  const uint32_t *sHash; const uint64_t *sSW; const uint32_t *bucketStart; int bucketShift, bucketW; uint32_t nIndex;
   const int32_t *minHitsLUT; int32_t lutMaxS;
   int L;
   int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
@@ -41,7 +42,7 @@ struct L1Args {
 // occurrences of hash h in the hash-sorted index: [first, first+cnt)
 __device__ __forceinline__ void l1_probe(const L1Args &a, uint32_t h, uint32_t &first, uint32_t &cnt)
 {
-  const uint32_t b = h >> a.bucketShift;
+  const uint32_t b = bucket_key(h, a.bucketW) >> a.bucketShift;
   uint32_t lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
   const uint32_t bhi = hi;
   while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a.sHash[mid] < h) lo = mid + 1; else hi = mid; }

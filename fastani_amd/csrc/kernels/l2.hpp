@@ -388,8 +388,8 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
   r.cStar -= INS ? cm : -cm;
 }
 
-// slowFlag protocol: 0 = class A, 4 = class B (s in 256..319), 1 = outside every fast-path limit,
-//                    3 = a gap counter overflowed -> general kernel
+// slowFlag protocol: 0 = class A (pending or done), 4 = class B pending (s in 256..319), 8 = class B done,
+//                    1 = outside every fast-path limit, 3 = a gap counter overflowed -> general kernel
 // `list` (optional): candidate ids to run, densely packed so that the few class-B candidates fill whole waves instead of
 // leaving one busy lane in every wave; *listCount is read on the device (no host round trip).
 template <class G>
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
     }
     if (R.ovf) a.slowFlag[i] = 3;
     else {
-      a.slowFlag[i] = 0;
+      a.slowFlag[i] = (G::kMaxS == 255) ? 0 : 8;     // class B runs concurrently with class A: its "done" must not read as class A
       a.g.outBest[c] = best; a.g.outFirst[c] = firstPos; a.g.outLast[c] = lastPos;
       cntE = (unsigned long long)m; cntS = (unsigned long long)steps; cntQ = (unsigned long long)R.s;
     }
@@ -504,12 +504,12 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
 }
 
 // candidates of the chunk that must take the general kernel -> list (order irrelevant)
-// after both simulation classes ran: slowFlag 1 = outside the fast-path limits, 3 = gap counter overflow, 0 = done
+// after both simulation classes ran: slowFlag 1 = outside the fast-path limits, 3 = gap counter overflow, 0 / 8 = done
 __global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t *__restrict__ list,
                                   unsigned int *__restrict__ count, unsigned long long *__restrict__ reasons /* [4] */)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && slowFlag[i]) { list[atomicAdd(count, 1u)] = c0 + i; atomicAdd(&reasons[slowFlag[i] & 3], 1ull); }
+  if (i < n && (slowFlag[i] & 3)) { list[atomicAdd(count, 1u)] = c0 + i; atomicAdd(&reasons[slowFlag[i] & 3], 1ull); }
 }
 
 // Candidates of a chunk ordered by the length of their code stream (counting sort on codeCount / 16): the 64 lanes of a wave
