@@ -174,7 +174,7 @@ struct ani_sketch {
   std::vector<int32_t> contigLen, genomeContigStart;
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
-  uint32_t *sHash = nullptr, *bucketStart = nullptr, *mWposF = nullptr;
+  uint32_t *sHash = nullptr, *bucketStart = nullptr; uint8_t *mDelta = nullptr;
   uint64_t *sSW = nullptr;
   int bucketShift = 0; uint32_t nBuckets = 0;
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
@@ -463,7 +463,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 
 void free_sketch_device(ani_sketch *sk)
 {
-  void *ptrs[] = {sk->sSW, sk->mWposF, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->bucketStart, sk->contigFirstMin,
+  void *ptrs[] = {sk->sSW, sk->mDelta, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->bucketStart, sk->contigFirstMin,
                   sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
   for (void *q : ptrs) if (q) pool_free(q);
 }
@@ -502,13 +502,13 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   const size_t n4 = (n ? n : 1) * 4;
   SK_HIP(pool_malloc((void **)&sk->mHash, n4)); SK_HIP(pool_malloc((void **)&sk->mSeq, n4)); SK_HIP(pool_malloc((void **)&sk->mWpos, n4));
   SK_HIP(pool_malloc((void **)&sk->prevSame, n4)); SK_HIP(pool_malloc((void **)&sk->nextSame, n4));
-  SK_HIP(pool_malloc((void **)&sk->sHash, n4)); SK_HIP(pool_malloc((void **)&sk->mWposF, n4)); SK_HIP(pool_malloc((void **)&sk->sSW, 2 * n4));
+  SK_HIP(pool_malloc((void **)&sk->sHash, n4)); SK_HIP(pool_malloc((void **)&sk->mDelta, n + 8)); SK_HIP(pool_malloc((void **)&sk->sSW, 2 * n4));
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
     uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
     SK_HIP(pool_malloc((void **)&tmpK, n4)); SK_HIP(pool_malloc((void **)&tmpV, 2 * n4));
     if (n) {
-      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, sk->mWposF,
+      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, sk->mDelta,
                          sk->prevSame, sk->nextSame, tmpK, tmpV);
       size_t tb = 0;
       int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, nullptr, &tb, ctx->stream);
@@ -520,7 +520,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     SK_HIP(pool_malloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
     hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
     if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
-                              (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mWposF, cnt_ptr(ctx, CNT_UNIQ));
+                              (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mDelta, cnt_ptr(ctx, CNT_UNIQ));
     // bucket table over the top bits of the (density-flattened) bucket key: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
     while (bits < 28 && (1ull << bits) < n) bits++;
@@ -733,7 +733,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mWposF = sk->mWposF; a.contigFirstMin = sk->contigFirstMin;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.contigFirstMin = sk->contigFirstMin;
     a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
     a.outBest = ctx->l2Best.as<int32_t>(); a.outFirst = ctx->l2First.as<int32_t>(); a.outLast = ctx->l2Last.as<int32_t>();
     a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS); a.sumQ = cnt_ptr(ctx, CNT_SUMQ);

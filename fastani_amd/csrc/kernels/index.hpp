@@ -2,7 +2,7 @@
 //
 // Replaces skch::Sketch::index (src/map/include/winSketch.hpp:181-193: unordered_map<hash, vector<{seqId,wpos}>>)
 // and skch::Sketch::searchIndex (:259-270) by flat device arrays:
-//   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n]      + contigFirstMin[nContigs+1]
+//   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n], mDelta[n] (wpos step + nearDup flag, 1 byte) + contigFirstMin[nContigs+1]
 //   hash order    (≙ minimizerPosLookupIndex)  sHash[n] (sorted), sSW[n] = seqId<<32|wpos carried through the stable sort, so
 //                                              every hash's occurrence list is one contiguous run in (seqId,wpos) order (:186-190)
 //   bucket table  bucketStart[2^bits + 1]      lower bounds of the top `bits` bits of bucket_key(hash) inside sHash
@@ -16,13 +16,18 @@ namespace ani {
 // records: 12-byte (hash, seqId, wpos) triples in position order -> SoA + sort input (key = hash, value = seqId<<32 | wpos)
 __global__ void k_index_split(const uint32_t *__restrict__ records, uint32_t n,
                               uint32_t *__restrict__ mHash, int32_t *__restrict__ mSeq, int32_t *__restrict__ mWpos,
-                              uint32_t *__restrict__ mWposF, int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame,
+                              uint8_t *__restrict__ mDelta, int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame,
                               uint32_t *__restrict__ keyOut, uint64_t *__restrict__ valOut)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t h = records[3 * (size_t)i], sq = records[3 * (size_t)i + 1], wp = records[3 * (size_t)i + 2];
     mHash[i] = h; mSeq[i] = (int32_t)sq; mWpos[i] = (int32_t)wp;
-    mWposF[i] = wp; prevSame[i] = -1; nextSame[i] = -1;          // links/flags are only written for near duplicates (rare)
+    // one byte per entry for the L2 code stream: bits 0..4 = wpos - previous wpos on the same contig (31 = larger / first entry of
+    // the contig: look the position up), bit 5 = nearDup, set by k_index_links
+    uint32_t dw = 31u;
+    if (i > 0 && records[3 * (size_t)i - 2] == sq) { dw = wp - records[3 * (size_t)i - 1]; dw = dw > 31u ? 31u : dw; }
+    mDelta[i] = (uint8_t)dw;
+    prevSame[i] = -1; nextSame[i] = -1;                          // links/flags are only written for near duplicates (rare)
     keyOut[i] = h; valOut[i] = ((uint64_t)sq << 32) | wp;
   }
 }
@@ -36,7 +41,7 @@ __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *
 }
 
 // After the stable sort by hash (sHash[r], sSW[r] = seqId<<32|wpos; equal hashes stay in position order): unique-hash count
-// and, for NEAR duplicates only, the same-hash links and the nearDup flag (bit 31 of mWposF).
+// and, for NEAR duplicates only, the same-hash links and the nearDup flag (bit 5 of mDelta).
 //   nearDup: two same-hash entries j' < j of one contig can share a super-window.  All entries of a window except its first
 //   lie within cmw = countMinimizerWindows positions; the first entry (MIIteratorL2 keeps the minimizer that is active at the
 //   window start) may trail by less than the gap to its successor: possible iff wpos[j] - wpos[j'] <= cmw + (wpos[j'+1] - wpos[j']).
@@ -44,7 +49,7 @@ __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *
 // for every consumer (they are only ever compared against the bounds of one window).
 __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t *__restrict__ sSW, uint32_t n,
                               const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin, int32_t cmw,
-                              int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame, uint32_t *__restrict__ mWposF,
+                              int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame, uint8_t *__restrict__ mDelta,
                               unsigned long long *__restrict__ nUnique)
 {
   unsigned long long uniq = 0;
@@ -67,7 +72,7 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t
     while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wb) lo = mid + 1; else hi = mid; }
     const int32_t ib = lo;
     nextSame[ia] = ib; prevSame[ib] = ia;
-    atomicOr(&mWposF[ia], 0x80000000u); atomicOr(&mWposF[ib], 0x80000000u);
+    atomicOr((uint32_t *)mDelta + (ia >> 2), 0x20u << (8 * (ia & 3))); atomicOr((uint32_t *)mDelta + (ib >> 2), 0x20u << (8 * (ib & 3)));
   }
   // one atomic per workgroup (the grid is small: a grid-stride loop covers the index)
   __shared__ unsigned long long part[8];

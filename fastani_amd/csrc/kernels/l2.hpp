@@ -188,7 +188,7 @@ struct L2Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS;
   // reference index, position order
   const uint32_t *mHash; const int32_t *mWpos; const int32_t *prevSame; const int32_t *nextSame;
-  const uint32_t *mWposF;          // wpos | nearDup << 31
+  const uint8_t *mDelta;           // min(wpos - previous wpos, 31) | nearDup << 5
   const int32_t *contigFirstMin;   // [nContigs+1]
   int L, w, k;
   // lane-interleaved scratch of the general kernel: (maxS+1) words per lane
@@ -307,15 +307,13 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     const L2Range r = a.ranges[i];
     uint16_t *out = (uint16_t *)a.codes + a.codeOff[i];
     for (int32_t j = r.beg0 + (int32_t)threadIdx.x; j < r.last; j += kTPB) {
-      const uint32_t wf = a.g.mWposF[j];
-      uint32_t dw = 0;
-      if (j > r.beg0) dw = (wf & 0x7fffffffu) - (a.g.mWposF[j - 1] & 0x7fffffffu);
-      if (dw > kL2DwEscape) dw = kL2DwEscape;
+      const uint32_t dl = a.g.mDelta[j];
+      const uint32_t dw = j > r.beg0 ? (dl & 31u) : 0u;
       const uint32_t h = a.g.mHash[j];
       int lo = st[h >> kL2RankShift], hi = st[(h >> kL2RankShift) + 1];
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h) lo = mid + 1; else hi = mid; }
       const uint32_t rk = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h);          // == q_rank(qs, s, h)
-      out[j - r.beg0] = (uint16_t)(rk | ((wf >> 31) ? kL2DupBit : 0u) | (dw << 11));
+      out[j - r.beg0] = (uint16_t)(rk | ((dl & 32u) ? kL2DupBit : 0u) | (dw << 11));
     }
   }
 }
@@ -423,7 +421,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
     // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
     auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
       const uint32_t dw = code >> 11;
-      return dw == kL2DwEscape ? (int32_t)(a.g.mWposF[r.beg0 + j] & 0x7fffffffu) : prev + (int32_t)dw;
+      return dw == kL2DwEscape ? a.g.mWpos[r.beg0 + j] : prev + (int32_t)dw;
     };
     const uint4 *base = (const uint4 *)((const uint16_t *)a.codes + a.codeOff[i]);
     L2Stream cb, ce;
