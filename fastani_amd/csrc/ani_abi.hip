@@ -144,7 +144,7 @@ struct ani_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
-  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr};
   // stage timers: event pairs are recorded as the launches go out and read back lazily (flush_timers), never by blocking the host
   std::vector<hipEvent_t> timerEvents; size_t timerUsed = 0;
   struct PendingTimer { size_t a, b; double *acc; };
@@ -161,7 +161,8 @@ struct ani_ctx {
   DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
-  DevBuf l2Ranges, l2CodeCount, l2CodeOff, l2Codes, l2SlowFlag, l2SlowList, l2ClassList, l2Order, l2LenHist;
+  DevBuf l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
+  DevBuf l2SlowList;
   DevBuf bins, queryFragments, rows;
 };
 
@@ -743,19 +744,32 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     HIP_TRY(hipMemcpyAsync(ordOff.data(), ctx->fragOrdOff.p, nF * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
 
+    // Chunks of 2^21 candidates, two buffer sets.  Main stream per chunk: ranges -> scan -> length ordering -> codes -> class-A
+    // simulation.  Side stream, after the chunk's class-A launch: the few class-B candidates (s in 256..319; their launch is
+    // bound by the serial length of one lane, not by throughput) and the collection of the leftovers — they run underneath the
+    // next chunk's ranges/codes kernels, which leave the LDS free, instead of extending every chunk by a latency-bound tail.
     const size_t CH = (size_t)1 << 21;       // candidates per chunk (a chunk whose code entries exceed 2^32 is rejected by the scan)
-    TRY(ctx->l2Ranges.ensure(CH * sizeof(L2Range))); TRY(ctx->l2CodeCount.ensure(CH * 4)); TRY(ctx->l2CodeOff.ensure(CH * 4));
-    TRY(ctx->l2SlowFlag.ensure(CH * 4)); TRY(ctx->l2SlowList.ensure(nCand * 4)); TRY(ctx->l2ClassList.ensure(CH * 4));
-    TRY(ctx->l2Order.ensure(CH * 4)); TRY(ctx->l2LenHist.ensure((kL2LenBuckets + 4) * 4));
+    for (int p = 0; p < 2; p++) {
+      TRY(ctx->l2Ranges[p].ensure(CH * sizeof(L2Range))); TRY(ctx->l2CodeCount[p].ensure(CH * 4)); TRY(ctx->l2CodeOff[p].ensure(CH * 4));
+      TRY(ctx->l2SlowFlag[p].ensure(CH * 4)); TRY(ctx->l2ClassList[p].ensure(CH * 4));
+      TRY(ctx->l2Order[p].ensure(CH * 4)); TRY(ctx->l2LenHist[p].ensure((kL2LenBuckets + 4) * 4));
+    }
+    TRY(ctx->l2SlowList.ensure(nCand * 4));
     HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->evSetDone[0], ctx->stream)); HIP_TRY(hipEventRecord(ctx->evSetDone[1], ctx->stream));   // both sets free, counters zeroed
+    HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->evSetDone[1], 0));
     size_t chunk = CH;
+    int nChunk = 0;
     for (size_t c0 = 0; c0 < nCand;) {
       const size_t c1 = std::min<size_t>(nCand, c0 + chunk);
       const size_t n = c1 - c0;
+      const int p = nChunk & 1;
+      HIP_TRY(hipEventSynchronize(ctx->evSetDone[p]));                 // host: set p may be reallocated; (long done: two chunks ago)
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evSetDone[p], 0));
       L2FastArgs fa;
       fa.g = a; fa.c0 = (int32_t)c0; fa.c1 = (int32_t)c1;
-      fa.ranges = ctx->l2Ranges.as<L2Range>(); fa.codeCount = ctx->l2CodeCount.as<int32_t>(); fa.codeOff = ctx->l2CodeOff.as<uint32_t>();
-      fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag.as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.nFrag = (int32_t)nF;
+      fa.ranges = ctx->l2Ranges[p].as<L2Range>(); fa.codeCount = ctx->l2CodeCount[p].as<int32_t>(); fa.codeOff = ctx->l2CodeOff[p].as<uint32_t>();
+      fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag[p].as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.nFrag = (int32_t)nF;
       // fragments that own candidates c0 and c1-1 (ordOff is non-decreasing; fragments without candidates repeat a value)
       const int32_t fA = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)c0) - ordOff.begin()) - 1;
       const int32_t fB = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)(c1 - 1)) - ordOff.begin()) - 1;
@@ -767,56 +781,55 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
       }
       uint64_t nCodes = 0;
       {
-        const int rc = device_scan(ctx, fa.codeCount, ctx->l2CodeOff.as<uint32_t>(), (uint32_t)n, &nCodes);
+        const int rc = device_scan(ctx, fa.codeCount, ctx->l2CodeOff[p].as<uint32_t>(), (uint32_t)n, &nCodes);
         if (rc == ANI_ERR_LIMIT && chunk > 4096) { chunk /= 2; continue; }     // very long candidate ranges: smaller chunk, same candidates again
         TRY(rc);
       }
-      TRY(ctx->l2Codes.ensure((nCodes + 64) * 2));
-      fa.codes = ctx->l2Codes.as<uint32_t>();
+      TRY(ctx->l2Codes[p].ensure((nCodes + 64) * 2));
+      fa.codes = ctx->l2Codes[p].as<uint32_t>();
       if (nCodes) {
         {
           // order the chunk's candidates by code-stream length (longest first) for the simulation
           StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
-          HIP_TRY(hipMemsetAsync(ctx->l2LenHist.p, 0, kL2LenBuckets * 4, ctx->stream));
-          HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->l2LenHist.as<unsigned int>() + kL2LenBuckets), (int)n, 1, ctx->stream));   // list length for the simulation launch
-          hipLaunchKernelGGL(k_l2_len_hist, dim3(grid_for(n, kTPB, 2048)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)n, ctx->l2LenHist.as<unsigned int>());
-          hipLaunchKernelGGL(k_l2_len_scan, dim3(1), dim3(kTPB), 0, ctx->stream, ctx->l2LenHist.as<unsigned int>());
+          HIP_TRY(hipMemsetAsync(ctx->l2LenHist[p].p, 0, kL2LenBuckets * 4, ctx->stream));
+          HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets), (int)n, 1, ctx->stream));   // list length for the simulation launch
+          hipLaunchKernelGGL(k_l2_len_hist, dim3(grid_for(n, kTPB, 2048)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)n, ctx->l2LenHist[p].as<unsigned int>());
+          hipLaunchKernelGGL(k_l2_len_scan, dim3(1), dim3(kTPB), 0, ctx->stream, ctx->l2LenHist[p].as<unsigned int>());
           hipLaunchKernelGGL(k_l2_len_scatter, dim3(grid_for(n, kTPB)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)c0, (int32_t)n,
-                             ctx->l2LenHist.as<unsigned int>(), ctx->l2Order.as<int32_t>());
+                             ctx->l2LenHist[p].as<unsigned int>(), ctx->l2Order[p].as<int32_t>());
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Codes, 1);
           hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)(fB - fA + 1)), dim3(kTPB), 0, ctx->stream, fa);
         }
-        // The few class-B candidates (s in 256..319) are compacted so that they fill whole waves; their launch is bound by the
-        // serial length of one lane, not by throughput, so it goes to the side stream and runs underneath the class-A launch.
-        HIP_TRY(hipEventRecord(ctx->evFork, ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
-        {
-          StageTimer tk(ctx, &ctx->counters.msL2SimB, 1, ctx->stream2);
-          HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CLASSB), 0, 8, ctx->stream2));
-          hipLaunchKernelGGL(k_l2_collect_class, dim3(grid_for(n)), dim3(256), 0, ctx->stream2, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag, 4,
-                             ctx->l2ClassList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
-          L2FastArgs fb = fa;       // class B accumulates its algorithmic-byte counters separately
-          fb.g.sumEntries = cnt_ptr(ctx, CNT_ENTRIES_B); fb.g.sumQ = cnt_ptr(ctx, CNT_SUMQ_B); fb.g.sumSteps = cnt_ptr(ctx, CNT_STEPS_B);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream2, fb, (const int32_t *)ctx->l2ClassList.as<int32_t>(),
-                             (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
-        }
-        HIP_TRY(hipEventRecord(ctx->evJoin, ctx->stream2));
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)ctx->l2Order.as<int32_t>(),
-                             (const unsigned int *)ctx->l2LenHist.as<unsigned int>() + kL2LenBuckets);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
+                             (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
         }
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
         ctx->counters.l2Launches++;
       }
+      HIP_TRY(hipEventRecord(ctx->evSimA[p], ctx->stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->evSimA[p], 0));
+      if (nCodes) {
+        StageTimer tk(ctx, &ctx->counters.msL2SimB, 1, ctx->stream2);
+        // class-B candidates are compacted first so that they fill whole waves
+        HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CLASSB), 0, 8, ctx->stream2));
+        hipLaunchKernelGGL(k_l2_collect_class, dim3(grid_for(n)), dim3(256), 0, ctx->stream2, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag, 4,
+                           ctx->l2ClassList[p].as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
+        L2FastArgs fb = fa;       // class B accumulates its algorithmic-byte counters separately
+        fb.g.sumEntries = cnt_ptr(ctx, CNT_ENTRIES_B); fb.g.sumQ = cnt_ptr(ctx, CNT_SUMQ_B); fb.g.sumSteps = cnt_ptr(ctx, CNT_STEPS_B);
+        hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream2, fb, (const int32_t *)ctx->l2ClassList[p].as<int32_t>(),
+                           (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
+      }
       // whatever did not qualify (or overflowed a gap counter) is appended to the sub-batch's list for the general kernel
-      hipLaunchKernelGGL(k_l2_collect_slow, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag,
+      hipLaunchKernelGGL(k_l2_collect_slow, dim3(grid_for(n)), dim3(256), 0, ctx->stream2, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag,
                          ctx->l2SlowList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG), cnt_ptr(ctx, CNT_REASON));
+      HIP_TRY(hipEventRecord(ctx->evSetDone[p], ctx->stream2));
       HIP_TRY(hipGetLastError());
-      c0 = c1;
+      c0 = c1; nChunk++;
     }
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evSetDone[0], 0)); HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->evSetDone[1], 0));
     unsigned long long nSlow64 = 0;
     HIP_TRY(hipMemcpyAsync(&nSlow64, cnt_ptr(ctx, CNT_NEG), 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -928,7 +941,7 @@ int ani_init(int device, ani_ctx **out)
   memset(&c->counters, 0, sizeof c->counters);
   HIP_TRY(hipStreamCreate(&c->stream));
   HIP_TRY(hipStreamCreate(&c->stream2));
-  HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+  for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
   int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }
   *out = c;
@@ -942,12 +955,12 @@ void ani_shutdown(ani_ctx *c)
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
                     &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
-                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges, &c->l2CodeCount, &c->l2CodeOff, &c->l2Codes, &c->l2SlowFlag, &c->l2SlowList, &c->l2ClassList, &c->l2Order, &c->l2LenHist, &c->l2Best,
+                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
+                    &c->l2Ranges[1], &c->l2CodeCount[1], &c->l2CodeOff[1], &c->l2Codes[1], &c->l2SlowFlag[1], &c->l2ClassList[1], &c->l2Order[1], &c->l2LenHist[1], &c->l2SlowList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
-  if (c->evFork) (void)hipEventDestroy(c->evFork);
-  if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+  for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); }
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

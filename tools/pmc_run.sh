@@ -16,7 +16,7 @@ for r in csv.DictReader(open(f[0])):
     agg[k][r['Counter_Name']]+=float(r['Counter_Value']); 
     cnt[(k,r['Counter_Name'])]+=1
 with open(out+'/pmc_summary.txt','w') as o:
-    for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1].values()))[:12]:
-        line=k+' '+' '.join('%s=%.4g(n=%d)'%(c,x,cnt[(k,c)]) for c,x in sorted(v.items()))
+    for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1].values()))[:60]:
+        line=k+' '+' '.join('%s=%.7g(n=%d)'%(c,x,cnt[(k,c)]) for c,x in sorted(v.items()))
         print(line); o.write(line+'\n')
 PY
