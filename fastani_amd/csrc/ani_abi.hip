@@ -12,6 +12,7 @@
 #include <array>
 #include <atomic>
 #include <thread>
+#include <memory>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -143,6 +144,9 @@ inline unsigned grid_for(size_t n, unsigned block = 256, unsigned maxBlocks = 65
 struct ani_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  uint64_t subBatchFragments = 1u << 20, subBatchBinBytes = (uint64_t)8 << 30;   // sub-batch bounds of ani_map_cgi_batch (env ANI_SUBBATCH_FRAGS)
+  std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
+  void *pinned[2] = {nullptr, nullptr}; size_t pinnedCap[2] = {0, 0};   // page-locked staging for the larger device->host reads
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
   hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr};
   // stage timers: event pairs are recorded as the launches go out and read back lazily (flush_timers), never by blocking the host
@@ -182,7 +186,7 @@ struct ani_sketch {
   uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr;
   uint32_t totalBins = 0;
   // LUTs
-  ani::stat::Luts luts;
+  ani::stat::Luts *luts = nullptr;        // host LUTs, shared by every sketch of the context with the same (k, identity cutoff)
   int32_t *dMinHits = nullptr, *dMinShared = nullptr; uint32_t *dIdLUT = nullptr; int dLutMaxS = 0;
 };
 
@@ -212,6 +216,20 @@ int read_counters(ani_ctx *c, unsigned long long *host)
 }
 
 // HIP-event bracket on the launch stream; `slot` selects an event pair so that timers can nest
+// page-locked host staging buffer `slot`, at least `bytes` long (device->host copies into pageable memory crawl)
+int pinned_buffer(ani_ctx *c, int slot, size_t bytes, void **out)
+{
+  if (c->pinnedCap[slot] < bytes) {
+    if (c->pinned[slot]) (void)hipHostFree(c->pinned[slot]);
+    c->pinned[slot] = nullptr; c->pinnedCap[slot] = 0;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc(&c->pinned[slot], cap, 0));
+    c->pinnedCap[slot] = cap;
+  }
+  *out = c->pinned[slot];
+  return ANI_OK;
+}
+
 // HIP-event stage timer.  Both events are recorded on the stream the timed launches go to; the elapsed time is added to *acc when
 // the timers are flushed (at a point where the host waits for the device anyway), so timing never serialises host and device.
 void flush_timers(ani_ctx *c)
@@ -474,14 +492,19 @@ int upload_luts(ani_sketch *sk, int maxS)
   if (maxS <= sk->dLutMaxS) return ANI_OK;
   int target = std::max(maxS, 512);
   if (target > sk->params.fragLen) target = std::max(maxS, std::min(target, sk->params.fragLen));
-  sk->luts.extend(sk->params.kmerSize, sk->params.percentageIdentity, target);
+  // the LUTs depend on (k, cutoff) only and cost milliseconds of host arithmetic: one growing copy per context
+  ani_ctx *ctx = sk->ctx;
+  sk->luts = nullptr;
+  for (auto &l : ctx->lutCache) if (l->k == sk->params.kmerSize && l->identityCutoff == sk->params.percentageIdentity) sk->luts = l.get();
+  if (!sk->luts) { ctx->lutCache.emplace_back(new ani::stat::Luts()); sk->luts = ctx->lutCache.back().get(); }
+  sk->luts->extend(sk->params.kmerSize, sk->params.percentageIdentity, target);
   if (sk->dMinHits) { pool_free(sk->dMinHits); pool_free(sk->dMinShared); pool_free(sk->dIdLUT); sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr; }
-  const size_t n1 = (size_t)sk->luts.maxS + 1, n2 = sk->luts.idBits.size();
+  const size_t n1 = (size_t)target + 1, n2 = ani::stat::Luts::off(target + 1);
   HIP_TRY(pool_malloc((void **)&sk->dMinHits, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dMinShared, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dIdLUT, n2 * 4 + 4));
-  HIP_TRY(hipMemcpy(sk->dMinHits, sk->luts.minHits.data(), n1 * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(sk->dMinShared, sk->luts.minShared.data(), n1 * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(sk->dIdLUT, sk->luts.idBits.data(), n2 * 4, hipMemcpyHostToDevice));
-  sk->dLutMaxS = sk->luts.maxS;
+  HIP_TRY(hipMemcpy(sk->dMinHits, sk->luts->minHits.data(), n1 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(sk->dMinShared, sk->luts->minShared.data(), n1 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(sk->dIdLUT, sk->luts->idBits.data(), n2 * 4, hipMemcpyHostToDevice));
+  sk->dLutMaxS = target;
   return ANI_OK;
 }
 
@@ -740,8 +763,9 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS); a.sumQ = cnt_ptr(ctx, CNT_SUMQ);
 
     // ordered candidate offset per fragment on the host: chunk [c0,c1) -> fragment range
-    std::vector<uint32_t> ordOff(nF);
-    HIP_TRY(hipMemcpyAsync(ordOff.data(), ctx->fragOrdOff.p, nF * 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t *ordOff = nullptr;
+    TRY(pinned_buffer(ctx, 0, nF * 4, (void **)&ordOff));
+    HIP_TRY(hipMemcpyAsync(ordOff, ctx->fragOrdOff.p, nF * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
 
     // Chunks of 2^21 candidates, two buffer sets.  Main stream per chunk: ranges -> scan -> length ordering -> codes -> class-A
@@ -771,8 +795,8 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
       fa.ranges = ctx->l2Ranges[p].as<L2Range>(); fa.codeCount = ctx->l2CodeCount[p].as<int32_t>(); fa.codeOff = ctx->l2CodeOff[p].as<uint32_t>();
       fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag[p].as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.nFrag = (int32_t)nF;
       // fragments that own candidates c0 and c1-1 (ordOff is non-decreasing; fragments without candidates repeat a value)
-      const int32_t fA = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)c0) - ordOff.begin()) - 1;
-      const int32_t fB = (int32_t)(std::upper_bound(ordOff.begin(), ordOff.end(), (uint32_t)(c1 - 1)) - ordOff.begin()) - 1;
+      const int32_t fA = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)c0) - ordOff) - 1;
+      const int32_t fB = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)(c1 - 1)) - ordOff) - 1;
       fa.fragBase = fA;
       { const char *ev = getenv("ANI_L2_PATH"); fa.allowFast = (ev && !strcmp(ev, "general")) ? 0 : (ev && !strcmp(ev, "classB")) ? 2 : 1; }
       {
@@ -888,8 +912,9 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuer
   if (nPairs) hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, ctx->stream, pa);   // one wave per pair
   }
   HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(hipGetLastError());
-  std::vector<uint32_t> dense(2 * nPairs);
-  if (nPairs) { HIP_TRY(hipMemcpyAsync(dense.data(), ctx->rows.p, nPairs * 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
+  uint32_t *dense = nullptr;
+  TRY(pinned_buffer(ctx, 1, nPairs * 8 + 8, (void **)&dense));
+  if (nPairs) { HIP_TRY(hipMemcpyAsync(dense, ctx->rows.p, nPairs * 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
   size_t m = 0;
   for (size_t p = 0; p < nPairs; p++) m += dense[p] != 0;
   const size_t old = rows->size();
@@ -941,6 +966,7 @@ int ani_init(int device, ani_ctx **out)
   memset(&c->counters, 0, sizeof c->counters);
   HIP_TRY(hipStreamCreate(&c->stream));
   HIP_TRY(hipStreamCreate(&c->stream2));
+  if (const char *ev = getenv("ANI_SUBBATCH_FRAGS")) { const long long v = atoll(ev); if (v > 0) c->subBatchFragments = (uint64_t)v; }
   for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
   int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }
@@ -962,6 +988,7 @@ void ani_shutdown(ani_ctx *c)
   for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); }
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  for (int i = 0; i < 2; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   cur_pool().trim();
@@ -1247,8 +1274,8 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t
   int32_t g0 = 0;
   while (g0 < queries->nGenomes) {
     int32_t g1 = g0; uint64_t fr = 0;
-    const uint64_t maxQ = std::max<uint64_t>(1, ((uint64_t)2 << 30) / (4ull * std::max<uint32_t>(sk->totalBins, 1)));
-    while (g1 < queries->nGenomes && (g1 == g0 || (fr < (1u << 18) && (uint64_t)(g1 - g0) < maxQ))) {
+    const uint64_t maxQ = std::max<uint64_t>(1, (ctx->subBatchBinBytes) / (4ull * std::max<uint32_t>(sk->totalBins, 1)));
+    while (g1 < queries->nGenomes && (g1 == g0 || (fr < ctx->subBatchFragments && (uint64_t)(g1 - g0) < maxQ))) {
       for (int32_t c = queries->genomeContigStart[g1]; c < queries->genomeContigStart[g1 + 1]; c++) fr += (uint64_t)(queries->contigLen[c] / L);
       g1++;
     }
