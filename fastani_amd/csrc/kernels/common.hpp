@@ -7,6 +7,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Use a freshly loaded register right here: the compiler then waits for the load at this point (inside a rarely taken branch)
+// instead of at a later use on the common path.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ANI_CONSUME(x) asm volatile("" : "+v"(x))
+#else
+#define ANI_CONSUME(x) (void)(x)
+#endif
+
 namespace ani {
 
 constexpr int kWave = 64;

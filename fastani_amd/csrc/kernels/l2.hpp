@@ -377,7 +377,9 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
   r.shared += isQ ? t : 0;
   r.cStar += isQ ? 0 : t;
   // insert: q_iStar leaves the s smallest;  delete: q_{iStar+1} joins them
-  const bool cond = INS ? (lt && r.iStar + r.cStar > r.s) : (r.iStar < r.s && r.iStar + 1 + r.cStar + cntj <= r.s);
+  const int tot = r.iStar + r.cStar;
+  const bool condI = lt & (tot > r.s), condD = (r.iStar < r.s) & (tot + 1 + cntj <= r.s);      // both sides, no control flow
+  const bool cond = INS ? condI : condD;
   const bool mv = act && !isQ && cond;
   const int mone = mv ? sg : 0;                                      // insert: -1 on everything, delete: +1
   const int cm = mv ? cntj : 0;
@@ -421,7 +423,9 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
     // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
     auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
       const uint32_t dw = code >> 11;
-      return dw == kL2DwEscape ? a.g.mWpos[r.beg0 + j] : prev + (int32_t)dw;
+      int32_t wp = prev + (int32_t)dw;
+      if (dw == kL2DwEscape) { wp = a.g.mWpos[r.beg0 + j]; ANI_CONSUME(wp); }     // rare; the load is waited for here, not in the loop body
+      return wp;
     };
     const uint4 *base = (const uint4 *)((const uint16_t *)a.codes + a.codeOff[i]);
     L2Stream cb, ce;
@@ -471,11 +475,12 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
             eff = !(nx >= 0 && nx < r.beg0 + end);
           } else eff = a.g.prevSame[r.beg0 + end] < r.beg0 + b1 - 1;       // new iff no same-hash entry in [beg, end)
         }
-        l2_apply(F, R, code, !del, eff);
-        // advance the event's cursor: fetch entry beg+2 resp. end+1 (both inside the range, see above)
+        // the cursor of this event advances: fetch entry beg+2 resp. end+1 (both inside the range, see above).  Read before the
+        // state update so that its LDS latency overlaps the field reads of l2_apply instead of following its byte store.
         const int jf = (del ? b1 : end) + 1;
         const uint16_t *h = (const uint16_t *)(ringB + (del ? 0 : 8 * kWave) + ((jf & 15) >> 1) * kWave);
         const uint32_t cf = h[jf & 1];
+        l2_apply(F, R, code, !del, eff);
         const int32_t wf = next_wpos(del ? wBegNext : wEnd, cf, jf);
         codeBeg = del ? codeBegNext : codeBeg; wBeg = del ? wBegNext : wBeg;
         codeBegNext = del ? cf : codeBegNext; wBegNext = del ? wf : wBegNext;
