@@ -187,8 +187,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     rows = None
+    step_ms = []
     for _ in range(args.steps):
-        rows = step()
+        ts = time.perf_counter()
+        rows = step()                                        # returns with the rows on the host: the step's device work is done
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -241,7 +244,7 @@ def main():
                "config": {"workload": "many-to-many %dx%d synthetic %d bp genomes (clusters of 20, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
                                       % (NG, NG * world, L, p.windowSize, "" if world == 1 else "; query stream sharded %d ways, reference sketch all-gathered over RCCL" % world),
                           "ref_genomes": NG, "query_genomes": NG * world, "genome_len": L, "inputs": "2-bit packed, resident in HBM"},
-               "rows_last_step": int(len(rows)),
+               "rows_last_step": int(len(rows)), "step_ms_rank0": step_ms,
                "stage_ms_per_step_rank0": stages,
                "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                               "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",

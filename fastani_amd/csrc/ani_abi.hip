@@ -12,6 +12,7 @@
 #include <array>
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include <memory>
 #include <cstdarg>
 #include <cstdint>
@@ -70,8 +71,12 @@ struct DevicePool {
       *out = it->second; live[*out] = it->first; cachedBytes -= it->first; cache.erase(it);
       return hipSuccess;
     }
+    static const bool trace = getenv("ANI_POOL_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, bytes);
     if (e != hipSuccess) { trim_locked(); (void)hipGetLastError(); e = hipMalloc(out, bytes); }
+    if (trace) fprintf(stderr, "[ani pool] hipMalloc %.1f MB: %.2f ms (cache %.1f MB in %zu blocks)\n", bytes / 1048576.0,
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), cachedBytes / 1048576.0, cache.size());
     if (e == hipSuccess) live[*out] = bytes;
     return e;
   }

@@ -354,6 +354,8 @@ struct L2Stream {
 // (byte-interleaved over the wave: one shift to address it; the only bank conflicts are between the four lanes of a dword
 // column whose g differ by a multiple of 4 — the LDS pipe has an order of magnitude of slack under the VALU work of a step).
 struct L2Regs { int s, iStar, cStar, shared; bool ovf; };
+constexpr bool kL2ByteInterleave = false;
+__device__ __forceinline__ int l2_field_off(int g) { return kL2ByteInterleave ? (g << 6) : (((g >> 2) << 8) + (g & 3)); }
 
 __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, bool INS, bool on)
 {
@@ -361,9 +363,9 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
   const int idx = (int)((code >> 1) & 0x1ffu);
   const int sg = INS ? 1 : -1;
   int j = r.iStar - (INS ? 1 : 0); j = j < 0 ? 0 : j;               // pivot-adjacent field: n[j], b[j+1]
-  uint8_t *pOwn = F + (idx << 6);
+  uint8_t *pOwn = F + l2_field_off(idx);
   const int own = *pOwn;
-  int fj = F[j << 6];
+  int fj = F[l2_field_off(j)];
   const int delta = isQ ? 1 : 2;                                     // counter lives in bits 1..7, presence in bit 0
   const bool full = INS && !isQ && own >= 254;
   r.ovf = r.ovf || (on && full);
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   __shared__ uint32_t lds[(kL2SimTPB / kWave) * G::kWords * kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   uint32_t *W = lds + wv * (G::kWords * kWave);                       // this wave's LDS
-  uint8_t *F = (uint8_t *)W + lane;                                   // field g of this lane: F[g << 6]
+  uint8_t *F = (uint8_t *)W + (kL2ByteInterleave ? lane : 4 * lane);   // field g of this lane: F[l2_field_off(g)]
   uint32_t *S = W + lane;                                             // dword x of this lane: S[x * kWave] (cursor rings)
   const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   int32_t c = a.c0 + slot;
