@@ -188,7 +188,7 @@ struct ani_sketch {
   uint64_t *sSW = nullptr;
   int bucketShift = 0; uint32_t nBuckets = 0;
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
-  uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr;
+  uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr, *posBase = nullptr, *posSample = nullptr;
   uint32_t totalBins = 0;
   // LUTs
   ani::stat::Luts *luts = nullptr;        // host LUTs, shared by every sketch of the context with the same (k, identity cutoff)
@@ -488,7 +488,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 void free_sketch_device(ani_sketch *sk)
 {
   void *ptrs[] = {sk->sSW, sk->mDelta, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->bucketStart, sk->contigFirstMin,
-                  sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
+                  sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->posBase, sk->posSample, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
   for (void *q : ptrs) if (q) pool_free(q);
 }
 
@@ -564,23 +564,29 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   }
   // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194)
   std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);
-  std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1);
+  std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1), posBase((size_t)nContigs + 1);
   const int32_t binW = p->fragLen - 20;
-  uint64_t run = 0;
+  uint64_t run = 0, runPos = 0;
   for (int32_t g = 0; g < nGenomes; g++) {
     gBin[g] = (uint32_t)run;
     for (int32_t c = genomeContigStart[g]; c < genomeContigStart[g + 1]; c++) {
       cg[c] = g; binBase[c] = (uint32_t)run; run += (uint64_t)(contigLen[c] / binW) + 1;
-      if (run > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "reference set has more than 2^32 position bins"));
+      posBase[c] = (uint32_t)runPos; runPos += ((uint64_t)contigLen[c] >> ani::kPosSampleShift) + 1;      // bins of the sampled position index
+      if (run > 0xfffffff0ull || runPos > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "reference set has more than 2^32 position bins"));
     }
   }
-  gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run;
+  gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run; posBase[nContigs] = (uint32_t)runPos;
   sk->totalBins = (uint32_t)run;
   SK_HIP(pool_malloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
   SK_HIP(pool_malloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4));
   SK_HIP(hipMemcpy(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
   SK_HIP(hipMemcpy(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice));
   SK_HIP(hipMemcpy(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice));
+  SK_HIP(pool_malloc((void **)&sk->posBase, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->posSample, ((size_t)runPos + 1) * 4));
+  SK_HIP(hipMemcpy(sk->posBase, posBase.data(), posBase.size() * 4, hipMemcpyHostToDevice));
+  if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)runPos + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
+                                  (uint32_t)runPos, (uint32_t)n, sk->posSample);
+  SK_HIP(hipGetLastError());
   SK_TRY(upload_luts(sk, 512));
   ctx->counters.refMinimizers += n; ctx->counters.refUniqueHashes += sk->nUnique; ctx->counters.refBases += sk->totalLen;
 #undef SK_TRY
@@ -762,7 +768,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.contigFirstMin = sk->contigFirstMin;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.posBase = sk->posBase; a.posSample = sk->posSample; a.contigFirstMin = sk->contigFirstMin;
     a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
     a.outBest = ctx->l2Best.as<int32_t>(); a.outFirst = ctx->l2First.as<int32_t>(); a.outLast = ctx->l2Last.as<int32_t>();
     a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS); a.sumQ = cnt_ptr(ctx, CNT_SUMQ);

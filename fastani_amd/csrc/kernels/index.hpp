@@ -129,4 +129,24 @@ __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t 
   }
 }
 
+// Sampled position index for the three searchIndex() calls of every L2 candidate (computeMap.hpp:424-436): posSample[posBase[c] + b]
+// = first position-ordered entry of contig c with wpos >= b << kPosSampleShift.  A search then is one table read plus a binary
+// search inside one 1024-position bin (<= ~80 entries) instead of over the whole contig.
+constexpr int kPosSampleShift = 10;
+__global__ void k_index_pos_sample(const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
+                                   const uint32_t *__restrict__ posBase, int32_t nContigs, uint32_t totalBins, uint32_t n,
+                                   uint32_t *__restrict__ posSample)
+{
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g <= totalBins; g += gridDim.x * blockDim.x) {
+    if (g == totalBins) { posSample[g] = n; continue; }
+    int32_t lo = 0, hi = nContigs - 1;                              // last contig with posBase[c] <= g
+    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (posBase[mid] <= g) lo = mid; else hi = mid - 1; }
+    const int32_t c = lo;
+    const int32_t pos = (int32_t)((g - posBase[c]) << kPosSampleShift);
+    int32_t a = contigFirstMin[c], b = contigFirstMin[c + 1];
+    while (a < b) { const int32_t mid = a + ((b - a) >> 1); if (mWpos[mid] < pos) a = mid + 1; else b = mid; }
+    posSample[g] = (uint32_t)a;
+  }
+}
+
 }  // namespace ani

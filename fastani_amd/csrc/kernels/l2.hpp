@@ -21,6 +21,7 @@
 // scratch[word * laneStride + l].
 #pragma once
 #include "common.hpp"
+#include "index.hpp"
 
 namespace ani {
 
@@ -190,6 +191,7 @@ struct L2Args {
   const uint32_t *mHash; const int32_t *mWpos; const int32_t *prevSame; const int32_t *nextSame;
   const uint8_t *mDelta;           // min(wpos - previous wpos, 31) | nearDup << 5
   const int32_t *contigFirstMin;   // [nContigs+1]
+  const uint32_t *posBase, *posSample;   // sampled position index (index.hpp: k_index_pos_sample)
   int L, w, k;
   // lane-interleaved scratch of the general kernel: (maxS+1) words per lane
   uint32_t *scratch; size_t laneStride;
@@ -266,10 +268,18 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
   const int32_t cLo = a.g.contigFirstMin[seq], cHi = a.g.contigFirstMin[seq + 1];
   const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
   L2Range r;
-  r.beg0 = lower_bound_wpos(a.g.mWpos, cLo, cHi, a.g.candStart[c]);
+  // lower_bound_wpos over the contig's slice through the sampled position index: the answer lies inside the target's bin
+  const uint32_t pb = a.g.posBase[seq]; const int32_t nb = (int32_t)(a.g.posBase[seq + 1] - pb);
+  auto search = [&](int32_t pos) -> int32_t {
+    int32_t bin = (pos < 0 ? 0 : pos) >> kPosSampleShift; bin = bin < nb ? bin : nb - 1;
+    const int32_t lo = (int32_t)a.g.posSample[pb + (uint32_t)bin];
+    const int32_t hi = bin + 1 < nb ? (int32_t)a.g.posSample[pb + (uint32_t)bin + 1] : cHi;
+    return lower_bound_wpos(a.g.mWpos, lo, hi, pos);
+  };
+  r.beg0 = search(a.g.candStart[c]);
   r.wposBeg0 = a.g.mWpos[r.beg0];
-  r.end0 = lower_bound_wpos(a.g.mWpos, cLo, cHi, r.wposBeg0 + cmw);
-  r.last = lower_bound_wpos(a.g.mWpos, cLo, cHi, a.g.candEnd[c] + a.g.L);
+  r.end0 = search(r.wposBeg0 + cmw);
+  r.last = search(a.g.candEnd[c] + a.g.L);
   a.ranges[i] = r;
   const int32_t m = r.last - r.beg0;
   const int32_t s = a.g.fragS[a.g.candFrag[c]];
@@ -354,7 +364,7 @@ struct L2Stream {
 // (byte-interleaved over the wave: one shift to address it; the only bank conflicts are between the four lanes of a dword
 // column whose g differ by a multiple of 4 — the LDS pipe has an order of magnitude of slack under the VALU work of a step).
 struct L2Regs { int s, iStar, cStar, shared; bool ovf; };
-constexpr bool kL2ByteInterleave = false;
+constexpr bool kL2ByteInterleave = true;
 __device__ __forceinline__ int l2_field_off(int g) { return kL2ByteInterleave ? (g << 6) : (((g >> 2) << 8) + (g & 3)); }
 
 __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, bool INS, bool on)
