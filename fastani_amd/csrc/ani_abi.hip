@@ -768,7 +768,9 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.posBase = sk->posBase; a.posSample = sk->posSample; a.contigFirstMin = sk->contigFirstMin;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.posBase = sk->posBase; a.posSample = sk->posSample;
+    a.contigFirstMin = sk->contigFirstMin;
+    { int lg = 0; while ((2 << lg) <= w) lg++; a.rankShift = 23 - std::max(0, lg - 1); }   // w = 24: 512 buckets over [0, 2^29)
     a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
     a.outBest = ctx->l2Best.as<int32_t>(); a.outFirst = ctx->l2First.as<int32_t>(); a.outLast = ctx->l2Last.as<int32_t>();
     a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS); a.sumQ = cnt_ptr(ctx, CNT_SUMQ);

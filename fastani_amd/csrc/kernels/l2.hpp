@@ -192,6 +192,8 @@ struct L2Args {
   const uint8_t *mDelta;           // min(wpos - previous wpos, 31) | nearDup << 5
   const int32_t *contigFirstMin;   // [nContigs+1]
   const uint32_t *posBase, *posSample;   // sampled position index (index.hpp: k_index_pos_sample)
+  int rankShift;                   // k_l2_codes rank table: 512 linear buckets of 2^rankShift hashes from 0; minimizer hashes are minima of w
+                                   // k-mer hashes, ~96 % of them lie below 2^32 * 3 / w, so the table covers [0, 2^(32 - floor(log2 w) + 1))
   int L, w, k;
   // lane-interleaved scratch of the general kernel: (maxS+1) words per lane
   uint32_t *scratch; size_t laneStride;
@@ -289,7 +291,9 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
 }
 
 constexpr uint32_t kL2DupBit = 1u << 10;
-constexpr int kL2RankShift = 23, kL2RankBuckets = 512;
+constexpr int kL2RankBuckets = 512;
+// rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
+__device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh; return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
 constexpr uint32_t kL2DwEscape = 31u;
 
 __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
@@ -304,10 +308,11 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   if (cA >= cB || s < 1 || s > kL2FastMaxS) return;
   const uint32_t *q = a.g.qPool + a.g.fragOff[f];
   for (int i = threadIdx.x; i < s; i += kTPB) qs[i] = q[i];
-  // hashes are uniform, so the top 9 bits bracket a rank to ~s/512 sketch entries: st[b] = #{q < b << 23}
+  // rank table: st[b] = #{q : bucket(q) < b}; a lookup then searches the one or two sketch entries of the hash's bucket
+  const int sh = a.g.rankShift;
   for (int i = threadIdx.x; i <= s; i += kTPB) {
-    const int b0 = i > 0 ? (int)(q[i - 1] >> kL2RankShift) + 1 : 0;
-    const int b1 = i < s ? (int)(q[i] >> kL2RankShift) : kL2RankBuckets;
+    const int b0 = i > 0 ? l2_rank_bucket(q[i - 1], sh) + 1 : 0;
+    const int b1 = i < s ? l2_rank_bucket(q[i], sh) : kL2RankBuckets;
     for (int b = b0; b <= b1; b++) st[b] = (uint16_t)i;
   }
   __syncthreads();
@@ -320,7 +325,8 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
       const uint32_t dl = a.g.mDelta[j];
       const uint32_t dw = j > r.beg0 ? (dl & 31u) : 0u;
       const uint32_t h = a.g.mHash[j];
-      int lo = st[h >> kL2RankShift], hi = st[(h >> kL2RankShift) + 1];
+      const int rb = l2_rank_bucket(h, sh);
+      int lo = st[rb], hi = st[rb + 1];
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h) lo = mid + 1; else hi = mid; }
       const uint32_t rk = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h);          // == q_rank(qs, s, h)
       out[j - r.beg0] = (uint16_t)(rk | ((dl & 32u) ? kL2DupBit : 0u) | (dw << 11));
