@@ -211,6 +211,11 @@ def fuzz(engine, seed, seconds=None, iterations=None):
         L = int(rng.choice([3000, 3000, 1000, 500, 2000]))
         base = rand_genome(int(rng.integers(L, 12 * L)))
         genomes = []
+        if rng.random() < 0.2:                       # many diverged copies: hundreds of scattered seed hits per fragment (L1 noise filter)
+            base = base[:4 * L]
+            for _ in range(int(rng.integers(20, 70))):
+                flank = rng_genome(int(rng.integers(1e9)), int(rng.integers(0, 1500)))
+                genomes.append([np.concatenate([flank, mutate(base, float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.25])), int(rng.integers(1e9)))])])
         for _ in range(int(rng.integers(1, 5))):
             if rng.random() < 0.6:
                 g = mutate(base, float(rng.choice([0, 0.01, 0.05, 0.1, 0.2])), int(rng.integers(1e9)))
