@@ -201,7 +201,8 @@ class Engine:
         if n == 0:
             out = np.zeros(0, dtype=dt)
         else:
-            out = np.frombuffer(C.string_at(ptr, n * dt.itemsize), dtype=dt).copy()
+            out = np.empty(n, dtype=dt)
+            C.memmove(out.ctypes.data, ptr, n * dt.itemsize)        # one copy; the library's buffer is released below
         self.lib.ani_free(ptr)
         return out
 

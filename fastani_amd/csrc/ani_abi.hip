@@ -899,7 +899,24 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
 }
 
 // 1-way / 2-way / mean for the candidates produced by query_stages; rows appended to `rows`
-int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuery, int32_t firstQueryId, std::vector<ani_cgi_t> *rows)
+// result rows in a malloc'ed, geometrically grown buffer that is handed to the caller as it is (ani_free releases it)
+struct RowBuf {
+  ani_cgi_t *p = nullptr; size_t n = 0, cap = 0;
+  ani_cgi_t *grow(size_t extra)
+  {
+    if (n + extra > cap || !p) {
+      size_t want = std::max<size_t>(n + extra, cap + cap / 2 + 1024);
+      void *q = realloc(p, want * sizeof(ani_cgi_t));
+      if (!q) return nullptr;
+      p = (ani_cgi_t *)q; cap = want;
+    }
+    return p + n;
+  }
+  ~RowBuf() { free(p); }
+  ani_cgi_t *release() { ani_cgi_t *r = p ? p : (ani_cgi_t *)malloc(sizeof(ani_cgi_t)); p = nullptr; return r; }
+};
+
+int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuery, int32_t firstQueryId, RowBuf *rows)
 {
   if (nQuery == 0) return ANI_OK;
   const size_t binsPerQuery = sk->totalBins;
@@ -930,9 +947,9 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuer
   if (nPairs) { HIP_TRY(hipMemcpyAsync(dense, ctx->rows.p, nPairs * 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
   size_t m = 0;
   for (size_t p = 0; p < nPairs; p++) m += dense[p] != 0;
-  const size_t old = rows->size();
-  rows->resize(old + m);
-  ani_cgi_t *out = rows->data() + old;
+  ani_cgi_t *out = rows->grow(m);
+  if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", m);
+  rows->n += m;
   for (int32_t qi = 0; qi < nQuery; qi++)                           // query ascending, reference ascending
     for (int32_t g = 0; g < sk->nGenomes; g++) {
       const size_t p = (size_t)qi * (size_t)sk->nGenomes + (size_t)g;
@@ -1270,9 +1287,11 @@ int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *skc, const ani_mapping_t *ma
     HIP_TRY(hipMemcpy(ctx->idBits.p, cBits.data(), n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(ctx->fragGenome.p, 0, nF * 4));
   }
-  std::vector<ani_cgi_t> rows;
+  RowBuf rows;
   TRY(reduce_stage(ctx, sk, qr, 1, queryFileNo, &rows));
-  return to_host_malloc(rows, out, m);
+  *m = rows.n; *out = rows.release();
+  if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
+  return ANI_OK;
 }
 
 int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t *queries, int32_t firstQueryId, ani_cgi_t **out, size_t *m)
@@ -1281,7 +1300,7 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t
   TRY(check_batch(queries));
   ani_sketch *sk = const_cast<ani_sketch *>(skc);
   HIP_TRY(hipSetDevice(ctx->device));
-  std::vector<ani_cgi_t> rows;
+  RowBuf rows;
   // sub-batches bounded by fragments (~2^18) and by the bin table (~2 GiB)
   const int L = sk->params.fragLen;
   int32_t g0 = 0;
@@ -1298,7 +1317,9 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t
     TRY(reduce_stage(ctx, sk, qr, g1 - g0, firstQueryId + g0, &rows));
     g0 = g1;
   }
-  return to_host_malloc(rows, out, m);
+  *m = rows.n; *out = rows.release();
+  if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
+  return ANI_OK;
 }
 
 int ani_synth_packed(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut)
