@@ -147,18 +147,36 @@ __device__ inline int block_array_excl_scan(int *a, int n, int *ws)
 }
 
 // Bitonic sort of n2 (power of two) keys, ascending, by the whole workgroup.  Works on LDS or global pointers.
+// Two consecutive stages (strides 2h and h) are fused: a thread loads the four elements i0 + {0, h, 2h, 3h}, runs the four
+// compare-exchanges of both stages in registers and stores them back — half the LDS passes and barriers of the plain network.
+template <class K>
+__device__ __forceinline__ void bitonic_ce(K &x, K &y, bool up) { if ((x > y) == up) { const K t = x; x = y; y = t; } }
+
 template <class K>
 __device__ inline void block_bitonic_sort(K *a, int n2)
 {
   for (int size = 2; size <= n2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    int stride = size >> 1;
+    while (stride >= 2) {
+      const int h = stride >> 1;
+      __syncthreads();
+      for (int q = threadIdx.x; q < (n2 >> 2); q += kTPB) {
+        const int i0 = ((q & ~(h - 1)) << 2) | (q & (h - 1));      // index with the `h` and `stride` bits cleared
+        const bool up = ((i0 & size) == 0);
+        K x0 = a[i0], x1 = a[i0 + h], x2 = a[i0 + stride], x3 = a[i0 + stride + h];
+        bitonic_ce(x0, x2, up); bitonic_ce(x1, x3, up);            // stage `stride`
+        bitonic_ce(x0, x1, up); bitonic_ce(x2, x3, up);            // stage `h`
+        a[i0] = x0; a[i0 + h] = x1; a[i0 + stride] = x2; a[i0 + stride + h] = x3;
+      }
+      stride >>= 2;
+    }
+    if (stride == 1) {
       __syncthreads();
       for (int t = threadIdx.x; t < (n2 >> 1); t += kTPB) {
-        int lo = 2 * t - (t & (stride - 1));          // index with the `stride` bit cleared
-        int hi = lo + stride;
-        bool up = ((lo & size) == 0);
-        K x = a[lo], y = a[hi];
-        if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+        const int lo = 2 * t;
+        const bool up = ((lo & size) == 0);
+        K x = a[lo], y = a[lo + 1];
+        if ((x > y) == up) { a[lo] = y; a[lo + 1] = x; }
       }
     }
   }
