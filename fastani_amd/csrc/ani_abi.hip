@@ -150,6 +150,7 @@ struct ani_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   uint64_t subBatchFragments = 1u << 20, subBatchBinBytes = (uint64_t)8 << 30;   // sub-batch bounds of ani_map_cgi_batch (env ANI_SUBBATCH_FRAGS)
+  size_t l2ChunkCandidates = (size_t)1 << 21;                                      // L2 chunk size (env ANI_L2_CHUNK, tests)
   std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
   void *pinned[2] = {nullptr, nullptr}; size_t pinnedCap[2] = {0, 0};   // page-locked staging for the larger device->host reads
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
@@ -785,7 +786,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     // simulation.  Side stream, after the chunk's class-A launch: the few class-B candidates (s in 256..319; their launch is
     // bound by the serial length of one lane, not by throughput) and the collection of the leftovers — they run underneath the
     // next chunk's ranges/codes kernels, which leave the LDS free, instead of extending every chunk by a latency-bound tail.
-    const size_t CH = (size_t)1 << 21;       // candidates per chunk (a chunk whose code entries exceed 2^32 is rejected by the scan)
+    const size_t CH = ctx->l2ChunkCandidates;   // candidates per chunk, 2^21 (a chunk whose code entries exceed 2^32 is rejected by the scan)
     for (int p = 0; p < 2; p++) {
       TRY(ctx->l2Ranges[p].ensure(CH * sizeof(L2Range))); TRY(ctx->l2CodeCount[p].ensure(CH * 4)); TRY(ctx->l2CodeOff[p].ensure(CH * 4));
       TRY(ctx->l2SlowFlag[p].ensure(CH * 4)); TRY(ctx->l2ClassList[p].ensure(CH * 4));
@@ -998,6 +999,7 @@ int ani_init(int device, ani_ctx **out)
   HIP_TRY(hipStreamCreate(&c->stream));
   HIP_TRY(hipStreamCreate(&c->stream2));
   if (const char *ev = getenv("ANI_SUBBATCH_FRAGS")) { const long long v = atoll(ev); if (v > 0) c->subBatchFragments = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
   for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
   int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }

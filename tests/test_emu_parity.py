@@ -24,3 +24,18 @@ def test_device_synth(emu_engine):
 
 def test_fuzz(emu_engine):
     assert pc.fuzz(emu_engine, seed=7, iterations=12) == 12
+
+
+def test_small_batches_and_chunks(monkeypatch):
+    """sub-batches of a few fragments and L2 chunks of a few candidates (fragments straddling chunk borders, both chunk buffer
+    sets, the side stream) must give the same mappings and rows as one big batch"""
+    import ctypes
+    import os
+    from fastani_amd.api import Engine
+    monkeypatch.setenv("ANI_SUBBATCH_FRAGS", "7")
+    monkeypatch.setenv("ANI_L2_CHUNK", "13")
+    e = Engine(ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libfastani_emu.so")), 0)
+    pc.case_synthetic_cluster(e, 30000)
+    pc.case_messy(e)
+    pc.case_tandem_repeats(e)
+    e.close()

@@ -82,3 +82,17 @@ def test_full_size_properties(gpu_engine):
 
 def test_fuzz(gpu_engine):
     assert pc.fuzz(gpu_engine, seed=11, iterations=150) == 150
+
+
+def test_small_batches_and_chunks(monkeypatch):
+    """sub-batches of a few fragments and L2 chunks of a few candidates (fragments straddling chunk borders, both chunk buffer
+    sets, the side stream) must give the same mappings and rows as one big batch"""
+    import fastani_amd
+    monkeypatch.setenv("ANI_SUBBATCH_FRAGS", "7")
+    monkeypatch.setenv("ANI_L2_CHUNK", "13")
+    e = fastani_amd.api.Engine(fastani_amd._lib.load(), 0)
+    pc.case_synthetic_cluster(e, 60000)
+    pc.case_messy(e)
+    pc.case_tandem_repeats(e)
+    pc.case_sparse_hits(e)
+    e.close()
