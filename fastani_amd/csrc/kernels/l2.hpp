@@ -174,12 +174,12 @@ __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
 //                  bit 0 = hash is a query hash, bits 1..9 = gap (or rank-1), bit 10 = a same-hash neighbour may share
 //                  a super-window with this entry (nearDup, precomputed at index build), bits 11..15 = wpos - previous
 //                  wpos (31 = escape: read the index)
-//   k_l2_sim     one lane per candidate: the sliding simulation over those entries.  State in LDS: one byte per sketch rank (7-bit gap
-//                counter + presence bit), word-interleaved over the wave so that lanes never collide on a bank.  Entries are
-//                streamed by two monotone cursors through 16-entry LDS rings (+ 8 entries prefetched in registers per cursor); refills are
-//                issued at wave-uniform points every 8 steps so that their latency never sits on a step's critical path.
-//                Entries flagged nearDup consult prevSame/nextSame (exact set semantics, slidingMap.hpp:150-154,:178).
-//                A gap counter that would pass 127 sends the candidate to k_l2.
+//   k_l2_sim     one lane per candidate: the sliding simulation over those entries, one window event per loop pass.  State in
+//                LDS: one byte per sketch rank (7-bit gap counter + presence bit), byte-interleaved over the wave.  Entries are
+//                streamed by two monotone cursors through 16-entry LDS rings (+ 8 entries prefetched in registers per cursor);
+//                refills are issued at wave-uniform points every 8 passes so that their latency never sits on an event's
+//                critical path.  Entries flagged nearDup consult prevSame/nextSame (exact set semantics,
+//                slidingMap.hpp:150-154,:178).  A gap counter that would pass 127 sends the candidate to k_l2.
 // ------------------------------------------------------------------------------------------------
 struct L2Args {
   // candidates (SoA)
@@ -230,8 +230,9 @@ constexpr int kL2FastMaxEntries = 16384;
 // LDS state of the simulation kernel: one 8-bit field per index g = 0..MAXS,
 //     field[g] = n[g] << 1 | b[g+1]        (7-bit gap counter + presence bit of the query hash that closes the gap)
 // so an event with code index idx — query hash of rank idx+1 or non-query hash of gap idx — touches exactly field[idx], and the
-// pivot logic, which needs n[j] together with b[j+1], reads exactly field[j].  Four fields per word, words interleaved over the
-// wave (byte address = ((g>>2)*64 + lane)*4 + (g&3)): every per-lane index hits bank = lane.
+// pivot logic, which needs n[j] together with b[j+1], reads exactly field[j].  Fields are byte-interleaved over the wave
+// (field g of lane l at byte g*64 + l, see l2_field_off; the conflict-free word-interleaved alternative costs three more
+// address instructions per access and measured the same kernel time).
 //   class A  s <= 255: 64 words + 16-entry cursor rings (16 words) = 320 B per lane -> 20 KiB per wave, 8 waves per CU
 //   class B  s <= 319: 80 words + rings                            = 384 B per lane -> 24 KiB per wave, 6 waves per CU
 // A counter that would pass 127 sends the candidate to the general kernel.
