@@ -655,7 +655,12 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     TRY(zero_counters(ctx));
     {
       StageTimer tm(ctx, &ctx->counters.msFragSketch);
-      hipLaunchKernelGGL(k_fragment_sketch, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigMode,
+      if (L - k + 1 <= kTile)
+        hipLaunchKernelGGL((k_fragment_sketch<true>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigMode,
+                         ctx->frags.as<FragDesc>(), L, k, w, ctx->qPool.as<uint32_t>(), (uint32_t)qcap, cnt_ptr(ctx, CNT_QPOOL),
+                         ctx->fragOff.as<uint32_t>(), ctx->fragS.as<int32_t>(), (int *)cnt_ptr(ctx, CNT_MAXS));
+      else
+        hipLaunchKernelGGL((k_fragment_sketch<false>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigMode,
                          ctx->frags.as<FragDesc>(), L, k, w, ctx->qPool.as<uint32_t>(), (uint32_t)qcap, cnt_ptr(ctx, CNT_QPOOL),
                          ctx->fragOff.as<uint32_t>(), ctx->fragS.as<int32_t>(), (int *)cnt_ptr(ctx, CNT_MAXS));
     }

@@ -369,16 +369,21 @@ __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ se
       if (i == 0 || hbuf[i] != hbuf[i - 1]) pool[base + r++] = hbuf[i];
 }
 
-__global__ __launch_bounds__(kTPB) void k_fragment_sketch(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
+// SINGLE: the fragment fits one tile (fragLen - k + 1 <= kTile, the default 3 kb fragments): the minimizer staging buffer then
+// reuses the window-key array, which is dead once the tile is winnowed — 26 KiB of LDS per workgroup instead of 42.
+template <bool SINGLE>
+__global__ __launch_bounds__(kTPB, SINGLE ? 4 : 3) void k_fragment_sketch(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
                                                           const int64_t *__restrict__ contigOff, const uint8_t *__restrict__ contigMode,
                                                           const FragDesc *__restrict__ frags, int fragLen, int k, int w,
                                                           uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
                                                           uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS, int *__restrict__ maxS)
 {
   __shared__ uint64_t keys[kTile];
-  __shared__ uint32_t hbuf[kFragHashCap];
+  __shared__ uint32_t hbufOwn[SINGLE ? 1 : kFragHashCap];
   __shared__ int ws[kTPB + 16];
   __shared__ unsigned long long sBase;
+  static_assert(kFragHashCap * 4 <= kTile * 8, "staging buffer fits the key array");
+  uint32_t *hbuf = SINGLE ? (uint32_t *)keys : hbufOwn;
   if (contigMode[frags[blockIdx.x].contig])
     fragment_sketch_body<true>(packed, contigOff, frags, fragLen, k, w, pool, poolCap, poolCount, fragOff, fragS, maxS, keys, hbuf, ws, &sBase);
   else
