@@ -245,7 +245,7 @@ struct L2Geom {
 };
 using L2GeomA = L2Geom<255>;
 using L2GeomB = L2Geom<319>;
-constexpr int kL2SimTPB = 128;
+constexpr int kL2SimTPB = 64;
 
 struct L2Range { int32_t beg0, end0, last, wposBeg0; };
 
