@@ -322,15 +322,18 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     if (a.codeCount[i] == 0) continue;
     const L2Range r = a.ranges[i];
     uint16_t *out = (uint16_t *)a.codes + a.codeOff[i];
-    for (int32_t j = r.beg0 + (int32_t)threadIdx.x; j < r.last; j += kTPB) {
-      const uint32_t dl = a.g.mDelta[j];
-      const uint32_t dw = j > r.beg0 ? (dl & 31u) : 0u;
-      const uint32_t h = a.g.mHash[j];
+    const uint8_t *__restrict__ dlt = a.g.mDelta + r.beg0;            // unsigned 32-bit offsets from per-candidate bases:
+    const uint32_t *__restrict__ hsh = a.g.mHash + r.beg0;            // scalar base + vector offset addressing, no 64-bit index math
+    const uint32_t m = (uint32_t)(r.last - r.beg0);
+    for (uint32_t j = threadIdx.x; j < m; j += kTPB) {
+      const uint32_t dl = dlt[j];
+      const uint32_t dw = j > 0 ? (dl & 31u) : 0u;
+      const uint32_t h = hsh[j];
       const int rb = l2_rank_bucket(h, sh);
       int lo = st[rb], hi = st[rb + 1];
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h) lo = mid + 1; else hi = mid; }
-      const uint32_t rk = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h);          // == q_rank(qs, s, h)
-      out[j - r.beg0] = (uint16_t)(rk | ((dl & 32u) ? kL2DupBit : 0u) | (dw << 11));
+      const uint32_t rk = ((uint32_t)lo << 1) | (uint32_t)((lo < s) & (qs[lo < s ? lo : s - 1] == h));   // == q_rank(qs, s, h), no branch
+      out[j] = (uint16_t)(rk | ((dl & 32u) ? kL2DupBit : 0u) | (dw << 11));
     }
   }
 }
