@@ -214,6 +214,12 @@ def main():
             "ani::k_sketch_tiles": (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"], "G/4 packed bases + 12 B x minimizers"),
             "ani::k_fragment_sketch": (c["msFragSketch"], c["queryBases"] / 4.0 + 4.0 * c["querySketchHashes"], "G/4 packed bases + 4 B x sketch hashes"),
         }
+        # whole-job figure of SURVEY.md §8d: B_total = N_r (G/4 + 36 M) + N_q (G/4 + 8 F s) + 8 H + sum(12 m_c + 4 s) + 112 #mappings
+        # (#mappings bounded below by the candidates: the fused path does not count the survivors of the identity filter separately)
+        b_total = (c["refBases"] / 4.0 + 36.0 * c["refMinimizers"] + c["queryBases"] / 4.0 + 8.0 * c["querySketchHashes"]
+                   + 8.0 * c["seedHits"] + l2_bytes)
+        job = {"algorithmic_bytes_per_step": round(b_total / args.steps, 1), "bytes_per_pair": round(b_total / args.steps / (NG * NG), 1),
+               "achieved_GBs": round(b_total * world / dt / 1e9, 2), "frac_of_hbm_peak": round(b_total / dt / 1e9 / HBM_PEAK_GBS, 5)}
         dom = max(cand, key=lambda k: cand[k][0])
         ms, nbytes, what = cand[dom]
         achieved = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
@@ -221,7 +227,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "algorithmic_bytes": what, "kernel_ms_per_step": round(ms / args.steps, 3),
                 "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in cand.items()},
-                "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()}}
+                "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()},
+                "whole_job": job}
         # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
         # + WRITE_SIZE, per launch; profiles/r01h_pmc_traffic.json) — only quoted when it is this default workload
         try:
