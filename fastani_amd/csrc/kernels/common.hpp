@@ -30,14 +30,32 @@ __device__ __forceinline__ unsigned long long *stat_slot(unsigned long long *bas
 // ---------------------------------------------------------------------------------------------
 // MurmurHash3_x64_128 -> low 32 bits of h1
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+// 64-bit rotate by a compile-time constant: two v_alignbit_b32 on the device (the generic form compiles to two 64-bit shifts
+// and two ORs)
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  if (r >= 32) { const uint32_t t = lo; lo = hi; hi = t; r -= 32; }
+  if (r == 0) return ((uint64_t)hi << 32) | lo;
+  const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - r), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - r);
+  return ((uint64_t)nh << 32) | nl;
+#else
+  return (x << r) | (x >> (64 - r));
+#endif
+}
 
+// z ^ (z >> 33) touches the low word only: lo ^= hi >> 1
+__host__ __device__ __forceinline__ uint64_t xorshr33(uint64_t z)
+{
+  const uint32_t hi = (uint32_t)(z >> 32);
+  return ((uint64_t)hi << 32) | ((uint32_t)z ^ (hi >> 1));
+}
 __host__ __device__ __forceinline__ uint64_t fmix64(uint64_t z)
 {
-  z ^= z >> 33; z *= 0xff51afd7ed558ccdULL;
-  z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL;
-  z ^= z >> 33;
-  return z;
+  z = xorshr33(z); z *= 0xff51afd7ed558ccdULL;
+  z = xorshr33(z); z *= 0xc4ceb9fe1a85ec53ULL;
+  return xorshr33(z);
 }
 
 // k == 16: exactly one body block, empty tail (murmur3.h:245-254, :290-298)
