@@ -188,7 +188,10 @@ def main():
     t0 = time.perf_counter()
     rows = None
     step_ms = []
-    for _ in range(args.steps):
+    trace = bool(os.environ.get("ANI_POOL_TRACE"))
+    for i in range(args.steps):
+        if trace:
+            print("[bench] timed step %d" % i, file=sys.stderr, flush=True)
         ts = time.perf_counter()
         rows = step()                                        # returns with the rows on the host: the step's device work is done
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))

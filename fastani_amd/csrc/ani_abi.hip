@@ -67,7 +67,9 @@ struct DevicePool {
     if (bytes == 0) bytes = 1;
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.lower_bound(bytes);
-    if (it != cache.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
+    // reuse only a closely fitting block: a looser fit lets a long-lived buffer capture the block a per-sketch array of a
+    // different size will ask for again, and that array then needs fresh memory in the middle of a later step
+    if (it != cache.end() && it->first <= bytes + bytes / 16 + (1u << 20)) {
       *out = it->second; live[*out] = it->first; cachedBytes -= it->first; cache.erase(it);
       return hipSuccess;
     }
@@ -91,10 +93,29 @@ struct DevicePool {
   void trim_locked() { for (auto &kv : cache) (void)hipFree(kv.second); cache.clear(); cachedBytes = 0; }
   void trim() { std::lock_guard<std::mutex> g(mu); trim_locked(); }
 };
-DevicePool g_pools[64];          // one per device ordinal (one process normally drives one GPU)
-inline DevicePool &cur_pool() { int d = 0; (void)hipGetDevice(&d); return g_pools[(d < 0 || d >= 64) ? 0 : d]; }
-inline hipError_t pool_malloc(void **p, size_t bytes) { return cur_pool().alloc(p, bytes); }
-inline void pool_free(void *p) { cur_pool().release(p); }
+// Two pools per device ordinal (one process normally drives one GPU): class 0 for what lives and dies with a sketch (its arrays
+// and the transient buffers of its build), class 1 for the grow-only buffers of a context.  Kept apart so that a context buffer
+// growing between two sketch builds cannot capture a block the next build will ask for again — fresh device memory in the
+// middle of a steady-state step costs up to ~30 us/MB on this stack (a 4.5 GB hipMalloc: 135 ms).
+DevicePool g_pools[64][2];
+inline DevicePool &cur_pool(int cls) { int d = 0; (void)hipGetDevice(&d); return g_pools[(d < 0 || d >= 64) ? 0 : d][cls]; }
+inline hipError_t pool_malloc(void **p, size_t bytes, int cls = 0)
+{
+  hipError_t e = cur_pool(cls).alloc(p, bytes);           // trims its own cache before giving up
+  if (e != hipSuccess) { cur_pool(cls ^ 1).trim(); (void)hipGetLastError(); e = cur_pool(cls).alloc(p, bytes); }
+  return e;
+}
+inline void pool_free(void *p)
+{
+  if (!p) return;
+  for (int cls = 0; cls < 2; cls++) {
+    DevicePool &pl = cur_pool(cls);
+    { std::lock_guard<std::mutex> g(pl.mu); if (!pl.live.count(p)) continue; }
+    pl.release(p);
+    return;
+  }
+  (void)hipFree(p);
+}
 
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
@@ -112,7 +133,7 @@ struct DevBuf {
     if (bytes <= cap) return ANI_OK;
     if (p) { pool_free(p); p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = pool_malloc(&p, want);
+    hipError_t e = pool_malloc(&p, want, 1);
     if (e != hipSuccess) { p = nullptr; return fail(ANI_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
     cap = want;
     return ANI_OK;
@@ -466,7 +487,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
     TRY(read_counters(ctx, host));
     if (host[CNT_POOL] <= cap) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "minimizer pool did not converge");
-    cap = host[CNT_POOL];
+    cap = host[CNT_POOL] + host[CNT_POOL] / 16;        // margin: the same input must not grow the pool again next time
   }
   StageTimer tm(ctx, &ctx->counters.msSketch);
   hipLaunchKernelGGL(k_sketch_tile_counts, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, ctx->tiles.as<TileDesc>(),
@@ -668,7 +689,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     TRY(read_counters(ctx, host));
     if (host[CNT_QPOOL] <= qcap) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "query sketch pool did not converge");
-    qcap = host[CNT_QPOOL];
+    qcap = host[CNT_QPOOL] + host[CNT_QPOOL] / 16;
   }
   const int maxS = (int)(uint32_t)host[CNT_MAXS];
   if (maxS >= 0x7fffffff) return fail(ANI_ERR_LIMIT, "a query fragment produced more than %d minimizers", kFragHashCap);
@@ -741,7 +762,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     if (attempt == 0) hitsTotal = host[CNT_HITS];
     if (host[CNT_CAND] <= ccap) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "candidate pool did not converge");
-    ccap = host[CNT_CAND];
+    ccap = (uint64_t)(1.25 * (double)host[CNT_CAND]) + 4096;       // = what candPerFrag will ask for next time
   }
   ctx->candPerFrag = std::max(ctx->candPerFrag, 1.25 * (double)host[CNT_CAND] / (double)nF);   // size the pool right next time
   if ((uint32_t)host[CNT_NEG] != 0)
@@ -1029,7 +1050,7 @@ void ani_shutdown(ani_ctx *c)
   for (int i = 0; i < 2; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
-  cur_pool().trim();
+  cur_pool(0).trim(); cur_pool(1).trim();
 }
 
 int ani_device_copy(ani_ctx *c, void *dst, const void *src, size_t bytes)
