@@ -233,14 +233,14 @@ def main():
                 "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()},
                 "whole_job": job}
         # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
-        # + WRITE_SIZE, per launch; profiles/r01h_pmc_traffic.json) — only quoted when it is this default workload
+        # + WRITE_SIZE, per launch; profiles/r01p_pmc_traffic.json) — only quoted when it is this default workload
         try:
             if NG == 1000 and L == 5_000_000 and world == 1:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01p_pmc_traffic.json")))
                 key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
                 if key in tj["kernels"]:
                     roof["traffic"] = tj["kernels"][key]["hbm_bytes_per_launch_corrected"]
-                    roof["traffic_source"] = "profiles/r01h_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    roof["traffic_source"] = "profiles/r01p_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except Exception:
             pass
         if dom == "ani::k_l2_sim":
