@@ -9,6 +9,8 @@ Everything here is plumbing: numpy arrays in, numpy record arrays out.  All comp
 libfastani_amd.so (hand-written HIP kernels, gfx950); there is no Python or CPU fallback.
 """
 import ctypes as C
+import weakref
+
 import numpy as np
 
 MINIMIZER_DT = np.dtype([("hash", "<u4"), ("seqId", "<i4"), ("wpos", "<i4")])
@@ -42,7 +44,7 @@ class SeqBatch(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
                                           "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
-                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows")] + \
+                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "l2ChunkHalvings")] + \
                [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB")]
 
     def as_dict(self):
@@ -69,6 +71,7 @@ def _bind(lib):
         "ani_sketch_export": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_sketch_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "ani_sketch_chunks": (C.c_int, [vp, C.POINTER(C.c_int32), vp, C.c_int32]),
         "ani_sketch_records": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_sketch_from_records": (C.c_int, [vp, C.POINTER(Params), vp, C.c_size_t, vp, C.c_int32, vp, C.c_int32, C.POINTER(vp)]),
         "ani_map_query": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
@@ -168,6 +171,7 @@ class Engine:
         h = C.c_void_p()
         self._chk(lib.ani_init(device, C.byref(h)))
         self.h = h
+        self._sketches = weakref.WeakSet()      # live sketches are destroyed before the context (see close)
 
     def _chk(self, rc):
         if rc != 0:
@@ -175,6 +179,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for sk in list(self._sketches):
+                sk.close()
             self.lib.ani_shutdown(self.h)
             self.h = None
 
@@ -251,6 +257,7 @@ class Sketch:
             b = g.batch()
             engine._chk(engine.lib.ani_sketch_build(engine.h, C.byref(params), C.byref(b), C.byref(h)))
         self.h = h
+        engine._sketches.add(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -267,6 +274,14 @@ class Sketch:
         p, n = C.c_void_p(), C.c_size_t()
         self.e._chk(self.e.lib.ani_sketch_export(self.h, C.byref(p), C.byref(n)))
         return self.e._take(p, n.value, MINIMIZER_DT)
+
+    def chunks(self):
+        """first genome id of every index chunk of the reference set"""
+        n = C.c_int32()
+        self.e._chk(self.e.lib.ani_sketch_chunks(self.h, C.byref(n), None, 0))
+        first = np.zeros(max(n.value, 1), dtype=np.int32)
+        self.e._chk(self.e.lib.ani_sketch_chunks(self.h, C.byref(n), first.ctypes.data, n.value))
+        return [int(x) for x in first[:n.value]]
 
     def stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -37,6 +37,8 @@
 #include "kernels/synth.hpp"
 
 extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
+extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
 extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
                                       size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
 
@@ -156,7 +158,9 @@ void parallel_for(size_t n, uint64_t work, F f)
   for (auto &x : th) x.join();
 }
 
-inline unsigned grid_for(size_t n, unsigned block = 256, unsigned maxBlocks = 65535u * 8u)
+// 1-D grid for n work items.  Kernels without a grid-stride loop are launched with the default (uncapped: gridDim.x may reach
+// 2^31 - 1 on HIP, and every count on this path is < 2^31); kernels that loop pass the cap they want.
+inline unsigned grid_for(size_t n, unsigned block = 256, unsigned maxBlocks = 0x7fffffffu)
 {
   size_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -172,8 +176,10 @@ struct ani_ctx {
   hipStream_t stream = nullptr;
   uint64_t subBatchFragments = 1u << 20, subBatchBinBytes = (uint64_t)8 << 30;   // sub-batch bounds of ani_map_cgi_batch (env ANI_SUBBATCH_FRAGS)
   size_t l2ChunkCandidates = (size_t)1 << 21;                                      // L2 chunk size (env ANI_L2_CHUNK, tests)
+  uint64_t l2CodeLimit = 0xfffffff0ull;                                             // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_L2_CODE_LIMIT, tests)
+  uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
   std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
-  void *pinned[2] = {nullptr, nullptr}; size_t pinnedCap[2] = {0, 0};   // page-locked staging for the larger device->host reads
+  void *pinned[3] = {nullptr, nullptr, nullptr}; size_t pinnedCap[3] = {0, 0, 0};   // page-locked staging: 0/1 result reads, 2 prefix-sum block totals
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
   hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr};
   // stage timers: event pairs are recorded as the launches go out and read back lazily (flush_timers), never by blocking the host
@@ -197,13 +203,14 @@ struct ani_ctx {
   DevBuf bins, queryFragments, rows;
 };
 
-struct ani_sketch {
-  ani_ctx *ctx = nullptr;
-  ani_params_t params;
+// One index over a contiguous run of reference genomes: < 2^31 minimizers, 32-bit indices, chunk-local seqIds.  A reference set
+// larger than that is a list of chunks (the reference's own answer to big databases is the same split, per OpenMP thread:
+// computeCoreIdentity.hpp:457-487, scripts/splitDatabase.sh) — exact, because a (query, reference) result does not depend on
+// what else is in the index.
+struct IndexChunk {
   uint32_t n = 0;
-  int32_t nContigs = 0, nGenomes = 0;
-  uint64_t nUnique = 0, totalLen = 0;
-  std::vector<int32_t> contigLen, genomeContigStart;
+  int32_t c0 = 0, nContigs = 0, g0 = 0, nGenomes = 0;   // global ids of the first contig / genome, and counts
+  uint64_t nUnique = 0;
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
   uint32_t *sHash = nullptr, *bucketStart = nullptr; uint8_t *mDelta = nullptr;
@@ -212,6 +219,19 @@ struct ani_sketch {
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
   uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr, *posBase = nullptr, *posSample = nullptr;
   uint32_t totalBins = 0;
+};
+
+struct ani_sketch {
+  ani_ctx *ctx = nullptr;
+  int device = 0;
+  ani_params_t params;
+  uint64_t n = 0;                          // minimizers over all chunks
+  int32_t nContigs = 0, nGenomes = 0;
+  uint64_t totalLen = 0;
+  uint64_t nUnique = 0; bool uniqueExact = false;   // distinct hashes over all chunks (computed on demand when there are several)
+  std::vector<int32_t> contigLen, genomeContigStart;
+  std::vector<IndexChunk *> chunks;
+  uint32_t maxChunkBins = 0;
   // LUTs
   ani::stat::Luts *luts = nullptr;        // host LUTs, shared by every sketch of the context with the same (k, identity cutoff)
   int32_t *dMinHits = nullptr, *dMinShared = nullptr; uint32_t *dIdLUT = nullptr; int dLutMaxS = 0;
@@ -289,36 +309,33 @@ struct StageTimer {
   }
 };
 
-// device-wide exclusive scan of int32 counts (n < 2^31) -> uint32 offsets; the total comes back through *total.
-// Two device levels of 2048-element blocks; the (<= 512) level-2 block totals are finished on the host.
-int device_scan(ani_ctx *c, const int32_t *in, uint32_t *out, uint32_t n, uint64_t *total)
+// device-wide exclusive scan of int32 counts (n < 2^31, every count >= 0) -> uint32 offsets; the total comes back through *total.
+// One device level of 2048-element blocks; the block totals (n / 2048 of them: 1024 for an L2 chunk, ~800 for a sub-batch's
+// fragment table) are scanned on the host in 64 bits, so a total beyond 2^32 is detected exactly and reported as ANI_ERR_LIMIT
+// (the L2 chunk loop halves its chunk on that) instead of wrapping.
+int device_scan(ani_ctx *c, const int32_t *in, uint32_t *out, uint32_t n, uint64_t *total, uint64_t limit = 0xfffffff0ull)
 {
   using namespace ani;
   *total = 0;
   if (n == 0) return ANI_OK;
   const uint32_t nb1 = (n + kScanPerBlock - 1) / kScanPerBlock;
-  const uint32_t nb2 = (nb1 + kScanPerBlock - 1) / kScanPerBlock;
-  TRY(c->scanTmpA.ensure((size_t)nb1 * 4)); TRY(c->scanTmpB.ensure((size_t)nb1 * 4)); TRY(c->scanTmpC.ensure((size_t)nb2 * 4)); TRY(c->scanTmpD.ensure((size_t)nb2 * 4));
+  TRY(c->scanTmpA.ensure((size_t)nb1 * 4)); TRY(c->scanTmpB.ensure((size_t)nb1 * 4));
   hipLaunchKernelGGL(k_scan_blocks, dim3(nb1), dim3(kTPB), 0, c->stream, in, out, n, c->scanTmpA.as<int32_t>());
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nb2), dim3(kTPB), 0, c->stream, (const int32_t *)c->scanTmpA.as<int32_t>(), c->scanTmpB.as<uint32_t>(), nb1,
-                     c->scanTmpC.as<int32_t>());
-  std::vector<int32_t> tot2(nb2);
-  HIP_TRY(hipMemcpyAsync(tot2.data(), c->scanTmpC.p, (size_t)nb2 * 4, hipMemcpyDeviceToHost, c->stream));
+  uint32_t *tot = nullptr;
+  TRY(pinned_buffer(c, 2, (size_t)nb1 * 8, (void **)&tot));
+  uint32_t *off = tot + nb1;
+  HIP_TRY(hipMemcpyAsync(tot, c->scanTmpA.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   uint64_t run = 0;
-  std::vector<uint32_t> off2(nb2);
-  for (uint32_t i = 0; i < nb2; i++) { off2[i] = (uint32_t)run; run += (uint64_t)(uint32_t)tot2[i]; }
-  if (run > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "prefix sum exceeds 2^32 elements");
+  for (uint32_t i = 0; i < nb1; i++) { off[i] = (uint32_t)run; run += (uint64_t)tot[i]; }     // block totals are < 2^31 each (see k_scan_blocks)
+  if (run > limit) return fail(ANI_ERR_LIMIT, "prefix sum of %llu elements exceeds the limit of %llu", (unsigned long long)run, (unsigned long long)limit);
   *total = run;
-  if (nb2 > 1) {
-    HIP_TRY(hipMemcpyAsync(c->scanTmpD.p, off2.data(), (size_t)nb2 * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));     // off2 dies at scope exit
-    hipLaunchKernelGGL(k_scan_add, dim3((nb1 + 255) / 256), dim3(256), 0, c->stream, c->scanTmpB.as<uint32_t>(), nb1, (const uint32_t *)c->scanTmpD.as<uint32_t>());
-  }
-  if (nb1 > 1)
+  if (nb1 > 1) {
+    HIP_TRY(hipMemcpyAsync(c->scanTmpB.p, off, (size_t)nb1 * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, c->stream, out, n, (const uint32_t *)c->scanTmpB.as<uint32_t>());
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));       // `off` (pinned, reused by the next scan) has been consumed
+  }
   return ANI_OK;
 }
 
@@ -507,11 +524,21 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
   return ANI_OK;
 }
 
+void free_chunk(IndexChunk *ch)
+{
+  if (!ch) return;
+  void *ptrs[] = {ch->sSW, ch->mDelta, ch->mHash, ch->mSeq, ch->mWpos, ch->prevSame, ch->nextSame, ch->sHash, ch->bucketStart, ch->contigFirstMin,
+                  ch->contigGenome, ch->contigBinBase, ch->genomeBinStart, ch->posBase, ch->posSample};
+  for (void *q : ptrs) if (q) pool_free(q);
+  delete ch;
+}
 void free_sketch_device(ani_sketch *sk)
 {
-  void *ptrs[] = {sk->sSW, sk->mDelta, sk->mHash, sk->mSeq, sk->mWpos, sk->prevSame, sk->nextSame, sk->sHash, sk->bucketStart, sk->contigFirstMin,
-                  sk->contigGenome, sk->contigBinBase, sk->genomeBinStart, sk->posBase, sk->posSample, sk->dMinHits, sk->dMinShared, sk->dIdLUT};
+  for (IndexChunk *ch : sk->chunks) free_chunk(ch);
+  sk->chunks.clear();
+  void *ptrs[] = {sk->dMinHits, sk->dMinShared, sk->dIdLUT};
   for (void *q : ptrs) if (q) pool_free(q);
+  sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr;
 }
 
 int upload_luts(ani_sketch *sk, int maxS)
@@ -536,18 +563,19 @@ int upload_luts(ani_sketch *sk, int maxS)
 }
 
 // -----------------------------------------------------------------------------------------------------
-// index over device-resident records (≙ Sketch::index, winSketch.hpp:181-193)
+// one index chunk over device-resident records (≙ Sketch::index, winSketch.hpp:181-193).  `dRecords` = the n records of the
+// chunk's genomes [g0, g0 + nGenomes) = contigs [c0, c0 + nContigs), position order, GLOBAL seqIds; contigLen / genomeContigStart
+// are the whole reference set's tables.
 // -----------------------------------------------------------------------------------------------------
-int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, size_t n, const int32_t *contigLen, int32_t nContigs,
-                const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, size_t n, const int32_t *contigLenAll, const int32_t *gcsAll,
+                int32_t g0, int32_t nGenomes, IndexChunk **out)
 {
-  if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "index of %zu minimizers exceeds 2^31; split the reference list (results are independent per reference genome)", n);
-  ani_sketch *sk = new ani_sketch();
-  sk->ctx = ctx; sk->params = *p; sk->n = (uint32_t)n; sk->nContigs = nContigs; sk->nGenomes = nGenomes;
-  sk->contigLen.assign(contigLen, contigLen + nContigs);
-  sk->genomeContigStart.assign(genomeContigStart, genomeContigStart + nGenomes + 1);
-  for (int32_t c = 0; c < nContigs; c++) sk->totalLen += (uint64_t)contigLen[c];
-  auto bail = [&](int rc) { free_sketch_device(sk); delete sk; return rc; };
+  if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "index chunk of %zu minimizers exceeds 2^31", n);
+  IndexChunk *sk = new IndexChunk();
+  const int32_t c0 = gcsAll[g0], nContigs = gcsAll[g0 + nGenomes] - c0;
+  const int32_t *contigLen = contigLenAll + c0;
+  sk->n = (uint32_t)n; sk->c0 = c0; sk->nContigs = nContigs; sk->g0 = g0; sk->nGenomes = nGenomes;
+  auto bail = [&](int rc) { free_chunk(sk); return rc; };
 #define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
 #define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const size_t n4 = (n ? n : 1) * 4;
@@ -557,9 +585,10 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
     uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
-    SK_HIP(pool_malloc((void **)&tmpK, n4)); SK_HIP(pool_malloc((void **)&tmpV, 2 * n4));
+    SK_HIP(pool_malloc((void **)&tmpK, n4));
+    { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
     if (n) {
-      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, sk->mHash, sk->mSeq, sk->mWpos, sk->mDelta,
+      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, (uint32_t)c0, sk->mHash, sk->mSeq, sk->mWpos, sk->mDelta,
                          sk->prevSame, sk->nextSame, tmpK, tmpV);
       size_t tb = 0;
       int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, nullptr, &tb, ctx->stream);
@@ -569,7 +598,7 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     pool_free(tmpK); pool_free(tmpV);
     SK_TRY(zero_counters(ctx));
     SK_HIP(pool_malloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
-    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
     if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
                               (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mDelta, cnt_ptr(ctx, CNT_UNIQ));
     // bucket table over the top bits of the (density-flattened) bucket key: about one bucket per entry, between 2^10 and 2^28 buckets
@@ -584,51 +613,174 @@ int build_index(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     SK_TRY(read_counters(ctx, host));
     sk->nUnique = host[CNT_UNIQ];
   }
-  // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194)
+  // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194); all chunk-local
   std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);
   std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1), posBase((size_t)nContigs + 1);
   const int32_t binW = p->fragLen - 20;
   uint64_t run = 0, runPos = 0;
   for (int32_t g = 0; g < nGenomes; g++) {
     gBin[g] = (uint32_t)run;
-    for (int32_t c = genomeContigStart[g]; c < genomeContigStart[g + 1]; c++) {
+    for (int32_t c = gcsAll[g0 + g] - c0; c < gcsAll[g0 + g + 1] - c0; c++) {
       cg[c] = g; binBase[c] = (uint32_t)run; run += (uint64_t)(contigLen[c] / binW) + 1;
       posBase[c] = (uint32_t)runPos; runPos += ((uint64_t)contigLen[c] >> ani::kPosSampleShift) + 1;      // bins of the sampled position index
-      if (run > 0xfffffff0ull || runPos > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "reference set has more than 2^32 position bins"));
+      if (run > 0xfffffff0ull || runPos > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "index chunk has more than 2^32 position bins"));
     }
   }
   gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run; posBase[nContigs] = (uint32_t)runPos;
   sk->totalBins = (uint32_t)run;
   SK_HIP(pool_malloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
   SK_HIP(pool_malloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4));
-  SK_HIP(hipMemcpy(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice));
-  SK_HIP(hipMemcpy(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice));
-  SK_HIP(hipMemcpy(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice));
+  SK_HIP(hipMemcpyAsync(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   SK_HIP(pool_malloc((void **)&sk->posBase, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->posSample, ((size_t)runPos + 1) * 4));
-  SK_HIP(hipMemcpy(sk->posBase, posBase.data(), posBase.size() * 4, hipMemcpyHostToDevice));
+  SK_HIP(hipMemcpyAsync(sk->posBase, posBase.data(), posBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)runPos + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
                                   (uint32_t)runPos, (uint32_t)n, sk->posSample);
   SK_HIP(hipGetLastError());
-  SK_TRY(upload_luts(sk, 512));
-  ctx->counters.refMinimizers += n; ctx->counters.refUniqueHashes += sk->nUnique; ctx->counters.refBases += sk->totalLen;
+  SK_HIP(hipStreamSynchronize(ctx->stream));      // the host tables above die at scope exit
+  ctx->counters.refMinimizers += n;
 #undef SK_TRY
 #undef SK_HIP
   *out = sk;
   return ANI_OK;
 }
 
+// A reference set = its contig/genome tables + the LUTs; index chunks are attached by add_chunks.
+ani_sketch *new_sketch(ani_ctx *ctx, const ani_params_t *p, const int32_t *contigLen, int32_t nContigs, const int32_t *genomeContigStart, int32_t nGenomes)
+{
+  ani_sketch *sk = new ani_sketch();
+  sk->ctx = ctx; sk->device = ctx->device; sk->params = *p; sk->nContigs = nContigs; sk->nGenomes = nGenomes;
+  sk->contigLen.assign(contigLen, contigLen + nContigs);
+  sk->genomeContigStart.assign(genomeContigStart, genomeContigStart + nGenomes + 1);
+  for (int32_t c = 0; c < nContigs; c++) sk->totalLen += (uint64_t)contigLen[c];
+  return sk;
+}
+
+// A piece of a position-ordered record stream with global seqIds: n records on the device that belong to genomes [g0, g1).
+struct RecordPart { uint32_t *rec = nullptr; size_t n = 0; int32_t g0 = 0, g1 = 0; bool owned = true; };
+
+// Cut the record parts into index chunks at genome borders (each chunk <= ctx->maxIndexMinimizers records, balanced) and build
+// them.  Owned parts are released as soon as the chunks that need them exist.
+int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
+{
+  const int32_t *gcs = sk->genomeContigStart.data();
+  // records per genome: first record of every contig inside its part (binary search on the device), then differences
+  std::vector<uint64_t> genomeRecs((size_t)sk->nGenomes, 0), genomeOffInPart((size_t)sk->nGenomes, 0);
+  std::vector<int32_t> genomePart((size_t)sk->nGenomes, -1);
+  uint64_t total = 0;
+  for (size_t pi = 0; pi < parts.size(); pi++) {
+    const RecordPart &pt = parts[pi];
+    if (pt.g1 <= pt.g0) continue;
+    const int32_t c0 = gcs[pt.g0], nc = gcs[pt.g1] - c0;
+    std::vector<uint64_t> first((size_t)nc + 1, 0);
+    if (pt.n) {
+      TRY(ctx->unitAux.ensure(((size_t)nc + 1) * 8));
+      hipLaunchKernelGGL(k_records_contig_first, dim3(grid_for((size_t)nc + 1, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)pt.rec, (uint64_t)pt.n, c0, nc,
+                         ctx->unitAux.as<uint64_t>());
+      HIP_TRY(hipMemcpyAsync(first.data(), ctx->unitAux.p, ((size_t)nc + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (first[nc] != pt.n || first[0] != 0) return fail(ANI_ERR_ARG, "minimizer records carry seqIds outside their genome range [%d, %d)", c0, c0 + nc);
+    }
+    for (int32_t g = pt.g0; g < pt.g1; g++) {
+      genomePart[g] = (int32_t)pi; genomeOffInPart[g] = first[gcs[g] - c0]; genomeRecs[g] = first[gcs[g + 1] - c0] - first[gcs[g] - c0];
+    }
+    total += pt.n;
+  }
+  for (int32_t g = 0; g < sk->nGenomes; g++) if (genomePart[g] < 0) return fail(ANI_ERR_INTERNAL, "genome %d is in no record part", g);
+  // balanced chunk sizes: ceil(total / max) chunks of about total / that
+  const uint64_t maxN = std::min<uint64_t>(ctx->maxIndexMinimizers, 0x7fffffe0ull);
+  const uint64_t nCh = std::max<uint64_t>(1, (total + maxN - 1) / maxN);
+  const uint64_t target = std::min<uint64_t>(maxN, (total + nCh - 1) / nCh + (total / nCh) / 50 + 1);
+  int32_t g0 = 0;
+  std::vector<int32_t> partLastUse(parts.size(), -1);
+  for (int32_t g = 0; g < sk->nGenomes; g++) partLastUse[genomePart[g]] = g;
+  while (g0 < sk->nGenomes || (sk->nGenomes == 0 && sk->chunks.empty())) {
+    int32_t g1 = g0; uint64_t n = 0;
+    while (g1 < sk->nGenomes && (g1 == g0 || n + genomeRecs[g1] <= target)) { n += genomeRecs[g1]; g1++; }
+    if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "reference genome %d alone yields %llu minimizers (>= 2^31)", g0, (unsigned long long)n);
+    // the chunk's records: one part's slice as it is, or a copy of several slices
+    const uint32_t *rec = nullptr; uint32_t *tmp = nullptr;
+    if (n) {
+      const int32_t pa = genomePart[g0], pb = genomePart[g1 - 1];
+      if (pa == pb) rec = parts[pa].rec + 3 * genomeOffInPart[g0];
+      else {
+        HIP_TRY(pool_malloc((void **)&tmp, n * 12));
+        size_t o = 0;
+        for (int32_t g = g0; g < g1;) {             // runs of genomes inside one part
+          const int32_t pi = genomePart[g]; int32_t h = g; uint64_t m = 0;
+          while (h < g1 && genomePart[h] == pi) { m += genomeRecs[h]; h++; }
+          if (m) { hipError_t e = hipMemcpyAsync(tmp + 3 * o, parts[pi].rec + 3 * genomeOffInPart[g], m * 12, hipMemcpyDeviceToDevice, ctx->stream);
+                   if (e != hipSuccess) { pool_free(tmp); HIP_TRY(e); } }
+          o += m; g = h;
+        }
+        rec = tmp;
+      }
+    }
+    IndexChunk *ch = nullptr;
+    const int rc = build_chunk(ctx, &sk->params, rec, (size_t)n, sk->contigLen.data(), gcs, g0, g1 - g0, &ch);
+    if (tmp) pool_free(tmp);
+    TRY(rc);
+    sk->chunks.push_back(ch);
+    sk->n += n; sk->maxChunkBins = std::max(sk->maxChunkBins, ch->totalBins);
+    for (size_t pi = 0; pi < parts.size(); pi++)
+      if (parts[pi].owned && parts[pi].rec && partLastUse[pi] < g1) { pool_free(parts[pi].rec); parts[pi].rec = nullptr; }
+    g0 = g1;
+    if (sk->nGenomes == 0) break;
+  }
+  sk->nUnique = 0;
+  for (IndexChunk *ch : sk->chunks) sk->nUnique += ch->nUnique;
+  sk->uniqueExact = sk->chunks.size() <= 1;
+  ctx->counters.refBases += sk->totalLen; ctx->counters.refUniqueHashes += sk->nUnique;
+  return upload_luts(sk, 512);
+}
+
+// distinct hashes over all chunks = sum of the chunks' own counts - hashes that already occur in an earlier chunk
+int exact_unique(ani_sketch *sk)
+{
+  if (sk->uniqueExact) return ANI_OK;
+  ani_ctx *ctx = sk->ctx;
+  uint64_t dup = 0;
+  for (size_t c = 1; c < sk->chunks.size(); c++) {
+    IndexChunk *C = sk->chunks[c];
+    if (!C->n) continue;
+    uint8_t *seen = nullptr;
+    HIP_TRY(pool_malloc((void **)&seen, C->n));
+    hipError_t e = hipMemsetAsync(seen, 0, C->n, ctx->stream);
+    for (size_t x = 0; x < c && e == hipSuccess; x++) {
+      IndexChunk *E = sk->chunks[x];
+      if (!E->n) continue;
+      hipLaunchKernelGGL(k_index_mark_shared, dim3(grid_for(C->n, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)C->sHash, C->n, (const uint32_t *)E->sHash,
+                         (const uint32_t *)E->bucketStart, E->bucketShift, sk->params.windowSize, seen);
+    }
+    int rc = e == hipSuccess ? zero_counters(ctx) : fail(ANI_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    unsigned long long host[CNT_N];
+    if (rc == ANI_OK) {
+      hipLaunchKernelGGL(k_count_flags, dim3(grid_for(C->n, 256, 4096)), dim3(256), 0, ctx->stream, (const uint8_t *)seen, C->n, cnt_ptr(ctx, CNT_UNIQ));
+      rc = read_counters(ctx, host);
+    }
+    pool_free(seen);
+    TRY(rc);
+    dup += host[CNT_UNIQ];
+  }
+  sk->nUnique -= dup; sk->uniqueExact = true;
+  return ANI_OK;
+}
+
 // -----------------------------------------------------------------------------------------------------
 // query path for one device-resident sub-batch
 // -----------------------------------------------------------------------------------------------------
-struct QueryRun {
-  int32_t nFrag = 0, nCand = 0;
+// fragment table + fragment sketches of one device-resident query sub-batch; the arrays live in the context's buffers
+// (frags, fragOff, fragS, fragGenome, fragQSeq, qPool) and stay valid across the index chunks the sub-batch is mapped against
+struct FragSet {
+  int32_t nFrag = 0, maxS = 0;
+  uint64_t nHashes = 0;
   std::vector<int32_t> genomeFragments;
 };
 
-int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *qr)
+int fragment_stage(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, FragSet *qr)
 {
   if (ctx->timerPending.size() > 4096) flush_timers(ctx);      // no stage timer is open here
-  const ani_params_t &p = sk->params;
   const int k = p.kmerSize, w = p.windowSize, L = p.fragLen;
   // ---- fragment table (computeMap.hpp:132-190) ----
   // per-contig fragment prefix; fragment descriptors are expanded on the device
@@ -650,7 +802,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   }
   fragStart[db.nContigs] = (uint32_t)nF64;
   const size_t nF = (size_t)nF64;
-  qr->nFrag = (int32_t)nF; qr->nCand = 0;
+  qr->nFrag = (int32_t)nF; qr->maxS = 0; qr->nHashes = 0;
   ctx->counters.queryGenomes += (uint64_t)db.nGenomes; ctx->counters.queryFragments += nF; ctx->counters.queryBases += db.totalBases;
   if (nF == 0) return ANI_OK;
   TRY(ctx->frags.ensure(nF * sizeof(FragDesc))); TRY(ctx->fragOff.ensure(nF * 4)); TRY(ctx->fragS.ensure(nF * 4));
@@ -694,7 +846,23 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
   const int maxS = (int)(uint32_t)host[CNT_MAXS];
   if (maxS >= 0x7fffffff) return fail(ANI_ERR_LIMIT, "a query fragment produced more than %d minimizers", kFragHashCap);
   ctx->counters.querySketchHashes += host[CNT_QPOOL];
-  TRY(upload_luts(sk, maxS));
+  qr->maxS = maxS; qr->nHashes = host[CNT_QPOOL];
+  return ANI_OK;
+}
+
+// L1 + L2 + identity for the fragments of `fs` against ONE index chunk; candidates and their results stay in the context's
+// buffers (ocFrag/ocSeq [chunk-local seqIds]/refStart/idBits/l2Best) for the reducer or the mapping export.
+int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, int32_t *nCandOut)
+{
+  if (ctx->timerPending.size() > 4096) flush_timers(ctx);
+  const ani_params_t &p = set->params;
+  const int k = p.kmerSize, w = p.windowSize, L = p.fragLen;
+  const size_t nF = (size_t)fs.nFrag;
+  const int maxS = fs.maxS;
+  *nCandOut = 0;
+  if (nF == 0) return ANI_OK;
+  unsigned long long host[CNT_N];
+  host[CNT_QPOOL] = fs.nHashes;
 
   // ---- L1 ----
   TRY(ctx->fragCandOff.ensure(nF * 4)); TRY(ctx->fragCandCnt.ensure(nF * 4)); TRY(ctx->fragCandCntClamped.ensure(nF * 4));
@@ -712,8 +880,8 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     else { HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CAND), 0, 8, ctx->stream)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
     L1Args a;
     a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>(); a.nFrag = (int32_t)nF;
-    a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.bucketW = sk->params.windowSize; a.nIndex = sk->n;
-    a.minHitsLUT = sk->dMinHits; a.lutMaxS = sk->dLutMaxS; a.L = L;
+    a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.bucketW = w; a.nIndex = sk->n;
+    a.minHitsLUT = set->dMinHits; a.lutMaxS = set->dLutMaxS; a.L = L;
     a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
     a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
@@ -782,7 +950,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
       HIP_TRY(hipGetLastError());
     }
   }
-  qr->nCand = (int32_t)nCand;
+  *nCandOut = (int32_t)nCand;
   ctx->counters.l1Candidates += nCand;
   if (nCand == 0) return ANI_OK;
 
@@ -846,8 +1014,8 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
       }
       uint64_t nCodes = 0;
       {
-        const int rc = device_scan(ctx, fa.codeCount, ctx->l2CodeOff[p].as<uint32_t>(), (uint32_t)n, &nCodes);
-        if (rc == ANI_ERR_LIMIT && chunk > 4096) { chunk /= 2; continue; }     // very long candidate ranges: smaller chunk, same candidates again
+        const int rc = device_scan(ctx, fa.codeCount, ctx->l2CodeOff[p].as<uint32_t>(), (uint32_t)n, &nCodes, ctx->l2CodeLimit);
+        if (rc == ANI_ERR_LIMIT && n > 1) { chunk = (n + 1) / 2; ctx->counters.l2ChunkHalvings++; continue; }     // very long candidate ranges: smaller chunk, same candidates again
         TRY(rc);
       }
       TRY(ctx->l2Codes[p].ensure((nCodes + 64) * 2));
@@ -913,7 +1081,7 @@ int query_stages(ani_ctx *ctx, ani_sketch *sk, const DeviceBatch &db, QueryRun *
     ctx->counters.l2SlowCandidates += nSlowTotal; ctx->counters.l2FastCandidates += nCand - nSlowTotal;
     FinishArgs fa;
     fa.nCand = (int32_t)nCand; fa.candFrag = a.candFrag; fa.candSeq = a.candSeq; fa.best = a.outBest; fa.firstPos = a.outFirst; fa.lastPos = a.outLast;
-    fa.fragS = a.fragS; fa.idLUT = sk->dIdLUT; fa.minShared = sk->dMinShared; fa.lutMaxS = sk->dLutMaxS;
+    fa.fragS = a.fragS; fa.idLUT = set->dIdLUT; fa.minShared = set->dMinShared; fa.lutMaxS = set->dLutMaxS;
     fa.refStart = ctx->refStart.as<int32_t>(); fa.idBits = ctx->idBits.as<uint32_t>();
     hipLaunchKernelGGL(k_finish_candidates, dim3(grid_for(nCand)), dim3(256), 0, ctx->stream, fa);
     HIP_TRY(hipGetLastError());
@@ -944,49 +1112,62 @@ struct RowBuf {
   ani_cgi_t *release() { ani_cgi_t *r = p ? p : (ani_cgi_t *)malloc(sizeof(ani_cgi_t)); p = nullptr; return r; }
 };
 
-int reduce_stage(ani_ctx *ctx, ani_sketch *sk, const QueryRun &qr, int32_t nQuery, int32_t firstQueryId, RowBuf *rows)
+// 1-way / 2-way / mean (computeCoreIdentity.hpp:214-297) for the candidates map_stage left in the context's buffers, against one
+// index chunk; the (count, identity) results go to the chunk's column block of the dense [nQuery][nRefGenomes] table in ctx->rows.
+int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, int32_t nCand, int32_t nQuery)
 {
-  if (nQuery == 0) return ANI_OK;
+  if (nQuery == 0 || sk->nGenomes == 0) return ANI_OK;
   const size_t binsPerQuery = sk->totalBins;
   const size_t nBins = binsPerQuery * (size_t)nQuery;
-  TRY(ctx->bins.ensure((nBins ? nBins : 1) * 4)); TRY(ctx->queryFragments.ensure((size_t)nQuery * 4));
-  const size_t nPairs = (size_t)nQuery * (size_t)sk->nGenomes;
-  TRY(ctx->rows.ensure((nPairs ? nPairs : 1) * 8));
-  hipError_t e1, e2;
+  TRY(ctx->bins.ensure((nBins ? nBins : 1) * 4));
+  const size_t nPairsAll = (size_t)nQuery * (size_t)set->nGenomes;
+  TRY(ctx->rows.ensure((nPairsAll ? nPairsAll : 1) * 8));
+  hipError_t e1;
   {
   StageTimer tm(ctx, &ctx->counters.msReduce);
   e1 = hipMemsetAsync(ctx->bins.p, 0, (nBins ? nBins : 1) * 4, ctx->stream);
-  e2 = hipMemcpyAsync(ctx->queryFragments.p, qr.genomeFragments.data(), (size_t)nQuery * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (qr.nCand) {
+  if (nCand) {
     OneWayArgs a;
-    a.nCand = qr.nCand; a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.refStart = ctx->refStart.as<int32_t>();
+    a.nCand = nCand; a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.refStart = ctx->refStart.as<int32_t>();
     a.idBits = ctx->idBits.as<uint32_t>(); a.fragGenome = ctx->fragGenome.as<int32_t>(); a.contigGenome = sk->contigGenome;
-    a.contigBinBase = sk->contigBinBase; a.binWidth = sk->params.fragLen - 20; a.bins = ctx->bins.as<uint32_t>(); a.binsPerQuery = binsPerQuery;
-    hipLaunchKernelGGL(k_oneway_bins, dim3(grid_for((size_t)qr.nCand)), dim3(256), 0, ctx->stream, a);
+    a.contigBinBase = sk->contigBinBase; a.binWidth = set->params.fragLen - 20; a.bins = ctx->bins.as<uint32_t>(); a.binsPerQuery = binsPerQuery;
+    hipLaunchKernelGGL(k_oneway_bins, dim3(grid_for((size_t)nCand)), dim3(256), 0, ctx->stream, a);
   }
   PairArgs pa;
   pa.nQuery = nQuery; pa.nRefGenomes = sk->nGenomes; pa.bins = ctx->bins.as<uint32_t>(); pa.binsPerQuery = binsPerQuery;
-  pa.genomeBinStart = sk->genomeBinStart; pa.pairCount = ctx->rows.as<uint32_t>(); pa.pairIdentity = ctx->rows.as<uint32_t>() + nPairs;
-  if (nPairs) hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, ctx->stream, pa);   // one wave per pair
+  pa.genomeBinStart = sk->genomeBinStart; pa.pairCount = ctx->rows.as<uint32_t>(); pa.pairIdentity = ctx->rows.as<uint32_t>() + nPairsAll;
+  pa.outStride = set->nGenomes; pa.outCol0 = sk->g0;
+  const size_t nPairs = (size_t)nQuery * (size_t)sk->nGenomes;
+  hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, ctx->stream, pa);   // one wave per pair
   }
-  HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(hipGetLastError());
+  HIP_TRY(e1); HIP_TRY(hipGetLastError());
+  return ANI_OK;
+}
+
+// the dense table of a sub-batch (all chunks reduced) -> rows in (query, reference genome) order, appended to `rows`
+int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows)
+{
+  const size_t nPairs = (size_t)nQuery * (size_t)set->nGenomes;
+  if (nPairs == 0) return ANI_OK;
   uint32_t *dense = nullptr;
   TRY(pinned_buffer(ctx, 1, nPairs * 8 + 8, (void **)&dense));
-  if (nPairs) { HIP_TRY(hipMemcpyAsync(dense, ctx->rows.p, nPairs * 8, hipMemcpyDeviceToHost, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
+  HIP_TRY(hipMemcpyAsync(dense, ctx->rows.p, nPairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   size_t m = 0;
   for (size_t p = 0; p < nPairs; p++) m += dense[p] != 0;
   ani_cgi_t *out = rows->grow(m);
   if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", m);
   rows->n += m;
-  for (int32_t qi = 0; qi < nQuery; qi++)                           // query ascending, reference ascending
-    for (int32_t g = 0; g < sk->nGenomes; g++) {
-      const size_t p = (size_t)qi * (size_t)sk->nGenomes + (size_t)g;
-      if (!dense[p]) continue;
-      ani_cgi_t r; r.refGenomeId = g; r.qryGenomeId = firstQueryId + qi; r.countSeq = (int32_t)dense[p];
-      r.totalQueryFragments = qr.genomeFragments[qi];
-      memcpy(&r.identity, &dense[nPairs + p], 4);
+  for (int32_t qi = 0; qi < nQuery; qi++) {                         // query ascending, reference ascending
+    const uint32_t *cnt = dense + (size_t)qi * (size_t)set->nGenomes, *idb = cnt + nPairs;
+    for (int32_t g = 0; g < set->nGenomes; g++) {
+      if (!cnt[g]) continue;
+      ani_cgi_t r; r.refGenomeId = g; r.qryGenomeId = firstQueryId + qi; r.countSeq = (int32_t)cnt[g];
+      r.totalQueryFragments = fs.genomeFragments[qi];
+      memcpy(&r.identity, &idb[g], 4);
       *out++ = r;
     }
+  }
   ctx->counters.cgiRows += m;
   return ANI_OK;
 }
@@ -1026,6 +1207,8 @@ int ani_init(int device, ani_ctx **out)
   HIP_TRY(hipStreamCreate(&c->stream2));
   if (const char *ev = getenv("ANI_SUBBATCH_FRAGS")) { const long long v = atoll(ev); if (v > 0) c->subBatchFragments = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
+  if (const char *ev = getenv("ANI_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_MAX_INDEX_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->maxIndexMinimizers = (uint64_t)v; }
   for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
   int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }
@@ -1047,7 +1230,7 @@ void ani_shutdown(ani_ctx *c)
   for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); }
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  for (int i = 0; i < 2; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+  for (int i = 0; i < 3; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   cur_pool(0).trim(); cur_pool(1).trim();
@@ -1104,34 +1287,10 @@ int ani_sketch_records(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_
   if (!ctx || !devRecords || !n) return fail(ANI_ERR_ARG, "null argument");
   TRY(check_params(p)); TRY(check_batch(refs));
   HIP_TRY(hipSetDevice(ctx->device));
-  DeviceBatch db;
-  TRY(upload_batch(ctx, refs, 0, refs->nGenomes, &db));
-  uint32_t *rec = nullptr;
-  TRY(sketch_records(ctx, p, db, seqIdBase, &rec, n));
-  *devRecords = rec;
-  return ANI_OK;
-}
-
-int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *devRecords, size_t n, const int32_t *contigLen, int32_t nContigs,
-                            const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
-{
-  if (!ctx || !out || (n && !devRecords) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
-    return fail(ANI_ERR_ARG, "invalid argument");
-  TRY(check_params(p));
-  HIP_TRY(hipSetDevice(ctx->device));
-  return build_index(ctx, p, (const uint32_t *)devRecords, n, contigLen, nContigs, genomeContigStart, nGenomes, out);
-}
-
-int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, ani_sketch **out)
-{
-  if (!ctx || !out) return fail(ANI_ERR_ARG, "null argument");
-  TRY(check_params(p)); TRY(check_batch(refs));
-  HIP_TRY(hipSetDevice(ctx->device));
-  // references are sketched in slices of genomes so that the temporary pools stay small; records are appended
-  // in genome order, i.e. position order with global seqIds
-  std::vector<uint32_t *> parts; std::vector<size_t> partN;
+  // slices of ~2^30 bases keep the temporary pools small; a single slice is handed over as it is
+  std::vector<RecordPart> parts;
+  auto cleanup = [&]() { for (auto &q : parts) if (q.rec) pool_free(q.rec); };
   size_t total = 0;
-  auto cleanup = [&]() { for (uint32_t *q : parts) if (q) pool_free(q); };
   int32_t g0 = 0;
   while (g0 < refs->nGenomes) {
     int32_t g1 = g0; uint64_t bases = 0;
@@ -1141,34 +1300,83 @@ int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
     }
     DeviceBatch db;
     int rc = upload_batch(ctx, refs, g0, g1, &db);
-    uint32_t *rec = nullptr; size_t n = 0;
-    if (rc == ANI_OK) rc = sketch_records(ctx, p, db, refs->genomeContigStart[g0], &rec, &n);
+    RecordPart pt; pt.g0 = g0; pt.g1 = g1;
+    if (rc == ANI_OK) rc = sketch_records(ctx, p, db, seqIdBase + refs->genomeContigStart[g0], &pt.rec, &pt.n);
     if (rc != ANI_OK) { cleanup(); return rc; }
-    parts.push_back(rec); partN.push_back(n); total += n;
+    parts.push_back(pt); total += pt.n;
     g0 = g1;
   }
   uint32_t *all = nullptr;
-  if (parts.size() == 1) { all = parts[0]; parts[0] = nullptr; }
+  if (parts.size() == 1) { all = parts[0].rec; parts[0].rec = nullptr; }
   else if (total) {
     hipError_t e = pool_malloc((void **)&all, total * 12);
-    if (e != hipSuccess) { cleanup(); return fail(ANI_ERR_NOMEM, "hipMalloc(%zu) failed", total * 12); }
     size_t o = 0;
-    for (size_t i = 0; i < parts.size(); i++) {
-      if (partN[i]) (void)hipMemcpyAsync(all + 3 * o, parts[i], partN[i] * 12, hipMemcpyDeviceToDevice, ctx->stream);
-      o += partN[i];
+    for (size_t i = 0; i < parts.size() && e == hipSuccess; i++) {
+      if (parts[i].n) e = hipMemcpyAsync(all + 3 * o, parts[i].rec, parts[i].n * 12, hipMemcpyDeviceToDevice, ctx->stream);
+      o += parts[i].n;
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { if (all) pool_free(all); cleanup(); return fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "gathering %zu records failed: %s", total, hipGetErrorString(e)); }
   }
   cleanup();
-  int rc = build_index(ctx, p, all, total, refs->contigLen, refs->nContigs, refs->genomeContigStart, refs->nGenomes, out);
-  if (all) pool_free(all);
-  return rc;
+  if (ctx->timerPending.size() > 1024) flush_timers(ctx);
+  *devRecords = all; *n = total;
+  return ANI_OK;
+}
+
+int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *devRecords, size_t n, const int32_t *contigLen, int32_t nContigs,
+                            const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  if (!ctx || !out || (n && !devRecords) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
+    return fail(ANI_ERR_ARG, "invalid argument");
+  if (genomeContigStart[0] != 0 || genomeContigStart[nGenomes] != nContigs) return fail(ANI_ERR_ARG, "genomeContigStart does not cover the contig table");
+  TRY(check_params(p));
+  HIP_TRY(hipSetDevice(ctx->device));
+  ani_sketch *sk = new_sketch(ctx, p, contigLen, nContigs, genomeContigStart, nGenomes);
+  std::vector<RecordPart> parts(1);
+  parts[0].rec = (uint32_t *)devRecords; parts[0].n = n; parts[0].g0 = 0; parts[0].g1 = nGenomes; parts[0].owned = false;
+  const int rc = add_chunks(ctx, sk, parts);
+  if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
+  *out = sk;
+  return ANI_OK;
+}
+
+int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, ani_sketch **out)
+{
+  if (!ctx || !out) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_params(p)); TRY(check_batch(refs));
+  HIP_TRY(hipSetDevice(ctx->device));
+  // references are sketched in slices of genomes so that the temporary pools stay small; the slices' records (position order,
+  // global seqIds) are then cut into index chunks at genome borders
+  std::vector<RecordPart> parts;
+  auto cleanup = [&]() { for (auto &q : parts) if (q.rec && q.owned) pool_free(q.rec); };
+  int32_t g0 = 0;
+  while (g0 < refs->nGenomes) {
+    int32_t g1 = g0; uint64_t bases = 0;
+    while (g1 < refs->nGenomes && (g1 == g0 || bases < (1ull << 30))) {
+      for (int32_t c = refs->genomeContigStart[g1]; c < refs->genomeContigStart[g1 + 1]; c++) bases += (uint64_t)refs->contigLen[c];
+      g1++;
+    }
+    DeviceBatch db;
+    int rc = upload_batch(ctx, refs, g0, g1, &db);
+    RecordPart pt; pt.g0 = g0; pt.g1 = g1;
+    if (rc == ANI_OK) rc = sketch_records(ctx, p, db, refs->genomeContigStart[g0], &pt.rec, &pt.n);
+    if (rc != ANI_OK) { cleanup(); return rc; }
+    parts.push_back(pt);
+    g0 = g1;
+  }
+  ani_sketch *sk = new_sketch(ctx, p, refs->contigLen, refs->nContigs, refs->genomeContigStart, refs->nGenomes);
+  const int rc = add_chunks(ctx, sk, parts);
+  cleanup();
+  if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
+  *out = sk;
+  return ANI_OK;
 }
 
 void ani_sketch_destroy(ani_sketch *sk)
 {
   if (!sk) return;
-  (void)hipSetDevice(sk->ctx->device);
+  (void)hipSetDevice(sk->device);       // the context may be gone already: device memory goes back to the per-device pools
   free_sketch_device(sk);
   delete sk;
 }
@@ -1178,28 +1386,47 @@ int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n)
   if (!sk || !out || !n) return fail(ANI_ERR_ARG, "null argument");
   ani_ctx *ctx = sk->ctx;
   HIP_TRY(hipSetDevice(ctx->device));
-  *n = sk->n;
+  *n = (size_t)sk->n;
   *out = (ani_minimizer_t *)malloc((sk->n ? (size_t)sk->n : 1) * sizeof(ani_minimizer_t));
   if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
-  if (sk->n == 0) return ANI_OK;
-  uint32_t *tmp = nullptr;
-  HIP_TRY(pool_malloc((void **)&tmp, (size_t)sk->n * 12));
-  hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(sk->n)), dim3(256), 0, ctx->stream, sk->mHash, sk->mSeq, sk->mWpos, sk->n, tmp);
-  hipError_t e = hipMemcpyAsync(*out, tmp, (size_t)sk->n * 12, hipMemcpyDeviceToHost, ctx->stream);
-  hipError_t e2 = hipStreamSynchronize(ctx->stream);
-  pool_free(tmp);
-  HIP_TRY(e); HIP_TRY(e2);
+  size_t o = 0;
+  for (const IndexChunk *ch : sk->chunks) {
+    if (ch->n == 0) continue;
+    uint32_t *tmp = nullptr;
+    hipError_t e = pool_malloc((void **)&tmp, (size_t)ch->n * 12);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(ch->n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash, ch->mSeq, ch->mWpos, ch->n, (uint32_t)ch->c0, tmp);
+      e = hipMemcpyAsync(*out + o, tmp, (size_t)ch->n * 12, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (tmp) pool_free(tmp);
+    if (e != hipSuccess || e2 != hipSuccess) { free(*out); *out = nullptr; HIP_TRY(e); HIP_TRY(e2); }
+    o += ch->n;
+  }
   return ANI_OK;
 }
 
-int ani_sketch_stats(const ani_sketch *sk, uint64_t *nMinimizers, uint64_t *nUnique, uint64_t *totalLength, int32_t *nContigs, int32_t *nGenomes)
+int ani_sketch_stats(const ani_sketch *skc, uint64_t *nMinimizers, uint64_t *nUnique, uint64_t *totalLength, int32_t *nContigs, int32_t *nGenomes)
 {
-  if (!sk) return fail(ANI_ERR_ARG, "null sketch");
+  if (!skc) return fail(ANI_ERR_ARG, "null sketch");
+  ani_sketch *sk = const_cast<ani_sketch *>(skc);
+  if (nUnique) {
+    HIP_TRY(hipSetDevice(sk->device));
+    TRY(exact_unique(sk));          // several index chunks: hashes shared between chunks are counted once (lazily, here)
+    *nUnique = sk->nUnique;
+  }
   if (nMinimizers) *nMinimizers = sk->n;
-  if (nUnique) *nUnique = sk->nUnique;
   if (totalLength) *totalLength = sk->totalLen;
   if (nContigs) *nContigs = sk->nContigs;
   if (nGenomes) *nGenomes = sk->nGenomes;
+  return ANI_OK;
+}
+
+int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGenome, int32_t cap)
+{
+  if (!sk || !nChunks) return fail(ANI_ERR_ARG, "null argument");
+  *nChunks = (int32_t)sk->chunks.size();
+  if (firstGenome) for (int32_t i = 0; i < cap && i < *nChunks; i++) firstGenome[i] = sk->chunks[i]->g0;
   return ANI_OK;
 }
 
@@ -1208,32 +1435,27 @@ int ani_query_sketch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
   if (!ctx || !hashes || !offsets || !nFragments) return fail(ANI_ERR_ARG, "null argument");
   TRY(check_params(p)); TRY(check_batch(query));
   HIP_TRY(hipSetDevice(ctx->device));
-  // run the fragment-sketch stage against an empty index
-  ani_sketch *sk = nullptr;
-  int32_t gcs[1] = {0};
-  TRY(build_index(ctx, p, nullptr, 0, nullptr, 0, gcs, 0, &sk));
-  DeviceBatch db; QueryRun qr;
-  int rc = upload_batch(ctx, query, 0, query->nGenomes, &db);
-  if (rc == ANI_OK) rc = query_stages(ctx, sk, db, &qr);
-  if (rc == ANI_OK) {
-    const size_t nF = (size_t)qr.nFrag;
-    std::vector<uint32_t> off(nF); std::vector<int32_t> s(nF);
-    if (nF) {
-      (void)hipMemcpy(off.data(), ctx->fragOff.p, nF * 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(s.data(), ctx->fragS.p, nF * 4, hipMemcpyDeviceToHost);
-    }
-    std::vector<uint64_t> offs(nF + 1, 0);
-    for (size_t f = 0; f < nF; f++) offs[f + 1] = offs[f] + (uint64_t)(s[f] > 0 ? s[f] : 0);
-    std::vector<uint32_t> h(offs[nF]);
-    for (size_t f = 0; f < nF; f++)
-      if (s[f] > 0) (void)hipMemcpy(h.data() + offs[f], ctx->qPool.as<uint32_t>() + off[f], (size_t)s[f] * 4, hipMemcpyDeviceToHost);
-    size_t dummy;
-    rc = to_host_malloc(h, hashes, &dummy);
-    if (rc == ANI_OK) rc = to_host_malloc(offs, offsets, &dummy);
-    *nFragments = nF;
+  DeviceBatch db; FragSet fs;
+  TRY(upload_batch(ctx, query, 0, query->nGenomes, &db));
+  TRY(fragment_stage(ctx, *p, db, &fs));
+  const size_t nF = (size_t)fs.nFrag;
+  std::vector<uint32_t> off(nF); std::vector<int32_t> s(nF);
+  if (nF) {
+    HIP_TRY(hipMemcpy(off.data(), ctx->fragOff.p, nF * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s.data(), ctx->fragS.p, nF * 4, hipMemcpyDeviceToHost));
   }
-  ani_sketch_destroy(sk);
-  return rc;
+  std::vector<uint64_t> offs(nF + 1, 0);
+  for (size_t f = 0; f < nF; f++) offs[f + 1] = offs[f] + (uint64_t)(s[f] > 0 ? s[f] : 0);
+  std::vector<uint32_t> pool((size_t)fs.nHashes), h(offs[nF]);
+  if (fs.nHashes) HIP_TRY(hipMemcpy(pool.data(), ctx->qPool.p, (size_t)fs.nHashes * 4, hipMemcpyDeviceToHost));
+  for (size_t f = 0; f < nF; f++)
+    if (s[f] > 0) memcpy(h.data() + offs[f], pool.data() + off[f], (size_t)s[f] * 4);
+  size_t dummy;
+  TRY(to_host_malloc(h, hashes, &dummy));
+  const int rc = to_host_malloc(offs, offsets, &dummy);
+  if (rc != ANI_OK) { free(*hashes); *hashes = nullptr; return rc; }
+  *nFragments = nF;
+  return ANI_OK;
 }
 
 int ani_map_query(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t *query, ani_mapping_t **out, size_t *n, uint64_t *totalQueryFragments)
@@ -1243,37 +1465,46 @@ int ani_map_query(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t *qu
   if (query->nGenomes != 1) return fail(ANI_ERR_ARG, "ani_map_query maps exactly one query genome (Map::Map takes one queryno, computeMap.hpp:93)");
   ani_sketch *sk = const_cast<ani_sketch *>(skc);
   HIP_TRY(hipSetDevice(ctx->device));
-  DeviceBatch db; QueryRun qr;
+  DeviceBatch db; FragSet fs;
   TRY(upload_batch(ctx, query, 0, 1, &db));
-  TRY(query_stages(ctx, sk, db, &qr));
-  if (totalQueryFragments) *totalQueryFragments = (uint64_t)qr.genomeFragments[0];
+  TRY(fragment_stage(ctx, sk->params, db, &fs));
+  TRY(upload_luts(sk, fs.maxS));
+  if (totalQueryFragments) *totalQueryFragments = (uint64_t)fs.genomeFragments[0];
   std::vector<ani_mapping_t> maps;
-  if (qr.nCand) {
-    const size_t nC = (size_t)qr.nCand;
+  for (IndexChunk *ch : sk->chunks) {
+    int32_t nCand = 0;
+    TRY(map_stage(ctx, sk, ch, fs, &nCand));
+    if (!nCand) continue;
+    const size_t nC = (size_t)nCand;
     TRY(ctx->keepFlags.ensure(nC * 4)); TRY(ctx->keepOff.ensure((nC + 1) * 4));
     hipLaunchKernelGGL(ani::k_keep_flags, dim3(grid_for(nC)), dim3(256), 0, ctx->stream, (int32_t)nC, ctx->idBits.as<uint32_t>(), ctx->keepFlags.as<int32_t>());
     uint64_t nKeep = 0;
     TRY(device_scan(ctx, ctx->keepFlags.as<int32_t>(), ctx->keepOff.as<uint32_t>(), (uint32_t)nC, &nKeep));
-    if (nKeep) {
-      TRY(ctx->mapOut.ensure(nKeep * 44));
-      hipLaunchKernelGGL(ani::k_emit_mappings, dim3(grid_for(nC)), dim3(256), 0, ctx->stream, (int32_t)nC, ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(),
-                         ctx->refStart.as<int32_t>(), ctx->idBits.as<uint32_t>(), ctx->l2Best.as<int32_t>(), ctx->fragS.as<int32_t>(),
-                         ctx->fragQSeq.as<int32_t>(), ctx->keepOff.as<uint32_t>(), sk->params.fragLen, ctx->mapOut.as<uint32_t>());
-      HIP_TRY(hipGetLastError());
-      maps.resize(nKeep);
-      HIP_TRY(hipMemcpy(maps.data(), ctx->mapOut.p, nKeep * 44, hipMemcpyDeviceToHost));
-      // nucIdentityUpperBound (computeMap.hpp:378-381) is a host scalar per (sketchSize, shared); memoised
-      std::unordered_map<uint64_t, float> memo;
-      for (auto &m : maps) {
-        const uint64_t key = ((uint64_t)(uint32_t)m.sketchSize << 32) | (uint32_t)m.conservedSketches;
-        auto it = memo.find(key);
-        if (it == memo.end()) {
-          float id, ub; ani::stat::identity(m.conservedSketches, m.sketchSize, sk->params.kmerSize, &id, &ub);
-          it = memo.emplace(key, ub).first;
-        }
-        m.nucIdentityUpperBound = it->second;
-      }
+    if (!nKeep) continue;
+    TRY(ctx->mapOut.ensure(nKeep * 44));
+    hipLaunchKernelGGL(ani::k_emit_mappings, dim3(grid_for(nC)), dim3(256), 0, ctx->stream, (int32_t)nC, ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(),
+                       ctx->refStart.as<int32_t>(), ctx->idBits.as<uint32_t>(), ctx->l2Best.as<int32_t>(), ctx->fragS.as<int32_t>(),
+                       ctx->fragQSeq.as<int32_t>(), ctx->keepOff.as<uint32_t>(), sk->params.fragLen, ch->c0, ctx->mapOut.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    const size_t o = maps.size();
+    maps.resize(o + nKeep);
+    HIP_TRY(hipMemcpyAsync(maps.data() + o, ctx->mapOut.p, nKeep * 44, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  // callback order (fragment, then reference position): every chunk's block is in that order and chunk c's contigs all precede
+  // chunk c+1's, so a stable sort by fragment merges the blocks
+  if (sk->chunks.size() > 1)
+    std::stable_sort(maps.begin(), maps.end(), [](const ani_mapping_t &a, const ani_mapping_t &b) { return a.querySeqId < b.querySeqId; });
+  // nucIdentityUpperBound (computeMap.hpp:378-381) is a host scalar per (sketchSize, shared); memoised
+  std::unordered_map<uint64_t, float> memo;
+  for (auto &m : maps) {
+    const uint64_t key = ((uint64_t)(uint32_t)m.sketchSize << 32) | (uint32_t)m.conservedSketches;
+    auto it = memo.find(key);
+    if (it == memo.end()) {
+      float id, ub; ani::stat::identity(m.conservedSketches, m.sketchSize, sk->params.kmerSize, &id, &ub);
+      it = memo.emplace(key, ub).first;
     }
+    m.nucIdentityUpperBound = it->second;
   }
   ctx->counters.mappings += maps.size();
   return to_host_malloc(maps, out, n);
@@ -1286,38 +1517,67 @@ int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *skc, const ani_mapping_t *ma
   ani_sketch *sk = const_cast<ani_sketch *>(skc);
   HIP_TRY(hipSetDevice(ctx->device));
   if (n > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "too many mappings");
-  // The device reducer expects mappings grouped by (fragment, reference contig): order them the way Map reports them
-  std::vector<uint32_t> ord(n);
-  for (size_t i = 0; i < n; i++) ord[i] = (uint32_t)i;
-  std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
-    const ani_mapping_t &a = mappings[x], &b = mappings[y];
-    if (a.querySeqId != b.querySeqId) return a.querySeqId < b.querySeqId;
-    if (a.refSeqId != b.refSeqId) return a.refSeqId < b.refSeqId;
-    return a.refStartPos < b.refStartPos;
-  });
-  std::vector<int32_t> cFrag(n), cSeq(n), cStart(n), fragIds; std::vector<uint32_t> cBits(n);
-  // compress querySeqId -> dense fragment index (all of one genome)
-  int32_t lastQ = -1, f = -1;
+  // The device reducer expects the mappings of one (fragment, reference genome) next to each other, which is how Map reports
+  // them (fragment, then reference position); only input that is not in that order is sorted (on the device, by
+  // (querySeqId, refSeqId) with the record index as payload).
+  bool ordered = true;
   for (size_t i = 0; i < n; i++) {
-    const ani_mapping_t &a = mappings[ord[i]];
+    const ani_mapping_t &a = mappings[i];
     if (a.refSeqId < 0 || a.refSeqId >= sk->nContigs) return fail(ANI_ERR_ARG, "mapping %zu refers to contig %d outside the sketch", i, a.refSeqId);
     if (a.refStartPos < 0 || a.refStartPos > sk->contigLen[a.refSeqId]) return fail(ANI_ERR_ARG, "mapping %zu has refStartPos outside its contig", i);
-    if (a.querySeqId != lastQ || f < 0) { f++; lastQ = a.querySeqId; fragIds.push_back(a.querySeqId); }
-    cFrag[i] = f; cSeq[i] = a.refSeqId; cStart[i] = a.refStartPos; memcpy(&cBits[i], &a.nucIdentity, 4);
     if (a.nucIdentity <= 0.0f) return fail(ANI_ERR_ARG, "mapping %zu has non-positive identity", i);
+    if (a.querySeqId < 0) return fail(ANI_ERR_ARG, "mapping %zu has a negative querySeqId", i);
+    if (i && (mappings[i - 1].querySeqId > a.querySeqId || (mappings[i - 1].querySeqId == a.querySeqId && mappings[i - 1].refSeqId > a.refSeqId))) ordered = false;
   }
-  QueryRun qr; qr.nCand = (int32_t)n; qr.nFrag = f + 1; qr.genomeFragments.assign(1, (int32_t)totalQueryFragments);
+  std::vector<uint32_t> ord;
+  if (!ordered) {
+    ord.resize(n);
+    std::vector<uint64_t> keys(n);
+    for (size_t i = 0; i < n; i++) { keys[i] = ((uint64_t)(uint32_t)mappings[i].querySeqId << 32) | (uint32_t)mappings[i].refSeqId; ord[i] = (uint32_t)i; }
+    TRY(ctx->l1BigHitsA.ensure(n * 8)); TRY(ctx->l1BigHitsB.ensure(n * 8)); TRY(ctx->keepFlags.ensure(n * 4)); TRY(ctx->keepOff.ensure(n * 4));
+    HIP_TRY(hipMemcpyAsync(ctx->l1BigHitsA.p, keys.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->keepFlags.p, ord.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    size_t tb = 0;
+    int rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, nullptr, &tb, ctx->stream);
+    if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 16)); rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, ctx->sortTmp.p, &tb, ctx->stream); }
+    if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of mappings failed (%d)", rc);
+    HIP_TRY(hipMemcpyAsync(ord.data(), ctx->keepOff.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  // compress querySeqId -> dense fragment index (all of one genome); split the candidate list by index chunk
+  FragSet fs; fs.genomeFragments.assign(1, (int32_t)totalQueryFragments);
+  const size_t nCh = sk->chunks.size();
+  std::vector<std::vector<int32_t>> cFrag(nCh), cSeq(nCh), cStart(nCh); std::vector<std::vector<uint32_t>> cBits(nCh);
+  int32_t lastQ = -1, f = -1;
+  size_t chunkOfSeqHint = 0;
+  for (size_t i = 0; i < n; i++) {
+    const ani_mapping_t &a = mappings[ordered ? i : ord[i]];
+    if (a.querySeqId != lastQ || f < 0) { f++; lastQ = a.querySeqId; }
+    size_t c = chunkOfSeqHint;
+    while (c + 1 < nCh && a.refSeqId >= sk->chunks[c]->c0 + sk->chunks[c]->nContigs) c++;
+    while (c > 0 && a.refSeqId < sk->chunks[c]->c0) c--;
+    chunkOfSeqHint = c;
+    uint32_t bits; memcpy(&bits, &a.nucIdentity, 4);
+    cFrag[c].push_back(f); cSeq[c].push_back(a.refSeqId - sk->chunks[c]->c0); cStart[c].push_back(a.refStartPos); cBits[c].push_back(bits);
+  }
+  fs.nFrag = f + 1;
   const size_t nF = (size_t)(f + 1);
-  if (n) {
-    TRY(ctx->ocFrag.ensure(n * 4)); TRY(ctx->ocSeq.ensure(n * 4)); TRY(ctx->refStart.ensure(n * 4)); TRY(ctx->idBits.ensure(n * 4)); TRY(ctx->fragGenome.ensure(nF * 4));
-    HIP_TRY(hipMemcpy(ctx->ocFrag.p, cFrag.data(), n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->ocSeq.p, cSeq.data(), n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->refStart.p, cStart.data(), n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ctx->idBits.p, cBits.data(), n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(ctx->fragGenome.p, 0, nF * 4));
+  TRY(ctx->fragGenome.ensure((nF ? nF : 1) * 4));
+  if (nF) HIP_TRY(hipMemsetAsync(ctx->fragGenome.p, 0, nF * 4, ctx->stream));
+  for (size_t c = 0; c < nCh; c++) {
+    const size_t nc = cFrag[c].size();
+    if (nc) {
+      TRY(ctx->ocFrag.ensure(nc * 4)); TRY(ctx->ocSeq.ensure(nc * 4)); TRY(ctx->refStart.ensure(nc * 4)); TRY(ctx->idBits.ensure(nc * 4));
+      HIP_TRY(hipMemcpyAsync(ctx->ocFrag.p, cFrag[c].data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->ocSeq.p, cSeq[c].data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->refStart.p, cStart[c].data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(ctx->idBits.p, cBits[c].data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    TRY(reduce_stage(ctx, sk, sk->chunks[c], fs, (int32_t)nc, 1));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));       // the next chunk reuses the candidate buffers
   }
   RowBuf rows;
-  TRY(reduce_stage(ctx, sk, qr, 1, queryFileNo, &rows));
+  TRY(collect_rows(ctx, sk, fs, 1, queryFileNo, &rows));
   *m = rows.n; *out = rows.release();
   if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
   return ANI_OK;
@@ -1330,20 +1590,27 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t
   ani_sketch *sk = const_cast<ani_sketch *>(skc);
   HIP_TRY(hipSetDevice(ctx->device));
   RowBuf rows;
-  // sub-batches bounded by fragments (~2^18) and by the bin table (~2 GiB)
+  // sub-batches bounded by fragments (2^20), by the bin table of the largest index chunk (8 GiB) and by the dense result table
   const int L = sk->params.fragLen;
   int32_t g0 = 0;
   while (g0 < queries->nGenomes) {
     int32_t g1 = g0; uint64_t fr = 0;
-    const uint64_t maxQ = std::max<uint64_t>(1, (ctx->subBatchBinBytes) / (4ull * std::max<uint32_t>(sk->totalBins, 1)));
+    const uint64_t maxQ = std::max<uint64_t>(1, std::min<uint64_t>((ctx->subBatchBinBytes) / (4ull * std::max<uint32_t>(sk->maxChunkBins, 1)),
+                                                               ((uint64_t)2 << 30) / (8ull * (uint64_t)std::max<int32_t>(sk->nGenomes, 1))));
     while (g1 < queries->nGenomes && (g1 == g0 || (fr < ctx->subBatchFragments && (uint64_t)(g1 - g0) < maxQ))) {
       for (int32_t c = queries->genomeContigStart[g1]; c < queries->genomeContigStart[g1 + 1]; c++) fr += (uint64_t)(queries->contigLen[c] / L);
       g1++;
     }
-    DeviceBatch db; QueryRun qr;
+    DeviceBatch db; FragSet fs;
     TRY(upload_batch(ctx, queries, g0, g1, &db));
-    TRY(query_stages(ctx, sk, db, &qr));
-    TRY(reduce_stage(ctx, sk, qr, g1 - g0, firstQueryId + g0, &rows));
+    TRY(fragment_stage(ctx, sk->params, db, &fs));          // once per sub-batch, whatever the number of index chunks
+    TRY(upload_luts(sk, fs.maxS));
+    for (IndexChunk *ch : sk->chunks) {
+      int32_t nCand = 0;
+      TRY(map_stage(ctx, sk, ch, fs, &nCand));
+      TRY(reduce_stage(ctx, sk, ch, fs, nCand, g1 - g0));
+    }
+    TRY(collect_rows(ctx, sk, fs, g1 - g0, firstQueryId + g0, &rows));
     g0 = g1;
   }
   *m = rows.n; *out = rows.release();

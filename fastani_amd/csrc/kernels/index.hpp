@@ -14,18 +14,18 @@
 namespace ani {
 
 // records: 12-byte (hash, seqId, wpos) triples in position order -> SoA + sort input (key = hash, value = seqId<<32 | wpos)
-__global__ void k_index_split(const uint32_t *__restrict__ records, uint32_t n,
+__global__ void k_index_split(const uint32_t *__restrict__ records, uint32_t n, uint32_t seqBase /* first contig of this index chunk */,
                               uint32_t *__restrict__ mHash, int32_t *__restrict__ mSeq, int32_t *__restrict__ mWpos,
                               uint8_t *__restrict__ mDelta, int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame,
                               uint32_t *__restrict__ keyOut, uint64_t *__restrict__ valOut)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t h = records[3 * (size_t)i], sq = records[3 * (size_t)i + 1], wp = records[3 * (size_t)i + 2];
+    const uint32_t h = records[3 * (size_t)i], sq = records[3 * (size_t)i + 1] - seqBase, wp = records[3 * (size_t)i + 2];   // chunk-local seqId
     mHash[i] = h; mSeq[i] = (int32_t)sq; mWpos[i] = (int32_t)wp;
     // one byte per entry for the L2 code stream: bits 0..4 = wpos - previous wpos on the same contig (31 = larger / first entry of
     // the contig: look the position up), bit 5 = nearDup, set by k_index_links
     uint32_t dw = 31u;
-    if (i > 0 && records[3 * (size_t)i - 2] == sq) { dw = wp - records[3 * (size_t)i - 1]; dw = dw > 31u ? 31u : dw; }
+    if (i > 0 && records[3 * (size_t)i - 2] - seqBase == sq) { dw = wp - records[3 * (size_t)i - 1]; dw = dw > 31u ? 31u : dw; }
     mDelta[i] = (uint8_t)dw;
     prevSame[i] = -1; nextSame[i] = -1;                          // links/flags are only written for near duplicates (rare)
     keyOut[i] = h; valOut[i] = ((uint64_t)sq << 32) | wp;
@@ -33,10 +33,10 @@ __global__ void k_index_split(const uint32_t *__restrict__ records, uint32_t n,
 }
 
 __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
-                             uint32_t n, uint32_t *__restrict__ records)
+                             uint32_t n, uint32_t seqBase, uint32_t *__restrict__ records)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    records[3 * (size_t)i] = mHash[i]; records[3 * (size_t)i + 1] = (uint32_t)mSeq[i]; records[3 * (size_t)i + 2] = (uint32_t)mWpos[i];
+    records[3 * (size_t)i] = mHash[i]; records[3 * (size_t)i + 1] = (uint32_t)mSeq[i] + seqBase; records[3 * (size_t)i + 2] = (uint32_t)mWpos[i];
   }
 }
 
@@ -60,7 +60,6 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t
     const uint64_t a = sSW[r - 1], b = sSW[r];                   // a is positionally before b
     if ((a >> 32) != (b >> 32)) continue;                        // different contigs never share a window
     const int32_t seq = (int32_t)(a >> 32), wa = (int32_t)(uint32_t)a, wb = (int32_t)(uint32_t)b;
-    if (wb - wa > cmw + 65536) continue;                         // cheap reject before the searches
     // positional indices: binary search on wpos inside the contig's slice
     int32_t lo = contigFirstMin[seq], hi = contigFirstMin[seq + 1];
     const int32_t cHi = hi;
@@ -127,6 +126,46 @@ __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t 
     }
     contigFirstMin[c] = (int32_t)lo;
   }
+}
+
+// 12-byte records in position order with GLOBAL seqIds: out[c] = first record with seqId >= seqIdBase + c, c = 0..nContigs.
+// Used to cut a record stream into index chunks at genome borders.
+__global__ void k_records_contig_first(const uint32_t *__restrict__ records, uint64_t n, int32_t seqIdBase, int32_t nContigs,
+                                       uint64_t *__restrict__ out)
+{
+  for (int32_t c = blockIdx.x * blockDim.x + threadIdx.x; c <= nContigs; c += gridDim.x * blockDim.x) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const uint64_t mid = lo + ((hi - lo) >> 1);
+      if ((int32_t)records[3 * mid + 1] < seqIdBase + c) lo = mid + 1; else hi = mid;
+    }
+    out[c] = lo;
+  }
+}
+
+// Exact number of distinct hashes over several index chunks (Sketch::sanityCheck needs it, winSketch.hpp:298-318): every
+// distinct hash of chunk C (its first entry in hash order) is looked up in one earlier chunk E; seen[r] is set when found.
+__global__ void k_index_mark_shared(const uint32_t *__restrict__ sHashC, uint32_t nC, const uint32_t *__restrict__ sHashE,
+                                    const uint32_t *__restrict__ bucketStartE, int shiftE, int w, uint8_t *__restrict__ seen)
+{
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nC; r += gridDim.x * blockDim.x) {
+    const uint32_t h = sHashC[r];
+    if (r > 0 && sHashC[r - 1] == h) continue;
+    if (seen[r]) continue;
+    const uint32_t b = bucket_key(h, w) >> shiftE;
+    uint32_t lo = bucketStartE[b], hi = bucketStartE[b + 1];
+    const uint32_t bhi = hi;
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (sHashE[mid] < h) lo = mid + 1; else hi = mid; }
+    if (lo < bhi && sHashE[lo] == h) seen[r] = 1;
+  }
+}
+__global__ void k_count_flags(const uint8_t *__restrict__ flags, uint32_t n, unsigned long long *__restrict__ total)
+{
+  unsigned long long c = 0;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) c += flags[r] != 0;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
 }
 
 // Sampled position index for the three searchIndex() calls of every L2 candidate (computeMap.hpp:424-436): posSample[posBase[c] + b]

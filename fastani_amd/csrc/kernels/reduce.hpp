@@ -78,9 +78,10 @@ struct PairArgs {
   int32_t nQuery, nRefGenomes;
   const uint32_t *bins; size_t binsPerQuery;
   const uint32_t *genomeBinStart;      // [nRefGenomes+1] first bin of each reference genome
-  // dense output [nQuery][nRefGenomes]: (countSeq, identity bits); countSeq == 0 = no row.  Dense and atomics-free, so the host
-  // reads the rows back already in (query, reference) order.
-  uint32_t *pairCount; uint32_t *pairIdentity;
+  // dense output [nQuery][outStride]: (countSeq, identity bits); countSeq == 0 = no row.  Dense and atomics-free, so the host
+  // reads the rows back already in (query, reference) order.  A reference set that is split into several index chunks
+  // fills one column block per chunk: this chunk's genome g goes to column outCol0 + g of the outStride genomes.
+  uint32_t *pairCount; uint32_t *pairIdentity; int32_t outStride, outCol0;
 };
 
 // One wave per (query genome, reference genome) pair.  The genome's bins are read 64 at a time (coalesced); the float sum has
@@ -106,8 +107,9 @@ __global__ __launch_bounds__(kTPB) void k_pair_reduce(PairArgs a)
     }
   }
   if (lane == 0) {
-    a.pairCount[p] = (uint32_t)cnt;
-    a.pairIdentity[p] = cnt ? __float_as_uint(sum / cnt) : 0u;
+    const size_t o = (size_t)qi * (size_t)a.outStride + (size_t)(a.outCol0 + g);
+    a.pairCount[o] = (uint32_t)cnt;
+    a.pairIdentity[o] = cnt ? __float_as_uint(sum / cnt) : 0u;
   }
 }
 
@@ -116,6 +118,7 @@ __global__ void k_emit_mappings(int32_t nCand, const int32_t *__restrict__ candF
                                 const int32_t *__restrict__ refStart, const uint32_t *__restrict__ idBits,
                                 const int32_t *__restrict__ best, const int32_t *__restrict__ fragS,
                                 const int32_t *__restrict__ fragQuerySeqId, const uint32_t *__restrict__ outOff, int L,
+                                int32_t seqBase /* first contig of the index chunk: refSeqId is global */,
                                 uint32_t *__restrict__ out /* 11 words per mapping; upper bound filled on the host */)
 {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +126,7 @@ __global__ void k_emit_mappings(int32_t nCand, const int32_t *__restrict__ candF
   uint32_t *m = out + 11 * (size_t)outOff[c];
   const int f = candFrag[c];
   m[0] = (uint32_t)L; m[1] = (uint32_t)refStart[c]; m[2] = (uint32_t)(refStart[c] + L - 1); m[3] = 0; m[4] = (uint32_t)(L - 1);
-  m[5] = (uint32_t)candSeq[c]; m[6] = (uint32_t)fragQuerySeqId[f]; m[7] = idBits[c]; m[8] = 0;
+  m[5] = (uint32_t)(candSeq[c] + seqBase); m[6] = (uint32_t)fragQuerySeqId[f]; m[7] = idBits[c]; m[8] = 0;
   m[9] = (uint32_t)fragS[f]; m[10] = (uint32_t)best[c];
 }
 

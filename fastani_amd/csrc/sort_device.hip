@@ -24,3 +24,13 @@ extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size
   if (e != hipSuccess || !tmp) return (int)e;
   return (int)hipStreamSynchronize(stream);
 }
+
+// (querySeqId<<32 | refSeqId, record index): orders mapping records handed to ani_compute_cgi in an arbitrary order
+extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream)
+{
+  if (n == 0) { if (!tmp) *tmpBytes = 0; return 0; }
+  hipError_t e = rocprim::radix_sort_pairs(tmp, *tmpBytes, keysIn, keysOut, valsIn, valsOut, n, 0, 64, stream);
+  if (e != hipSuccess || !tmp) return (int)e;
+  return (int)hipStreamSynchronize(stream);
+}

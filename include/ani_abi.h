@@ -103,6 +103,7 @@ typedef struct {
   uint64_t l2SlowLimit, l2SlowDup, l2SlowOverflow;   /* ... by reason: size limits / same-hash neighbour or wide gap / counter overflow */
   uint64_t mappings;
   uint64_t cgiRows;
+  uint64_t l2ChunkHalvings;   /* L2 chunks redone at half size because their code stream passed the 32-bit offset limit */
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
   double msL2Kernel;          /* HIP-event time of the class-A ani::k_l2_sim launches alone (on the launch stream) */
   double msL2Ranges, msL2Codes, msL2Slow;   /* ani::k_l2_ranges, ani::k_l2_codes, ani::k_l2 */
@@ -134,6 +135,13 @@ int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n);
 /* the numbers Sketch::sanityCheck needs (winSketch.hpp:298-318): Σ occurrences, #unique hashes, Σ contig length */
 int ani_sketch_stats(const ani_sketch *sk, uint64_t *nMinimizers, uint64_t *nUnique, uint64_t *totalLength,
                      int32_t *nContigs, int32_t *nGenomes);
+
+/* A reference set whose minimizers do not fit one 32-bit index (> ANI_MAX_INDEX_MINIMIZERS, default 1.7e9 ~ 4000 bacterial
+ * genomes) is held as several index chunks cut at genome borders; every entry point below works on the whole set (global
+ * seqIds / genome ids), results are identical to a single index.  This is the device-side form of the
+ * reference's own database split (src/cgi/include/computeCoreIdentity.hpp:457-487, scripts/splitDatabase.sh:12-26).
+ * Returns the number of chunks and (optionally, up to `cap`) the first genome id of each. */
+int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGenome, int32_t cap);
 
 /* Multi-GPU staging: rank r sketches its share of the reference genomes into device-resident
  * 12-byte records with GLOBAL seqIds (seqIdBase = contigs before this shard), the caller all-gathers the

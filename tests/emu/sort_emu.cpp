@@ -22,3 +22,14 @@ extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size
   for (size_t i = 0; i < n; i++) keysOut[i] = v[i];
   return 0;
 }
+
+extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t)
+{
+  if (!tmp) { *tmpBytes = 16; return 0; }
+  std::vector<uint32_t> ord(n);
+  std::iota(ord.begin(), ord.end(), 0u);
+  std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return keysIn[a] < keysIn[b]; });
+  for (size_t i = 0; i < n; i++) { keysOut[i] = keysIn[ord[i]]; valsOut[i] = valsIn[ord[i]]; }
+  return 0;
+}

@@ -174,6 +174,46 @@ def case_device_synth(engine, alloc):
     assert np.array_equal(r1, r2) and len(r1) >= n
 
 
+def case_chunked(engine):
+    """run on an engine created with a small ANI_MAX_INDEX_MINIMIZERS: the reference set is held as several index chunks cut at
+    genome borders (the device-side form of the reference's database split, computeCoreIdentity.hpp:457-487); minimizers,
+    the exact unique-hash count, mappings (global refSeqId, callback order), CGI rows and the fused batch path must not change"""
+    genomes = [[orc.synth_genome(7, g, 45000)] for g in (0, 1, 4, 11, 16, 19, 20)] + [messy_genome(5, 50000)]
+    p, sk, osk = check_sketch(engine, genomes)
+    assert len(sk.chunks()) >= 3 and sk.chunks()[0] == 0, sk.chunks()
+    rows = check_queries(engine, p, sk, osk, [genomes[0], genomes[7], genomes[6]])
+    assert len(rows) >= 8
+    # mappings handed to the reducer in arbitrary order (device sort) give the same rows
+    maps, tot = sk.map_query(genomes[3])
+    perm = np.random.default_rng(3).permutation(len(maps))
+    assert np.array_equal(sk.compute_cgi(maps[perm], tot, 5), sk.compute_cgi(maps, tot, 5))
+    case_messy(engine)
+    case_tandem_repeats(engine)
+    case_empty_and_short(engine)
+
+
+def case_limits(engine):
+    """documented limits fail loudly with ANI_ERR_LIMIT (-4), never silently"""
+    from fastani_amd.api import AniError
+    p = engine.params(16, 3000)
+    p.windowSize = 1                                   # every position is a minimizer: > 4096 per 3-kb... 2985 only; use a long fragment
+    p.fragLen = 6000
+    g = [[rng_genome(17, 20000)]]
+    sk = Sketch(engine, p, g)
+    try:
+        sk.map_cgi_batch(g, 0)
+        raise AssertionError("a fragment with > 4096 minimizers must be rejected")
+    except AniError as e:
+        assert e.code == -4 and "minimizers" in str(e), str(e)
+    p2 = engine.params(16, 3000)
+    p2.windowSize = 100000
+    try:
+        Sketch(engine, p2, g)
+        raise AssertionError("window beyond the tile limit must be rejected")
+    except AniError as e:
+        assert e.code == -4
+
+
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
              case_low_complexity_big, case_sparse_hits, case_empty_and_short]
 

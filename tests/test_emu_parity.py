@@ -39,3 +39,41 @@ def test_small_batches_and_chunks(monkeypatch):
     pc.case_messy(e)
     pc.case_tandem_repeats(e)
     e.close()
+
+
+def _emu_engine_with(monkeypatch, **env):
+    import ctypes
+    import os
+    from fastani_amd.api import Engine
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    return Engine(ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libfastani_emu.so")), 0)
+
+
+def test_chunked_reference_set(monkeypatch):
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=8000)
+    pc.case_chunked(e)
+    assert pc.fuzz(e, seed=23, iterations=5) == 5
+    e.close()
+
+
+def test_chunked_with_small_batches(monkeypatch):
+    """index chunks x query sub-batches x L2 chunks, all tiny"""
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_L2_CHUNK=11)
+    pc.case_synthetic_cluster(e, 30000)
+    pc.case_sparse_hits(e)
+    e.close()
+
+
+def test_limits(emu_engine):
+    pc.case_limits(emu_engine)
+
+
+def test_l2_code_overflow_halves_the_chunk(monkeypatch):
+    """a chunk whose 16-bit code stream would pass the offset limit is cut in half and redone (ani_abi.hip, L2 chunk loop);
+    the limit is lowered through a test knob so that small inputs reach the branch"""
+    e = _emu_engine_with(monkeypatch, ANI_L2_CODE_LIMIT=6000, ANI_L2_CHUNK=64)
+    e.reset_counters()
+    pc.case_synthetic_cluster(e, 30000)
+    assert e.counters()["l2ChunkHalvings"] > 0
+    e.close()

@@ -135,3 +135,59 @@ def test_sharded_sketch_records_on_device(gpu_engine):
         maps, tot = osk.map_genome(g)
         exp.append(osk.compute_cgi(maps, tot, qi))
     assert np.array_equal(rows, np.concatenate(exp))
+
+
+def _engine_with(monkeypatch, **env):
+    import fastani_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    return fastani_amd.api.Engine(fastani_amd._lib.load(), 0)
+
+
+def test_chunked_reference_set(monkeypatch):
+    """>= 3 index chunks on small inputs (ANI_MAX_INDEX_MINIMIZERS): same minimizers, mappings and rows as the oracle"""
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=8000)
+    pc.case_chunked(e)
+    assert pc.fuzz(e, seed=23, iterations=25) == 25
+    e.close()
+
+
+def test_chunked_with_small_batches(monkeypatch):
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_L2_CHUNK=11)
+    pc.case_synthetic_cluster(e, 60000)
+    pc.case_sparse_hits(e)
+    e.close()
+
+
+def test_chunked_full_size_equals_unchunked(gpu_engine, monkeypatch):
+    """24 x 5 Mbp, 5 chunks against one index: identical rows (and the device-resident input path)"""
+    import torch
+    from fastani_amd.api import DeviceGenomes, Sketch
+    n, L = 24, 5_000_000
+    words = (L + 15) // 16
+    buf = torch.zeros(n * words + 64, dtype=torch.int32, device="cuda:0")
+    gpu_engine.synth_packed(99, 0, n, L, buf.data_ptr())
+    dg = DeviceGenomes(buf.data_ptr(), n, L)
+    p = gpu_engine.params()
+    sk = Sketch(gpu_engine, p, dg)
+    rows = sk.map_cgi_batch(dg, 0)
+    st = sk.stats()
+    sk.close()
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=2_000_000)
+    sk2 = Sketch(e, p, dg)
+    assert len(sk2.chunks()) >= 5
+    assert sk2.stats() == st
+    assert np.array_equal(sk2.map_cgi_batch(dg, 0), rows)
+    e.close()
+
+
+def test_limits(gpu_engine):
+    pc.case_limits(gpu_engine)
+
+
+def test_l2_code_overflow_halves_the_chunk(monkeypatch):
+    e = _engine_with(monkeypatch, ANI_L2_CODE_LIMIT=6000, ANI_L2_CHUNK=64)
+    e.reset_counters()
+    pc.case_synthetic_cluster(e, 60000)
+    assert e.counters()["l2ChunkHalvings"] > 0
+    e.close()
