@@ -1,30 +1,40 @@
 #!/usr/bin/env python3
 """bench.py — ANI pairs/sec, many-to-many NxN ~5 Mbp genomes (BASELINE.json metric) on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config many-to-many|one-to-many|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one pass of the whole hot path over the workload with the packed genomes already resident in HBM:
 reference sketch + index build (skch::Sketch), mapping of every query genome (skch::Map) and the ANI reducer
 (cgi::computeCGI), ending with the CGI rows on the host.
 
-Workload (config.workload): BASELINE.json configs[2], "Many-to-many 1000x1000 synthetic ~5 Mbp genomes, k=16 fragLen=3000".
-  N = 1 : 1000 reference genomes x 1000 query genomes (the same set: all-vs-all).
-  N > 1 : weak scaling over the query stream — the 1000-genome reference database is fixed, every GPU maps its own
-          1000 query genomes (rank r maps variant r of the clustered set: same ancestors and divergences, fresh
-          substitutions), so the job is 1000 x (1000*N) pairs.  Each rank sketches 1/N of the references; the 12-byte
-          minimizer records are all-gathered once over RCCL/xGMI and every rank builds the full index.
+Workloads (config.workload):
+  many-to-many (default) = BASELINE.json configs[2], 1000x1000 synthetic ~5 Mbp genomes, k=16 fragLen=3000.
+      N = 1 : 1000 reference genomes x 1000 query genomes (the same set: all-vs-all).
+      N > 1 : weak scaling over the query stream — the 1000-genome reference database is fixed, every GPU maps its own
+              1000 query genomes (rank r maps variant r of the clustered set: same ancestors and divergences, fresh
+              substitutions), so the job is 1000 x (1000*N) pairs.  Each rank sketches 1/N of the references; the 12-byte
+              minimizer records are all-gathered once over RCCL/xGMI and every rank builds the full index.
+  one-to-many = configs[1]: 1 query genome (cluster 0, member 1) against the 1000-genome set; a step still sketches and
+      indexes the references (the reference does too); the map-only latency is reported beside it.
+  c4 = configs[3]: 10000 x 10000 (all-vs-all, 500 clusters), the reference set held as several index chunks; queries
+      sharded over the GPUs (rank r maps genomes [r*10000/N, (r+1)*10000/N)), reference records all-gathered.
+      --queries bounds the query count for a single-GPU run.
 
 Prints ONE JSON line on rank 0 (see the driver contract): value = whole-job pairs/sec, plus
   roofline     — the dominant kernel (L2 sliding MinHash), algorithmic bytes (12*m_c + 4*s per candidate)
-                 over its HIP-event time on the launch stream, against the 8 TB/s HBM peak;
-  cpu_baseline — the untouched reference (oracle/_ref/fastANI_ref, built from /root/reference by oracle/Makefile)
-                 timed on this box's host cores on a bounded sample of the same clustered workload (rank 0, N = 1 only),
-                 with the GPU timed on the identical sample and the two outputs compared.
+                 over its HIP-event time on the launch stream, against the 8 TB/s HBM peak; .stage = the L2 stage as a
+                 whole on the same bytes; .int_ops = the two hashing kernels against the VALU integer ceiling;
+  parity_timed_rows — the rows of the LAST TIMED STEP compared with the untouched reference binary (every reference x
+                 the CPU-baseline queries) and with the C oracle on >= 200 random pairs;
+  cpu_baseline — oracle/_ref/fastANI_ref (the untouched reference, built by oracle/Makefile) timed on this box's host cores
+                 on a bounded sample of the same workload: ALL references x 8 queries, -t <physical cores> (rank 0, N = 1);
+  end_to_end   — the drop-in CLI (fastani_amd/fastANI) on the same FASTA files on local disk -> output file, wall clock.
 """
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -34,6 +44,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU integer ceiling for the MurmurHash3 kernels (tools/ubench_valu.hip on MI355X, profiles/r02_ubench_valu.txt):
+# a 64x64->64 multiply costs 3 quarter-rate multiplier instructions; one hash = 8 of them + >= 57 full-rate instructions
+# (rotates, xors, 64-bit adds).  Rates in wave64-instructions per cycle per SIMD; 1024 SIMDs at 2.4 GHz.
+UBENCH = {"full_rate_cyc": 2.0, "mul32_cyc": 8.0, "clock_ghz": 2.4, "simds": 1024,
+          "mul_instr_per_hash": 24, "other_instr_per_hash": 57}
 
 
 def parse():
@@ -41,73 +56,243 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genomes", type=int, default=1000, help="reference genomes (= query genomes per GPU)")
+    ap.add_argument("--config", default="many-to-many", choices=["many-to-many", "one-to-many", "c4"])
+    ap.add_argument("--genomes", type=int, default=0, help="reference genomes (0 = the config's: 1000, c4: 10000)")
+    ap.add_argument("--queries", type=int, default=0, help="query genomes per GPU (0 = the config's)")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-refs", type=int, default=40)
-    ap.add_argument("--cpu-queries", type=int, default=0, help="0 = pick from the core count")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=8)
+    ap.add_argument("--cpu-refs", type=int, default=0, help="0 = all references of the workload")
+    ap.add_argument("--oracle-pairs", type=int, default=240)
+    ap.add_argument("--workdir", default="", help="where the FASTA copies of the synthetic set go (default: a temp dir)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, engine, params):
-    """Reference CPU path on a bounded sample + the GPU on the same sample + output comparison."""
+def host_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return {"cpu_model": model, "logical_cpus": logical, "physical_cores": len(phys) or logical}
+
+
+def write_fasta_set(orc, seed, ids, L, td, threads):
+    """FASTA copies of genomes `ids` of the synthetic set (the oracle's generator is the CPU twin of ani_synth_packed,
+    byte-compared in the tests)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(g):
+        p = os.path.join(td, "g%05d.fa" % g)
+        if not os.path.exists(p):
+            seq = orc.synth_genome(seed, g, L)
+            with open(p + ".tmp", "wb") as f:
+                f.write(b">g%d\n" % g)
+                f.write(seq.tobytes())
+                f.write(b"\n")
+            os.replace(p + ".tmp", p)
+        return p
+    with ThreadPoolExecutor(max(1, min(threads, 32))) as ex:
+        return list(ex.map(one, ids))
+
+
+def trusted(cnt, L, frag=3000, min_fraction=0.2):
+    import numpy as np
+    glen = (L // frag) * frag
+    return cnt * frag >= glen * np.float32(min_fraction)       # computeCoreIdentity.hpp:328-332 (both genomes have length L)
+
+
+def read_ref_out(path, index_of):
+    rows = {}
+    for line in open(path):
+        q, r, ani, cnt, tot = line.rstrip("\n").split("\t")
+        rows[(index_of[q], index_of[r])] = (float(ani), int(cnt), int(tot))
+    return rows
+
+
+def compare_with_reference(rows_by_pair, ref_rows, queries, nrefs, L):
+    """rows of the timed step for the given query genomes vs the reference binary's output file (every printed row)"""
+    got = {k: v for k, v in rows_by_pair.items() if k[0] in queries and k[1] < nrefs and trusted(v[1], L)}
+    ok = set(got) == set(ref_rows)
+    max_d = 0.0
+    bad = 0
+    for key, (ani, cnt, tot) in ref_rows.items():
+        if key not in got:
+            bad += 1
+            continue
+        g_ani, g_cnt, g_tot = got[key]
+        if cnt != g_cnt or tot != g_tot:
+            bad += 1
+        max_d = max(max_d, abs(ani - g_ani))                   # the reference prints 6 significant digits
+    ok = ok and bad == 0 and max_d <= 1e-3
+    return {"rows_compared": len(ref_rows), "ok": bool(ok), "mismatching_rows": bad + len(set(got) ^ set(ref_rows)), "max_abs_ani_diff": round(max_d, 6)}
+
+
+def oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, window, pairs_wanted):
+    """>= pairs_wanted (query, reference) pairs of the timed result against the C oracle, pair by pair (SURVEY.md App. A.7:
+    a pair's result does not depend on what else is in the index, so a small oracle index over the sampled references is
+    comparable with the 1000-genome GPU index).  Bit-exact: countSeq, totalQueryFragments and the float identity.
+    Half of the sampled queries come from the sampled references' clusters, so related pairs are covered."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(args.seed + 17)
+    query_ids = sorted(int(q) for q in query_ids)
+    n_r = 12 if len(query_ids) >= 20 else min(n_refs, 24)
+    n_q = min(len(query_ids), max(1, (pairs_wanted + n_r - 1) // n_r))
+    rel = rng.choice(query_ids, size=min(len(query_ids), 4), replace=False)            # reference clusters = clusters of some queries
+    clusters = sorted(set(int(q) // 20 for q in rel))
+    per = max(1, n_r // max(1, len(clusters)))
+    ref_ids = []
+    for cl in clusters:
+        members = [cl * 20 + m for m in range(20) if cl * 20 + m < n_refs]
+        ref_ids += [int(x) for x in rng.choice(members, size=min(per, len(members)), replace=False)] if members else []
+    while len(ref_ids) < min(n_r, n_refs):
+        g = int(rng.integers(n_refs))
+        if g not in ref_ids:
+            ref_ids.append(g)
+    ref_ids = sorted(ref_ids)[:n_r]
+    near = [q for q in query_ids if q // 20 in clusters]
+    q_ids = set(int(x) for x in rng.choice(near, size=min(len(near), (n_q + 1) // 2), replace=False)) if near else set()
+    for q in rng.permutation(query_ids):
+        if len(q_ids) >= n_q:
+            break
+        q_ids.add(int(q))
+    q_ids = sorted(q_ids)
+    t0 = time.time()
+    refs = [[orc.synth_genome(args.seed, g, L)] for g in ref_ids]
+    osk = orc.Sketch(refs, 16, window)
+
+    def one(q):
+        maps, tot = osk.map_genome([orc.synth_genome(args.seed, q, L)])
+        return q, osk.compute_cgi(maps, tot, q)
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(one, q_ids))
+    checked = mism = rows_found = 0
+    for q, cg in res:
+        exp = {int(r["refGenomeId"]): (np.float32(r["identity"]), int(r["countSeq"]), int(r["totalQueryFragments"])) for r in cg}
+        for j, g in enumerate(ref_ids):
+            checked += 1
+            got = rows_by_pair.get((q, g))
+            e = exp.get(j)
+            if (got is None) != (e is None):
+                mism += 1
+            elif got is not None:
+                rows_found += 1
+                if not (np.float32(got[0]) == e[0] and got[1] == e[1] and got[2] == e[2]):
+                    mism += 1
+    return {"pairs_checked": checked, "pairs_with_rows": rows_found, "mismatches": mism, "ok": mism == 0, "bar": "bit-exact (countSeq, totalQueryFragments, float identity)",
+            "queries": len(q_ids), "refs": len(ref_ids), "oracle_seconds": round(time.time() - t0, 1)}
+
+
+def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
+    """rank 0, N = 1: FASTA copies of the set on local disk, the reference binary on a bounded sample, the drop-in CLI end to
+    end, and the parity of the timed step's rows against both the reference's output and the oracle."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    import orc   # oracle helpers: synthetic genome generator (CPU twin of ani_synth_packed) and paths of oracle/_ref
-    from fastani_amd.api import Sketch
-    if not os.path.exists(orc.REF_BIN):
-        return {"value": None, "unit": "pairs/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref/fastANI_ref not built"}
-    cores = os.cpu_count() or 1
-    nr = min(args.cpu_refs, args.genomes)
-    nq = args.cpu_queries or 10
-    nq = min(nq, nr)
-    L = args.genome_len
-    with tempfile.TemporaryDirectory(prefix="ani_cpu_") as td:
-        genomes = []
-        paths = []
-        for g in range(nr):
-            seq = orc.synth_genome(args.seed, g, L)
-            genomes.append([seq])
-            p = os.path.join(td, "g%d.fa" % g)
-            orc.write_fasta(p, [seq], names=["g%d" % g])
-            paths.append(p)
-        with open(os.path.join(td, "rl.txt"), "w") as f:
-            f.write("\n".join(paths) + "\n")
-        with open(os.path.join(td, "ql.txt"), "w") as f:
-            f.write("\n".join(paths[:nq]) + "\n")
-        out = os.path.join(td, "ref.out")
+    import orc   # oracle helpers (checker only): synthetic genome generator = CPU twin of ani_synth_packed, paths of oracle/_ref
+    hi = host_info()
+    out = {"host": hi}
+    rows_by_pair = {(int(q), int(r)): (float(a), int(c), int(t)) for q, r, a, c, t in
+                    zip(rows["qryGenomeId"], rows["refGenomeId"], rows["identity"], rows["countSeq"], rows["totalQueryFragments"])}
+    parity = {}
+    td = args.workdir or tempfile.mkdtemp(prefix="ani_bench_")
+    os.makedirs(td, exist_ok=True)
+    try:
+        n_cpu_refs = min(args.cpu_refs or n_refs, n_refs)
+        need_all = not args.no_e2e and args.config == "many-to-many"
+        if args.config == "c4" and not args.cpu_refs:
+            args.no_cpu_baseline = True                      # 10000 FASTA files = 50 GB: only on request (--cpu-refs N)
+        n_queries = len(query_ids)
+        want_ref = not args.no_cpu_baseline and os.path.exists(orc.REF_BIN)
+        ids = list(range(n_refs if need_all else (n_cpu_refs if want_ref else 0)))
         t0 = time.time()
-        subprocess.check_call([orc.REF_BIN, "--ql", os.path.join(td, "ql.txt"), "--rl", os.path.join(td, "rl.txt"),
-                               "-t", str(cores), "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        t_cpu = time.time() - t0
-        ref_rows = {}
-        for line in open(out):
-            q, r, ani, cnt, tot = line.split("\t")
-            ref_rows[(paths.index(q), paths.index(r))] = (float(ani), int(cnt), int(tot))
-    # GPU on the identical sample, host FASTA bytes in (PCIe-inclusive), rows out
-    t0 = time.time()
-    sk = Sketch(engine, params, genomes)
-    rows = sk.map_cgi_batch(genomes[:nq], 0)
-    t_gpu = time.time() - t0
-    sk.close()
-    # fastANI prints a row iff countSeq*fragLen >= min(lenQ, lenR)*minFraction (computeCoreIdentity.hpp:328-332)
-    glen = (L // 3000) * 3000
-    got = {(int(r["qryGenomeId"]), int(r["refGenomeId"])): (float(r["identity"]), int(r["countSeq"]), int(r["totalQueryFragments"]))
-           for r in rows if int(r["countSeq"]) * 3000 >= glen * np.float32(0.2)}
-    ok = set(got) == set(ref_rows)
-    max_dani = 0.0
-    if ok:
-        for key, (ani, cnt, tot) in ref_rows.items():
-            g_ani, g_cnt, g_tot = got[key]
-            ok = ok and cnt == g_cnt and tot == g_tot
-            max_dani = max(max_dani, abs(ani - g_ani))   # the reference prints 6 significant digits
-        ok = ok and max_dani <= 1e-3
-    return {"value": round(nq * nr / t_cpu, 3), "unit": "pairs/s", "cores": cores, "kind": "reference",
-            "sample": "%d queries x %d refs of the clustered %d bp set (genomes 0..%d), fastANI_ref -t %d, wall %.1f s incl. FASTA parse"
-                      % (nq, nr, L, nr - 1, cores, t_cpu),
-            "gpu_same_sample_pairs_per_s": round(nq * nr / t_gpu, 1), "gpu_same_sample_note": "host ASCII in, PCIe + 2-bit packing included",
-            "rows_compared": len(ref_rows), "parity_vs_reference": "ok" if ok else "MISMATCH", "max_abs_ani_diff": round(max_dani, 6)}
+        paths = write_fasta_set(orc, args.seed, ids, L, td, hi["logical_cpus"])
+        out["fasta_set"] = {"files": len(paths), "bytes": int(sum(os.path.getsize(p) for p in paths)), "seconds": round(time.time() - t0, 1), "dir": "local disk (%s)" % td}
+        index_of = {p: i for i, p in enumerate(paths)}
+        # ---- reference binary: every reference x the first cpu_queries genomes (or the one query of one-to-many) ----
+        if want_ref:
+            q_ids = [q for q in query_ids if q < len(paths)][:args.cpu_queries]
+            rl, ql = os.path.join(td, "rl.txt"), os.path.join(td, "ql.txt")
+            open(rl, "w").write("\n".join(paths[:n_cpu_refs]) + "\n")
+            open(ql, "w").write("\n".join(paths[q] for q in q_ids) + "\n")
+            ref_out = os.path.join(td, "ref.out")
+            threads = hi["physical_cores"]
+            t0 = time.time()
+            subprocess.check_call([orc.REF_BIN, "--ql", ql, "--rl", rl, "-t", str(threads), "-o", ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t_cpu = time.time() - t0
+            out["cpu_baseline"] = {"value": round(len(q_ids) * n_cpu_refs / t_cpu, 3), "unit": "pairs/s", "cores": threads, "kind": "reference",
+                                   "cpu_model": hi["cpu_model"], "logical_cpus": hi["logical_cpus"],
+                                   "sample": "%d query genome(s) x %d references of the same clustered %d bp set (FASTA on local disk), fastANI_ref -t %d, wall %.1f s incl. FASTA parse"
+                                             % (len(q_ids), n_cpu_refs, L, threads, t_cpu)}
+            if not args.no_verify:
+                parity["vs_reference_binary"] = compare_with_reference(rows_by_pair, read_ref_out(ref_out, index_of), set(q_ids), n_cpu_refs, L)
+                parity["vs_reference_binary"]["what"] = "rows of the LAST TIMED STEP for query genomes %s vs fastANI_ref's output file on the same genomes" % q_ids
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "reference", "sample": "oracle/_ref/fastANI_ref not built"}
+        # ---- oracle, pair by pair ----
+        if not args.no_verify:
+            parity["vs_oracle"] = oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, params.windowSize, args.oracle_pairs)
+        # ---- drop-in CLI, FASTA on disk -> output file ----
+        cli = os.path.join(ROOT, "fastani_amd", "fastANI")
+        if need_all and os.path.exists(cli):
+            lst = os.path.join(td, "all.txt")
+            open(lst, "w").write("\n".join(paths[:n_refs]) + "\n")
+            e2e_out = os.path.join(td, "e2e.out")
+            threads = min(hi["logical_cpus"], 64)
+            t0 = time.time()
+            r = subprocess.run([cli, "--ql", lst, "--rl", lst, "-t", str(threads), "-o", e2e_out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            t_e2e = time.time() - t0
+            e2e = {"seconds": round(t_e2e, 2), "pairs_per_s": round(n_refs * n_refs / t_e2e, 1), "threads": threads, "returncode": r.returncode,
+                   "what": "fastani_amd/fastANI --ql all --rl all (%d x %d FASTA files, %.1f GB, local disk) -> output file; first FASTA byte to output closed"
+                           % (n_refs, n_refs, out["fasta_set"]["bytes"] / 1e9)}
+            tl = [ln for ln in r.stderr.decode(errors="replace").splitlines() if "Time spent" in ln or "time spent" in ln]
+            if tl:
+                e2e["stderr_timers"] = tl[-6:]
+            if r.returncode == 0 and not args.no_verify:
+                printed = read_ref_out(e2e_out, index_of)
+                want = {k: v for k, v in rows_by_pair.items() if trusted(v[1], L)}
+                bad = sum(1 for k, v in printed.items() if k not in want or want[k][1:] != v[1:] or abs(want[k][0] - v[0]) > 1e-3)
+                e2e["rows"] = len(printed)
+                e2e["rows_equal_timed_step"] = bool(bad == 0 and len(printed) == len(want))
+            out["end_to_end"] = e2e
+    finally:
+        if not args.workdir:
+            shutil.rmtree(td, ignore_errors=True)
+    if parity:
+        parity["ok"] = all(v.get("ok", True) for v in parity.values() if isinstance(v, dict))
+        out["parity_timed_rows"] = parity
+    return out
+
+
+def int_ops_block(c, steps):
+    """MurmurHash3 kernels against the VALU integer ceiling: 2 hashes (both strands) per k-mer start position."""
+    u = UBENCH
+    cyc_per_hash = u["mul_instr_per_hash"] * u["mul32_cyc"] + u["other_instr_per_hash"] * u["full_rate_cyc"]     # per wave of 64 hashes
+    ceiling = u["simds"] * u["clock_ghz"] * 1e9 * 64.0 / cyc_per_hash
+    out = {"ceiling_hashes_per_s": round(ceiling, 1),
+           "ceiling_model": "per 64 hashes: %d quarter-rate 32-bit multiplier instr x %.0f cyc + %d full-rate instr x %.0f cyc on 1 of %d SIMDs at %.1f GHz (hash arithmetic only: no base decoding, no winnowing)"
+                            % (u["mul_instr_per_hash"], u["mul32_cyc"], u["other_instr_per_hash"], u["full_rate_cyc"], u["simds"], u["clock_ghz"])}
+    for name, ms, bases in (("ani::k_sketch_tiles", c["msSketch"], c["refBases"]), ("ani::k_fragment_sketch", c["msFragSketch"], c["queryBases"])):
+        if ms > 0:
+            hps = 2.0 * bases / (ms / 1e3)
+            out[name] = {"hashes_per_s": round(hps, 1), "mul64_per_s": round(8 * hps, 1), "frac_of_valu_ceiling": round(hps / ceiling, 4),
+                         "ms_per_step": round(ms / steps, 3)}
+    return out
 
 
 def main():
@@ -132,47 +317,81 @@ def main():
     from fastani_amd.api import DeviceGenomes, Sketch
     e = fastani_amd.engine(local)
     p = e.params(16, 3000)
-    NG, L = args.genomes, args.genome_len
+    L = args.genome_len
     words = (L + 15) // 16
-
+    cfg = args.config
+    NR = args.genomes or (10000 if cfg == "c4" else 1000)                # reference genomes
     # ---- synthetic input, generated straight into HBM (untimed) ----
-    ref_buf = torch.empty(NG * words + 64, dtype=torch.int32, device=dev)
-    e.synth_packed(args.seed, 0, NG, L, ref_buf.data_ptr(), variant=0)
-    if rank == 0 and world == 1:
-        qry_buf = ref_buf                                   # all-vs-all
+    lo, hi = (NR * rank) // world, (NR * (rank + 1)) // world            # this rank's share of the references
+    if cfg == "c4":
+        # all-vs-all: the rank's query genomes ARE its share of the references; only that share is resident
+        nq_local = min(args.queries or (hi - lo), hi - lo)
+        ref_buf = torch.empty((hi - lo) * words + 64, dtype=torch.int32, device=dev)
+        e.synth_packed(args.seed, lo, hi - lo, L, ref_buf.data_ptr(), variant=0)
+        my_refs = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L)
+        refs = my_refs if world == 1 else None
+        qrys = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L, first=0, count=nq_local)
+        first_query_id = lo
+        n_queries_total = nq_local * world
     else:
-        qry_buf = torch.empty(NG * words + 64, dtype=torch.int32, device=dev)
-        e.synth_packed(args.seed, 0, NG, L, qry_buf.data_ptr(), variant=rank)
-    refs = DeviceGenomes(ref_buf.data_ptr(), NG, L)
-    qrys = DeviceGenomes(qry_buf.data_ptr(), NG, L)
-    lo, hi = (NG * rank) // world, (NG * (rank + 1)) // world
-    my_refs = DeviceGenomes(ref_buf.data_ptr(), NG, L, first=lo, count=hi - lo)
-    contig_len = np.full(NG, L, dtype=np.int32)
-    gcs = np.arange(NG + 1, dtype=np.int32)
+        ref_buf = torch.empty(NR * words + 64, dtype=torch.int32, device=dev)
+        e.synth_packed(args.seed, 0, NR, L, ref_buf.data_ptr(), variant=0)
+        refs = DeviceGenomes(ref_buf.data_ptr(), NR, L)
+        my_refs = DeviceGenomes(ref_buf.data_ptr(), NR, L, first=lo, count=hi - lo)
+        if cfg == "one-to-many":
+            nq_local = 1
+            qrys = DeviceGenomes(ref_buf.data_ptr(), NR, L, first=1, count=1)     # cluster 0, member 1
+            first_query_id = 1
+        else:
+            nq_local = args.queries or NR
+            if rank == 0 and world == 1:
+                qry_buf = ref_buf                                   # all-vs-all
+            else:
+                qry_buf = torch.empty(nq_local * words + 64, dtype=torch.int32, device=dev)
+                e.synth_packed(args.seed, 0, nq_local, L, qry_buf.data_ptr(), variant=rank)
+            qrys = DeviceGenomes(qry_buf.data_ptr(), nq_local, L)
+            first_query_id = rank * nq_local
+        n_queries_total = nq_local * world
+    contig_len = np.full(NR, L, dtype=np.int32)
+    gcs = np.arange(NR + 1, dtype=np.int32)
+
+    # multi-GPU staging buffers (allocated once): every rank's records land in its slot of `allrec`; the slot's first record
+    # carries the count, so ONE all-gather moves counts and records (no count all-reduce, no compaction copy in the step)
+    if world > 1:
+        slot = int((hi - lo + 1) * (2.3 * L / (p.windowSize + 1))) + 4096          # records per rank, upper bound
+        allrec = torch.empty(world * (slot + 1) * 3, dtype=torch.int32, device=dev)
+        mine = allrec[rank * (slot + 1) * 3:(rank + 1) * (slot + 1) * 3]
+        part_g0 = np.array([(NR * r) // world for r in range(world + 1)], dtype=np.int32)
+    timers = {"allgather_ms": 0.0, "ref_records_ms": 0.0, "index_ms": 0.0, "map_ms": 0.0}
 
     def step():
+        t_a = time.perf_counter()
         if world == 1:
             sk = Sketch(e, p, refs)
+            t_b = t_c = time.perf_counter()
         else:
             ptr, n = e.sketch_records(p, my_refs, lo)         # records with global seqIds
-            counts = torch.zeros(world, dtype=torch.int64, device=dev)
-            counts[rank] = n
-            dist.all_reduce(counts)
-            cl = counts.tolist()
-            mx = max(cl)
-            mine = torch.zeros(mx * 3, dtype=torch.int32, device=dev)
-            torch.cuda.synchronize()                          # the library copies on its own stream
+            if n > slot:
+                raise SystemExit("record slot too small: %d > %d" % (n, slot))
+            hdr = torch.tensor([n, 0, 0], dtype=torch.int32)
+            mine[:3].copy_(hdr)
             if n:
-                e.device_copy(mine.data_ptr(), ptr, n * 12)
+                e.device_copy(mine.data_ptr() + 12, ptr, n * 12)
                 e.device_free(ptr)
-            allrec = torch.empty(world * mx * 3, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()                          # the library copies on its own stream
+            t_b = time.perf_counter()
             dist.all_gather_into_tensor(allrec, mine)         # one collective: the reference sketch over RCCL/xGMI
-            parts = [allrec[r * mx * 3: r * mx * 3 + cl[r] * 3] for r in range(world)]
-            rec = torch.cat(parts) if world > 1 else parts[0]
             torch.cuda.synchronize()
-            sk = Sketch(e, p, records=(rec.data_ptr(), int(sum(cl)), contig_len, gcs))
-        rows = sk.map_cgi_batch(qrys, rank * NG)
+            t_c = time.perf_counter()
+            counts = [int(x) for x in allrec[0::(slot + 1) * 3][:world].tolist()]
+            ptrs = [allrec.data_ptr() + (r * (slot + 1) + 1) * 12 for r in range(world)]
+            sk = Sketch(e, p, record_parts=(ptrs, counts, part_g0, contig_len, gcs))
+        t_d = time.perf_counter()
+        rows = sk.map_cgi_batch(qrys, first_query_id)
+        t_e = time.perf_counter()
         sk.close()
+        timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["allgather_ms"] += (t_c - t_b) * 1e3
+        timers["index_ms"] += (t_d - t_c) * 1e3; timers["map_ms"] += (t_e - t_d) * 1e3
         return rows
 
     def sync():
@@ -184,6 +403,8 @@ def main():
     for _ in range(args.warmup):
         step()
     e.reset_counters()
+    for k in timers:
+        timers[k] = 0.0
     sync()
     t0 = time.perf_counter()
     rows = None
@@ -196,24 +417,49 @@ def main():
         rows = step()                                        # returns with the rows on the host: the step's device work is done
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
     sync()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    rank_info = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine_info = torch.tensor([dt_local * 1e3 / args.steps, timers["allgather_ms"] / args.steps, timers["ref_records_ms"] / args.steps,
+                                  timers["index_ms"] / args.steps, timers["map_ms"] / args.steps, float(len(rows))], dtype=torch.float64, device=dev)
+        gathered = torch.empty(world * 6, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, mine_info)
+        g = gathered.view(world, 6).tolist()
+        rank_info = {"ranks_seen_by_rccl": dist.get_world_size(), "step_ms": [round(x[0], 2) for x in g], "allgather_ms": [round(x[1], 2) for x in g],
+                     "ref_records_ms": [round(x[2], 2) for x in g], "index_ms": [round(x[3], 2) for x in g], "map_ms": [round(x[4], 2) for x in g],
+                     "rows": [int(x[5]) for x in g],
+                     "allgather_bytes_per_rank": int((slot + 1) * 12 * world) if world > 1 else 0}
     c = e.counters()
 
+    # one-to-many: the latency-shaped number — map the one query against a resident index
+    map_only = None
+    if cfg == "one-to-many" and rank == 0:
+        sk = Sketch(e, p, refs)
+        sk.map_cgi_batch(qrys, first_query_id)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(max(3, args.steps)):
+            t1 = time.perf_counter()
+            sk.map_cgi_batch(qrys, first_query_id)
+            ts.append((time.perf_counter() - t1) * 1e3)
+        sk.close()
+        map_only = {"ms": round(min(ts), 3), "ms_all": [round(x, 3) for x in ts], "what": "ani_map_cgi_batch of the one query genome (1666 fragments) against the resident 1000-genome index, rows on the host"}
+
     if rank == 0:
-        pairs = NG * NG * world
+        pairs = NR * n_queries_total
         value = pairs * args.steps / dt
         # roofline of the dominant kernel: algorithmic bytes / HIP-event time of its launches, timed region only
         l2_bytes = 12.0 * c["l2WindowEntries"] + 4.0 * c["l2QueryHashes"]
         cand = {
             "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes - (12.0 * c["l2WindowEntriesB"] + 4.0 * c["l2QueryHashesB"]),
                               "class-A launches (k_l2_sim<L2Geom<255>>): 12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per class-A candidate"),
-            "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate"),
+            "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate (the SAME bytes as k_l2_sim: the two kernels share one set of algorithmic bytes, see roofline.stage)"),
             "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
-            "ani::k_l1": (c["msL1"], 4.0 * c["querySketchHashes"] + 8.0 * c["seedHits"], "4 B x fragment sketch hashes + 8 B x seed hits"),
+            "ani::k_l1": (c["msL1"], 4.0 * c["l1Probes"] + 8.0 * c["seedHits"], "4 B x fragment sketch hashes probed (per index chunk) + 8 B x seed hits"),
             "ani::k_sketch_tiles": (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"], "G/4 packed bases + 12 B x minimizers"),
             "ani::k_fragment_sketch": (c["msFragSketch"], c["queryBases"] / 4.0 + 4.0 * c["querySketchHashes"], "G/4 packed bases + 4 B x sketch hashes"),
         }
@@ -221,7 +467,7 @@ def main():
         # (#mappings bounded below by the candidates: the fused path does not count the survivors of the identity filter separately)
         b_total = (c["refBases"] / 4.0 + 36.0 * c["refMinimizers"] + c["queryBases"] / 4.0 + 8.0 * c["querySketchHashes"]
                    + 8.0 * c["seedHits"] + l2_bytes)
-        job = {"algorithmic_bytes_per_step": round(b_total / args.steps, 1), "bytes_per_pair": round(b_total / args.steps / (NG * NG), 1),
+        job = {"algorithmic_bytes_per_step": round(b_total / args.steps, 1), "bytes_per_pair": round(b_total / args.steps / max(1, NR * nq_local), 1),
                "achieved_GBs": round(b_total * world / dt / 1e9, 2), "frac_of_hbm_peak": round(b_total / dt / 1e9 / HBM_PEAK_GBS, 5)}
         dom = max(cand, key=lambda k: cand[k][0])
         ms, nbytes, what = cand[dom]
@@ -232,15 +478,27 @@ def main():
                 "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in cand.items()},
                 "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()},
                 "whole_job": job}
+        # the L2 stage as a whole (ranges + length order + codes + simulation + leftovers) on the one set of L2 bytes
+        if c["msL2"] > 0:
+            st = l2_bytes / (c["msL2"] / 1e3) / 1e9
+            roof["stage"] = {"stage": "L2 (k_l2_ranges + k_l2_len_* + k_l2_codes + k_l2_sim<A,B> + k_l2)", "ms_per_step": round(c["msL2"] / args.steps, 3),
+                             "algorithmic_bytes_per_step": round(l2_bytes / args.steps, 1), "achieved": round(st, 2), "unit": "GB/s", "frac": round(st / HBM_PEAK_GBS, 5)}
+        roof["int_ops"] = int_ops_block(c, args.steps)
         # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
-        # + WRITE_SIZE, per launch; profiles/r01p_pmc_traffic.json) — only quoted when it is this default workload
+        # + WRITE_SIZE, per launch) — only quoted when it is this default workload
         try:
-            if NG == 1000 and L == 5_000_000 and world == 1:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01p_pmc_traffic.json")))
-                key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
-                if key in tj["kernels"]:
-                    roof["traffic"] = tj["kernels"][key]["hbm_bytes_per_launch_corrected"]
-                    roof["traffic_source"] = "profiles/r01p_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            if cfg == "many-to-many" and NR == 1000 and L == 5_000_000 and world == 1:
+                for tag in ("r02", "r01p"):
+                    fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+                    if not os.path.exists(fn):
+                        continue
+                    tj = json.load(open(fn))
+                    key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
+                    hit = [k for k in tj["kernels"] if k.startswith(key)]
+                    if hit:
+                        roof["traffic"] = tj["kernels"][hit[0]]["hbm_bytes_per_launch_corrected"]
+                        roof["traffic_source"] = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag
+                        break
         except Exception:
             pass
         if dom == "ani::k_l2_sim":
@@ -248,21 +506,29 @@ def main():
             roof.update({"launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
                          "algorithmic_bytes_per_launch": round(nbytes / launches, 1)})
         stages = {k: round(c[k] / args.steps, 3) for k in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce")}
+        wl = {"many-to-many": "many-to-many %dx%d" % (NR, n_queries_total), "one-to-many": "one-to-many 1x%d (query = cluster 0 member 1)" % NR,
+              "c4": "many-to-many %dx%d (configs[3] shape, all-vs-all%s)" % (NR, n_queries_total, "" if n_queries_total == NR else ", query count bounded by --queries")}[cfg]
         out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-               "config": {"workload": "many-to-many %dx%d synthetic %d bp genomes (clusters of 20, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
-                                      % (NG, NG * world, L, p.windowSize, "" if world == 1 else "; query stream sharded %d ways, reference sketch all-gathered over RCCL" % world),
-                          "ref_genomes": NG, "query_genomes": NG * world, "genome_len": L, "inputs": "2-bit packed, resident in HBM"},
+               "higher_is_better": True, "scaling": "weak" if cfg != "c4" else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "config": {"workload": "%s synthetic %d bp genomes (clusters of 20, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
+                                      % (wl, L, p.windowSize, "" if world == 1 else "; queries sharded %d ways, reference sketch all-gathered over RCCL" % world),
+                          "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM",
+                          "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
                "rows_last_step": int(len(rows)), "step_ms_rank0": step_ms,
                "stage_ms_per_step_rank0": stages,
                "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                               "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
                                                                               "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows")},
                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, e, p)
-        elif world == 1:
+        if rank_info:
+            out["ranks"] = rank_info
+        if map_only:
+            out["map_only"] = map_only
+        if world == 1 and not (args.no_cpu_baseline and args.no_e2e and args.no_verify):
+            legs = cpu_legs(args, e, p, rows, NR, list(range(first_query_id, first_query_id + nq_local)), L)
+            out.update(legs)
+        if "cpu_baseline" not in out:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     e.close()

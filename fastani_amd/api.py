@@ -44,7 +44,7 @@ class SeqBatch(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
                                           "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
-                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "l2ChunkHalvings")] + \
+                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "indexChunks", "l1Probes", "l2ChunkHalvings")] + \
                [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB")]
 
     def as_dict(self):
@@ -74,6 +74,7 @@ def _bind(lib):
         "ani_sketch_chunks": (C.c_int, [vp, C.POINTER(C.c_int32), vp, C.c_int32]),
         "ani_sketch_records": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_sketch_from_records": (C.c_int, [vp, C.POINTER(Params), vp, C.c_size_t, vp, C.c_int32, vp, C.c_int32, C.POINTER(vp)]),
+        "ani_sketch_from_record_parts": (C.c_int, [vp, C.POINTER(Params), C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.POINTER(vp)]),
         "ani_map_query": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
         "ani_query_sketch": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_compute_cgi": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
@@ -240,13 +241,23 @@ class Engine:
 
 
 class Sketch:
-    def __init__(self, engine, params, genomes=None, records=None):
-        """Either `genomes` (≙ Sketch::Sketch over the reference files) or
-        records=(dev_ptr, n, contig_len[int32], genome_contig_start[int32]) for the multi-GPU staging path."""
+    def __init__(self, engine, params, genomes=None, records=None, record_parts=None):
+        """Either `genomes` (≙ Sketch::Sketch over the reference files), or for the multi-GPU staging path
+        records=(dev_ptr, n, contig_len[int32], genome_contig_start[int32]) or
+        record_parts=(dev_ptrs, counts, part_genome_start[nParts+1], contig_len, genome_contig_start)."""
         self.e = engine
         self.params = params
         h = C.c_void_p()
-        if records is not None:
+        if record_parts is not None:
+            ptrs, counts, pgs, clen, gcs = record_parts
+            ptrs = np.ascontiguousarray(ptrs, dtype=np.uint64)
+            counts = np.ascontiguousarray(counts, dtype=np.uint64)
+            pgs = np.ascontiguousarray(pgs, dtype=np.int32)
+            clen = np.ascontiguousarray(clen, dtype=np.int32)
+            gcs = np.ascontiguousarray(gcs, dtype=np.int32)
+            engine._chk(engine.lib.ani_sketch_from_record_parts(engine.h, C.byref(params), len(ptrs), ptrs.ctypes.data, counts.ctypes.data,
+                                                                pgs.ctypes.data, clen.ctypes.data, len(clen), gcs.ctypes.data, len(gcs) - 1, C.byref(h)))
+        elif records is not None:
             ptr, n, clen, gcs = records
             clen = np.ascontiguousarray(clen, dtype=np.int32)
             gcs = np.ascontiguousarray(gcs, dtype=np.int32)

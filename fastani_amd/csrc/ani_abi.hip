@@ -721,7 +721,7 @@ int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
     const int rc = build_chunk(ctx, &sk->params, rec, (size_t)n, sk->contigLen.data(), gcs, g0, g1 - g0, &ch);
     if (tmp) pool_free(tmp);
     TRY(rc);
-    sk->chunks.push_back(ch);
+    sk->chunks.push_back(ch); ctx->counters.indexChunks++;
     sk->n += n; sk->maxChunkBins = std::max(sk->maxChunkBins, ch->totalBins);
     for (size_t pi = 0; pi < parts.size(); pi++)
       if (parts[pi].owned && parts[pi].rec && partLastUse[pi] < g1) { pool_free(parts[pi].rec); parts[pi].rec = nullptr; }
@@ -863,6 +863,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   if (nF == 0) return ANI_OK;
   unsigned long long host[CNT_N];
   host[CNT_QPOOL] = fs.nHashes;
+  ctx->counters.l1Probes += fs.nHashes;
 
   // ---- L1 ----
   TRY(ctx->fragCandOff.ensure(nF * 4)); TRY(ctx->fragCandCnt.ensure(nF * 4)); TRY(ctx->fragCandCntClamped.ensure(nF * 4));
@@ -1335,6 +1336,29 @@ int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *dev
   ani_sketch *sk = new_sketch(ctx, p, contigLen, nContigs, genomeContigStart, nGenomes);
   std::vector<RecordPart> parts(1);
   parts[0].rec = (uint32_t *)devRecords; parts[0].n = n; parts[0].g0 = 0; parts[0].g1 = nGenomes; parts[0].owned = false;
+  const int rc = add_chunks(ctx, sk, parts);
+  if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
+  *out = sk;
+  return ANI_OK;
+}
+
+int ani_sketch_from_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords, const uint64_t *n,
+                                 const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                                 const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  if (!ctx || !out || nParts < 0 || (nParts && (!devRecords || !n || !partGenomeStart)) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
+    return fail(ANI_ERR_ARG, "invalid argument");
+  if (genomeContigStart[0] != 0 || genomeContigStart[nGenomes] != nContigs) return fail(ANI_ERR_ARG, "genomeContigStart does not cover the contig table");
+  if (nParts && (partGenomeStart[0] != 0 || partGenomeStart[nParts] != nGenomes)) return fail(ANI_ERR_ARG, "partGenomeStart does not cover the genomes");
+  if (!nParts && nGenomes) return fail(ANI_ERR_ARG, "no record parts for %d genomes", nGenomes);
+  TRY(check_params(p));
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<RecordPart> parts((size_t)nParts);
+  for (int32_t i = 0; i < nParts; i++) {
+    if (partGenomeStart[i + 1] < partGenomeStart[i] || (n[i] && !devRecords[i])) return fail(ANI_ERR_ARG, "record part %d is malformed", i);
+    parts[i].rec = (uint32_t *)devRecords[i]; parts[i].n = (size_t)n[i]; parts[i].g0 = partGenomeStart[i]; parts[i].g1 = partGenomeStart[i + 1]; parts[i].owned = false;
+  }
+  ani_sketch *sk = new_sketch(ctx, p, contigLen, nContigs, genomeContigStart, nGenomes);
   const int rc = add_chunks(ctx, sk, parts);
   if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
   *out = sk;

@@ -103,6 +103,8 @@ typedef struct {
   uint64_t l2SlowLimit, l2SlowDup, l2SlowOverflow;   /* ... by reason: size limits / same-hash neighbour or wide gap / counter overflow */
   uint64_t mappings;
   uint64_t cgiRows;
+  uint64_t indexChunks;       /* index chunks built (one per reference set unless it passes ANI_MAX_INDEX_MINIMIZERS) */
+  uint64_t l1Probes;          /* sketch hashes looked up in an index: querySketchHashes x index chunks probed */
   uint64_t l2ChunkHalvings;   /* L2 chunks redone at half size because their code stream passed the 32-bit offset limit */
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
   double msL2Kernel;          /* HIP-event time of the class-A ani::k_l2_sim launches alone (on the launch stream) */
@@ -151,6 +153,13 @@ int ani_sketch_records(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_
 int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *devRecords, size_t n,
                             const int32_t *contigLen, int32_t nContigs,
                             const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out);
+
+/* The same from several record buffers (what an all-gather with one slot per rank delivers): part i holds the n[i] records of
+ * genomes [partGenomeStart[i], partGenomeStart[i+1]), position order, global seqIds.  No concatenation copy is made. */
+int ani_sketch_from_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords,
+                                 const uint64_t *n, const int32_t *partGenomeStart,
+                                 const int32_t *contigLen, int32_t nContigs,
+                                 const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out);
 
 /* ---- mapping: replaces skch::Map::Map + callback (computeMap.hpp:93-102, mapQuery :112) for ONE query genome.
  * Mappings are returned in the reference's callback order (fragment, then candidate).  *totalQueryFragments is

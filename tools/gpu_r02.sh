@@ -1,0 +1,36 @@
+#!/bin/bash
+# One GPU-box visit of round 2: parity tests, VALU microbenchmark, the three bench configurations, rocprofv3 kernel stats.
+# usage: tools/gpu_r02.sh <tag> [what...]   what: tests ubench bench o2m c4 prof profo2m (default: all)
+set -u
+TAG=${1:-r02a}; shift || true
+WHAT=${*:-tests ubench bench o2m c4 prof profo2m}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+if has tests; then
+  { echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+    echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12; } | tee "$OUT/tests.log"
+fi
+if has ubench; then timeout 300 tools/ubench/valu > "$OUT/ubench_valu.txt" 2>&1; tail -22 "$OUT/ubench_valu.txt"; fi
+if has bench; then
+  echo "== bench (default)"; timeout 1500 python bench.py --steps 3 --warmup 1 2> "$OUT/bench.err" | tee "$OUT/bench.json"; tail -5 "$OUT/bench.err"
+fi
+if has o2m; then
+  echo "== bench one-to-many"; timeout 600 python bench.py --config one-to-many --steps 5 --warmup 1 --no-e2e 2> "$OUT/bench_o2m.err" | tee "$OUT/bench_o2m.json"; tail -3 "$OUT/bench_o2m.err"
+fi
+if has c4; then
+  echo "== bench c4 (10000 refs, 200 queries, 1 GPU)"; timeout 900 python bench.py --config c4 --queries 200 --steps 1 --warmup 0 --no-e2e 2> "$OUT/bench_c4.err" | tee "$OUT/bench_c4.json"; tail -3 "$OUT/bench_c4.err"
+fi
+prof() {  # name, bench args...
+  local name=$1; shift
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof_$name" -o bench --output-format csv -- python "$REPO/bench.py" "$@" --no-cpu-baseline --no-e2e --no-verify > "$OUT/prof_$name.log" 2>&1)
+  tail -1 "$OUT/prof_$name.log" | cut -c1-400
+  local f=$(find "$OUT/prof_$name" -name "*kernel_stats*.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv" && head -12 "$f" | cut -c1-200
+  find "$OUT/prof_$name" -name "*kernel_trace*" -size +20M -delete 2>/dev/null
+}
+if has prof; then echo "== rocprofv3 kernel stats (default workload)"; prof m2m --steps 3 --warmup 1; fi
+if has profo2m; then echo "== rocprofv3 kernel stats (one-to-many)"; prof o2m --config one-to-many --steps 5 --warmup 1; fi
+du -sh "$OUT" | tail -1
