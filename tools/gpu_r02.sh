@@ -17,6 +17,19 @@ if has ubench; then timeout 300 tools/ubench/valu > "$OUT/ubench_valu.txt" 2>&1;
 if has bench; then
   echo "== bench (default)"; timeout 1500 python bench.py --steps 3 --warmup 1 2> "$OUT/bench.err" | tee "$OUT/bench.json"; tail -5 "$OUT/bench.err"
 fi
+if has benchfast; then
+  echo "== bench (default, no reference leg)"; timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --workdir /tmp/ani_fa 2> "$OUT/bench.err" | tee "$OUT/bench.json" | cut -c1-300; tail -3 "$OUT/bench.err"
+fi
+if has refscale; then
+  # how does the untouched reference scale with -t on this host? (1 query x 1000 references, FASTA in /tmp/ani_fa from benchfast)
+  ls /tmp/ani_fa/g*.fa | head -1000 > /tmp/ani_fa/rl1000.txt; head -1 /tmp/ani_fa/rl1000.txt > /tmp/ani_fa/q1.txt; head -8 /tmp/ani_fa/rl1000.txt > /tmp/ani_fa/q8.txt
+  for t in 16 32 64; do
+    s=$(date +%s.%N); oracle/_ref/fastANI_ref --ql /tmp/ani_fa/q1.txt --rl /tmp/ani_fa/rl1000.txt -t $t -o /tmp/ani_fa/o.$t > /dev/null 2> "$OUT/ref_t$t.err"; e=$(date +%s.%N)
+    echo "fastANI_ref 1x1000 -t $t: $(echo "$e - $s" | bc) s" | tee -a "$OUT/refscale.txt"; grep -i "time spent" "$OUT/ref_t$t.err" | tail -3 >> "$OUT/refscale.txt"
+  done
+  s=$(date +%s.%N); oracle/_ref/fastANI_ref --ql /tmp/ani_fa/q8.txt --rl /tmp/ani_fa/rl1000.txt -t 32 -o /tmp/ani_fa/o.8 > /dev/null 2>&1; e=$(date +%s.%N)
+  echo "fastANI_ref 8x1000 -t 32: $(echo "$e - $s" | bc) s" | tee -a "$OUT/refscale.txt"
+fi
 if has o2m; then
   echo "== bench one-to-many"; timeout 600 python bench.py --config one-to-many --steps 5 --warmup 1 --no-e2e 2> "$OUT/bench_o2m.err" | tee "$OUT/bench_o2m.json"; tail -3 "$OUT/bench_o2m.err"
 fi
