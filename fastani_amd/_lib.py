@@ -3,7 +3,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libfastani_amd.so")
+LIB_PATH = os.environ.get("ANI_LIB_PATH") or os.path.join(HERE, "csrc", "libfastani_amd.so")   # ANI_LIB_PATH: A/B builds of the same sources (profiling)
 
 _lib = None
 

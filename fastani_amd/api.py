@@ -22,6 +22,8 @@ CGI_DT = np.dtype([("refGenomeId", "<i4"), ("qryGenomeId", "<i4"), ("countSeq", 
 
 ANI_SEQ_HOST_ASCII = 0
 ANI_SEQ_DEVICE_PACKED2 = 1
+ANI_SEQ_HOST_ASCII_PTRS = 2
+ANI_SEQ_DEVICE_BATCH = 3
 
 
 class AniError(RuntimeError):
@@ -60,6 +62,10 @@ def _bind(lib):
         "ani_free": (None, [vp]),
         "ani_device_free": (None, [vp, vp]),
         "ani_device_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ani_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "ani_device_copy_peer": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+        "ani_batch_upload": (C.c_int, [vp, C.POINTER(SeqBatch), C.POINTER(vp)]),
+        "ani_batch_free": (None, [vp]),
         "ani_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
         "ani_reset_counters": (C.c_int, [vp]),
         "ani_params_default": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int]),
@@ -156,8 +162,44 @@ class DeviceGenomes:
         return b
 
 
+class UploadedGenomes:
+    """Host genomes packed and copied to the device once (ani_batch_upload); usable as references and as queries."""
+
+    def __init__(self, engine, genomes, ptrs=False):
+        self.e = engine
+        self.host = genomes if isinstance(genomes, HostGenomes) else HostGenomes(genomes)
+        b = self.host.batch()
+        if ptrs:                                   # per-contig pointer layout (ANI_SEQ_HOST_ASCII_PTRS)
+            self._ptrs = (self.host.data.ctypes.data + self.host.off[:max(self.host.n_contigs, 1)]).astype(np.uint64)
+            b.layout = ANI_SEQ_HOST_ASCII_PTRS
+            b.data = self._ptrs.ctypes.data
+            b.contigOffset = None
+        h = C.c_void_p()
+        engine._chk(engine.lib.ani_batch_upload(engine.h, C.byref(b), C.byref(h)))
+        self.h = h
+        self.n_genomes = self.host.n_genomes
+        self.n_contigs = self.host.n_contigs
+
+    def batch(self):
+        b = self.host.batch()
+        b.layout = ANI_SEQ_DEVICE_BATCH
+        b.data = self.h
+        return b
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.e.lib.ani_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _as_batch(g):
-    if isinstance(g, (HostGenomes, DeviceGenomes)):
+    if isinstance(g, (HostGenomes, DeviceGenomes, UploadedGenomes)):
         return g
     return HostGenomes(g)
 
@@ -302,7 +344,7 @@ class Sketch:
 
     def map_query(self, genome):
         """genome = list of contigs of ONE query genome -> (mappings, totalQueryFragments)"""
-        g = _as_batch([genome]) if not isinstance(genome, (HostGenomes, DeviceGenomes)) else genome
+        g = _as_batch([genome]) if not isinstance(genome, (HostGenomes, DeviceGenomes, UploadedGenomes)) else genome
         b = g.batch()
         p, n, tot = C.c_void_p(), C.c_size_t(), C.c_uint64()
         self.e._chk(self.e.lib.ani_map_query(self.e.h, self.h, C.byref(b), C.byref(p), C.byref(n), C.byref(tot)))

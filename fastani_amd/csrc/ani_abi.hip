@@ -148,7 +148,7 @@ struct DevBuf {
 template <class F>
 void parallel_for(size_t n, uint64_t work, F f)
 {
-  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 32) nt = 32;
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64;
   if (const char *ev = getenv("ANI_HOST_THREADS")) { int v = atoi(ev); if (v >= 1) nt = (unsigned)v; }
   if (nt > n) nt = (unsigned)n;
   if (nt <= 1 || work < (1u << 22)) { for (size_t i = 0; i < n; i++) f(i); return; }
@@ -179,7 +179,7 @@ struct ani_ctx {
   uint64_t l2CodeLimit = 0xfffffff0ull;                                             // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_L2_CODE_LIMIT, tests)
   uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
   std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
-  void *pinned[3] = {nullptr, nullptr, nullptr}; size_t pinnedCap[3] = {0, 0, 0};   // page-locked staging: 0/1 result reads, 2 prefix-sum block totals
+  void *pinned[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t pinnedCap[5] = {0, 0, 0, 0, 0};   // page-locked staging: 0/1 result reads, 2 prefix-sum block totals, 3/4 ingest (packed / raw bytes)
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
   hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr};
   // stage timers: event pairs are recorded as the launches go out and read back lazily (flush_timers), never by blocking the host
@@ -354,17 +354,63 @@ struct DeviceBatch {
 
 int check_batch(const ani_seq_batch_t *b)
 {
-  if (!b || b->nGenomes < 0 || b->nContigs < 0 || (b->nContigs && (!b->genomeContigStart || !b->contigOffset || !b->contigLen)))
+  if (!b || b->nGenomes < 0 || b->nContigs < 0 || (b->nContigs && (!b->genomeContigStart || !b->contigLen)))
     return fail(ANI_ERR_ARG, "invalid sequence batch");
+  if (b->layout == ANI_SEQ_DEVICE_BATCH) return b->data ? ANI_OK : fail(ANI_ERR_ARG, "sequence batch without its device batch handle");
   if (b->nContigs && !b->data) return fail(ANI_ERR_ARG, "sequence batch without data");
-  if (b->layout != ANI_SEQ_HOST_ASCII && b->layout != ANI_SEQ_DEVICE_PACKED2) return fail(ANI_ERR_ARG, "unknown sequence layout %d", b->layout);
+  if (b->layout != ANI_SEQ_HOST_ASCII && b->layout != ANI_SEQ_DEVICE_PACKED2 && b->layout != ANI_SEQ_HOST_ASCII_PTRS) return fail(ANI_ERR_ARG, "unknown sequence layout %d", b->layout);
+  if (b->layout != ANI_SEQ_HOST_ASCII_PTRS && b->nContigs && !b->contigOffset) return fail(ANI_ERR_ARG, "sequence batch without contig offsets");
   for (int32_t c = 0; c < b->nContigs; c++) if (b->contigLen[c] < 0) return fail(ANI_ERR_LIMIT, "contig %d has a negative length (>= 2^31 bases?)", c);
   return ANI_OK;
 }
 
-// genomes [g0, g1) of `b` -> device (packs pure-ACGT contigs to 2 bits per base on the way)
-int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1, DeviceBatch *out)
+// 8 ASCII bases -> 16 bits of 2-bit codes (A0 C1 G2 T3, either case) + "all eight are A/C/G/T", without a table: bits 1..2 of
+// the byte give A0 C1 G3 T2, x ^ (x >> 1) swaps the last two; the byte is then rebuilt from its code and compared.
+inline uint32_t pack8(uint64_t x, bool *pure)
 {
+  const uint64_t k01 = 0x0101010101010101ull;
+  uint64_t c = (x >> 1) & (3 * k01);
+  c ^= (c >> 1) & k01;
+  const uint64_t lo = c & k01, hi = (c >> 1) & k01, both = lo & hi;
+  // code -> upper-case letter: 'A' + {0, 2, 6, 19}
+  const uint64_t rec = 0x41 * k01 + (lo << 1) + (hi << 1) + (hi << 2) + both + (both << 1) + (both << 3);
+  *pure = ((x & ~(0x20 * k01)) == rec);
+  c = (c | (c >> 6)) & 0x000F000F000F000Full;
+  c = (c | (c >> 12)) & 0x000000FF000000FFull;
+  c = (c | (c >> 24)) & 0xFFFFull;
+  return (uint32_t)c;
+}
+
+// A batch of genomes in device memory that outlives the call that uploaded it (ani_batch_upload): the all-vs-all command line
+// sketches it as references and maps it as queries without reading or packing the files a second time.
+}  // namespace
+struct ani_dev_batch {
+  ani_ctx *ctx = nullptr; int device = 0;
+  DeviceBatch db;
+  void *bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // packed, ascii, contigOff, contigLen, contigMode
+};
+namespace {
+
+// genomes [g0, g1) of `b` -> device (packs pure-ACGT contigs to 2 bits per base on the way).  `keep` = allocate the device
+// arrays for a persistent ani_dev_batch instead of using the context's staging buffers.
+int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1, DeviceBatch *out, ani_dev_batch *keep = nullptr)
+{
+  if (b->layout == ANI_SEQ_DEVICE_BATCH) {       // a view of genomes [g0, g1) of an uploaded batch
+    const ani_dev_batch *src = (const ani_dev_batch *)b->data;
+    if (src->device != ctx->device) return fail(ANI_ERR_ARG, "device batch lives on device %d, context on %d", src->device, ctx->device);
+    if (g1 > src->db.nGenomes) return fail(ANI_ERR_ARG, "genome range beyond the device batch");
+    const DeviceBatch &sb = src->db;
+    const int32_t c0 = sb.genomeContigStart[g0], c1 = sb.genomeContigStart[g1];
+    out->nGenomes = g1 - g0; out->nContigs = c1 - c0;
+    out->genomeContigStart.resize(out->nGenomes + 1);
+    for (int32_t g = g0; g <= g1; g++) out->genomeContigStart[g - g0] = sb.genomeContigStart[g] - c0;
+    out->contigLen.assign(sb.contigLen.begin() + c0, sb.contigLen.begin() + c1);
+    out->totalBases = 0;
+    for (int32_t c = 0; c < out->nContigs; c++) out->totalBases += (uint64_t)out->contigLen[c];
+    out->dPacked = sb.dPacked; out->dAscii = sb.dAscii;
+    out->dContigOff = sb.dContigOff + c0; out->dContigLen = sb.dContigLen + c0; out->dContigMode = sb.dContigMode + c0;
+    return ANI_OK;
+  }
   const int32_t c0 = b->genomeContigStart[g0], c1 = b->genomeContigStart[g1];
   out->nGenomes = g1 - g0; out->nContigs = c1 - c0;
   out->genomeContigStart.resize(out->nGenomes + 1);
@@ -373,70 +419,100 @@ int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1,
   out->contigOff.resize(out->nContigs); out->contigPacked.resize(out->nContigs);
   out->totalBases = 0;
   for (int32_t c = 0; c < out->nContigs; c++) out->totalBases += (uint64_t)out->contigLen[c];
+  const size_t nc = (size_t)out->nContigs;
+  void *dPacked = nullptr, *dAscii = nullptr;
 
   if (b->layout == ANI_SEQ_DEVICE_PACKED2) {
     for (int32_t c = 0; c < out->nContigs; c++) { out->contigOff[c] = b->contigOffset[c0 + c]; out->contigPacked[c] = 1; }
-    out->dPacked = (const uint32_t *)b->data; out->dAscii = nullptr;
+    dPacked = const_cast<void *>(b->data);
   } else {
-    // Ingest: classify every contig (pure ACGT -> 2 bits per base, anything else -> raw bytes) and pack, on host threads
-    // (contigs are split into segments of <= 4 Mbases so that one long chromosome still spreads over the threads).
-    static const std::array<uint8_t, 256> code = [] {
-      std::array<uint8_t, 256> t; t.fill(4);
-      t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
-      return t;
-    }();
-    const uint8_t *src = (const uint8_t *)b->data;
+    // Ingest: classify every contig (pure ACGT -> 2 bits per base, anything else -> raw bytes) and pack, on host threads, straight
+    // into page-locked staging (contigs are split into segments of 4 Mbases so that one long chromosome still spreads over the
+    // threads).  Segments are packed optimistically; a contig with any other byte is copied raw in a second, rare, pass.
+    const uint8_t *flat = b->layout == ANI_SEQ_HOST_ASCII ? (const uint8_t *)b->data : nullptr;
+    const uint8_t *const *ptrs = b->layout == ANI_SEQ_HOST_ASCII_PTRS ? (const uint8_t *const *)b->data : nullptr;
+    auto contig_ptr = [&](int32_t c) -> const uint8_t * { return flat ? flat + b->contigOffset[c0 + c] : ptrs[c0 + c]; };
     const int32_t nC = out->nContigs;
     struct Seg { int32_t c; int32_t lo, hi; };
     std::vector<Seg> segs;
     const int32_t kSeg = 1 << 22;                       // multiple of 16: segments pack whole words
-    for (int32_t c = 0; c < nC; c++)
-      for (int32_t lo = 0; lo < out->contigLen[c] || lo == 0; lo += kSeg) { segs.push_back(Seg{c, lo, std::min(out->contigLen[c], lo + kSeg)}); if (out->contigLen[c] == 0) break; }
+    size_t nWordsAll = 0;
+    std::vector<size_t> wordOff((size_t)nC + 1, 0);
+    for (int32_t c = 0; c < nC; c++) {
+      wordOff[c] = nWordsAll; nWordsAll += ((size_t)out->contigLen[c] + 15) / 16 + 2;                          // +2 words of slack for the 3-word fetch
+      for (int32_t lo = 0; lo < out->contigLen[c]; lo += kSeg) segs.push_back(Seg{c, lo, std::min(out->contigLen[c], lo + kSeg)});
+    }
+    wordOff[nC] = nWordsAll;
+    uint32_t *hPacked = nullptr;
+    TRY(pinned_buffer(ctx, 3, nWordsAll * 4 + 64, (void **)&hPacked));
     std::vector<uint8_t> segImpure(segs.size(), 0);
     parallel_for(segs.size(), out->totalBases, [&](size_t i) {
       const Seg &sg = segs[i];
-      const uint8_t *sp = src + b->contigOffset[c0 + sg.c];
-      uint8_t bad = 0;
-      for (int32_t x = sg.lo; x < sg.hi; x++) bad |= (uint8_t)(code[sp[x]] >> 2);
-      segImpure[i] = bad;
+      const uint8_t *sp = contig_ptr(sg.c);
+      uint32_t *dst = hPacked + wordOff[sg.c];
+      bool allPure = true;
+      int32_t x = sg.lo;
+      for (; x + 16 <= sg.hi; x += 16) {
+        uint64_t a, bb; memcpy(&a, sp + x, 8); memcpy(&bb, sp + x + 8, 8);
+        bool p1, p2;
+        const uint32_t wd = pack8(a, &p1) | (pack8(bb, &p2) << 16);
+        allPure &= p1 & p2;
+        dst[x >> 4] = wd;
+      }
+      if (x < sg.hi) {                                  // last, partial word of the contig
+        uint8_t tail[16]; memset(tail, 'A', 16); memcpy(tail, sp + x, (size_t)(sg.hi - x));
+        uint64_t a, bb; memcpy(&a, tail, 8); memcpy(&bb, tail + 8, 8);
+        bool p1, p2;
+        uint32_t wd = pack8(a, &p1) | (pack8(bb, &p2) << 16);
+        allPure &= p1 & p2;
+        const int nb = sg.hi - x;
+        if (nb < 16) wd &= (1u << (2 * nb)) - 1u;
+        dst[x >> 4] = wd;
+      }
+      if (sg.hi == out->contigLen[sg.c]) { const size_t e = ((size_t)sg.hi + 15) / 16; dst[e] = 0; dst[e + 1] = 0; }
+      segImpure[i] = !allPure;
     });
+    for (int32_t c = 0; c < nC; c++) if (out->contigLen[c] == 0) { hPacked[wordOff[c]] = 0; hPacked[wordOff[c] + 1] = 0; }
     std::vector<uint8_t> impure(nC, 0);
     for (size_t i = 0; i < segs.size(); i++) impure[segs[i].c] |= segImpure[i];
-    size_t nWords = 0, nBytes = 0;
+    size_t nBytes = 0;
     for (int32_t c = 0; c < nC; c++) {
-      const int32_t len = out->contigLen[c];
       out->contigPacked[c] = !impure[c];
-      if (!impure[c]) { out->contigOff[c] = (int64_t)nWords; nWords += ((size_t)len + 15) / 16 + 2; }   // +2 words of slack for the 3-word fetch
-      else { out->contigOff[c] = (int64_t)nBytes; nBytes += ((size_t)len + 3) & ~(size_t)3; }
+      if (!impure[c]) out->contigOff[c] = (int64_t)wordOff[c];
+      else { out->contigOff[c] = (int64_t)nBytes; nBytes += ((size_t)out->contigLen[c] + 3) & ~(size_t)3; }
     }
-    std::vector<uint32_t> packed(nWords, 0u); std::vector<uint8_t> ascii(nBytes, 0);
-    parallel_for(segs.size(), out->totalBases, [&](size_t i) {
-      const Seg &sg = segs[i];
-      const uint8_t *sp = src + b->contigOffset[c0 + sg.c];
-      if (!impure[sg.c]) {
-        uint32_t *dst = packed.data() + out->contigOff[sg.c];
-        for (int32_t x = sg.lo; x < sg.hi; x += 16) {
-          uint32_t wd = 0; const int32_t e = std::min(sg.hi, x + 16);
-          for (int32_t y = x; y < e; y++) wd |= (uint32_t)code[sp[y]] << (2 * (y & 15));
-          dst[x >> 4] = wd;
-        }
-      } else memcpy(ascii.data() + out->contigOff[sg.c] + sg.lo, sp + sg.lo, (size_t)(sg.hi - sg.lo));
-    });
-    TRY(ctx->seqPacked.ensure(packed.size() * 4 + 16)); TRY(ctx->seqAscii.ensure(ascii.size() + 16));
-    if (!packed.empty()) HIP_TRY(hipMemcpyAsync(ctx->seqPacked.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (!ascii.empty()) HIP_TRY(hipMemcpyAsync(ctx->seqAscii.p, ascii.data(), ascii.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));    // host vectors die at scope exit
-    out->dPacked = ctx->seqPacked.as<uint32_t>(); out->dAscii = ctx->seqAscii.as<uint8_t>();
+    uint8_t *hAscii = nullptr;
+    if (nBytes) {
+      TRY(pinned_buffer(ctx, 4, nBytes + 64, (void **)&hAscii));
+      for (int32_t c = 0; c < nC; c++) if (impure[c]) memcpy(hAscii + out->contigOff[c], contig_ptr(c), (size_t)out->contigLen[c]);
+    }
+    if (keep) {
+      HIP_TRY(pool_malloc(&keep->bufs[0], nWordsAll * 4 + 64)); HIP_TRY(pool_malloc(&keep->bufs[1], nBytes + 64));
+      dPacked = keep->bufs[0]; dAscii = keep->bufs[1];
+    } else {
+      TRY(ctx->seqPacked.ensure(nWordsAll * 4 + 64)); TRY(ctx->seqAscii.ensure(nBytes + 64));
+      dPacked = ctx->seqPacked.p; dAscii = ctx->seqAscii.p;
+    }
+    if (nWordsAll) HIP_TRY(hipMemcpyAsync(dPacked, hPacked, nWordsAll * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nBytes) HIP_TRY(hipMemcpyAsync(dAscii, hAscii, nBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));    // the staging buffers are reused by the next upload
   }
-  const size_t nc = (size_t)out->nContigs;
-  TRY(ctx->contigOff.ensure(nc * 8 + 8)); TRY(ctx->contigLen.ensure(nc * 4 + 4)); TRY(ctx->contigMode.ensure(nc + 4));
+  out->dPacked = (const uint32_t *)dPacked; out->dAscii = (const uint8_t *)dAscii;
+  void *dOff = nullptr, *dLen = nullptr, *dMode = nullptr;
+  if (keep) {
+    HIP_TRY(pool_malloc(&keep->bufs[2], nc * 8 + 8)); HIP_TRY(pool_malloc(&keep->bufs[3], nc * 4 + 4)); HIP_TRY(pool_malloc(&keep->bufs[4], nc + 4));
+    dOff = keep->bufs[2]; dLen = keep->bufs[3]; dMode = keep->bufs[4];
+  } else {
+    TRY(ctx->contigOff.ensure(nc * 8 + 8)); TRY(ctx->contigLen.ensure(nc * 4 + 4)); TRY(ctx->contigMode.ensure(nc + 4));
+    dOff = ctx->contigOff.p; dLen = ctx->contigLen.p; dMode = ctx->contigMode.p;
+  }
   if (nc) {
-    HIP_TRY(hipMemcpyAsync(ctx->contigOff.p, out->contigOff.data(), nc * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->contigLen.p, out->contigLen.data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->contigMode.p, out->contigPacked.data(), nc, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dOff, out->contigOff.data(), nc * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dLen, out->contigLen.data(), nc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dMode, out->contigPacked.data(), nc, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  out->dContigOff = ctx->contigOff.as<int64_t>(); out->dContigLen = ctx->contigLen.as<int32_t>(); out->dContigMode = ctx->contigMode.as<uint8_t>();
+  out->dContigOff = (const int64_t *)dOff; out->dContigLen = (const int32_t *)dLen; out->dContigMode = (const uint8_t *)dMode;
   return ANI_OK;
 }
 
@@ -1231,7 +1307,7 @@ void ani_shutdown(ani_ctx *c)
   for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); }
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  for (int i = 0; i < 3; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+  for (int i = 0; i < 5; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   cur_pool(0).trim(); cur_pool(1).trim();
@@ -1243,6 +1319,53 @@ int ani_device_copy(ani_ctx *c, void *dst, const void *src, size_t bytes)
   HIP_TRY(hipSetDevice(c->device));
   if (bytes) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
   return ANI_OK;
+}
+
+int ani_device_alloc(ani_ctx *c, size_t bytes, void **out)
+{
+  if (!c || !out) return fail(ANI_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(pool_malloc(out, bytes ? bytes : 1));
+  return ANI_OK;
+}
+
+// device-to-device copy between two contexts (the same or different GPUs; over xGMI when peer access is possible), synchronous
+int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void *src, size_t bytes)
+{
+  if (!dstCtx || !srcCtx || (bytes && (!dst || !src))) return fail(ANI_ERR_ARG, "null argument");
+  if (!bytes) return ANI_OK;
+  HIP_TRY(hipSetDevice(dstCtx->device));
+  if (dstCtx->device == srcCtx->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dstCtx->stream));
+  else {
+    int can = 0;
+    (void)hipDeviceCanAccessPeer(&can, dstCtx->device, srcCtx->device);
+    if (can) { hipError_t e = hipDeviceEnablePeerAccess(srcCtx->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e); (void)hipGetLastError(); }
+    HIP_TRY(hipMemcpyPeerAsync(dst, dstCtx->device, src, srcCtx->device, bytes, dstCtx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(dstCtx->stream));
+  return ANI_OK;
+}
+
+int ani_batch_upload(ani_ctx *ctx, const ani_seq_batch_t *genomes, ani_dev_batch **out)
+{
+  if (!ctx || !out) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_batch(genomes));
+  if (genomes->layout == ANI_SEQ_DEVICE_BATCH || genomes->layout == ANI_SEQ_DEVICE_PACKED2) return fail(ANI_ERR_ARG, "ani_batch_upload takes host sequences");
+  HIP_TRY(hipSetDevice(ctx->device));
+  ani_dev_batch *b = new ani_dev_batch();
+  b->ctx = ctx; b->device = ctx->device;
+  const int rc = upload_batch(ctx, genomes, 0, genomes->nGenomes, &b->db, b);
+  if (rc != ANI_OK) { ani_batch_free(b); return rc; }
+  *out = b;
+  return ANI_OK;
+}
+
+void ani_batch_free(ani_dev_batch *b)
+{
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (void *q : b->bufs) if (q) pool_free(q);
+  delete b;
 }
 
 int ani_get_counters(ani_ctx *c, ani_counters_t *out)

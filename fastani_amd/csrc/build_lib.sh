@@ -1,0 +1,29 @@
+#!/bin/bash
+# Builds libfastani_amd.so for gfx950.
+#
+# The device code of ani_abi.hip goes through a one-line assembly peephole between hipcc's code generation and the assembler:
+#     v_cndmask_b32_e32 vD, a, vB, vcc   ->   v_cndmask_b32_e64 vD, a, vB, vcc
+# On MI355X two VOP2-encoded v_cndmask_b32 in a row cost ~18-22 cycles each instead of 4 (tools/ubench/valu.hip,
+# profiles/r02_ubench_valu.txt: "1 v_cmp + 7 v_cndmask_e32" 16 cycles per instruction, the same with the VOP3 encoding 4.3);
+# LLVM's instruction shrinking always picks the VOP2 form, and select chains (64-bit compare-exchange = 4 selects, the event
+# selects of the L2 simulation) are all over the hot kernels.  ANI_NO_ASM_PEEPHOLE=1 builds straight through hipcc instead.
+set -euo pipefail
+HERE=$(cd "$(dirname "$0")" && pwd)
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+LLVM=${LLVM_BIN:-/opt/rocm/lib/llvm/bin}
+OUT=${1:-$HERE/libfastani_amd.so}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
+if [ "${ANI_NO_ASM_PEEPHOLE:-0}" = "1" ]; then
+  exec $HIPCC $FLAGS -shared -o "$OUT" "$HERE/ani_abi.hip" "$HERE/sort_device.hip"
+fi
+T=$(mktemp -d)
+trap 'rm -rf "$T"' EXIT
+$HIPCC $FLAGS -S --cuda-device-only -o "$T/dev.s" "$HERE/ani_abi.hip" 2> "$T/dev.err" || { cat "$T/dev.err" >&2; exit 1; }
+sed -E 's/v_cndmask_b32_e32 (v[0-9]+), ([^,]+), (v[0-9]+), vcc/v_cndmask_b32_e64 \1, \2, \3, vcc/' "$T/dev.s" > "$T/dev_pp.s"
+$LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c "$T/dev_pp.s" -o "$T/dev.o"
+$LLVM/ld.lld -shared "$T/dev.o" -o "$T/dev.hsaco"
+$LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 \
+  -input=/dev/null -input="$T/dev.hsaco" -output="$T/dev.hipfb"
+$HIPCC $FLAGS -c --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang "$T/dev.hipfb" -o "$T/host.o" "$HERE/ani_abi.hip"
+$HIPCC $FLAGS -c -o "$T/sort.o" "$HERE/sort_device.hip"
+$HIPCC --offload-arch=gfx950 -fPIC -shared -o "$OUT" "$T/host.o" "$T/sort.o"

@@ -3,24 +3,41 @@
 // Mirrors the reference driver core_genome_identity() (src/cgi/core_genome_identity.cpp:27-167): same flags and
 // defaults (src/map/include/parseCmdArgs.hpp:114-234), same output files and formats (cgi::outputCGI
 // src/cgi/include/computeCoreIdentity.hpp:307-344, cgi::outputPhylip :353-448, cgi::outputVisualizationFile :103-153,
-// cgi::computeGenomeLengths :48-92), same error messages and exit codes.  Sketch / Map / computeCGI run on the GPU through
-// the C-ABI; this file is host-side text I/O only.  `-t` is accepted for compatibility: results do not depend on it
-// (tests/fastani_tests.cpp:199-255), except that with `-s` the reference checks each of its T reference splits separately
-// (core_genome_identity.cpp:76-79), which is reproduced by sketching the same round-robin splits.
+// cgi::computeGenomeLengths :48-92), same log lines, error messages and exit codes.  Sketch / Map / computeCGI run on the GPU(s)
+// through the C-ABI; this file is host-side text I/O and orchestration only.
+//
+// Ingest: files are parsed block-wise on `-t` reader threads, a slice (~1 Gbase) ahead of the GPU; a slice is
+// handed to the library as per-contig pointers (no concatenation), packed to 2 bits per base into page-locked staging and copied
+// to the device while the readers are already parsing the next slice; host memory is O(slice).  Genome lengths
+// (computeGenomeLengths) come out of the same pass — no file is read twice.  When the query list IS the reference list (all-vs-
+// all, the paper's use) every genome is read, packed and uploaded once and stays on the device for both roles.
+// Reference sets of any size: the library cuts them into index chunks (ani_sketch_chunks).
+//
+// `--gpus N` (extension): one host thread and one context per GPU; the reference slices are sketched round-robin over the GPUs,
+// every GPU pulls the other GPUs' minimizer records peer-to-peer over xGMI (an all-gather on the fully connected mesh: each of
+// the 7 links of a GPU carries one peer's shard) and builds the full index; query slices are mapped round-robin.  `-t` keeps its
+// meaning for the readers; results do not depend on it (tests/fastani_tests.cpp:199-255), except that with `-s` the reference
+// checks each of its T reference splits separately (core_genome_identity.cpp:76-79), which is reproduced by sketching the same
+// round-robin splits.
 #include <zlib.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
-#include <thread>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -29,11 +46,15 @@
 
 namespace {
 
+using Clock = std::chrono::steady_clock;
+double secs_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
 struct Options {
   int kmerSize = 16, fragLen = 3000, threads = 1;
   float minFraction = 0.2f, maxRatioDiff = 100.0f;     // parseCmdArgs.hpp:121,:128 (the help text says 10.0; the code sets 100.0)
   bool visualize = false, matrix = false, sanityCheck = false;
   std::vector<std::string> refs, queries;
+  std::vector<int> devices{0};
   std::string out;
 };
 
@@ -47,7 +68,7 @@ struct Options {
     "SYNOPSIS\n"
     "     " << argv0 << " [-h] [-r <value>] [--rl <value>] [-q <value>] [--ql <value>] [-k <value>] [-t <value>]\n"
     "             [--fragLen <value>] [--minFraction <value>] [--maxRatioDiff <value>] [--visualize] [--matrix]\n"
-    "             [-o <value>] [-s] [-v]\n\n"
+    "             [-o <value>] [-s] [-v] [--gpus <value>]\n\n"
     "OPTIONS\n"
     "     -h, --help  print this help page\n"
     "     -r, --ref <value>  reference genome (fasta/fastq)[.gz]\n"
@@ -63,7 +84,8 @@ struct Options {
     "     --matrix    also output ANI values as lower triangular matrix (.matrix) [disabled by default]\n"
     "     -o, --output <value>  output file name\n"
     "     -s, --sanityCheck  run sanity check\n"
-    "     -v, --version  show version\n" << std::endl;
+    "     -v, --version  show version\n"
+    "     --gpus <value>  number of GPUs to use [default : 1] (--devices a,b,.. names them)\n" << std::endl;
   exit(code);
 }
 
@@ -111,6 +133,8 @@ Options parse(int argc, char **argv)
     else if (a == "-o" || a == "--output") o.out = need(i);
     else if (a == "-s" || a == "--sanityCheck") o.sanityCheck = true;
     else if (a == "-v" || a == "--version") version = true;
+    else if (a == "--gpus") { const int n = atoi(need(i)); o.devices.clear(); for (int d = 0; d < std::max(1, n); d++) o.devices.push_back(d); }
+    else if (a == "--devices") { o.devices.clear(); std::stringstream ss(need(i)); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (o.devices.empty()) o.devices.push_back(0); }
     else usage(argv[0], 1);
   }
   if (help) usage(argv[0], 0);
@@ -126,111 +150,161 @@ Options parse(int argc, char **argv)
 // ---------------------------------------------------------------------------------------------------------------
 // FASTA/FASTQ(.gz) records with the semantics of the vendored kseq.h (src/common/kseq.h:176-214): the name ends at the first
 // white space, sequence lines are appended whole (minus the line terminator) until a line starts with '>', '@' or '+'.
+// Block-wise: zlib hands over 1 MiB blocks, lines are located with memchr and appended with one copy.
 // ---------------------------------------------------------------------------------------------------------------
-struct GzReader {
-  gzFile fp; unsigned char buf[1 << 16]; int n = 0, p = 0; bool eof = false;
-  explicit GzReader(const std::string &path) { fp = gzopen(path.c_str(), "r"); }
-  ~GzReader() { if (fp) gzclose(fp); }
-  int getc()
+struct BlockReader {
+  gzFile fp; std::vector<unsigned char> buf; size_t n = 0, p = 0; bool eof = false;
+  explicit BlockReader(const std::string &path) : buf(1 << 20) { fp = gzopen(path.c_str(), "r"); if (fp) gzbuffer(fp, 1 << 20); }
+  ~BlockReader() { if (fp) gzclose(fp); }
+  bool fill()
   {
-    if (p >= n) {
-      if (eof || !fp) return -1;
-      n = gzread(fp, buf, sizeof buf); p = 0;
-      if (n <= 0) { eof = true; return -1; }
-    }
-    return buf[p++];
+    if (eof || !fp) return false;
+    const int got = gzread(fp, buf.data(), (unsigned)buf.size());
+    if (got <= 0) { eof = true; n = p = 0; return false; }
+    n = (size_t)got; p = 0;
+    return true;
   }
-};
-
-struct Record { std::string name; std::string seq; };
-
-struct SeqReader {
-  GzReader gz; int last = 0;
-  explicit SeqReader(const std::string &path) : gz(path) {}
-  // returns false at end of file / malformed FASTQ (kseq_read < 0)
-  bool next(Record &r)
+  int getc() { if (p >= n && !fill()) return -1; return buf[p++]; }
+  // appends the rest of the current line to `dst` (without the '\n'); returns false if the input ended before a '\n'
+  template <class V> bool rest_of_line(V *dst, size_t *count)
   {
-    int c;
-    if (last == 0) {
-      while ((c = gz.getc()) >= 0 && c != '>' && c != '@') {}
-      if (c < 0) return false;
-      last = c;
+    for (;;) {
+      if (p >= n && !fill()) return false;
+      const unsigned char *s = buf.data() + p;
+      const unsigned char *nl = (const unsigned char *)memchr(s, '\n', n - p);
+      const size_t len = nl ? (size_t)(nl - s) : n - p;
+      if (dst) dst->insert(dst->end(), s, s + len);
+      if (count) *count += len;
+      p += len + (nl ? 1 : 0);
+      if (nl) return true;
     }
-    r.name.clear(); r.seq.clear();
-    while ((c = gz.getc()) >= 0 && !std::isspace(c)) r.name.push_back((char)c);
-    if (c < 0 && r.name.empty()) return false;
-    if (c >= 0 && c != '\n') while ((c = gz.getc()) >= 0 && c != '\n') {}
-    while ((c = gz.getc()) >= 0 && c != '>' && c != '+' && c != '@') {
-      if (c == '\n') continue;
-      r.seq.push_back((char)c);
-      while ((c = gz.getc()) >= 0 && c != '\n') r.seq.push_back((char)c);
-      if (!r.seq.empty() && r.seq.back() == '\r') r.seq.pop_back();
-    }
-    if (c == '>' || c == '@') last = c;
-    if (c != '+') { if (c < 0) last = 0; return true; }
-    while ((c = gz.getc()) >= 0 && c != '\n') {}
-    if (c < 0) return false;
-    size_t q = 0;
-    while (q < r.seq.size()) {
-      size_t line = 0;
-      while ((c = gz.getc()) >= 0 && c != '\n') line++;
-      q += line;
-      if (c < 0) break;
-    }
-    last = 0;
-    return q == r.seq.size();
   }
 };
 
 struct Genome { std::vector<std::string> names; std::vector<int32_t> lens; };
 
-struct FileData { std::vector<uint8_t> data; Genome g; };
+struct FileData {
+  std::vector<uint8_t> data;            // all contigs of the file back to back
+  std::vector<size_t> off;              // start of every contig in `data`
+  Genome g;
+  void clear() { std::vector<uint8_t>().swap(data); std::vector<size_t>().swap(off); }
+};
 
-FileData readFile(const std::string &path)
+// one file -> contigs; returns false at a contig of >= 2^31 bases
+bool readFile(const std::string &path, FileData &fd)
 {
-  FileData fd;
-  SeqReader rd(path);
-  Record r;
-  while (rd.next(r)) {
-    if (r.seq.size() >= 0x7fffffffull) { std::cerr << "ERROR, contig of " << r.seq.size() << " bases in " << path << " exceeds the 2^31 limit of offset_t" << std::endl; exit(1); }
-    fd.data.insert(fd.data.end(), r.seq.begin(), r.seq.end());
-    fd.g.names.push_back(r.name); fd.g.lens.push_back((int32_t)r.seq.size());
+  BlockReader rd(path);
+  struct stat st;
+  if (stat(path.c_str(), &st) == 0 && st.st_size > 0) {
+    const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    fd.data.reserve((size_t)st.st_size * (gz ? 4 : 1) + 64);
   }
-  return fd;
+  int last = 0, c;
+  std::string name;
+  for (;;) {
+    if (last == 0) {                                                  // kseq.h:182-186: jump to the next header
+      while ((c = rd.getc()) >= 0 && c != '>' && c != '@') {}
+      if (c < 0) break;
+      last = c;
+    }
+    name.clear();
+    while ((c = rd.getc()) >= 0 && !std::isspace(c)) name.push_back((char)c);
+    if (c < 0 && name.empty()) break;
+    if (c >= 0 && c != '\n') rd.rest_of_line((std::vector<uint8_t> *)nullptr, nullptr);      // comment
+    const size_t start = fd.data.size();
+    while ((c = rd.getc()) >= 0 && c != '>' && c != '+' && c != '@') {   // kseq.h:194-199
+      if (c == '\n') continue;
+      fd.data.push_back((uint8_t)c);
+      rd.rest_of_line(&fd.data, nullptr);
+      if (fd.data.size() > start && fd.data.back() == '\r') fd.data.pop_back();
+    }
+    const size_t len = fd.data.size() - start;
+    bool ok = true;
+    if (c == '>' || c == '@') last = c;
+    else if (c < 0) last = 0;
+    if (c == '+') {                                                   // FASTQ: skip the quality block (kseq.h:204-213)
+      rd.rest_of_line((std::vector<uint8_t> *)nullptr, nullptr);
+      size_t q = 0;
+      while (q < len) { size_t line = 0; const bool more = rd.rest_of_line((std::vector<uint8_t> *)nullptr, &line); q += line; if (!more) break; }
+      last = 0;
+      ok = (q == len);                                                // kseq_read < 0: truncated quality string ends the file
+    }
+    if (!ok) { fd.data.resize(start); break; }
+    if (len >= 0x7fffffffull) { std::cerr << "ERROR, contig of " << len << " bases in " << path << " exceeds the 2^31 limit of offset_t" << std::endl; return false; }
+    fd.off.push_back(start); fd.g.names.push_back(name); fd.g.lens.push_back((int32_t)len);
+    if (c < 0 && last == 0) break;
+  }
+  return true;
 }
 
-// gz + FASTA parsing is the wall-clock floor of a run once the kernels are fast: files are parsed on `threads` host threads
-// (this is what -t buys here; the reference uses it to split the references over OpenMP threads)
-std::vector<FileData> readFiles(const std::vector<std::string> &paths, int threads)
-{
-  std::vector<FileData> out(paths.size());
-  std::atomic<size_t> next{0};
-  const int nt = std::max(1, std::min<int>(threads, (int)paths.size()));
-  auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < paths.size();) out[i] = readFile(paths[i]); };
-  if (nt == 1) work();
-  else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto &x : th) x.join(); }
-  return out;
-}
-
-struct HostBatch {
-  std::vector<uint8_t> data; std::vector<int64_t> off; std::vector<int32_t> len, gcs{0};
-  std::vector<Genome> meta;
-  void add(FileData &&fd)
+// ---------------------------------------------------------------------------------------------------------------
+// Reader pool: parses files[0..n) in order on `threads` threads, at most `window` bytes (file sizes) ahead of the consumer.
+// ---------------------------------------------------------------------------------------------------------------
+struct FilePipeline {
+  std::vector<std::string> paths;
+  std::vector<FileData> slot; std::vector<uint8_t> ready;
+  std::vector<uint64_t> sizeEst, sizePrefix;
+  std::mutex mu; std::condition_variable cv;
+  size_t next = 0; uint64_t releasedBytes = 0, window; bool failed = false;
+  std::vector<std::thread> th;
+  FilePipeline(const std::vector<std::string> &p, int threads, uint64_t windowBytes) : paths(p), slot(p.size()), ready(p.size(), 0), sizeEst(p.size()), sizePrefix(p.size() + 1, 0), window(windowBytes)
   {
-    int64_t o = (int64_t)data.size();
-    for (int32_t l : fd.g.lens) { off.push_back(o); len.push_back(l); o += l; }
-    data.insert(data.end(), fd.data.begin(), fd.data.end());
-    gcs.push_back((int32_t)len.size());
-    meta.push_back(std::move(fd.g));
+    for (size_t i = 0; i < p.size(); i++) {
+      struct stat st; uint64_t sz = (stat(p[i].c_str(), &st) == 0) ? (uint64_t)st.st_size : 0;
+      if (p[i].size() > 3 && p[i].compare(p[i].size() - 3, 3, ".gz") == 0) sz *= 4;
+      sizeEst[i] = sz + 1; sizePrefix[i + 1] = sizePrefix[i] + sizeEst[i];
+    }
+    const int nt = std::max(1, std::min<int>(threads, (int)std::max<size_t>(p.size(), 1)));
+    for (int t = 0; t < nt; t++) th.emplace_back([this]() { work(); });
   }
-  void add(const std::string &path) { add(readFile(path)); }
+  ~FilePipeline() { { std::lock_guard<std::mutex> g(mu); next = paths.size(); releasedBytes = ~0ull; } cv.notify_all(); for (auto &t : th) t.join(); }
+  void work()
+  {
+    for (;;) {
+      size_t i;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return next >= paths.size() || sizePrefix[next] < releasedBytes + window || releasedBytes == ~0ull; });
+        if (next >= paths.size()) return;
+        i = next++;
+      }
+      FileData fd;
+      const bool ok = readFile(paths[i], fd);
+      { std::lock_guard<std::mutex> g(mu); slot[i] = std::move(fd); ready[i] = 1; if (!ok) failed = true; }
+      cv.notify_all();
+    }
+  }
+  // blocks until files [a, b) are parsed
+  bool wait(size_t a, size_t b)
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&]() { for (size_t i = a; i < b; i++) if (!ready[i]) return false; return true; });
+    return !failed;
+  }
+  // the consumer is done with files [a, b): free them and let the readers move on
+  void release(size_t a, size_t b)
+  {
+    for (size_t i = a; i < b; i++) slot[i].clear();
+    { std::lock_guard<std::mutex> g(mu); releasedBytes = std::max(releasedBytes, sizePrefix[b]); }
+    cv.notify_all();
+  }
+};
+
+// a slice of files as one sequence batch (per-contig pointers: no concatenation)
+struct SliceBatch {
+  std::vector<const uint8_t *> ptr; std::vector<int32_t> len, gcs{0};
+  void add(const FileData &fd)
+  {
+    for (size_t c = 0; c < fd.off.size(); c++) { ptr.push_back(fd.data.data() + fd.off[c]); len.push_back(fd.g.lens[c]); }
+    gcs.push_back((int32_t)len.size());
+  }
   ani_seq_batch_t batch() const
   {
-    static const uint8_t dummy = 0;
+    static const uint8_t *dummyPtr = nullptr; static const int32_t dummyLen = 0;
     ani_seq_batch_t b;
-    b.layout = ANI_SEQ_HOST_ASCII; b.nGenomes = (int32_t)meta.size(); b.nContigs = (int32_t)len.size();
-    b.genomeContigStart = gcs.data(); b.contigOffset = off.data(); b.contigLen = len.data();
-    b.data = data.empty() ? &dummy : data.data();
+    b.layout = ANI_SEQ_HOST_ASCII_PTRS; b.nGenomes = (int32_t)gcs.size() - 1; b.nContigs = (int32_t)len.size();
+    b.genomeContigStart = gcs.data(); b.contigOffset = nullptr; b.contigLen = len.empty() ? &dummyLen : len.data();
+    b.data = ptr.empty() ? (const void *)&dummyPtr : (const void *)ptr.data();
     return b;
   }
 };
@@ -239,10 +313,29 @@ void die(const char *what) { std::cerr << "ERROR, " << what << ": " << ani_last_
 
 struct VisRow { std::string q, r; float id; int64_t qs, qe, rs, re; };
 
+// files -> slices of about `sliceBytes` (by file size)
+std::vector<std::pair<size_t, size_t>> make_slices(const FilePipeline &fp, size_t a, size_t b, uint64_t sliceBytes)
+{
+  std::vector<std::pair<size_t, size_t>> out;
+  size_t s = a;
+  while (s < b) {
+    size_t e = s; uint64_t bytes = 0;
+    while (e < b && (e == s || bytes + fp.sizeEst[e] <= sliceBytes)) bytes += fp.sizeEst[e++];
+    out.emplace_back(s, e);
+    s = e;
+  }
+  return out;
+}
+
+struct Device { int id = 0; ani_ctx *ctx = nullptr; };
+
+struct RefPart { void *rec = nullptr; uint64_t n = 0; int dev = 0; int32_t g0 = 0, g1 = 0; };
+
 }  // namespace
 
 int main(int argc, char **argv)
 {
+  const auto tStart = Clock::now();
   Options o = parse(argc, argv);
   ani_params_t ap;
   if (ani_params_default(&ap, o.kmerSize, o.fragLen)) die("parameters");
@@ -261,59 +354,226 @@ int main(int argc, char **argv)
   for (auto &e : o.queries) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
   for (auto &e : o.refs) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
 
-  ani_ctx *ctx = nullptr;
-  if (ani_init(0, &ctx)) die("ani_init");
-  std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
+  const uint64_t kSliceBytes = getenv("ANI_SLICE_BYTES") ? (uint64_t)atoll(getenv("ANI_SLICE_BYTES")) : (1ull << 30);
+  const int nRef = (int)o.refs.size(), nQry = (int)o.queries.size();
+  const bool allVsAll = (o.queries == o.refs) && !o.visualize && !o.sanityCheck;
+  if (o.visualize || o.sanityCheck) o.devices.resize(1);            // the per-split / per-mapping paths are single-device
 
-  // ---- queries are read once (the reference re-reads them in every thread) ----
-  HostBatch Q;
-  { auto files = readFiles(o.queries, o.threads); for (auto &fd : files) Q.add(std::move(fd)); }
-  ani_seq_batch_t qb = Q.batch();
+  std::unordered_map<std::string, uint64_t> genomeLengths;          // computeCoreIdentity.hpp:48-92, filled while the files pass through
+  std::mutex lenMu;
+  auto lengthOf = [&](const Genome &g) {
+    uint64_t s = 0;
+    for (int32_t l : g.lens) if (l >= ap.fragLen) s += (uint64_t)(l / ap.fragLen) * (uint64_t)ap.fragLen;
+    return s;
+  };
+  auto noteLength = [&](const std::string &path, const Genome &g) { const uint64_t l = lengthOf(g); std::lock_guard<std::mutex> lk(lenMu); genomeLengths.emplace(path, l); };
 
-  // ---- reference splits: one sketch, unless -s asks for the reference's per-split sanity check ----
-  const int nSplits = o.sanityCheck ? o.threads : 1;
   std::vector<ani_cgi_t> finalResults;
   std::vector<VisRow> vis;
   std::vector<int> failedSplits; std::vector<float> failedRatio;
-  for (int sp = 0; sp < nSplits; sp++) {
-    std::vector<int> refIdx;
-    for (int j = 0; j < (int)o.refs.size(); j++) if (nSplits == 1 || j % nSplits == sp) refIdx.push_back(j);   // computeCoreIdentity.hpp:467-472
-    if (refIdx.empty()) continue;                                       // more threads than references: an empty split maps nothing
-    HostBatch R;
-    { std::vector<std::string> paths; for (int j : refIdx) paths.push_back(o.refs[j]);
-      auto files = readFiles(paths, o.threads); for (auto &fd : files) R.add(std::move(fd)); }
-    ani_seq_batch_t rb = R.batch();
-    ani_sketch *sk = nullptr;
-    if (ani_sketch_build(ctx, &ap, &rb, &sk)) die("ani_sketch_build");
-    uint64_t occ = 0, uniq = 0, tot = 0;
-    ani_sketch_stats(sk, &occ, &uniq, &tot, nullptr, nullptr);
-    if (sp == 0) {
+
+  // ---- devices ----
+  std::vector<Device> dev(o.devices.size());
+  for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx)) die("ani_init"); }
+  const int nDev = (int)dev.size();
+  std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
+  std::cerr << "INFO [thread 0], skch::main, Count of threads executing parallel_for : " << (o.sanityCheck ? o.threads : nDev) << std::endl;
+
+  if (!o.visualize && !o.sanityCheck) {
+    // =================================================================================================================
+    // Streaming path.  File order: references, then (unless all-vs-all) queries; one reader pool over all of them.
+    // =================================================================================================================
+    std::vector<std::string> files = o.refs;
+    if (!allVsAll) files.insert(files.end(), o.queries.begin(), o.queries.end());
+    FilePipeline fp(files, o.threads, 3 * kSliceBytes);
+    const auto refSlices = make_slices(fp, 0, (size_t)nRef, kSliceBytes);
+    const auto qrySlices = allVsAll ? refSlices : make_slices(fp, (size_t)nRef, files.size(), kSliceBytes);
+
+    // reference tables, filled slice by slice
+    std::vector<int32_t> contigLenAll, gcsAll{0};
+    std::vector<RefPart> parts(refSlices.size());
+    std::vector<ani_dev_batch *> kept(allVsAll ? refSlices.size() : 0, nullptr);
+    std::vector<std::vector<int32_t>> keptLen(kept.size()), keptGcs(kept.size());
+    std::vector<int32_t> sliceSeqBase(refSlices.size() + 1, 0);
+    const auto t0 = Clock::now();
+    // Slices are prepared in order (contig numbering is global), the device work of slice k runs on device k % nDev in its own
+    // thread, so that upload + sketching of consecutive slices overlap across devices and with the readers.
+    {
+      std::vector<std::thread> workers;
+      std::vector<std::string> errs((size_t)nDev);
+      std::mutex orderMu; std::condition_variable orderCv; size_t nextSlice = 0;   // slices enter the tables in order
+      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
+        for (size_t k = (size_t)d; k < refSlices.size(); k += (size_t)nDev) {
+          const size_t a = refSlices[k].first, b = refSlices[k].second;
+          if (!fp.wait(a, b)) { errs[d] = "input"; return; }
+          SliceBatch sb;
+          for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
+          int32_t seqBase;
+          {
+            std::unique_lock<std::mutex> lk(orderMu);
+            orderCv.wait(lk, [&]() { return nextSlice == k; });
+            seqBase = (int32_t)contigLenAll.size();
+            sliceSeqBase[k] = seqBase;
+            const int32_t gBase = (int32_t)gcsAll.size() - 1;
+            contigLenAll.insert(contigLenAll.end(), sb.len.begin(), sb.len.end());
+            for (size_t g = 1; g < sb.gcs.size(); g++) gcsAll.push_back(seqBase + sb.gcs[g]);
+            parts[k].g0 = gBase; parts[k].g1 = gBase + (int32_t)sb.gcs.size() - 1; parts[k].dev = d;
+            nextSlice = k + 1;
+          }
+          orderCv.notify_all();
+          ani_seq_batch_t hb = sb.batch();
+          size_t n = 0;
+          if (allVsAll) {
+            if (ani_batch_upload(dev[d].ctx, &hb, &kept[k])) { errs[d] = ani_last_error(); return; }
+            keptLen[k] = sb.len; keptGcs[k] = sb.gcs;
+            fp.release(a, b);                                         // host copy no longer needed
+            ani_seq_batch_t db = hb; db.layout = ANI_SEQ_DEVICE_BATCH; db.data = kept[k]; db.contigLen = keptLen[k].data(); db.genomeContigStart = keptGcs[k].data();
+            if (ani_sketch_records(dev[d].ctx, &ap, &db, seqBase, &parts[k].rec, &n)) { errs[d] = ani_last_error(); return; }
+          } else {
+            if (ani_sketch_records(dev[d].ctx, &ap, &hb, seqBase, &parts[k].rec, &n)) { errs[d] = ani_last_error(); return; }
+            fp.release(a, b);
+          }
+          parts[k].n = n;
+        }
+      });
+      for (auto &w : workers) w.join();
+      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, reference sketch: " << e << std::endl; exit(1); }
+    }
+    // every device gets every part (peer-to-peer pulls), then builds the full index
+    std::vector<ani_sketch *> sk((size_t)nDev, nullptr);
+    {
+      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
+      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
+        std::vector<const void *> recs(parts.size()); std::vector<uint64_t> ns(parts.size()); std::vector<int32_t> pgs(parts.size() + 1, 0);
+        std::vector<void *> pulled;
+        for (size_t k = 0; k < parts.size(); k++) {
+          ns[k] = parts[k].n; pgs[k] = parts[k].g0; pgs[k + 1] = parts[k].g1;
+          if (parts[k].dev == d || parts[k].n == 0) { recs[k] = parts[k].rec; continue; }
+          void *p = nullptr;
+          if (ani_device_alloc(dev[d].ctx, parts[k].n * 12, &p) || ani_device_copy_peer(dev[d].ctx, p, dev[parts[k].dev].ctx, parts[k].rec, parts[k].n * 12)) { errs[d] = ani_last_error(); return; }
+          recs[k] = p; pulled.push_back(p);
+        }
+        if (ani_sketch_from_record_parts(dev[d].ctx, &ap, (int32_t)parts.size(), recs.data(), ns.data(), pgs.data(), contigLenAll.data(), (int32_t)contigLenAll.size(),
+                                         gcsAll.data(), (int32_t)gcsAll.size() - 1, &sk[d])) { errs[d] = ani_last_error(); return; }
+        for (void *p : pulled) ani_device_free(dev[d].ctx, p);
+      });
+      for (auto &w : workers) w.join();
+      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, reference index: " << e << std::endl; exit(1); }
+      for (auto &pt : parts) if (pt.rec) ani_device_free(dev[pt.dev].ctx, pt.rec);
+    }
+    {
+      uint64_t occ = 0, uniq = 0; int32_t nChunks = 0;
+      ani_sketch_stats(sk[0], &occ, nullptr, nullptr, nullptr, nullptr);
+      ani_sketch_chunks(sk[0], &nChunks, nullptr, 0);
       std::cerr << "INFO [thread 0], skch::Sketch::build, minimizers picked from reference = " << occ << std::endl;
-      std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl;
+      if (nChunks <= 1) { ani_sketch_stats(sk[0], nullptr, &uniq, nullptr, nullptr, nullptr); std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl; }
+      else std::cerr << "INFO [thread 0], skch::Sketch::index, reference set held as " << nChunks << " index chunks" << std::endl;
+      std::cerr << "INFO [thread 0], skch::main, Time spent sketching the reference : " << secs_since(t0) << " sec" << std::endl;
     }
-    bool ok = true;
-    if (o.sanityCheck) {                                                // winSketch.hpp:298-318
-      const float hashRatio = float(tot) / float(occ), uniqHashRatio = float(tot) / float(uniq);
-      const float diff = std::abs(hashRatio - uniqHashRatio);
-      if (diff > o.maxRatioDiff) { ok = false; failedSplits.push_back(sp); failedRatio.push_back(diff); }
+
+    // ---- queries: slices round-robin over the devices; rows are collected per slice so that the order does not depend on timing ----
+    std::vector<std::vector<ani_cgi_t>> sliceRows(qrySlices.size());
+    {
+      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
+      std::mutex logMu;
+      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
+        for (size_t k = (size_t)d; k < qrySlices.size(); k += (size_t)nDev) {
+          const size_t a = qrySlices[k].first, b = qrySlices[k].second;
+          const int32_t firstQ = (int32_t)(allVsAll ? a : a - (size_t)nRef);
+          const auto tm = Clock::now();
+          ani_counters_t c0, c1;
+          ani_get_counters(dev[d].ctx, &c0);
+          ani_cgi_t *rows = nullptr; size_t m = 0;
+          if (allVsAll) {
+            // slice k was uploaded by device k % nDev = d
+            ani_seq_batch_t db; db.layout = ANI_SEQ_DEVICE_BATCH; db.nGenomes = (int32_t)keptGcs[k].size() - 1; db.nContigs = (int32_t)keptLen[k].size();
+            static const int32_t zero = 0;
+            db.genomeContigStart = keptGcs[k].data(); db.contigOffset = nullptr; db.contigLen = keptLen[k].empty() ? &zero : keptLen[k].data(); db.data = kept[k];
+            if (ani_map_cgi_batch(dev[d].ctx, sk[d], &db, firstQ, &rows, &m)) { errs[d] = ani_last_error(); return; }
+            ani_batch_free(kept[k]); kept[k] = nullptr;
+          } else {
+            if (!fp.wait(a, b)) { errs[d] = "input"; return; }
+            SliceBatch sb;
+            for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
+            ani_seq_batch_t hb = sb.batch();
+            if (ani_map_cgi_batch(dev[d].ctx, sk[d], &hb, firstQ, &rows, &m)) { errs[d] = ani_last_error(); return; }
+            fp.release(a, b);
+          }
+          sliceRows[k].assign(rows, rows + m);
+          ani_free(rows);
+          ani_get_counters(dev[d].ctx, &c1);
+          const double total = secs_since(tm), post = (c1.msReduce - c0.msReduce) / 1e3;
+          std::lock_guard<std::mutex> lk(logMu);
+          std::cerr << "INFO [thread " << d << "], skch::main, Time spent mapping fragments in query #" << firstQ + 1 << "-#" << firstQ + (int32_t)(b - a) << " : " << std::max(0.0, total - post) << " sec" << std::endl;
+          std::cerr << "INFO [thread " << d << "], skch::main, Time spent post mapping : " << post << " sec" << std::endl;
+        }
+      });
+      for (auto &w : workers) w.join();
+      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, mapping: " << e << std::endl; exit(1); }
     }
-    if (ok) {
-      if (!o.visualize) {
+    for (auto &v : sliceRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }
+    for (int d = 0; d < nDev; d++) { ani_sketch_destroy(sk[d]); std::cerr << "INFO [thread " << d << "], skch::main, ready to exit the loop" << std::endl; }
+  } else {
+    // =================================================================================================================
+    // -s (per-split sanity check, winSketch.hpp:298-318) and --visualize (mappings back on the host): whole sets in memory,
+    // one device.  These are small-input modes of the reference.
+    // =================================================================================================================
+    ani_ctx *ctx = dev[0].ctx;
+    auto loadAll = [&](const std::vector<std::string> &paths, std::vector<FileData> &out) {
+      FilePipeline fp(paths, o.threads, ~0ull >> 2);
+      if (!fp.wait(0, paths.size())) exit(1);
+      out.resize(paths.size());
+      for (size_t i = 0; i < paths.size(); i++) { out[i] = std::move(fp.slot[i]); noteLength(paths[i], out[i].g); }
+    };
+    std::vector<FileData> Q, R;
+    loadAll(o.queries, Q); loadAll(o.refs, R);
+    SliceBatch qbAll; for (auto &fd : Q) qbAll.add(fd);
+    ani_seq_batch_t qb = qbAll.batch();
+    const int nSplits = o.sanityCheck ? o.threads : 1;
+    for (int sp = 0; sp < nSplits; sp++) {
+      std::vector<int> refIdx;
+      for (int j = 0; j < nRef; j++) if (nSplits == 1 || j % nSplits == sp) refIdx.push_back(j);   // computeCoreIdentity.hpp:467-472
+      if (refIdx.empty()) continue;                                       // more threads than references: an empty split maps nothing
+      SliceBatch rbS; for (int j : refIdx) rbS.add(R[j]);
+      ani_seq_batch_t rb = rbS.batch();
+      const auto t0 = Clock::now();
+      ani_sketch *sk = nullptr;
+      if (ani_sketch_build(ctx, &ap, &rb, &sk)) die("ani_sketch_build");
+      uint64_t occ = 0, uniq = 0, tot = 0;
+      if (ani_sketch_stats(sk, &occ, &uniq, &tot, nullptr, nullptr)) die("ani_sketch_stats");
+      if (sp == 0) {
+        std::cerr << "INFO [thread 0], skch::Sketch::build, minimizers picked from reference = " << occ << std::endl;
+        std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl;
+        std::cerr << "INFO [thread 0], skch::main, Time spent sketching the reference : " << secs_since(t0) << " sec" << std::endl;
+      }
+      bool ok = true;
+      if (o.sanityCheck) {                                                // winSketch.hpp:298-318
+        const float hashRatio = float(tot) / float(occ), uniqHashRatio = float(tot) / float(uniq);
+        const float diff = std::abs(hashRatio - uniqHashRatio);
+        if (diff > o.maxRatioDiff) { ok = false; failedSplits.push_back(sp); failedRatio.push_back(diff); }
+      }
+      if (ok && !o.visualize) {
+        const auto tm = Clock::now();
         ani_cgi_t *rows = nullptr; size_t m = 0;
         if (ani_map_cgi_batch(ctx, sk, &qb, 0, &rows, &m)) die("ani_map_cgi_batch");
         for (size_t i = 0; i < m; i++) { ani_cgi_t e = rows[i]; e.refGenomeId = refIdx[e.refGenomeId]; finalResults.push_back(e); }
         ani_free(rows);
-      } else {
+        if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #1-#" << nQry << " : " << secs_since(tm) << " sec" << std::endl;
+      } else if (ok) {
         // per query genome: mappings back to the host for the .visual rows (computeCoreIdentity.hpp:186-261)
-        std::vector<int64_t> refOff(R.len.size(), 0);
-        for (size_t i = 1; i < R.len.size(); i++) refOff[i] = refOff[i - 1] + R.len[i - 1];
-        std::vector<int32_t> contigGenome(R.len.size());
-        for (size_t g = 0; g + 1 < R.gcs.size(); g++) for (int32_t c = R.gcs[g]; c < R.gcs[g + 1]; c++) contigGenome[c] = (int32_t)g;
-        for (size_t qi = 0; qi < Q.meta.size(); qi++) {
-          HostBatch one; one.add(o.queries[qi]);          // --visualize is a one-to-one mode: re-reading the query is cheap
+        std::vector<int64_t> refOff(rbS.len.size(), 0);
+        for (size_t i = 1; i < rbS.len.size(); i++) refOff[i] = refOff[i - 1] + rbS.len[i - 1];
+        std::vector<int32_t> contigGenome(rbS.len.size());
+        for (size_t g = 0; g + 1 < rbS.gcs.size(); g++) for (int32_t c = rbS.gcs[g]; c < rbS.gcs[g + 1]; c++) contigGenome[c] = (int32_t)g;
+        for (size_t qi = 0; qi < Q.size(); qi++) {
+          SliceBatch one; one.add(Q[qi]);
           ani_seq_batch_t ob = one.batch();
+          auto tm = Clock::now();
+          std::cerr << "INFO [thread 0], skch::main, Start Map " << qi + 1 << std::endl;
           ani_mapping_t *maps = nullptr; size_t n = 0; uint64_t totalFr = 0;
           if (ani_map_query(ctx, sk, &ob, &maps, &n, &totalFr)) die("ani_map_query");
+          std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #" << qi + 1 << " : " << secs_since(tm) << " sec" << std::endl;
+          tm = Clock::now();
           ani_cgi_t *rows = nullptr; size_t m = 0;
           if (ani_compute_cgi(ctx, sk, maps, n, totalFr, (int32_t)qi, &rows, &m)) die("ani_compute_cgi");
           for (size_t i = 0; i < m; i++) { ani_cgi_t e = rows[i]; e.refGenomeId = refIdx[e.refGenomeId]; finalResults.push_back(e); }
@@ -321,8 +581,7 @@ int main(int argc, char **argv)
           // fragment offsets inside the query genome (computeMap.hpp:160-167, computeCoreIdentity.hpp:117-124)
           std::vector<int64_t> qOff;
           { int64_t run = 0;
-            for (int32_t c = Q.gcs[qi]; c < Q.gcs[qi + 1]; c++) {
-              const int32_t len = Q.len[c];
+            for (int32_t len : Q[qi].g.lens) {
               if (len < ap.windowSize || len < ap.kmerSize || len < ap.fragLen) { qOff.push_back(run); run += len; continue; }
               const int fc = len / ap.fragLen;
               for (int i = 0; i < fc; i++) { qOff.push_back(run); run += (i != fc - 1) ? ap.fragLen : ap.fragLen + len % ap.fragLen; }
@@ -344,60 +603,70 @@ int main(int argc, char **argv)
           for (auto &e : two_way)
             vis.push_back(VisRow{o.queries[qi], o.refs[refIdx[e.genome]], e.id, 0 + qOff[e.qSeq], 0 + ap.fragLen - 1 + qOff[e.qSeq],
                                  e.refStart + refOff[e.refSeq], e.refStart + ap.fragLen - 1 + refOff[e.refSeq]});
+          std::cerr << "INFO [thread 0], skch::main, Time spent post mapping : " << secs_since(tm) << " sec" << std::endl;
         }
       }
+      ani_sketch_destroy(sk);
     }
-    ani_sketch_destroy(sk);
+    std::cerr << "INFO [thread 0], skch::main, ready to exit the loop" << std::endl;
   }
   std::cerr << "INFO, skch::main, parallel_for execution finished" << std::endl;
   for (size_t i = 0; i < failedSplits.size(); i++)
     std::cerr << "ERROR :: SPLIT " << failedSplits[i] << "'s ratio difference " << failedRatio[i] << " exceeds maximum thresholds." << std::endl;
 
-  // ---- genome lengths (computeCoreIdentity.hpp:48-92): query files first, then unseen reference files ----
-  std::unordered_map<std::string, uint64_t> genomeLengths;
-  auto lengthOf = [&](const Genome &g) {
-    uint64_t s = 0;
-    for (int32_t l : g.lens) if (l >= ap.fragLen) s += (uint64_t)(l / ap.fragLen) * (uint64_t)ap.fragLen;
-    return s;
-  };
-  for (size_t i = 0; i < o.queries.size(); i++) genomeLengths[o.queries[i]] = lengthOf(Q.meta[i]);
-  for (auto &f : o.refs)
-    if (!genomeLengths.count(f)) { HostBatch one; one.add(f); genomeLengths[f] = lengthOf(one.meta[0]); }
-
   // ---- outputCGI (computeCoreIdentity.hpp:307-344): query ascending, identity descending ----
+  const auto tOut = Clock::now();
   std::stable_sort(finalResults.begin(), finalResults.end(), [](const ani_cgi_t &x, const ani_cgi_t &y) {
     if (x.qryGenomeId != y.qryGenomeId) return x.qryGenomeId < y.qryGenomeId;
     return x.identity > y.identity; });
+  std::vector<uint64_t> qLen((size_t)nQry), rLen((size_t)nRef);
+  for (int i = 0; i < nQry; i++) qLen[i] = genomeLengths[o.queries[i]];
+  for (int i = 0; i < nRef; i++) rLen[i] = genomeLengths[o.refs[i]];
   auto trusted = [&](const ani_cgi_t &e) {
-    const uint64_t minLen = std::min(genomeLengths[o.queries[e.qryGenomeId]], genomeLengths[o.refs[e.refGenomeId]]);
+    const uint64_t minLen = std::min(qLen[e.qryGenomeId], rLen[e.refGenomeId]);
     const uint64_t shared = (uint64_t)e.countSeq * (uint64_t)ap.fragLen;
     return shared >= minLen * o.minFraction;                            // uint64 * float, as in :328
   };
   {
     std::ofstream out(o.out);
+    std::vector<char> obuf(1 << 20); out.rdbuf()->pubsetbuf(obuf.data(), (std::streamsize)obuf.size());
     for (auto &e : finalResults)
       if (trusted(e))
         out << o.queries[e.qryGenomeId] << "\t" << o.refs[e.refGenomeId] << "\t" << e.identity << "\t" << e.countSeq << "\t" << e.totalQueryFragments << "\n";
   }
-  // ---- outputPhylip (computeCoreIdentity.hpp:353-448) ----
+  // ---- outputPhylip (computeCoreIdentity.hpp:353-448), streamed: the reference fills a dense N x N float matrix (32 GB at 90 k
+  // genomes); here every trusted result becomes a (row, column, identity) entry, the entries are ordered by (row, column) with the
+  // result order kept inside a cell (first value sets the cell, a later one averages: :411-421), and the lower triangle is written
+  // row by row.  Memory is O(results).
   if (o.matrix) {
     std::unordered_map<std::string, int> g2i; std::vector<std::string> names;
     for (auto &e : o.queries) if (!g2i.count(e)) { g2i[e] = (int)names.size(); names.push_back(e); }
     for (auto &e : o.refs) if (!g2i.count(e)) { g2i[e] = (int)names.size(); names.push_back(e); }
+    std::vector<int> qIdx((size_t)nQry), rIdx((size_t)nRef);
+    for (int i = 0; i < nQry; i++) qIdx[i] = g2i[o.queries[i]];
+    for (int i = 0; i < nRef; i++) rIdx[i] = g2i[o.refs[i]];
     const int n = (int)names.size();
-    std::vector<std::vector<float>> mat(n, std::vector<float>(n, 0.0f));
+    struct Cell { int32_t row, col; float id; };
+    std::vector<Cell> cells;
     for (auto &e : finalResults)
       if (trusted(e)) {
-        int a = g2i[o.queries[e.qryGenomeId]], b = g2i[o.refs[e.refGenomeId]];
+        int a = qIdx[e.qryGenomeId], b = rIdx[e.refGenomeId];
         if (a == b) continue;
         if (a < b) std::swap(a, b);
-        mat[a][b] = mat[a][b] > 0 ? (mat[a][b] + e.identity) / 2 : e.identity;
+        cells.push_back(Cell{a, b, e.identity});
       }
+    std::stable_sort(cells.begin(), cells.end(), [](const Cell &x, const Cell &y) { return x.row != y.row ? x.row < y.row : x.col < y.col; });
     std::ofstream out(o.out + ".matrix");
+    std::vector<char> obuf(1 << 20); out.rdbuf()->pubsetbuf(obuf.data(), (std::streamsize)obuf.size());
     out << n << "\n";
+    size_t p = 0;
     for (int i = 0; i < n; i++) {
       out << names[i];
-      for (int j = 0; j < i; j++) out << "\t" << (mat[i][j] > 0.0 ? std::to_string(mat[i][j]) : std::string("NA"));
+      for (int j = 0; j < i; j++) {
+        float v = 0.0f;
+        while (p < cells.size() && cells[p].row == i && cells[p].col == j) { v = v > 0 ? (v + cells[p].id) / 2 : cells[p].id; p++; }
+        if (v > 0.0) out << "\t" << std::to_string(v); else out << "\tNA";
+      }
       out << "\n";
     }
   }
@@ -406,6 +675,7 @@ int main(int argc, char **argv)
     for (auto &r : vis)
       out << r.q << "\t" << r.r << "\t" << r.id << "\tNA\tNA\tNA\t" << r.qs << "\t" << r.qe << "\t" << r.rs << "\t" << r.re << "\tNA\tNA\n";
   }
-  ani_shutdown(ctx);
+  std::cerr << "INFO, skch::main, Time spent writing the output : " << secs_since(tOut) << " sec; total : " << secs_since(tStart) << " sec" << std::endl;
+  for (auto &d : dev) ani_shutdown(d.ctx);
   return 0;
 }

@@ -435,106 +435,87 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   unsigned long long cntE = 0, cntS = 0, cntQ = 0;
   const int myFlag = c < a.c1 ? a.slowFlag[c - a.c0] : 1;
   const bool mine = (G::kMaxS == 255) ? (myFlag == 0) : (myFlag == 4);
-  // Control flow is wave-uniform from here on: a lane without a candidate gets an empty range and runs no-op events.  Loops end on
-  // wave votes; the rare paths — an entry with a near same-hash neighbour, a position step that does not fit 5 bits — sit behind
-  // wave votes too.  No per-lane break and no divergent branch on the common path.
-  const int32_t i = mine ? c - a.c0 : 0;
-  L2Range r; r.beg0 = 0; r.end0 = 0; r.last = 0; r.wposBeg0 = 0;
-  if (mine) r = a.ranges[i];
-  const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
-  const int m = r.last - r.beg0;
-  L2Regs R; R.s = mine ? a.g.fragS[a.g.candFrag[c]] : 1; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = false;
-  const uint4 *base = (const uint4 *)((const uint16_t *)a.codes + (mine ? a.codeOff[i] : 0u));      // lanes without a candidate read the head of the buffer
-  L2Stream cb, ce;
-  cb.init(base, S + G::kStateWords * kWave);
-  ce.init(base, S + (G::kStateWords + 8) * kWave);
-  // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up; rare, the load is waited for
-  // inside its branch, not in the loop body)
-  auto next_wpos = [&](int32_t prev, uint32_t code, int j, bool on) -> int32_t {
-    const uint32_t dw = code >> 11;
-    int32_t wp = prev + (int32_t)dw;
-    if (__any(on && dw == kL2DwEscape)) {
-      if (on && dw == kL2DwEscape) { wp = a.g.mWpos[r.beg0 + j]; ANI_CONSUME(wp); }
+  if (mine) {
+    const int32_t i = c - a.c0;
+    const L2Range r = a.ranges[i];
+    const int32_t f = a.g.candFrag[c];
+    const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
+    const int m = r.last - r.beg0;
+    L2Regs R; R.s = a.g.fragS[f]; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = false;
+    // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
+    auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
+      const uint32_t dw = code >> 11;
+      int32_t wp = prev + (int32_t)dw;
+      if (dw == kL2DwEscape) { wp = a.g.mWpos[r.beg0 + j]; ANI_CONSUME(wp); }     // rare; the load is waited for here, not in the loop body
+      return wp;
+    };
+    const uint4 *base = (const uint4 *)((const uint16_t *)a.codes + a.codeOff[i]);
+    L2Stream cb, ce;
+    cb.init(base, S + G::kStateWords * kWave);
+    ce.init(base, S + (G::kStateWords + 8) * kWave);
+    // first super-window: entries [0, end0-beg0)  (computeMap.hpp:448)
+    int end = r.end0 - r.beg0, beg = 0;
+    int32_t wEnd = r.wposBeg0;                       // becomes wpos of entry `end`
+    for (int j = 0; j < end; j++) {
+      if ((j & 7) == 0) ce.sync(j);
+      const uint32_t cd = ce.get(j);
+      if (j > 0) wEnd = next_wpos(wEnd, cd, j);
+      bool eff = true;
+      if (cd & kL2DupBit) eff = a.g.prevSame[r.beg0 + j] < r.beg0;
+      l2_apply(F, R, cd, true, eff);
     }
-    return wp;
-  };
-  // first super-window: entries [0, end0-beg0)  (computeMap.hpp:448)
-  int end = r.end0 - r.beg0;
-  int32_t wEnd = r.wposBeg0;                       // becomes wpos of entry `end`
-  for (int j = 0; __any(j < end); j++) {
-    const bool on = j < end;
-    if ((j & 7) == 0) ce.sync(on ? j : end);
-    const uint32_t cd = ce.get(j);
-    if (j > 0) { const int32_t wn = next_wpos(wEnd, cd, j, on); wEnd = on ? wn : wEnd; }
-    bool eff = on;
-    if (__any(on && (cd & kL2DupBit) != 0)) {
-      if (on && (cd & kL2DupBit)) eff = a.g.prevSame[r.beg0 + j] < r.beg0;
-    }
-    l2_apply(F, R, cd, true, eff);
-  }
-  bool active = end < m;
-  uint32_t codeEnd = ce.get(end);
-  { const int32_t wn = next_wpos(wEnd, codeEnd, end, active); wEnd = active ? wn : wEnd; }
-  int32_t wBeg = r.wposBeg0;
-  uint32_t codeBeg = cb.get(0);
-  uint32_t codeBegNext = cb.get(1);
-  int32_t wBegNext = next_wpos(wBeg, codeBegNext, 1, 1 < m);
-  // Event-driven form of the loop at computeMap.hpp:455-481.  A step of the reference advances MIIteratorL2 to the nearer of
-  //   pB = wpos[beg+1]            (the first entry leaves:  delete_ref(beg),  beg++)
-  //   pE = wpos[end] - cmw + 1    (entry `end` fits:        insert_ref(end),  end++)
-  // applies the delete and/or the insert and evaluates the window; the loop ends, unevaluated, with the insert that takes
-  // `end` to the end of the range.  Nearly every step carries one event only, so one pass of this loop is ONE event: apply it,
-  // advance its cursor, evaluate unless the insert of the same position (pB == pE: delete first, as the reference does) is
-  // still to come.  wpos is strictly increasing inside a contig, so after such a delete the next event is that insert.
-  // A lane whose range is exhausted (or whose gap counter overflowed) turns inactive and idles until the last lane of the wave
-  // is done (lanes are ordered by stream length, so that is a few passes).
-  int best = active ? R.shared : 0;                // first pass of :455, no events
-  int32_t firstPos = (active && R.shared > 0) ? wBeg : 0, lastPos = active ? wBeg : 0;
-  int steps = active ? 1 : 0;
-  active = active && !R.ovf;
-  {
-    const int32_t cmw1 = cmw - 1;
-    int b1 = 1;                                    // beg + 1
-    const uint32_t *ringB = S + G::kStateWords * kWave;
-    for (int it = 0; __any(active); it++) {
-      if ((it & 7) == 0) { cb.sync(b1); ce.sync(end); }
-      const int32_t pE = wEnd - cmw1;
-      const bool del = wBegNext <= pE;
-      active = active && (del || end + 1 < m);     // the insert that takes `end` to the end of the range is never applied
-      const bool more = del && wBegNext == pE;     // the insert of this step follows
-      const uint32_t code = del ? codeBeg : codeEnd;
-      bool eff = active;
-      if (__any(active && (code & kL2DupBit) != 0)) {
-        if (active && (code & kL2DupBit)) {
-          if (del) {                               // stays iff a later same-hash entry is already in the window
+    uint32_t codeEnd = 0;
+    if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
+    int32_t wBeg = r.wposBeg0;
+    uint32_t codeBeg = cb.get(0);
+    uint32_t codeBegNext = (1 < m) ? cb.get(1) : 0u;
+    int32_t wBegNext = (1 < m) ? next_wpos(wBeg, codeBegNext, 1) : wBeg;
+    int best = 0; int32_t firstPos = 0, lastPos = 0; int steps = 0;
+    // Event-driven form of the loop at computeMap.hpp:455-481.  A step of the reference advances MIIteratorL2 to the nearer of
+    //   pB = wpos[beg+1]            (the first entry leaves:  delete_ref(beg),  beg++)
+    //   pE = wpos[end] - cmw + 1    (entry `end` fits:        insert_ref(end),  end++)
+    // applies the delete and/or the insert and evaluates the window; the loop ends, unevaluated, with the insert that takes
+    // `end` to the end of the range.  Nearly every step carries one event only, so one pass of this loop is ONE event: apply it,
+    // advance its cursor, evaluate unless the insert of the same position (pB == pE: delete first, as the reference does) is
+    // still to come.  wpos is strictly increasing inside a contig, so after such a delete the next event is that insert.
+    if (end < m) {
+      best = R.shared; firstPos = R.shared > 0 ? wBeg : 0; lastPos = wBeg; steps = 1;     // first pass of :455, no events
+      const int32_t cmw1 = cmw - 1;
+      int b1 = 1;                                    // beg + 1
+      const uint32_t *ringB = S + G::kStateWords * kWave;
+      for (int it = 0; !R.ovf; it++) {
+        if ((it & 7) == 0) { cb.sync(b1); ce.sync(end); }
+        const int32_t pE = wEnd - cmw1;
+        const bool del = wBegNext <= pE;
+        if (!del && end + 1 >= m) break;
+        const bool more = del && wBegNext == pE;     // the insert of this step follows
+        const uint32_t code = del ? codeBeg : codeEnd;
+        bool eff = true;
+        if (code & kL2DupBit) {
+          if (del) {                                 // stays iff a later same-hash entry is already in the window
             const int32_t nx = a.g.nextSame[r.beg0 + b1 - 1];
             eff = !(nx >= 0 && nx < r.beg0 + end);
           } else eff = a.g.prevSame[r.beg0 + end] < r.beg0 + b1 - 1;       // new iff no same-hash entry in [beg, end)
         }
+        // the cursor of this event advances: fetch entry beg+2 resp. end+1 (both inside the range, see above).  Read before the
+        // state update so that its LDS latency overlaps the field reads of l2_apply instead of following its byte store.
+        const int jf = (del ? b1 : end) + 1;
+        const uint16_t *h = (const uint16_t *)(ringB + (del ? 0 : 8 * kWave) + ((jf & 15) >> 1) * kWave);
+        const uint32_t cf = h[jf & 1];
+        l2_apply(F, R, code, !del, eff);
+        const int32_t wf = next_wpos(del ? wBegNext : wEnd, cf, jf);
+        codeBeg = del ? codeBegNext : codeBeg; wBeg = del ? wBegNext : wBeg;
+        codeBegNext = del ? cf : codeBegNext; wBegNext = del ? wf : wBegNext;
+        codeEnd = del ? codeEnd : cf; wEnd = del ? wEnd : wf;
+        b1 += del ? 1 : 0; end += del ? 0 : 1;
+        // evaluate (:468-476)
+        const bool better = !more && R.shared > best, tieOrBetter = !more && R.shared >= best;
+        best = better ? R.shared : best;
+        firstPos = better ? wBeg : firstPos;
+        lastPos = tieOrBetter ? wBeg : lastPos;
+        steps += more ? 0 : 1;
       }
-      // the cursor of this event advances: fetch entry beg+2 resp. end+1 (inside the ring whether or not the lane is active).  Read
-      // before the state update so that its LDS latency overlaps the field reads of l2_apply instead of following its byte store.
-      const int jf = (del ? b1 : end) + 1;
-      const uint16_t *h = (const uint16_t *)(ringB + (del ? 0 : 8 * kWave) + ((jf & 15) >> 1) * kWave);
-      const uint32_t cf = h[jf & 1];
-      l2_apply(F, R, code, !del, eff);
-      active = active && !R.ovf;
-      const int32_t wf = next_wpos(del ? wBegNext : wEnd, cf, jf, active);
-      const bool advB = active && del, advE = active && !del;
-      codeBeg = advB ? codeBegNext : codeBeg; wBeg = advB ? wBegNext : wBeg;
-      codeBegNext = advB ? cf : codeBegNext; wBegNext = advB ? wf : wBegNext;
-      codeEnd = advE ? cf : codeEnd; wEnd = advE ? wf : wEnd;
-      b1 += advB ? 1 : 0; end += advE ? 1 : 0;
-      // evaluate (:468-476)
-      const bool ev = active && !more;
-      const bool better = ev && R.shared > best, tieOrBetter = ev && R.shared >= best;
-      best = better ? R.shared : best;
-      firstPos = better ? wBeg : firstPos;
-      lastPos = tieOrBetter ? wBeg : lastPos;
-      steps += ev ? 1 : 0;
     }
-  }
-  if (mine) {
     if (R.ovf) a.slowFlag[i] = 3;
     else {
       a.slowFlag[i] = (G::kMaxS == 255) ? 0 : 8;     // class B runs concurrently with class A: its "done" must not read as class A

@@ -71,8 +71,14 @@ typedef struct {
  *   layout ANI_SEQ_DEVICE_PACKED2: `data` is DEVICE memory, 2-bit codes A=0 C=1 G=2 T=3, 16 bases per little-endian
  *                                 uint32 (base j of a word in bits 2j..2j+1); contig c starts at WORD contigOffset[c]
  *                                 (contigs are word-aligned).  Only valid for pure-ACGT data.
+ *   layout ANI_SEQ_HOST_ASCII_PTRS: as HOST_ASCII, but `data` is an array of nContigs host pointers (const uint8_t *const *), one
+ *                                 per contig; contigOffset is ignored.  Lets a reader hand over per-file buffers without
+ *                                 concatenating them.
+ *   layout ANI_SEQ_DEVICE_BATCH   : `data` is an ani_dev_batch* returned by ani_batch_upload (genomes already packed and
+ *                                 resident on the device); the table fields must describe that batch (nGenomes, nContigs,
+ *                                 genomeContigStart, contigLen), contigOffset is ignored.
  */
-typedef enum { ANI_SEQ_HOST_ASCII = 0, ANI_SEQ_DEVICE_PACKED2 = 1 } ani_seq_layout;
+typedef enum { ANI_SEQ_HOST_ASCII = 0, ANI_SEQ_DEVICE_PACKED2 = 1, ANI_SEQ_HOST_ASCII_PTRS = 2, ANI_SEQ_DEVICE_BATCH = 3 } ani_seq_layout;
 typedef struct {
   int32_t layout;
   int32_t nGenomes;
@@ -85,6 +91,7 @@ typedef struct {
 
 typedef struct ani_ctx ani_ctx;
 typedef struct ani_sketch ani_sketch;
+typedef struct ani_dev_batch ani_dev_batch;
 
 /* Run-time counters for the measurement contract: the algorithmic-byte figure of a run is
  * computed from these, never estimated. */
@@ -120,6 +127,15 @@ void ani_free(void *hostPtr);
 void ani_device_free(ani_ctx *ctx, void *devPtr);
 /* copy between device buffers of this context (used by the host side to stage records into communication buffers) */
 int ani_device_copy(ani_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* device memory of this context (released with ani_device_free) and a copy between two contexts' devices — the host side of a
+ * multi-GPU run stages minimizer records with these (peer-to-peer over xGMI when the devices can access each other) */
+int ani_device_alloc(ani_ctx *ctx, size_t bytes, void **out);
+int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void *src, size_t bytes);
+/* Ingest: classify + 2-bit pack host sequences on host threads into page-locked staging, copy them to the
+ * device and keep them there.  The handle can be passed to every entry point that takes a sequence batch (layout
+ * ANI_SEQ_DEVICE_BATCH), any number of times: an all-vs-all run sketches and maps the same upload. */
+int ani_batch_upload(ani_ctx *ctx, const ani_seq_batch_t *genomes, ani_dev_batch **out);
+void ani_batch_free(ani_dev_batch *b);
 int ani_get_counters(ani_ctx *ctx, ani_counters_t *out);
 int ani_reset_counters(ani_ctx *ctx);
 

@@ -1,5 +1,6 @@
 /* TEST INFRASTRUCTURE ONLY — fiber scheduler behind tests/emu/include/hip/hip_runtime.h. */
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <ucontext.h>
 #include <vector>
 #include <stdexcept>
@@ -56,7 +57,9 @@ const uint64_t *wave_gather(uint64_t v, uint64_t *mask) {
 }
 void wave_done() { yield(WAIT_WAVE); /* rendezvous #2: everyone has read */ }
 
+static std::mutex g_launchMu;      // one kernel at a time: host threads driving several contexts (fastANI --devices) take turns
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+  std::lock_guard<std::mutex> launchLock(g_launchMu);
   size_t nthreads = (size_t)block.x * block.y * block.z;
   if (nthreads == 0 || (size_t)grid.x * grid.y * grid.z == 0) return;
   if (g_fibers.size() < nthreads) {

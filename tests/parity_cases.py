@@ -192,6 +192,28 @@ def case_chunked(engine):
     case_empty_and_short(engine)
 
 
+def case_uploaded(engine):
+    """ani_batch_upload: genomes packed and copied to the device once, then used as references AND as queries (the all-vs-all
+    command line does that); both host layouts (flat buffer, per-contig pointers); sub-ranges through ani_sketch_records"""
+    from fastani_amd.api import UploadedGenomes
+    genomes = [messy_genome(5, 50000), [orc.synth_genome(5, 0, 40000)], [rng_genome(1, 10, b"ACGT")], [orc.synth_genome(5, 3, 35001)], [b""]]
+    p = engine.params()
+    sk0 = Sketch(engine, p, genomes)
+    rows0 = sk0.map_cgi_batch(genomes, 0)
+    for ptrs in (False, True):
+        up = UploadedGenomes(engine, genomes, ptrs=ptrs)
+        sk = Sketch(engine, p, up)
+        assert np.array_equal(sk.minimizers(), sk0.minimizers())
+        assert np.array_equal(sk.map_cgi_batch(up, 0), rows0)
+        assert np.array_equal(sk0.map_cgi_batch(up, 0), rows0)
+        maps, tot = sk.map_query(genomes[1])
+        maps0, tot0 = sk0.map_query(genomes[1])
+        assert tot == tot0 and np.array_equal(maps, maps0)
+        up.close()
+    osk = orc.Sketch(genomes, 16, p.windowSize)
+    assert np.array_equal(sk0.minimizers(), osk.minimizers())
+
+
 def case_limits(engine):
     """documented limits fail loudly with ANI_ERR_LIMIT (-4), never silently"""
     from fastani_amd.api import AniError
@@ -215,7 +237,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_sparse_hits, case_empty_and_short]
+             case_low_complexity_big, case_sparse_hits, case_empty_and_short, case_uploaded]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):

@@ -50,6 +50,94 @@ def _run_both(binary, tmp):
         assert ra.returncode == rb.returncode == 1 and msg in ra.stderr and msg in rb.stderr
 
 
+def _run_streaming_variants(binary, tmp):
+    """the streaming paths of the command line: queries != references, several file slices, several index chunks, and two
+    device contexts (here: the same device twice) — every variant must print what the reference binary prints"""
+    gs = [[orc.synth_genome(7, i, 36000)] for i in (0, 3, 11, 20, 21, 40)] + [golden_cases.messy(5, 40000)]
+    paths = []
+    for i, g in enumerate(gs):
+        p = os.path.join(tmp, "s%d.fa" % i)
+        orc.write_fasta(p, g, names=["c%d_%d" % (i, j) for j in range(len(g))])
+        paths.append(p)
+    rl, ql = os.path.join(tmp, "rl.txt"), os.path.join(tmp, "ql.txt")
+    open(rl, "w").write("\n".join(paths[:5]) + "\n")
+    open(ql, "w").write("\n".join(paths[3:]) + "\n")
+    al = os.path.join(tmp, "al.txt")
+    open(al, "w").write("\n".join(paths) + "\n")
+    ref = {}
+    for name, args in (("qr", ["--ql", ql, "--rl", rl]), ("all", ["--ql", al, "--rl", al, "--matrix"])):
+        out = os.path.join(tmp, "ref_%s.out" % name)
+        ra = subprocess.run([orc.REF_BIN] + args + ["-t", "2", "-o", out], capture_output=True)
+        assert ra.returncode == 0
+        ref[name] = (args, out)
+    envs = [({}, []), ({"ANI_SLICE_BYTES": "40000"}, []), ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000"}, []),
+            ({"ANI_SLICE_BYTES": "40000"}, ["--devices", "0,0"]), ({"ANI_SLICE_BYTES": "80000", "ANI_MAX_INDEX_MINIMIZERS": "7000"}, ["--devices", "0,0,0"])]
+    for env, extra in envs:
+        for name, (args, rout) in ref.items():
+            out = os.path.join(tmp, "new_%s.out" % name)
+            rb = subprocess.run([binary] + args + ["-t", "3", "-o", out] + extra, capture_output=True, env=dict(os.environ, **env))
+            assert rb.returncode == 0, rb.stderr.decode()[-2000:]
+            assert _lines(rout) == _lines(out), (env, extra, name)
+            assert len(_lines(out)) > 0
+            if "--matrix" in args:
+                assert open(rout + ".matrix").read() == open(out + ".matrix").read(), (env, extra)
+            err = rb.stderr.decode()
+            assert "Time spent sketching the reference" in err and "Time spent mapping fragments in query" in err and "Time spent post mapping" in err
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+def test_cli_streaming_variants_cpu_build(tmp_path):
+    emu = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "all"])
+    _run_streaming_variants(os.path.join(emu, "fastANI_emu"), str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not shipped")
+def test_cli_streaming_variants_gpu(tmp_path):
+    _run_streaming_variants(os.path.join(ROOT, "fastani_amd", "fastANI"), str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_cli_matrix_at_scale_gpu(tmp_path):
+    """--matrix for 20 000 genomes: the reference fills a dense N x N float matrix (1.6 GB here, 32 GB at 90 k genomes,
+    computeCoreIdentity.hpp:353-448); the streamed writer must stay far below that and print the same values"""
+    import resource
+    n = 20000
+    rng = np.random.default_rng(5)
+    base = orc.synth_genome(3, 0, 6400)
+    paths = []
+    for i in range(n):
+        p = os.path.join(str(tmp_path), "m%05d.fa" % i)
+        if i < 6:
+            g = base.copy()
+            m = rng.random(len(g)) < 0.01 * i
+            g[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+        else:
+            g = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 3300)]
+        with open(p, "wb") as f:
+            f.write(b">m%d\n" % i + g.tobytes() + b"\n")
+        paths.append(p)
+    lst = os.path.join(str(tmp_path), "l.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    out = os.path.join(str(tmp_path), "m.out")
+    before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    rb = subprocess.run([os.path.join(ROOT, "fastani_amd", "fastANI"), "--ql", lst, "--rl", lst, "--matrix", "-t", "16", "-o", out], capture_output=True)
+    assert rb.returncode == 0, rb.stderr.decode()[-2000:]
+    rss_mb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1024.0
+    lines = open(out + ".matrix").read().split("\n")
+    assert lines[0] == str(n) and len(lines) == n + 2
+    for i in (0, 1, 5, 6, 19999):
+        f = lines[1 + i].split("\t")
+        assert f[0] == paths[i] and len(f) == 1 + i
+    row5 = lines[1 + 5].split("\t")[1:]
+    assert all(v != "NA" and 90.0 < float(v) <= 100.0 for v in row5)          # the six related genomes
+    assert set(lines[1 + 19999].split("\t")[1:]) == {"NA"}
+    rows = _lines(out)
+    assert len(rows) >= 36 + (n - 6)                                          # 6 x 6 related pairs + every genome against itself
+    assert rss_mb < 1200 or before / 1024.0 >= 1200, "max RSS %.0f MB: the dense matrix alone would be %.0f MB" % (rss_mb, n * n * 4 / 2**20)
+
+
 @pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
 def test_cli_matches_reference_cpu_build(tmp_path):
     emu = os.path.join(ROOT, "tests", "emu")

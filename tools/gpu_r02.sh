@@ -23,12 +23,25 @@ fi
 if has refscale; then
   # how does the untouched reference scale with -t on this host? (1 query x 1000 references, FASTA in /tmp/ani_fa from benchfast)
   ls /tmp/ani_fa/g*.fa | head -1000 > /tmp/ani_fa/rl1000.txt; head -1 /tmp/ani_fa/rl1000.txt > /tmp/ani_fa/q1.txt; head -8 /tmp/ani_fa/rl1000.txt > /tmp/ani_fa/q8.txt
-  for t in 16 32 64; do
-    s=$(date +%s.%N); oracle/_ref/fastANI_ref --ql /tmp/ani_fa/q1.txt --rl /tmp/ani_fa/rl1000.txt -t $t -o /tmp/ani_fa/o.$t > /dev/null 2> "$OUT/ref_t$t.err"; e=$(date +%s.%N)
-    echo "fastANI_ref 1x1000 -t $t: $(echo "$e - $s" | bc) s" | tee -a "$OUT/refscale.txt"; grep -i "time spent" "$OUT/ref_t$t.err" | tail -3 >> "$OUT/refscale.txt"
+  TIMEFORMAT=%R
+  for t in 16 32 64 128; do
+    w=$( { time oracle/_ref/fastANI_ref --ql /tmp/ani_fa/q1.txt --rl /tmp/ani_fa/rl1000.txt -t $t -o /tmp/ani_fa/o.$t > /dev/null 2> "$OUT/ref_t$t.err"; } 2>&1 )
+    echo "fastANI_ref 1x1000 -t $t: wall $w s" | tee -a "$OUT/refscale.txt"; grep -i "time spent" "$OUT/ref_t$t.err" | tail -3 >> "$OUT/refscale.txt"
   done
-  s=$(date +%s.%N); oracle/_ref/fastANI_ref --ql /tmp/ani_fa/q8.txt --rl /tmp/ani_fa/rl1000.txt -t 32 -o /tmp/ani_fa/o.8 > /dev/null 2>&1; e=$(date +%s.%N)
-  echo "fastANI_ref 8x1000 -t 32: $(echo "$e - $s" | bc) s" | tee -a "$OUT/refscale.txt"
+  for t in 32 64; do
+    w=$( { time oracle/_ref/fastANI_ref --ql /tmp/ani_fa/q8.txt --rl /tmp/ani_fa/rl1000.txt -t $t -o /tmp/ani_fa/o.8 > /dev/null 2>&1; } 2>&1 )
+    echo "fastANI_ref 8x1000 -t $t: wall $w s" | tee -a "$OUT/refscale.txt"
+  done
+fi
+if has ab; then
+  echo "== A/B: plain hipcc build vs assembly peephole (device-only, 3 steps)"
+  for v in plain amd plain amd; do
+    ANI_LIB_PATH=$REPO/fastani_amd/csrc/libfastani_$v.so timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('$v', d['value'], d['ms_per_step'], d['stage_ms_per_step_rank0'], d['roofline']['all_kernels_ms_per_step'])" | tee -a "$OUT/ab.txt"
+  done
+fi
+if has c4w; then
+  echo "== bench c4 (10000 refs, 300 queries, 1 GPU, warm)"; timeout 900 python bench.py --config c4 --queries 300 --steps 2 --warmup 1 --no-e2e 2> "$OUT/bench_c4.err" | tee "$OUT/bench_c4.json" | cut -c1-400; tail -3 "$OUT/bench_c4.err"
 fi
 if has o2m; then
   echo "== bench one-to-many"; timeout 600 python bench.py --config one-to-many --steps 5 --warmup 1 --no-e2e 2> "$OUT/bench_o2m.err" | tee "$OUT/bench_o2m.json"; tail -3 "$OUT/bench_o2m.err"

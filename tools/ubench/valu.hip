@@ -9,9 +9,9 @@
 #include <algorithm>
 
 #define REP8(X) X X X X X X X X
-enum Op { ADD, XOR, ALIGNBIT, LSHL, LSHL_ADD, ADD64, MUL_LO, MUL_HI, MAD_U64_U32, MUL_U24, MAD_U24, CNDMASK, BFE, PERM, MIN_U32, LSHL64, DS_READ_U8, DS_READ_B32, DS_WRITE_B8, DS_READ_U16, CND_E64, CND_VCCSET, CMP_VCC, CMP_E64, CMP_CND, BFI, ADD3, AND_OR, MAX_I32, SALU_AND64, SALU_ADD, MIX_VS, READLANE, CMP_CND_E64, SUBREV_ASHR, NOPS };
+enum Op { ADD, XOR, ALIGNBIT, LSHL, LSHL_ADD, ADD64, MUL_LO, MUL_HI, MAD_U64_U32, MUL_U24, MAD_U24, CNDMASK, BFE, PERM, MIN_U32, LSHL64, DS_READ_U8, DS_READ_B32, DS_WRITE_B8, DS_READ_U16, CND_E64, CND_VCCSET, CMP_VCC, CMP_E64, CMP_CND, BFI, ADD3, AND_OR, MAX_I32, SALU_AND64, SALU_ADD, MIX_VS, READLANE, CMP_CND_E64, SUBREV_ASHR, CND_E64_VCC, CMP1_CND7, CMP1_CND7_S, CMP1_CND7_E64VCC, CMP_ADD_CND, CND_VCC_SPACED, NOPS };
 static const char *names[] = {"v_add_u32", "v_xor_b32", "v_alignbit_b32", "v_lshlrev_b32", "v_lshl_add_u32", "v_add_co_u32+v_addc_co_u32 (pair)", "v_mul_lo_u32", "v_mul_hi_u32",
-                              "v_mad_u64_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_cndmask_b32", "v_bfe_u32", "v_perm_b32", "v_min_u32", "v_lshlrev_b64", "ds_read_u8", "ds_read_b32", "ds_write_b8", "ds_read_u16", "v_cndmask_b32_e64 (sgpr pair mask)", "v_cndmask_b32 vcc (vcc set by s_mov in loop)", "v_cmp_lt_u32 vcc", "v_cmp_lt_u32_e64 s[..]", "v_cmp vcc + v_cndmask vcc (pair=2 instr)", "v_bfi_b32", "v_add3_u32", "v_and_or_b32", "v_max_i32", "s_and_b64 (x8)", "s_add_i32 (x8)", "4 v_add_u32 + 4 s_add_i32 interleaved", "v_readlane_b32 (x8)", "v_cmp_e64 s + v_cndmask_e64 s (pair)", "v_sub_u32 + v_ashrrev_i32 (pair: mask in vgpr)"};
+                              "v_mad_u64_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_cndmask_b32", "v_bfe_u32", "v_perm_b32", "v_min_u32", "v_lshlrev_b64", "ds_read_u8", "ds_read_b32", "ds_write_b8", "ds_read_u16", "v_cndmask_b32_e64 (sgpr pair mask)", "v_cndmask_b32 vcc (vcc set by s_mov in loop)", "v_cmp_lt_u32 vcc", "v_cmp_lt_u32_e64 s[..]", "v_cmp vcc + v_cndmask vcc (pair=2 instr)", "v_bfi_b32", "v_add3_u32", "v_and_or_b32", "v_max_i32", "s_and_b64 (x8)", "s_add_i32 (x8)", "4 v_add_u32 + 4 s_add_i32 interleaved", "v_readlane_b32 (x8)", "v_cmp_e64 s + v_cndmask_e64 s (pair)", "v_sub_u32 + v_ashrrev_i32 (pair: mask in vgpr)", "v_cndmask_b32_e64 with vcc operand (stale vcc)", "1 v_cmp vcc + 7 v_cndmask_e32 vcc", "1 v_cmp_e64 s + 7 v_cndmask_e64 s", "1 v_cmp vcc + 7 v_cndmask_e64 vcc", "v_cmp vcc; v_add; v_cndmask vcc; v_add (x2)", "v_cndmask vcc, v_add, v_cndmask vcc, v_add ... (stale vcc)"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint64_t *out, int iters, uint32_t seed)
@@ -61,6 +61,13 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, int iters, uint32_t seed
     if (OP == SALU_ADD) asm volatile("s_add_i32 s20, s20, 3\n s_add_i32 s21, s21, 3\n s_add_i32 s22, s22, 3\n s_add_i32 s23, s23, 3\n s_add_i32 s24, s24, 3\n s_add_i32 s25, s25, 3\n s_add_i32 s26, s26, 3\n s_add_i32 s27, s27, 3" : : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");
     if (OP == MIX_VS) asm volatile("v_add_u32 %0, %0, %4\n s_add_i32 s20, s20, 3\n v_add_u32 %1, %1, %4\n s_add_i32 s21, s21, 3\n v_add_u32 %2, %2, %4\n s_add_i32 s22, s22, 3\n v_add_u32 %3, %3, %4\n s_add_i32 s23, s23, 3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s20", "s21", "s22", "s23", "scc");
     if (OP == READLANE) asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5\n v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %3, 9\n v_readlane_b32 s24, %4, 11\n v_readlane_b32 s25, %5, 13\n v_readlane_b32 s26, %6, 15\n v_readlane_b32 s27, %7, 17" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+
+    if (OP == CND_E64_VCC) asm volatile("v_cndmask_b32_e64 %0, %0, %8, vcc\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc\n v_cndmask_b32_e64 %4, %4, %8, vcc\n v_cndmask_b32_e64 %5, %5, %8, vcc\n v_cndmask_b32_e64 %6, %6, %8, vcc\n v_cndmask_b32_e64 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+    if (OP == CMP1_CND7) asm volatile("v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+    if (OP == CMP1_CND7_S) asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_cndmask_b32_e64 %7, %7, %8, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "s20", "s21");
+    if (OP == CMP1_CND7_E64VCC) asm volatile("v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc\n v_cndmask_b32_e64 %4, %4, %8, vcc\n v_cndmask_b32_e64 %5, %5, %8, vcc\n v_cndmask_b32_e64 %6, %6, %8, vcc\n v_cndmask_b32_e64 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+    if (OP == CMP_ADD_CND) asm volatile("v_cmp_lt_u32 vcc, %0, %8\n v_add_u32 %1, %1, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_add_u32 %3, %3, %8\n v_cmp_lt_u32 vcc, %4, %8\n v_add_u32 %5, %5, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_add_u32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+    if (OP == CND_VCC_SPACED) asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_add_u32 %1, %1, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_add_u32 %3, %3, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_add_u32 %5, %5, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_add_u32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
   }
   const uint64_t t1 = clock64();
   uint32_t sink = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)(w0 ^ w1 ^ w2 ^ w3) ^ (uint32_t)((w0 ^ w1 ^ w2 ^ w3) >> 32);
@@ -98,7 +105,7 @@ int main()
   printf("(ticks = clock64() = s_memtime; 'cyc/instr/SIMD' from wall time assumes the nominal clock)\n");
   uint64_t *d; hipMalloc(&d, (2 + (size_t)cus * 8 * 4) * 8);
   const int iters = 20000;
-  for (int occ : {1, 2, 4, 8}) {
+  for (int occ : {2, 8}) {
     run<ADD>(d, cus, occ, iters, ghz); run<XOR>(d, cus, occ, iters, ghz); run<ALIGNBIT>(d, cus, occ, iters, ghz); run<LSHL>(d, cus, occ, iters, ghz);
     run<LSHL_ADD>(d, cus, occ, iters, ghz); run<ADD64>(d, cus, occ, iters, ghz); run<MUL_LO>(d, cus, occ, iters, ghz); run<MUL_HI>(d, cus, occ, iters, ghz);
     run<MAD_U64_U32>(d, cus, occ, iters, ghz); run<MUL_U24>(d, cus, occ, iters, ghz); run<MAD_U24>(d, cus, occ, iters, ghz); run<CNDMASK>(d, cus, occ, iters, ghz);
@@ -107,6 +114,8 @@ int main()
     run<CMP_CND>(d, cus, occ, iters, ghz); run<CMP_CND_E64>(d, cus, occ, iters, ghz); run<SUBREV_ASHR>(d, cus, occ, iters, ghz); run<BFI>(d, cus, occ, iters, ghz); run<ADD3>(d, cus, occ, iters, ghz);
     run<AND_OR>(d, cus, occ, iters, ghz); run<MAX_I32>(d, cus, occ, iters, ghz); run<SALU_AND64>(d, cus, occ, iters, ghz); run<SALU_ADD>(d, cus, occ, iters, ghz); run<MIX_VS>(d, cus, occ, iters, ghz);
     run<READLANE>(d, cus, occ, iters, ghz);
+    run<CND_E64_VCC>(d, cus, occ, iters, ghz); run<CMP1_CND7>(d, cus, occ, iters, ghz); run<CMP1_CND7_S>(d, cus, occ, iters, ghz); run<CMP1_CND7_E64VCC>(d, cus, occ, iters, ghz);
+    run<CMP_ADD_CND>(d, cus, occ, iters, ghz); run<CND_VCC_SPACED>(d, cus, occ, iters, ghz);
     run<DS_READ_U8>(d, cus, occ, iters / 4, ghz); run<DS_READ_U16>(d, cus, occ, iters / 4, ghz); run<DS_READ_B32>(d, cus, occ, iters / 4, ghz); run<DS_WRITE_B8>(d, cus, occ, iters / 4, ghz);
     printf("\n");
   }
