@@ -28,7 +28,8 @@ Prints ONE JSON line on rank 0 (see the driver contract): value = whole-job pair
   parity_timed_rows — the rows of the LAST TIMED STEP compared with the untouched reference binary (every reference x
                  the CPU-baseline queries) and with the C oracle on >= 200 random pairs;
   cpu_baseline — oracle/_ref/fastANI_ref (the untouched reference, built by oracle/Makefile) timed on this box's host cores
-                 on a bounded sample of the same workload: ALL references x 8 queries, -t <physical cores> (rank 0, N = 1);
+                 on a bounded sample of the same workload: ALL references x 8 queries, -t 16 = its fastest thread count on the
+                 128-core host (rank 0, N = 1);
   end_to_end   — the drop-in CLI (fastani_amd/fastANI) on the same FASTA files on local disk -> output file, wall clock.
 """
 import argparse
@@ -65,6 +66,9 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="fastANI_ref -t: 16 is where the reference is fastest on the 128-core benchmark host (1 x 1000: 39.6 s at 16, 51.9 at 32, "
+                         "83.5 at 64, 117.4 at 128 threads — every thread builds its own hash-map index; profiles/r02_refscale.txt)")
     ap.add_argument("--cpu-refs", type=int, default=0, help="0 = all references of the workload")
     ap.add_argument("--oracle-pairs", type=int, default=240)
     ap.add_argument("--workdir", default="", help="where the FASTA copies of the synthetic set go (default: a temp dir)")
@@ -231,12 +235,13 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
             open(rl, "w").write("\n".join(paths[:n_cpu_refs]) + "\n")
             open(ql, "w").write("\n".join(paths[q] for q in q_ids) + "\n")
             ref_out = os.path.join(td, "ref.out")
-            threads = hi["physical_cores"]
+            threads = max(1, min(args.cpu_threads, hi["physical_cores"]))
             t0 = time.time()
             subprocess.check_call([orc.REF_BIN, "--ql", ql, "--rl", rl, "-t", str(threads), "-o", ref_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             t_cpu = time.time() - t0
             out["cpu_baseline"] = {"value": round(len(q_ids) * n_cpu_refs / t_cpu, 3), "unit": "pairs/s", "cores": threads, "kind": "reference",
-                                   "cpu_model": hi["cpu_model"], "logical_cpus": hi["logical_cpus"],
+                                   "cpu_model": hi["cpu_model"], "logical_cpus": hi["logical_cpus"], "physical_cores": hi["physical_cores"],
+                                   "threads_note": "-t %d = the thread count at which the reference is fastest on this host class (profiles/r02_refscale.txt)" % threads,
                                    "sample": "%d query genome(s) x %d references of the same clustered %d bp set (FASTA on local disk), fastANI_ref -t %d, wall %.1f s incl. FASTA parse"
                                              % (len(q_ids), n_cpu_refs, L, threads, t_cpu)}
             if not args.no_verify:

@@ -213,7 +213,7 @@ struct IndexChunk {
   uint64_t nUnique = 0;
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
-  uint32_t *sHash = nullptr, *bucketStart = nullptr; uint8_t *mDelta = nullptr;
+  uint32_t *sHash = nullptr, *bucketStart = nullptr, *mWin = nullptr; uint8_t *mDelta = nullptr;
   uint64_t *sSW = nullptr;
   int bucketShift = 0; uint32_t nBuckets = 0;
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
@@ -603,7 +603,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 void free_chunk(IndexChunk *ch)
 {
   if (!ch) return;
-  void *ptrs[] = {ch->sSW, ch->mDelta, ch->mHash, ch->mSeq, ch->mWpos, ch->prevSame, ch->nextSame, ch->sHash, ch->bucketStart, ch->contigFirstMin,
+  void *ptrs[] = {ch->mWin, ch->sSW, ch->mDelta, ch->mHash, ch->mSeq, ch->mWpos, ch->prevSame, ch->nextSame, ch->sHash, ch->bucketStart, ch->contigFirstMin,
                   ch->contigGenome, ch->contigBinBase, ch->genomeBinStart, ch->posBase, ch->posSample};
   for (void *q : ptrs) if (q) pool_free(q);
   delete ch;
@@ -658,6 +658,7 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
   SK_HIP(pool_malloc((void **)&sk->mHash, n4)); SK_HIP(pool_malloc((void **)&sk->mSeq, n4)); SK_HIP(pool_malloc((void **)&sk->mWpos, n4));
   SK_HIP(pool_malloc((void **)&sk->prevSame, n4)); SK_HIP(pool_malloc((void **)&sk->nextSame, n4));
   SK_HIP(pool_malloc((void **)&sk->sHash, n4)); SK_HIP(pool_malloc((void **)&sk->mDelta, n + 8)); SK_HIP(pool_malloc((void **)&sk->sSW, 2 * n4));
+  SK_HIP(pool_malloc((void **)&sk->mWin, n4));
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
     uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
@@ -677,6 +678,13 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
     if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
                               (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mDelta, cnt_ptr(ctx, CNT_UNIQ));
+    // window links of the L2 event stream (after the links kernel: both write flag bits of mDelta)
+    {
+      const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
+      if (n && cmw >= 1 && cmw + 2 <= 0xffff)        // otherwise the L2 fast path is off (map_stage) and the links are never read
+        hipLaunchKernelGGL(k_index_window_links, dim3(grid_for((n + kWinRun - 1) / kWinRun, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
+                           (const int32_t *)sk->contigFirstMin, (uint32_t)n, cmw - 1, sk->mWin, sk->mDelta);
+    }
     // bucket table over the top bits of the (density-flattened) bucket key: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
     while (bits < 28 && (1ull << bits) < n) bits++;
@@ -1040,9 +1048,9 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.posBase = sk->posBase; a.posSample = sk->posSample;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.mWin = sk->mWin; a.posBase = sk->posBase; a.posSample = sk->posSample;
     a.contigFirstMin = sk->contigFirstMin;
-    { int lg = 0; while ((2 << lg) <= w) lg++; a.rankShift = 23 - std::max(0, lg - 1); }   // w = 24: 512 buckets over [0, 2^29)
+    { int lg = 0; while ((2 << lg) <= w) lg++; a.rankShift = 21 - std::max(0, lg - 1); }   // w = 24: 2048 buckets over [0, 2^29)
     a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
     a.outBest = ctx->l2Best.as<int32_t>(); a.outFirst = ctx->l2First.as<int32_t>(); a.outLast = ctx->l2Last.as<int32_t>();
     a.sumEntries = cnt_ptr(ctx, CNT_ENTRIES); a.sumSteps = cnt_ptr(ctx, CNT_STEPS); a.sumQ = cnt_ptr(ctx, CNT_SUMQ);
@@ -1085,6 +1093,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       const int32_t fB = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)(c1 - 1)) - ordOff) - 1;
       fa.fragBase = fA;
       { const char *ev = getenv("ANI_L2_PATH"); fa.allowFast = (ev && !strcmp(ev, "general")) ? 0 : (ev && !strcmp(ev, "classB")) ? 2 : 1; }
+      if (L - (w - 1) - (k - 1) + 2 > 0xffff || L - (w - 1) - (k - 1) < 1) fa.allowFast = 0;      // the 16-bit window links need cmw + 2 < 2^16 (and a window at all)
       {
         StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
         hipLaunchKernelGGL(k_l2_ranges, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);

@@ -1,19 +1,20 @@
 #!/bin/bash
 # Builds libfastani_amd.so for gfx950.
 #
-# The device code of ani_abi.hip goes through a one-line assembly peephole between hipcc's code generation and the assembler:
+# Default: hipcc straight through.  ANI_ASM_PEEPHOLE=1 routes the device code of ani_abi.hip through a one-line assembly peephole
+# between hipcc's code generation and the assembler:
 #     v_cndmask_b32_e32 vD, a, vB, vcc   ->   v_cndmask_b32_e64 vD, a, vB, vcc
-# On MI355X two VOP2-encoded v_cndmask_b32 in a row cost ~18-22 cycles each instead of 4 (tools/ubench/valu.hip,
-# profiles/r02_ubench_valu.txt: "1 v_cmp + 7 v_cndmask_e32" 16 cycles per instruction, the same with the VOP3 encoding 4.3);
-# LLVM's instruction shrinking always picks the VOP2 form, and select chains (64-bit compare-exchange = 4 selects, the event
-# selects of the L2 simulation) are all over the hot kernels.  ANI_NO_ASM_PEEPHOLE=1 builds straight through hipcc instead.
+# On MI355X two VOP2-encoded v_cndmask_b32 issued back to back on one SIMD cost ~18-22 cycles each instead of 4
+# (tools/ubench/valu.hip, profiles/r02_ubench_valu.txt: "1 v_cmp + 7 v_cndmask_e32" 16 cycles per instruction, the VOP3 encoding
+# 4.3).  Measured on the product kernels (profiles/r02d_ab.txt) it is worth 1.5 % of k_l2_sim and nothing elsewhere — with
+# several waves per SIMD other waves' instructions separate the selects — so it is not the default build.
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd)
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 LLVM=${LLVM_BIN:-/opt/rocm/lib/llvm/bin}
 OUT=${1:-$HERE/libfastani_amd.so}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
-if [ "${ANI_NO_ASM_PEEPHOLE:-0}" = "1" ]; then
+if [ "${ANI_ASM_PEEPHOLE:-0}" != "1" ]; then
   exec $HIPCC $FLAGS -shared -o "$OUT" "$HERE/ani_abi.hip" "$HERE/sort_device.hip"
 fi
 T=$(mktemp -d)

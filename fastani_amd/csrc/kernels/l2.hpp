@@ -168,17 +168,20 @@ __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
 //
 // Fast path (k_l2_ranges -> k_l2_codes -> k_l2_sim), taken when s <= kL2FastMaxS and the candidate's index range is
 // <= kL2FastMaxEntries long:
-//   k_l2_ranges  one lane per candidate: the three searchIndex() calls of computeMap.hpp:424-436
+//   k_l2_ranges  one lane per candidate: the three searchIndex() calls of computeMap.hpp:424-436 and the length of the
+//                candidate's event stream
 //   k_l2_codes   one workgroup per fragment: the fragment sketch sits in LDS; every reference minimizer of every
-//                candidate range is ranked against it once and stored as one 16-bit entry
-//                  bit 0 = hash is a query hash, bits 1..9 = gap (or rank-1), bit 10 = a same-hash neighbour may share
-//                  a super-window with this entry (nearDup, precomputed at index build), bits 11..15 = wpos - previous
-//                  wpos (31 = escape: read the index)
-//   k_l2_sim     one lane per candidate: the sliding simulation over those entries, one window event per loop pass.  State in
-//                LDS: one byte per sketch rank (7-bit gap counter + presence bit), byte-interleaved over the wave.  Entries are
-//                streamed by two monotone cursors through 16-entry LDS rings (+ 8 entries prefetched in registers per cursor);
-//                refills are issued at wave-uniform points every 8 passes so that their latency never sits on an event's
-//                critical path.  Entries flagged nearDup consult prevSame/nextSame (exact set semantics,
+//                candidate range is ranked against it once and written as its (at most) two window events — it enters the
+//                super-window, it leaves it — at their places in the candidate's MERGED event stream.  The merged order of the
+//                events depends on the reference positions only and is precomputed per index entry (index.hpp:
+//                k_index_window_links), so a place is a few integer operations.  One event = 16 bits:
+//                  bit 0 = hash is a query hash, bits 1..9 = gap (or rank-1), bit 10 = a same-hash neighbour may share a
+//                  super-window with this entry (nearDup, precomputed at index build), bit 11 = insert (else delete),
+//                  bit 12 = do not evaluate the window after this event (first super-window still filling / the insert of
+//                  the same position follows)
+//   k_l2_sim     one lane per candidate: applies its events in order, one per loop pass, 8 events per 16-byte load, no position
+//                arithmetic and no second cursor.  State in LDS: one byte per sketch rank (7-bit gap counter + presence bit),
+//                byte-interleaved over the wave.  Entries flagged nearDup consult prevSame/nextSame (exact set semantics,
 //                slidingMap.hpp:150-154,:178).  A gap counter that would pass 127 sends the candidate to k_l2.
 // ------------------------------------------------------------------------------------------------
 struct L2Args {
@@ -189,10 +192,11 @@ struct L2Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS;
   // reference index, position order
   const uint32_t *mHash; const int32_t *mWpos; const int32_t *prevSame; const int32_t *nextSame;
-  const uint8_t *mDelta;           // min(wpos - previous wpos, 31) | nearDup << 5
+  const uint8_t *mDelta;           // flags per entry: bit 5 = nearDup, bit 6 = its delete is followed by the insert of the same position
+  const uint32_t *mWin;            // window links per entry (index.hpp: k_index_window_links): A16 << 16 | B16
   const int32_t *contigFirstMin;   // [nContigs+1]
   const uint32_t *posBase, *posSample;   // sampled position index (index.hpp: k_index_pos_sample)
-  int rankShift;                   // k_l2_codes rank table: 512 linear buckets of 2^rankShift hashes from 0; minimizer hashes are minima of w
+  int rankShift;                   // k_l2_codes rank table: 2048 linear buckets of 2^rankShift hashes from 0; minimizer hashes are minima of w
                                    // k-mer hashes, ~96 % of them lie below 2^32 * 3 / w, so the table covers [0, 2^(32 - floor(log2 w) + 1))
   int L, w, k;
   // lane-interleaved scratch of the general kernel: (maxS+1) words per lane
@@ -233,27 +237,26 @@ constexpr int kL2FastMaxEntries = 16384;
 // pivot logic, which needs n[j] together with b[j+1], reads exactly field[j].  Fields are byte-interleaved over the wave
 // (field g of lane l at byte g*64 + l, see l2_field_off; the conflict-free word-interleaved alternative costs three more
 // address instructions per access and measured the same kernel time).
-//   class A  s <= 255: 64 words + 16-entry cursor rings (16 words) = 320 B per lane -> 20 KiB per wave, 8 waves per CU
-//   class B  s <= 319: 80 words + rings                            = 384 B per lane -> 24 KiB per wave, 6 waves per CU
+//   class A  s <= 255: 64 words = 256 B per lane -> 16 KiB per wave, 10 waves per CU
+//   class B  s <= 319: 80 words = 320 B per lane -> 20 KiB per wave,  8 waves per CU
 // A counter that would pass 127 sends the candidate to the general kernel.
 template <int MAXS>
 struct L2Geom {
   static constexpr int kMaxS = MAXS;
   static constexpr int kStateWords = (MAXS + 1 + 3) / 4;
-  static constexpr int kRingWords = 16;                     // 2 cursors x 16 entries x 16 bit
-  static constexpr int kWords = kStateWords + kRingWords;
+  static constexpr int kWords = kStateWords;
 };
 using L2GeomA = L2Geom<255>;
 using L2GeomB = L2Geom<319>;
 constexpr int kL2SimTPB = 64;
 
-struct L2Range { int32_t beg0, end0, last, wposBeg0; };
+struct L2Range { int32_t beg0, end0, last, nEvents; };    // nEvents = length of the candidate's event stream
 
 struct L2FastArgs {
   L2Args g;
   int32_t c0, c1;                  // candidate chunk [c0, c1)
   L2Range *ranges;                 // [c1-c0]
-  int32_t *codeCount;              // [c1-c0] 16-bit entries per candidate rounded up to 8, 0 = not on the fast path
+  int32_t *codeCount;              // [c1-c0] 16-bit events per candidate rounded up to 8, 0 = not on the fast path (or nothing to simulate)
   const uint32_t *codeOff;         // [c1-c0] exclusive scan of codeCount (in entries)
   uint32_t *codes;
   int32_t *slowFlag;               // [c1-c0] 1 = take the general kernel
@@ -280,26 +283,44 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
     return lower_bound_wpos(a.g.mWpos, lo, hi, pos);
   };
   r.beg0 = search(a.g.candStart[c]);
-  r.wposBeg0 = a.g.mWpos[r.beg0];
-  r.end0 = search(r.wposBeg0 + cmw);
+  const int32_t wposBeg0 = a.g.mWpos[r.beg0];
+  r.end0 = search(wposBeg0 + cmw);
   r.last = search(a.g.candEnd[c] + a.g.L);
-  a.ranges[i] = r;
   const int32_t m = r.last - r.beg0;
   const int32_t s = a.g.fragS[a.g.candFrag[c]];
   const bool fast = a.allowFast && s >= 1 && s <= kL2FastMaxS && m >= 1 && m <= kL2FastMaxEntries;
-  a.codeCount[i] = fast ? ((m + 7) & ~7) : 0;      // 16-bit entries, padded to 16-byte blocks
+  // event stream: the first super-window's entries [beg0, end0), then one insert per entry of [end0, last-1) and one delete per
+  // entry up to the last one that leaves before entry last-1 would enter (which ends the loop, computeMap.hpp:455)
+  int32_t nEv = 0;
+  if (fast && r.end0 < r.last) {
+    const int32_t lastDel = (r.last - 1) - (int32_t)(a.g.mWin[r.last - 1] & 0xffffu) - 2;     // deletes with D_j <= I_(last-1)
+    const int32_t nDel = lastDel >= r.beg0 ? lastDel - r.beg0 + 1 : 0;
+    nEv = (r.end0 - r.beg0) + (r.last - 1 - r.end0) + nDel;
+  }
+  r.nEvents = nEv;
+  a.ranges[i] = r;
+  if (fast && nEv == 0) {                            // the window never fits: the loop of :455 does not run, nothing is evaluated
+    a.g.outBest[c] = 0; a.g.outFirst[c] = 0; a.g.outLast[c] = 0;
+    a.codeCount[i] = 0; a.slowFlag[i] = 16;          // done
+    return;
+  }
+  a.codeCount[i] = fast ? ((nEv + 7) & ~7) : 0;      // 16-bit events, padded to 16-byte blocks
   a.slowFlag[i] = fast ? ((s <= L2GeomA::kMaxS && a.allowFast != 2) ? 0 : 4) : 1;
 }
 
-constexpr uint32_t kL2DupBit = 1u << 10;
-constexpr int kL2RankBuckets = 512;
+constexpr uint32_t kL2DupBit = 1u << 10, kL2InsBit = 1u << 11, kL2NoEvalBit = 1u << 12;
+constexpr int kL2RankBuckets = 2048;
 // rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
 __device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh; return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
-constexpr uint32_t kL2DwEscape = 31u;
 
+// One workgroup per fragment.  The kernel is instruction-issue-bound (every wave instruction, vector or scalar, costs about four
+// SIMD cycles on MI355X: tools/ubench/valu.hip), so the loop is built for few instructions per entry: a thread ranks four
+// consecutive entries per pass (one address computation, one 8-byte store), and the rank lookup has no loop — the rank table has
+// 2048 buckets for ~240 sketch hashes, so a bucket holds at most two of them except in rare cases, which a wave vote sends to a
+// binary search.
 __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
-  __shared__ uint32_t qs[kL2FastMaxS + 1];
+  __shared__ uint32_t qs[kL2FastMaxS + 2];
   __shared__ uint16_t st[kL2RankBuckets + 2];
   const int32_t f = a.fragBase + blockIdx.x;
   const int32_t s = a.g.fragS[f];
@@ -309,7 +330,8 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   if (cA >= cB || s < 1 || s > kL2FastMaxS) return;
   const uint32_t *q = a.g.qPool + a.g.fragOff[f];
   for (int i = threadIdx.x; i < s; i += kTPB) qs[i] = q[i];
-  // rank table: st[b] = #{q : bucket(q) < b}; a lookup then searches the one or two sketch entries of the hash's bucket
+  if (threadIdx.x < 2) qs[s + threadIdx.x] = 0xffffffffu;             // the two-entry probe may read one or two slots past the sketch
+  // rank table: st[b] = #{q : bucket(q) < b}; a lookup then looks at the (at most two, as a rule) sketch entries of the hash's bucket
   const int sh = a.g.rankShift;
   for (int i = threadIdx.x; i <= s; i += kTPB) {
     const int b0 = i > 0 ? l2_rank_bucket(q[i - 1], sh) + 1 : 0;
@@ -324,49 +346,59 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     uint16_t *out = (uint16_t *)a.codes + a.codeOff[i];
     const uint8_t *__restrict__ dlt = a.g.mDelta + r.beg0;            // unsigned 32-bit offsets from per-candidate bases:
     const uint32_t *__restrict__ hsh = a.g.mHash + r.beg0;            // scalar base + vector offset addressing, no 64-bit index math
+    const uint32_t *__restrict__ win = a.g.mWin + r.beg0;
     const uint32_t m = (uint32_t)(r.last - r.beg0);
-    for (uint32_t j = threadIdx.x; j < m; j += kTPB) {
-      const uint32_t dl = dlt[j];
-      const uint32_t dw = j > 0 ? (dl & 31u) : 0u;
-      const uint32_t h = hsh[j];
-      const int rb = l2_rank_bucket(h, sh);
-      int lo = st[rb], hi = st[rb + 1];
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h) lo = mid + 1; else hi = mid; }
-      const uint32_t rk = ((uint32_t)lo << 1) | (uint32_t)((lo < s) & (qs[lo < s ? lo : s - 1] == h));   // == q_rank(qs, s, h), no branch
-      out[j] = (uint16_t)(rk | ((dl & 32u) ? kL2DupBit : 0u) | (dw << 11));
+    const int32_t nInit = r.end0 - r.beg0, nInsAll = (int32_t)m - 1;  // inserts (first window included) are the entries [0, m-1)
+    const int32_t nDel = r.nEvents - nInsAll;                         // deletes are the entries [0, nDel)
+    for (uint32_t j = 4u * threadIdx.x; j < m; j += 4u * kTPB) {
+      uint32_t h[4], dl[4], wl[4], rk[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { const uint32_t x = j + e < m ? j + e : m - 1; h[e] = hsh[x]; dl[e] = dlt[x]; wl[e] = win[x]; }
+      bool deep = false;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int rb = l2_rank_bucket(h[e], sh);
+        const uint32_t lo = st[rb], nb = st[rb + 1] - lo;
+        const uint32_t q0 = qs[lo], q1 = qs[lo + 1];                  // sentinels 0xffffffff behind the sketch
+        const uint32_t in0 = nb > 0, in1 = nb > 1;
+        const uint32_t lt = (in0 & (q0 < h[e])) + (in1 & (q1 < h[e]));
+        const uint32_t eq = (in0 & (q0 == h[e])) | (in1 & (q1 == h[e]));
+        rk[e] = ((lo + lt) << 1) | eq;
+        deep |= nb > 2 && q1 < h[e];                                  // more than two sketch hashes in the bucket and the answer lies beyond them
+      }
+      if (__any(deep)) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int rb = l2_rank_bucket(h[e], sh);
+          int lo = st[rb], hi = st[rb + 1];
+          if (hi - lo > 2) {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h[e]) lo = mid + 1; else hi = mid; }
+            rk[e] = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h[e]);    // == q_rank(qs, s, h)
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int32_t x = (int32_t)(j + e);
+        if (x >= (int32_t)m) break;
+        const uint32_t cd = rk[e] | ((dl[e] & 32u) << 5);             // nearDup: bit 5 of mDelta -> kL2DupBit
+        // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B16 - 2
+        if (x < nInsAll) {
+          int32_t db = x - (int32_t)(wl[e] & 0xffffu) - 1;            // deletes that precede it
+          db = db < 0 ? 0 : db;
+          out[x + db] = (uint16_t)(cd | kL2InsBit | (x < nInit - 1 ? kL2NoEvalBit : 0u));
+        }
+        // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A16 (at least the
+        // first window's)
+        if (x < nDel) {
+          int32_t ib = x + (int32_t)(wl[e] >> 16);
+          ib = ib < nInit ? nInit : ib;
+          out[x + ib] = (uint16_t)(cd | ((dl[e] & 64u) ? kL2NoEvalBit : 0u));
+        }
+      }
     }
   }
 }
-
-// One monotone cursor over a candidate's 16-bit entries.  Entries [8b, 8b+16) sit in a 16-entry LDS ring (entry j at ring
-// slot j & 15, lane-interleaved dwords => conflict-free ds_read_u16), block b+2 is in flight in registers.  sync() is called
-// at wave-uniform points at most 8 consumed entries apart; its global load is unconditional and outside divergent control
-// flow on purpose, so that it stays in flight until the next sync() instead of being waited for at a branch join.
-struct L2Stream {
-  const uint4 *p; int b; uint4 B;
-  uint32_t *ring;                // this lane's dword 0 of the cursor's ring: dword d at ring[d * kWave]
-  __device__ __forceinline__ void put(int blk, const uint4 v)
-  {
-    uint32_t *r = ring + ((blk & 1) * 4) * kWave;
-    r[0] = v.x; r[kWave] = v.y; r[2 * kWave] = v.z; r[3 * kWave] = v.w;
-  }
-  __device__ __forceinline__ void init(const uint4 *p_, uint32_t *ring_)
-  {
-    p = p_; ring = ring_; b = 0;
-    put(0, p[0]); put(1, p[1]); B = p[2];
-  }
-  __device__ __forceinline__ void sync(int j)
-  {
-    if (j - 8 * b >= 8) { put(b, B); b++; }      // block b is consumed: block b+2 takes its ring slot
-    B = p[b + 2];
-  }
-  __device__ __forceinline__ uint32_t get(int j) const
-  {
-    const int e = j & 15;
-    const uint16_t *h = (const uint16_t *)(ring + (e >> 1) * kWave);
-    return h[e & 1];
-  }
-};
 
 // One window event, written without control flow (selects only).  INS: the entry enters the window (slidingMap.hpp:137-161
 // + :231-254), otherwise it leaves (:167-211 + :261-284).  Both LDS reads (the entry's own field and the field next to the
@@ -410,10 +442,18 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
   r.cStar -= INS ? cm : -cm;
 }
 
-// slowFlag protocol: 0 = class A (pending or done), 4 = class B pending (s in 256..319), 8 = class B done,
-//                    1 = outside every fast-path limit, 3 = a gap counter overflowed -> general kernel
+// slowFlag protocol: 0 = class A (pending or done), 4 = class B pending (s in 256..319), 8 = class B done, 16 = done without a
+//                    simulation (the window never fits the range), 1 = outside every fast-path limit,
+//                    3 = a gap counter overflowed -> general kernel
 // `list` (optional): candidate ids to run, densely packed so that the few class-B candidates fill whole waves instead of
 // leaving one busy lane in every wave; *listCount is read on the device (no host round trip).
+//
+// The kernel is instruction-issue-bound, so the loop carries nothing but the events: 8 events arrive per 16-byte load (the next
+// block is in flight while the current one is applied), an event is a register field — no ring, no position arithmetic, no
+// choice between two cursors — and control flow is wave-uniform: a lane whose stream has ended idles (`on` = false) until the
+// longest stream of the wave is done (lanes are ordered by stream length), the rare same-hash-neighbour look-ups sit behind a
+// wave vote.  Positions are not tracked at all: the window start of an evaluation is "entry number delCount", and the two
+// positions the result needs are read from the index when the stream is done.
 template <class G>
 __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_t *__restrict__ list, const unsigned int *__restrict__ listCount)
 {
@@ -421,7 +461,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   uint32_t *W = lds + wv * (G::kWords * kWave);                       // this wave's LDS
   uint8_t *F = (uint8_t *)W + (kL2ByteInterleave ? lane : 4 * lane);   // field g of this lane: F[l2_field_off(g)]
-  uint32_t *S = W + lane;                                             // dword x of this lane: S[x * kWave] (cursor rings)
+  uint32_t *S = W + lane;                                             // dword x of this lane: S[x * kWave]
   const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   int32_t c = a.c0 + slot;
   if (list) {
@@ -435,92 +475,53 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   unsigned long long cntE = 0, cntS = 0, cntQ = 0;
   const int myFlag = c < a.c1 ? a.slowFlag[c - a.c0] : 1;
   const bool mine = (G::kMaxS == 255) ? (myFlag == 0) : (myFlag == 4);
-  if (mine) {
-    const int32_t i = c - a.c0;
-    const L2Range r = a.ranges[i];
-    const int32_t f = a.g.candFrag[c];
-    const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
-    const int m = r.last - r.beg0;
-    L2Regs R; R.s = a.g.fragS[f]; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = false;
-    // wpos of entry j given the previous entry's wpos and the entry's 5-bit delta (31 = look it up)
-    auto next_wpos = [&](int32_t prev, uint32_t code, int j) -> int32_t {
-      const uint32_t dw = code >> 11;
-      int32_t wp = prev + (int32_t)dw;
-      if (dw == kL2DwEscape) { wp = a.g.mWpos[r.beg0 + j]; ANI_CONSUME(wp); }     // rare; the load is waited for here, not in the loop body
-      return wp;
-    };
-    const uint4 *base = (const uint4 *)((const uint16_t *)a.codes + a.codeOff[i]);
-    L2Stream cb, ce;
-    cb.init(base, S + G::kStateWords * kWave);
-    ce.init(base, S + (G::kStateWords + 8) * kWave);
-    // first super-window: entries [0, end0-beg0)  (computeMap.hpp:448)
-    int end = r.end0 - r.beg0, beg = 0;
-    int32_t wEnd = r.wposBeg0;                       // becomes wpos of entry `end`
-    for (int j = 0; j < end; j++) {
-      if ((j & 7) == 0) ce.sync(j);
-      const uint32_t cd = ce.get(j);
-      if (j > 0) wEnd = next_wpos(wEnd, cd, j);
-      bool eff = true;
-      if (cd & kL2DupBit) eff = a.g.prevSame[r.beg0 + j] < r.beg0;
-      l2_apply(F, R, cd, true, eff);
-    }
-    uint32_t codeEnd = 0;
-    if (end < m) { codeEnd = ce.get(end); wEnd = next_wpos(wEnd, codeEnd, end); }
-    int32_t wBeg = r.wposBeg0;
-    uint32_t codeBeg = cb.get(0);
-    uint32_t codeBegNext = (1 < m) ? cb.get(1) : 0u;
-    int32_t wBegNext = (1 < m) ? next_wpos(wBeg, codeBegNext, 1) : wBeg;
-    int best = 0; int32_t firstPos = 0, lastPos = 0; int steps = 0;
-    // Event-driven form of the loop at computeMap.hpp:455-481.  A step of the reference advances MIIteratorL2 to the nearer of
-    //   pB = wpos[beg+1]            (the first entry leaves:  delete_ref(beg),  beg++)
-    //   pE = wpos[end] - cmw + 1    (entry `end` fits:        insert_ref(end),  end++)
-    // applies the delete and/or the insert and evaluates the window; the loop ends, unevaluated, with the insert that takes
-    // `end` to the end of the range.  Nearly every step carries one event only, so one pass of this loop is ONE event: apply it,
-    // advance its cursor, evaluate unless the insert of the same position (pB == pE: delete first, as the reference does) is
-    // still to come.  wpos is strictly increasing inside a contig, so after such a delete the next event is that insert.
-    if (end < m) {
-      best = R.shared; firstPos = R.shared > 0 ? wBeg : 0; lastPos = wBeg; steps = 1;     // first pass of :455, no events
-      const int32_t cmw1 = cmw - 1;
-      int b1 = 1;                                    // beg + 1
-      const uint32_t *ringB = S + G::kStateWords * kWave;
-      for (int it = 0; !R.ovf; it++) {
-        if ((it & 7) == 0) { cb.sync(b1); ce.sync(end); }
-        const int32_t pE = wEnd - cmw1;
-        const bool del = wBegNext <= pE;
-        if (!del && end + 1 >= m) break;
-        const bool more = del && wBegNext == pE;     // the insert of this step follows
-        const uint32_t code = del ? codeBeg : codeEnd;
-        bool eff = true;
-        if (code & kL2DupBit) {
-          if (del) {                                 // stays iff a later same-hash entry is already in the window
-            const int32_t nx = a.g.nextSame[r.beg0 + b1 - 1];
-            eff = !(nx >= 0 && nx < r.beg0 + end);
-          } else eff = a.g.prevSame[r.beg0 + end] < r.beg0 + b1 - 1;       // new iff no same-hash entry in [beg, end)
+  const int32_t i = mine ? c - a.c0 : 0;
+  L2Range r; r.beg0 = 0; r.end0 = 0; r.last = 0; r.nEvents = 0;
+  if (mine) r = a.ranges[i];
+  const int n = r.nEvents;                                            // 0 for a lane without a candidate: it idles
+  L2Regs R; R.s = mine ? a.g.fragS[a.g.candFrag[c]] : 1; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = false;
+  const uint4 *p = (const uint4 *)((const uint16_t *)a.codes + (mine ? a.codeOff[i] : 0u));      // idle lanes read the head of the buffer
+  const int nBlk = (n + 7) >> 3;
+  int best = 0, begAtBest = -1, begAtLast = -1, steps = 0, delCount = 0;
+  uint4 cur = p[0];
+  for (int blk = 0; __any(blk < nBlk); blk++) {
+    const int nb = blk + 1 < nBlk ? blk + 1 : blk;                     // never beyond the lane's own stream
+    const uint4 nxt = p[nb];
+    const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const uint32_t code = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffffu);
+      const int ev = 8 * blk + e;                                     // events applied so far
+      const bool on = ev < n;
+      const bool INS = (code & kL2InsBit) != 0;
+      bool eff = on;
+      if (__any(on && (code & kL2DupBit) != 0)) {
+        if (on && (code & kL2DupBit)) {
+          const int insCount = ev - delCount;                         // entries [delCount, insCount) are in the window
+          if (INS) eff = a.g.prevSame[r.beg0 + insCount] < r.beg0 + delCount;            // new iff no same-hash entry in [beg, end)
+          else { const int32_t nx = a.g.nextSame[r.beg0 + delCount]; eff = !(nx >= 0 && nx < r.beg0 + insCount); }   // stays iff a later same-hash entry is in the window
         }
-        // the cursor of this event advances: fetch entry beg+2 resp. end+1 (both inside the range, see above).  Read before the
-        // state update so that its LDS latency overlaps the field reads of l2_apply instead of following its byte store.
-        const int jf = (del ? b1 : end) + 1;
-        const uint16_t *h = (const uint16_t *)(ringB + (del ? 0 : 8 * kWave) + ((jf & 15) >> 1) * kWave);
-        const uint32_t cf = h[jf & 1];
-        l2_apply(F, R, code, !del, eff);
-        const int32_t wf = next_wpos(del ? wBegNext : wEnd, cf, jf);
-        codeBeg = del ? codeBegNext : codeBeg; wBeg = del ? wBegNext : wBeg;
-        codeBegNext = del ? cf : codeBegNext; wBegNext = del ? wf : wBegNext;
-        codeEnd = del ? codeEnd : cf; wEnd = del ? wEnd : wf;
-        b1 += del ? 1 : 0; end += del ? 0 : 1;
-        // evaluate (:468-476)
-        const bool better = !more && R.shared > best, tieOrBetter = !more && R.shared >= best;
-        best = better ? R.shared : best;
-        firstPos = better ? wBeg : firstPos;
-        lastPos = tieOrBetter ? wBeg : lastPos;
-        steps += more ? 0 : 1;
       }
+      l2_apply(F, R, code, INS, eff);
+      delCount += (on && !INS) ? 1 : 0;
+      // evaluate (computeMap.hpp:468-476) with the window starting at entry number delCount
+      const bool evl = on && (code & kL2NoEvalBit) == 0;
+      const bool better = evl && R.shared > best, tieOrBetter = evl && R.shared >= best;
+      best = better ? R.shared : best;
+      begAtBest = better ? delCount : begAtBest;
+      begAtLast = tieOrBetter ? delCount : begAtLast;
+      steps += evl ? 1 : 0;
     }
+    cur = nxt;
+  }
+  if (mine) {
     if (R.ovf) a.slowFlag[i] = 3;
     else {
       a.slowFlag[i] = (G::kMaxS == 255) ? 0 : 8;     // class B runs concurrently with class A: its "done" must not read as class A
-      a.g.outBest[c] = best; a.g.outFirst[c] = firstPos; a.g.outLast[c] = lastPos;
-      cntE = (unsigned long long)m; cntS = (unsigned long long)steps; cntQ = (unsigned long long)R.s;
+      a.g.outBest[c] = best;
+      a.g.outFirst[c] = begAtBest >= 0 ? a.g.mWpos[r.beg0 + begAtBest] : 0;
+      a.g.outLast[c] = begAtLast >= 0 ? a.g.mWpos[r.beg0 + begAtLast] : 0;
+      cntE = (unsigned long long)(r.last - r.beg0); cntS = (unsigned long long)steps; cntQ = (unsigned long long)R.s;
     }
   }
 #pragma unroll
@@ -539,14 +540,14 @@ __global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restri
 
 // Candidates of a chunk ordered by the length of their code stream (counting sort on codeCount / 16): the 64 lanes of a wave
 // then run about the same number of steps instead of waiting for the longest of 64 random candidates.
-constexpr int kL2LenBuckets = 1024;      // codeCount <= 16384 -> bucket = codeCount >> 4
+constexpr int kL2LenBuckets = 1024;      // codeCount <= 2 * 16384 -> bucket = codeCount >> 5
 __global__ __launch_bounds__(kTPB) void k_l2_len_hist(const int32_t *__restrict__ codeCount, int32_t n, unsigned int *__restrict__ hist)
 {
   __shared__ unsigned int h[kL2LenBuckets];
   for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) h[i] = 0;
   __syncthreads();
   for (int i = blockIdx.x * kTPB + threadIdx.x; i < n; i += gridDim.x * kTPB) {
-    int b = codeCount[i] >> 4; b = b >= kL2LenBuckets ? kL2LenBuckets - 1 : b;
+    int b = codeCount[i] >> 5; b = b >= kL2LenBuckets ? kL2LenBuckets - 1 : b;
     atomicAdd(&h[kL2LenBuckets - 1 - b], 1u);                  // longest first
   }
   __syncthreads();
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_len_scatter(const int32_t *__restri
   const int i = blockIdx.x * kTPB + threadIdx.x;
   int b = 0; unsigned int r = 0;
   if (i < n) {
-    b = codeCount[i] >> 4; b = b >= kL2LenBuckets ? kL2LenBuckets - 1 : b;
+    b = codeCount[i] >> 5; b = b >= kL2LenBuckets ? kL2LenBuckets - 1 : b;
     b = kL2LenBuckets - 1 - b;
     r = atomicAdd(&cnt[b], 1u);
   }

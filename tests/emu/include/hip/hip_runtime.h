@@ -34,6 +34,7 @@ struct dim3 {
 struct emu_uint3 { unsigned x, y, z; };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 
 namespace hipemu {
 extern emu_uint3 g_threadIdx, g_blockIdx;
