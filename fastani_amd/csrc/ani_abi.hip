@@ -681,9 +681,9 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     // window links of the L2 event stream (after the links kernel: both write flag bits of mDelta)
     {
       const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
-      if (n && cmw >= 1 && cmw + 2 <= 0xffff)        // otherwise the L2 fast path is off (map_stage) and the links are never read
-        hipLaunchKernelGGL(k_index_window_links, dim3(grid_for((n + kWinRun - 1) / kWinRun, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
-                           (const int32_t *)sk->contigFirstMin, (uint32_t)n, cmw - 1, sk->mWin, sk->mDelta);
+      if (n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask)        // otherwise the L2 fast path is off (map_stage) and the links are never read
+        hipLaunchKernelGGL(k_index_window_links, dim3(grid_for(n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
+                           (const int32_t *)sk->contigFirstMin, (const uint8_t *)sk->mDelta, (uint32_t)n, cmw - 1, sk->mWin);
     }
     // bucket table over the top bits of the (density-flattened) bucket key: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
@@ -1048,7 +1048,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mDelta = sk->mDelta; a.mWin = sk->mWin; a.posBase = sk->posBase; a.posSample = sk->posSample;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mWin = sk->mWin; a.posBase = sk->posBase; a.posSample = sk->posSample;
     a.contigFirstMin = sk->contigFirstMin;
     { int lg = 0; while ((2 << lg) <= w) lg++; a.rankShift = 21 - std::max(0, lg - 1); }   // w = 24: 2048 buckets over [0, 2^29)
     a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
@@ -1093,7 +1093,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       const int32_t fB = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)(c1 - 1)) - ordOff) - 1;
       fa.fragBase = fA;
       { const char *ev = getenv("ANI_L2_PATH"); fa.allowFast = (ev && !strcmp(ev, "general")) ? 0 : (ev && !strcmp(ev, "classB")) ? 2 : 1; }
-      if (L - (w - 1) - (k - 1) + 2 > 0xffff || L - (w - 1) - (k - 1) < 1) fa.allowFast = 0;      // the 16-bit window links need cmw + 2 < 2^16 (and a window at all)
+      if (L - (w - 1) - (k - 1) + 2 > (int)kWinMask || L - (w - 1) - (k - 1) < 1) fa.allowFast = 0;      // the 14-bit window links need cmw + 2 < 2^14 (and a window at all)
       {
         StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
         hipLaunchKernelGGL(k_l2_ranges, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);
@@ -1119,7 +1119,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Codes, 1);
-          hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)(fB - fA + 1)), dim3(kTPB), 0, ctx->stream, fa);
+          fa.nFragChunk = fB - fA + 1;
+          hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)((fa.nFragChunk + 7) / 8 * 8)), dim3(kTPB), 0, ctx->stream, fa);
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);

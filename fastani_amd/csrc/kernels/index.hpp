@@ -22,8 +22,7 @@ __global__ void k_index_split(const uint32_t *__restrict__ records, uint32_t n, 
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t h = records[3 * (size_t)i], sq = records[3 * (size_t)i + 1] - seqBase, wp = records[3 * (size_t)i + 2];   // chunk-local seqId
     mHash[i] = h; mSeq[i] = (int32_t)sq; mWpos[i] = (int32_t)wp;
-    // one flag byte per entry for the L2 event stream: bit 5 = nearDup (k_index_links), bit 6 = its delete is directly followed by
-    // the insert of the same position (k_index_window_links)
+    // one flag byte per entry: bit 5 = nearDup (k_index_links; k_index_window_links copies it into mWin)
     mDelta[i] = 0;
     prevSame[i] = -1; nextSame[i] = -1;                          // links/flags are only written for near duplicates (rare)
     keyOut[i] = h; valOut[i] = ((uint64_t)sq << 32) | wp;
@@ -129,50 +128,35 @@ __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t 
 // Window links for the L2 event stream (l2.hpp).  A candidate's sliding super-window (MIIteratorL2.hpp:74-96) deletes entry j at
 // position D_j = wpos[j+1] and inserts entry e at I_e = wpos[e] - cmw + 1; the merged order of those events (a delete before an
 // insert at the same position, as the reference applies them) does not depend on the candidate or the query, only on the
-// reference positions, so it is computed once per index:
-//   hi 16 bits  A16[j] = (first e with I_e >= D_j) - j          inserts that precede the delete of j: entries below j + A16[j]
-//   lo 16 bits  B16[e] = e - (first x with wpos[x] > wpos[e] - cmw + 1)   deletes that precede the insert of e: entries up to e - B16[e] - 2
-//   bit 6 of mDelta[j] = the insert at the same position follows the delete of j (I_e == D_j): no evaluation in between
-// Both offsets count entries inside one super-window (<= cmw + 1 < 2^16, checked by the host).  One thread walks kWinRun
-// consecutive entries: a binary search for the first, then the two pointers only move forward.
-constexpr int kWinRun = 32;
+// reference positions, so it is computed once per index, one 32-bit word per entry:
+//   bits 14..27  A[j] = (first e with I_e >= D_j) - j            inserts that precede the delete of j: entries below j + A[j]
+//   bits  0..13  B[e] = e - (first x with wpos[x] > wpos[e] - cmw + 1)   deletes that precede the insert of e: entries up to e - B[e] - 2
+//   bit 30       the insert at the same position follows the delete of j (I_e == D_j): no evaluation in between
+//   bit 31       nearDup (copied from mDelta bit 5, set by k_index_links)
+// Both offsets count entries inside one super-window (<= cmw + 1 < 2^14, checked by the host).  One thread per entry, two binary
+// searches over at most cmw entries; the lanes of a wave search neighbouring ranges with the same step pattern, so the loads
+// coalesce.
+constexpr uint32_t kWinMask = 0x3fffu, kWinMoreBit = 1u << 30, kWinDupBit = 1u << 31;
+constexpr int kWinShiftA = 14;
 __global__ void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
-                                     uint32_t n, int32_t cmw1, uint32_t *__restrict__ mWin, uint8_t *__restrict__ mDelta)
+                                     const uint8_t *__restrict__ mDelta, uint32_t n, int32_t cmw1, uint32_t *__restrict__ mWin)
 {
-  for (uint32_t j0 = (blockIdx.x * blockDim.x + threadIdx.x) * (uint32_t)kWinRun; j0 < n; j0 += gridDim.x * blockDim.x * (uint32_t)kWinRun) {
-    int32_t seq = -1, cLo = 0, cHi = 0, a = 0, u = 0;
-    const uint32_t j1 = j0 + kWinRun < n ? j0 + kWinRun : n;
-    for (uint32_t j = j0; j < j1; j++) {
-      const int32_t sq = mSeq[j];
-      const int32_t wj = mWpos[j];
-      if (sq != seq) {
-        seq = sq; cLo = contigFirstMin[sq]; cHi = contigFirstMin[sq + 1];
-        // u = first x in [cLo, j] with wpos[x] > wj - cmw1
-        int32_t lo = cLo, hi = (int32_t)j;
-        while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] <= wj - cmw1) lo = mid + 1; else hi = mid; }
-        u = lo;
-        a = (int32_t)j + 1;
-        if ((int32_t)j + 1 < cHi) {
-          const int32_t tgt = mWpos[j + 1] + cmw1;
-          lo = (int32_t)j + 1; hi = cHi;
-          while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < tgt) lo = mid + 1; else hi = mid; }
-          a = lo;
-        }
-      } else {
-        while (mWpos[u] <= wj - cmw1) u++;                            // stops at j at the latest (cmw1 >= 0)
-      }
-      uint32_t a16 = 0, more = 0;
-      if ((int32_t)j + 1 < cHi) {
-        const int32_t tgt = mWpos[j + 1] + cmw1;
-        if (a < (int32_t)j + 1) a = (int32_t)j + 1;
-        while (a < cHi && mWpos[a] < tgt) a++;
-        a16 = (uint32_t)(a - (int32_t)j);
-        more = (a < cHi && mWpos[a] == tgt) ? 1u : 0u;
-      }
-      const uint32_t b16 = (uint32_t)((int32_t)j - u);
-      mWin[j] = (a16 > 0xffffu ? 0xffffu : a16) << 16 | (b16 > 0xffffu ? 0xffffu : b16);
-      if (more) mDelta[j] |= 0x40u;                                   // this thread owns the bytes of its run (k_index_links is done)
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int32_t sq = mSeq[j], wj = mWpos[j];
+    const int32_t cLo = contigFirstMin[sq], cHi = contigFirstMin[sq + 1];
+    // u = first x in [max(cLo, j - cmw1), j] with wpos[x] > wj - cmw1   (wpos is strictly increasing: at most one entry per position)
+    int32_t lo = (int32_t)j - cmw1 > cLo ? (int32_t)j - cmw1 : cLo, hi = (int32_t)j;
+    while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] <= wj - cmw1) lo = mid + 1; else hi = mid; }
+    const uint32_t b = (uint32_t)((int32_t)j - lo);
+    uint32_t a = 0, more = 0;
+    if ((int32_t)j + 1 < cHi) {
+      const int32_t tgt = mWpos[j + 1] + cmw1;
+      lo = (int32_t)j + 1; hi = (int32_t)j + 2 + cmw1 < cHi ? (int32_t)j + 2 + cmw1 : cHi;
+      while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < tgt) lo = mid + 1; else hi = mid; }
+      a = (uint32_t)(lo - (int32_t)j);
+      more = (lo < cHi && mWpos[lo] == tgt) ? kWinMoreBit : 0u;
     }
+    mWin[j] = (a > kWinMask ? kWinMask : a) << kWinShiftA | (b > kWinMask ? kWinMask : b) | more | ((mDelta[j] & 0x20u) ? kWinDupBit : 0u);
   }
 }
 

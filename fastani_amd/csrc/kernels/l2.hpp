@@ -192,8 +192,7 @@ struct L2Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS;
   // reference index, position order
   const uint32_t *mHash; const int32_t *mWpos; const int32_t *prevSame; const int32_t *nextSame;
-  const uint8_t *mDelta;           // flags per entry: bit 5 = nearDup, bit 6 = its delete is followed by the insert of the same position
-  const uint32_t *mWin;            // window links per entry (index.hpp: k_index_window_links): A16 << 16 | B16
+  const uint32_t *mWin;            // window links + flags per entry (index.hpp: k_index_window_links)
   const int32_t *contigFirstMin;   // [nContigs+1]
   const uint32_t *posBase, *posSample;   // sampled position index (index.hpp: k_index_pos_sample)
   int rankShift;                   // k_l2_codes rank table: 2048 linear buckets of 2^rankShift hashes from 0; minimizer hashes are minima of w
@@ -261,7 +260,7 @@ struct L2FastArgs {
   uint32_t *codes;
   int32_t *slowFlag;               // [c1-c0] 1 = take the general kernel
   const uint32_t *fragCandOff;     // ordered candidate offset per fragment [nFrag]
-  int32_t nFrag, fragBase;         // first fragment of the chunk
+  int32_t nFrag, fragBase, nFragChunk;   // first fragment of the chunk, fragments that own its candidates
   int32_t allowFast;               // test knob ANI_L2_PATH: 0 = everything to the general kernel, 2 = everything to class B
 };
 
@@ -293,7 +292,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
   // entry up to the last one that leaves before entry last-1 would enter (which ends the loop, computeMap.hpp:455)
   int32_t nEv = 0;
   if (fast && r.end0 < r.last) {
-    const int32_t lastDel = (r.last - 1) - (int32_t)(a.g.mWin[r.last - 1] & 0xffffu) - 2;     // deletes with D_j <= I_(last-1)
+    const int32_t lastDel = (r.last - 1) - (int32_t)(a.g.mWin[r.last - 1] & kWinMask) - 2;     // deletes with D_j <= I_(last-1)
     const int32_t nDel = lastDel >= r.beg0 ? lastDel - r.beg0 + 1 : 0;
     nEv = (r.end0 - r.beg0) + (r.last - 1 - r.end0) + nDel;
   }
@@ -322,7 +321,12 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
   __shared__ uint32_t qs[kL2FastMaxS + 2];
   __shared__ uint16_t st[kL2RankBuckets + 2];
-  const int32_t f = a.fragBase + blockIdx.x;
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive fragments of a query map to overlapping
+  // reference ranges, so XCD x takes a contiguous eighth of the chunk's fragments: neighbours share their reference reads in L2.
+  const int32_t per = (int32_t)(gridDim.x >> 3);
+  const int32_t fl = (int32_t)(blockIdx.x & 7) * per + (int32_t)(blockIdx.x >> 3);
+  if (fl >= a.nFragChunk) return;
+  const int32_t f = a.fragBase + fl;
   const int32_t s = a.g.fragS[f];
   int32_t cA = (int32_t)a.fragCandOff[f], cB = (f + 1 < a.nFrag) ? (int32_t)a.fragCandOff[f + 1] : a.g.nCand;
   if (cA < a.c0) cA = a.c0;
@@ -344,16 +348,15 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     if (a.codeCount[i] == 0) continue;
     const L2Range r = a.ranges[i];
     uint16_t *out = (uint16_t *)a.codes + a.codeOff[i];
-    const uint8_t *__restrict__ dlt = a.g.mDelta + r.beg0;            // unsigned 32-bit offsets from per-candidate bases:
-    const uint32_t *__restrict__ hsh = a.g.mHash + r.beg0;            // scalar base + vector offset addressing, no 64-bit index math
-    const uint32_t *__restrict__ win = a.g.mWin + r.beg0;
+    const uint32_t *__restrict__ hsh = a.g.mHash + r.beg0;            // unsigned 32-bit offsets from per-candidate bases:
+    const uint32_t *__restrict__ win = a.g.mWin + r.beg0;             // scalar base + vector offset addressing, no 64-bit index math
     const uint32_t m = (uint32_t)(r.last - r.beg0);
     const int32_t nInit = r.end0 - r.beg0, nInsAll = (int32_t)m - 1;  // inserts (first window included) are the entries [0, m-1)
     const int32_t nDel = r.nEvents - nInsAll;                         // deletes are the entries [0, nDel)
     for (uint32_t j = 4u * threadIdx.x; j < m; j += 4u * kTPB) {
-      uint32_t h[4], dl[4], wl[4], rk[4];
+      uint32_t h[4], wl[4], rk[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) { const uint32_t x = j + e < m ? j + e : m - 1; h[e] = hsh[x]; dl[e] = dlt[x]; wl[e] = win[x]; }
+      for (int e = 0; e < 4; e++) { const uint32_t x = j + e < m ? j + e : m - 1; h[e] = hsh[x]; wl[e] = win[x]; }
       bool deep = false;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -381,19 +384,19 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
       for (int e = 0; e < 4; e++) {
         const int32_t x = (int32_t)(j + e);
         if (x >= (int32_t)m) break;
-        const uint32_t cd = rk[e] | ((dl[e] & 32u) << 5);             // nearDup: bit 5 of mDelta -> kL2DupBit
+        const uint32_t cd = rk[e] | ((wl[e] & kWinDupBit) ? kL2DupBit : 0u);
         // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B16 - 2
         if (x < nInsAll) {
-          int32_t db = x - (int32_t)(wl[e] & 0xffffu) - 1;            // deletes that precede it
+          int32_t db = x - (int32_t)(wl[e] & kWinMask) - 1;           // deletes that precede it
           db = db < 0 ? 0 : db;
           out[x + db] = (uint16_t)(cd | kL2InsBit | (x < nInit - 1 ? kL2NoEvalBit : 0u));
         }
         // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A16 (at least the
         // first window's)
         if (x < nDel) {
-          int32_t ib = x + (int32_t)(wl[e] >> 16);
+          int32_t ib = x + (int32_t)((wl[e] >> kWinShiftA) & kWinMask);
           ib = ib < nInit ? nInit : ib;
-          out[x + ib] = (uint16_t)(cd | ((dl[e] & 64u) ? kL2NoEvalBit : 0u));
+          out[x + ib] = (uint16_t)(cd | ((wl[e] & kWinMoreBit) ? kL2NoEvalBit : 0u));
         }
       }
     }
