@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-self", action="store_true", help="all-vs-all: sketch the query role separately (as for unrelated query sets)")
     ap.add_argument("--cpu-queries", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="fastANI_ref -t: 16 is where the reference is fastest on the 128-core benchmark host (1 x 1000: 39.6 s at 16, 51.9 at 32, "
@@ -359,6 +360,8 @@ def main():
         n_queries_total = nq_local * world
     contig_len = np.full(NR, L, dtype=np.int32)
     gcs = np.arange(NR + 1, dtype=np.int32)
+    # all-vs-all on one GPU (the query set IS the reference set): every genome is hashed once for both roles
+    self_mode = (not args.no_self) and world == 1 and ((cfg == "many-to-many" and not args.queries) or (cfg == "c4" and nq_local == NR))
 
     # multi-GPU staging buffers (allocated once): every rank's records land in its slot of `allrec`; the slot's first record
     # carries the count, so ONE all-gather moves counts and records (no count all-reduce, no compaction copy in the step)
@@ -371,7 +374,15 @@ def main():
 
     def step():
         t_a = time.perf_counter()
-        if world == 1:
+        frags = None
+        if world == 1 and self_mode:
+            # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
+            ptr, n, frags = e.sketch_records_self(p, refs, 0)
+            sk = Sketch(e, p, records=(ptr, n, contig_len, gcs))
+            if n:
+                e.device_free(ptr)
+            t_b = t_c = time.perf_counter()
+        elif world == 1:
             sk = Sketch(e, p, refs)
             t_b = t_c = time.perf_counter()
         else:
@@ -392,7 +403,11 @@ def main():
             ptrs = [allrec.data_ptr() + (r * (slot + 1) + 1) * 12 for r in range(world)]
             sk = Sketch(e, p, record_parts=(ptrs, counts, part_g0, contig_len, gcs))
         t_d = time.perf_counter()
-        rows = sk.map_cgi_batch(qrys, first_query_id)
+        if frags is not None:
+            rows = sk.map_cgi_fragset(frags, first_query_id)
+            frags.close()
+        else:
+            rows = sk.map_cgi_batch(qrys, first_query_id)
         t_e = time.perf_counter()
         sk.close()
         timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["allgather_ms"] += (t_c - t_b) * 1e3
@@ -518,7 +533,7 @@ def main():
                "higher_is_better": True, "scaling": "weak" if cfg != "c4" else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                "config": {"workload": "%s synthetic %d bp genomes (clusters of 20, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
                                       % (wl, L, p.windowSize, "" if world == 1 else "; queries sharded %d ways, reference sketch all-gathered over RCCL" % world),
-                          "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM",
+                          "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM", "all_vs_all_single_hash_pass": bool(self_mode),
                           "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
                "rows_last_step": int(len(rows)), "step_ms_rank0": step_ms,
                "stage_ms_per_step_rank0": stages,

@@ -84,6 +84,10 @@ def _bind(lib):
         "ani_map_query": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
         "ani_query_sketch": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_compute_cgi": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_fragset_build": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp)]),
+        "ani_sketch_records_self": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]),
+        "ani_map_cgi_fragset": (C.c_int, [vp, vp, vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_fragset_free": (None, [vp]),
         "ani_map_cgi_batch": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
     }
@@ -275,11 +279,45 @@ class Engine:
         self._chk(self.lib.ani_sketch_records(self.h, C.byref(params), C.byref(b), seq_id_base, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def sketch_records_self(self, params, genomes, seq_id_base):
+        """all-vs-all: -> (device pointer to 12-byte records, count, FragmentSet of the same genomes)"""
+        g = _as_batch(genomes)
+        b = g.batch()
+        p, n, f = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        self._chk(self.lib.ani_sketch_records_self(self.h, C.byref(params), C.byref(b), seq_id_base, C.byref(p), C.byref(n), C.byref(f)))
+        return p.value, n.value, FragmentSet(self, f)
+
+    def fragment_set(self, params, genomes):
+        g = _as_batch(genomes)
+        b = g.batch()
+        f = C.c_void_p()
+        self._chk(self.lib.ani_fragset_build(self.h, C.byref(params), C.byref(b), C.byref(f)))
+        return FragmentSet(self, f)
+
     def device_free(self, ptr):
         self.lib.ani_device_free(self.h, ptr)
 
     def device_copy(self, dst, src, nbytes):
         self._chk(self.lib.ani_device_copy(self.h, dst, src, nbytes))
+
+
+class FragmentSet:
+    """Fragment sketches of a batch of query genomes kept on the device (ani_fragset)."""
+
+    def __init__(self, engine, handle):
+        self.e = engine
+        self.h = handle
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.e.lib.ani_fragset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Sketch:
@@ -355,6 +393,11 @@ class Sketch:
         p, n = C.c_void_p(), C.c_size_t()
         self.e._chk(self.e.lib.ani_compute_cgi(self.e.h, self.h, m.ctypes.data if len(m) else None, len(m), total_fragments,
                                                query_id, C.byref(p), C.byref(n)))
+        return self.e._take(p, n.value, CGI_DT)
+
+    def map_cgi_fragset(self, fragset, first_query_id=0):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.e._chk(self.e.lib.ani_map_cgi_fragset(self.e.h, self.h, fragset.h, first_query_id, C.byref(p), C.byref(n)))
         return self.e._take(p, n.value, CGI_DT)
 
     def map_cgi_batch(self, genomes, first_query_id=0):

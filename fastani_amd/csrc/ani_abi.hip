@@ -192,7 +192,7 @@ struct ani_ctx {
   DevBuf dCounters;
   // workspaces reused across calls
   DevBuf seqPacked, seqAscii, contigOff, contigLen, contigMode;
-  DevBuf sortTmp, unitStart, unitAux, tiles, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
+  DevBuf sortTmp, unitStart, unitAux, tiles, tileInfo, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
   DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
@@ -389,6 +389,7 @@ struct ani_dev_batch {
   DeviceBatch db;
   void *bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // packed, ascii, contigOff, contigLen, contigMode
 };
+struct ani_fragset;
 namespace {
 
 // genomes [g0, g1) of `b` -> device (packs pure-ACGT contigs to 2 bits per base on the way).  `keep` = allocate the device
@@ -533,9 +534,83 @@ using namespace ani;
 // -----------------------------------------------------------------------------------------------------
 // reference minimizer records of a device-resident batch (position order, global seqIds)
 // -----------------------------------------------------------------------------------------------------
-int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, int32_t seqIdBase, uint32_t **dRecords, size_t *nOut)
+// fragment table + fragment sketches of one device-resident query sub-batch; the arrays live in the context's buffers
+// (frags, fragOff, fragS, fragGenome, fragQSeq, qPool) and stay valid across the index chunks the sub-batch is mapped against
+struct FragSet {
+  int32_t nFrag = 0, maxS = 0;
+  uint64_t nHashes = 0;              // sketch hashes of these fragments
+  uint64_t poolSize = 0;             // length of the pool fragOff points into (>= nHashes: a slice of a kept set points into the whole pool)
+  std::vector<int32_t> genomeFragments;
+  // device arrays (the context's buffers after fragment_stage, or a slice of a kept ani_fragset)
+  const uint32_t *qPool = nullptr, *fragOff = nullptr; const int32_t *fragS = nullptr, *fragGenome = nullptr, *fragQSeq = nullptr;
+  int32_t genomeBase = 0;            // fragGenome values are relative to the set the slice was cut from: query index = fragGenome - genomeBase
+};
+
+// device arrays of a fragment-sketch set: the context's buffers (fragment_stage) or arrays of their own (ani_fragset)
+struct FragArrays { uint32_t *fragOff = nullptr; int32_t *fragS = nullptr, *fragGenome = nullptr, *fragQSeq = nullptr; };
+
+// fragment table of a device-resident batch (computeMap.hpp:132-190): per-contig fragment prefix on the host (returned in
+// fragStart, nContigs + 1 entries), fragment descriptors + fragment -> (genome, running id) expanded on the device
+int frag_tables(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, FragSet *qr, std::vector<uint32_t> *fragStartOut, const FragArrays &fa, bool alloc,
+                FragArrays *owned)
 {
-  const int k = p->kmerSize, w = p->windowSize;
+  const int k = p.kmerSize, w = p.windowSize, L = p.fragLen;
+  std::vector<uint32_t> &fragStart = *fragStartOut;
+  fragStart.assign((size_t)db.nContigs + 1, 0);
+  std::vector<int32_t> cGenome((size_t)db.nContigs + 1, 0), cQBase((size_t)db.nContigs + 1, 0);
+  qr->genomeFragments.assign(db.nGenomes, 0);
+  uint64_t nF64 = 0;
+  for (int32_t g = 0; g < db.nGenomes; g++) {
+    int32_t seqCounter = 0;
+    for (int32_t c = db.genomeContigStart[g]; c < db.genomeContigStart[g + 1]; c++) {
+      fragStart[c] = (uint32_t)nF64; cGenome[c] = g; cQBase[c] = seqCounter;
+      const int32_t len = db.contigLen[c];
+      if (len < w || len < k || len < L) continue;            // :138
+      const int32_t fc = len / L;                              // :152
+      seqCounter += fc; nF64 += (uint64_t)fc;
+      if (nF64 > 0x3fffffffull) return fail(ANI_ERR_LIMIT, "too many fragments in one query batch");
+    }
+    qr->genomeFragments[g] = seqCounter;
+  }
+  fragStart[db.nContigs] = (uint32_t)nF64;
+  const size_t nF = (size_t)nF64;
+  qr->nFrag = (int32_t)nF; qr->maxS = 0; qr->nHashes = 0;
+  ctx->counters.queryGenomes += (uint64_t)db.nGenomes; ctx->counters.queryFragments += nF; ctx->counters.queryBases += db.totalBases;
+  if (nF == 0) return ANI_OK;
+  FragArrays arr = fa;
+  if (alloc) {
+    HIP_TRY(pool_malloc((void **)&owned->fragOff, nF * 4)); HIP_TRY(pool_malloc((void **)&owned->fragS, nF * 4));
+    HIP_TRY(pool_malloc((void **)&owned->fragGenome, nF * 4)); HIP_TRY(pool_malloc((void **)&owned->fragQSeq, nF * 4));
+    arr = *owned;
+  }
+  TRY(ctx->frags.ensure(nF * sizeof(FragDesc)));
+  const size_t nc1 = (size_t)db.nContigs + 1;
+  TRY(ctx->unitStart.ensure(nc1 * 4)); TRY(ctx->unitAux.ensure(nc1 * 8));
+  HIP_TRY(hipMemcpyAsync(ctx->unitStart.p, fragStart.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->unitAux.p, cGenome.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->unitAux.as<int32_t>() + nc1, cQBase.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_expand_frags, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), (const int32_t *)ctx->unitAux.as<int32_t>(),
+                     (const int32_t *)(ctx->unitAux.as<int32_t>() + nc1), db.nContigs, (uint32_t)nF, L, ctx->frags.as<FragDesc>(), arr.fragGenome, arr.fragQSeq);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  qr->fragOff = arr.fragOff; qr->fragS = arr.fragS; qr->fragGenome = arr.fragGenome; qr->fragQSeq = arr.fragQSeq; qr->genomeBase = 0;
+  return ANI_OK;
+}
+
+// `fused` (optional): the batch's genomes are queries as well — their fragment sketches come out of the same pass over the
+// hashes (k_sketch_fused) into arrays owned by the caller's ani_fragset.  Only when a fragment plus its w-1 lead-in fits one tile.
+struct FusedOut { FragSet *fs; FragArrays *arr; uint32_t **qPool; };
+inline bool fusable(const ani_params_t *p) { return p->fragLen + p->windowSize - 1 <= kTile && p->fragLen >= p->windowSize && p->fragLen >= p->kmerSize; }
+
+int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, int32_t seqIdBase, uint32_t **dRecords, size_t *nOut, FusedOut *fused = nullptr)
+{
+  const int k = p->kmerSize, w = p->windowSize, L = p->fragLen;
+  *dRecords = nullptr; *nOut = 0;
+  std::vector<uint32_t> fragStart;
+  size_t nF = 0;
+  if (fused) {
+    TRY(frag_tables(ctx, *p, db, fused->fs, &fragStart, FragArrays(), true, fused->arr));
+    nF = (size_t)fused->fs->nFrag;
+  }
   // per-contig tile prefix; the 1.6 M tile descriptors of a 1000-genome batch are expanded on the device
   std::vector<uint32_t> tileStart((size_t)db.nContigs + 1, 0);
   const int stride = kTile - (w - 1);
@@ -546,41 +621,76 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
     if (len < w || len < k) continue;                       // winSketch.hpp:153
     const int32_t nPos = len - k + 1;
     positions += (uint64_t)nPos;
-    uint64_t cnt = 1;                                       // tiles B = 0, stride, ... while B + (w-1) < nPos
-    if (nPos > w - 1) cnt = ((uint64_t)(nPos - (w - 1)) + stride - 1) / stride;
+    uint64_t cnt;
+    if (!fused) {
+      cnt = 1;                                              // tiles B = 0, stride, ... while B + (w-1) < nPos
+      if (nPos > w - 1) cnt = ((uint64_t)(nPos - (w - 1)) + stride - 1) / stride;
+    } else {
+      // one tile per whole fragment (it emits the windows that end inside the fragment), then plain tiles for the rest of the contig
+      const int32_t nFragC = (int32_t)(fragStart[c + 1] - fragStart[c]);
+      const int32_t base = nFragC > 0 ? nFragC * L - (w - 1) : 0;
+      uint64_t tail = nFragC > 0 ? 0 : 1;
+      if (nPos > base + (w - 1)) tail = ((uint64_t)(nPos - (base + w - 1)) + stride - 1) / stride;
+      cnt = (uint64_t)nFragC + tail;
+    }
     nT64 += cnt;
     if (nT64 > 0x7fffffffull) return fail(ANI_ERR_LIMIT, "too many tiles in one reference batch");
   }
   tileStart[db.nContigs] = (uint32_t)nT64;
   const size_t nT = (size_t)nT64;
-  *dRecords = nullptr; *nOut = 0;
   if (nT == 0) return ANI_OK;
   TRY(ctx->tiles.ensure(nT * sizeof(TileDesc))); TRY(ctx->tileMeta.ensure(nT * sizeof(TileMeta)));
   TRY(ctx->tileCnt.ensure(nT * 4)); TRY(ctx->tileDrop.ensure(nT)); TRY(ctx->tileOff.ensure((nT + 1) * 4));
   TRY(ctx->unitStart.ensure(tileStart.size() * 4));
   HIP_TRY(hipMemcpyAsync(ctx->unitStart.p, tileStart.data(), tileStart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_expand_tiles, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), db.nContigs, (uint32_t)nT, stride,
-                     ctx->tiles.as<TileDesc>());
+  if (!fused)
+    hipLaunchKernelGGL(k_expand_tiles, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), db.nContigs, (uint32_t)nT, stride,
+                       ctx->tiles.as<TileDesc>());
+  else {
+    TRY(ctx->tileInfo.ensure(nT * sizeof(FusedInfo))); TRY(ctx->unitAux.ensure(fragStart.size() * 4));
+    HIP_TRY(hipMemcpyAsync(ctx->unitAux.p, fragStart.data(), fragStart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_expand_fused, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), (const uint32_t *)ctx->unitAux.as<uint32_t>(), db.nContigs,
+                       (uint32_t)nT, L, w, stride, ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>());
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
 
   uint64_t cap = (uint64_t)((double)positions * 2.6 / (w + 1)) + 64 * nT + 4096;
   if (cap > positions + nT) cap = positions + nT;
+  uint64_t qcap = fused ? (uint64_t)nF * (uint64_t)((2.6 * L) / (w + 1) + 32) + 1024 : 0;
   unsigned long long host[CNT_N];
   for (int attempt = 0;; attempt++) {
     if (cap > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "reference batch yields more than 2^32 minimizers; split the reference list");
+    if (qcap > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "query batch sketch exceeds 2^32 hashes");
     TRY(ctx->poolHash.ensure(cap * 4)); TRY(ctx->poolWpos.ensure(cap * 4));
+    if (fused && (!*fused->qPool || attempt > 0)) {
+      if (*fused->qPool) { pool_free(*fused->qPool); *fused->qPool = nullptr; }
+      HIP_TRY(pool_malloc((void **)fused->qPool, (qcap ? qcap : 1) * 4));
+    }
     TRY(zero_counters(ctx));
     {
       StageTimer tm(ctx, &ctx->counters.msSketch);
-      hipLaunchKernelGGL(k_sketch_tiles, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff,
-                         db.dContigLen, db.dContigMode, ctx->tiles.as<TileDesc>(), k, w, ctx->poolHash.as<uint32_t>(),
-                         ctx->poolWpos.as<int32_t>(), (uint32_t)cap, cnt_ptr(ctx, CNT_POOL), ctx->tileMeta.as<TileMeta>());
+      if (!fused)
+        hipLaunchKernelGGL(k_sketch_tiles, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff,
+                           db.dContigLen, db.dContigMode, ctx->tiles.as<TileDesc>(), k, w, ctx->poolHash.as<uint32_t>(),
+                           ctx->poolWpos.as<int32_t>(), (uint32_t)cap, cnt_ptr(ctx, CNT_POOL), ctx->tileMeta.as<TileMeta>());
+      else
+        hipLaunchKernelGGL(k_sketch_fused, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigLen, db.dContigMode,
+                           ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>(), k, w, L, ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(), (uint32_t)cap,
+                           cnt_ptr(ctx, CNT_POOL), ctx->tileMeta.as<TileMeta>(), *fused->qPool, (uint32_t)qcap, cnt_ptr(ctx, CNT_QPOOL), fused->arr->fragOff, fused->arr->fragS,
+                           (int *)cnt_ptr(ctx, CNT_MAXS));
     }
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
-    if (host[CNT_POOL] <= cap) break;
+    if (host[CNT_POOL] <= cap && (!fused || host[CNT_QPOOL] <= qcap)) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "minimizer pool did not converge");
-    cap = host[CNT_POOL] + host[CNT_POOL] / 16;        // margin: the same input must not grow the pool again next time
+    if (host[CNT_POOL] > cap) cap = host[CNT_POOL] + host[CNT_POOL] / 16;        // margin: the same input must not grow the pool again next time
+    if (fused && host[CNT_QPOOL] > qcap) qcap = host[CNT_QPOOL] + host[CNT_QPOOL] / 16;
+  }
+  if (fused) {
+    const int maxS = (int)(uint32_t)host[CNT_MAXS];
+    if (maxS >= 0x7fffffff) return fail(ANI_ERR_LIMIT, "a query fragment produced more than %d minimizers", kFragHashCap);
+    ctx->counters.querySketchHashes += host[CNT_QPOOL];
+    fused->fs->maxS = maxS; fused->fs->nHashes = host[CNT_QPOOL]; fused->fs->poolSize = host[CNT_QPOOL]; fused->fs->qPool = *fused->qPool;
   }
   StageTimer tm(ctx, &ctx->counters.msSketch);
   hipLaunchKernelGGL(k_sketch_tile_counts, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, ctx->tiles.as<TileDesc>(),
@@ -594,8 +704,9 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
   hipLaunchKernelGGL(k_sketch_gather, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, ctx->tiles.as<TileDesc>(), ctx->tileMeta.as<TileMeta>(),
                      ctx->tileDrop.as<uint8_t>(), ctx->tileOff.as<uint32_t>(), ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(),
                      seqIdBase, rec);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { pool_free(rec); HIP_TRY(e); }
   *dRecords = rec; *nOut = (size_t)total;
   return ANI_OK;
 }
@@ -854,54 +965,21 @@ int exact_unique(ani_sketch *sk)
 // -----------------------------------------------------------------------------------------------------
 // query path for one device-resident sub-batch
 // -----------------------------------------------------------------------------------------------------
-// fragment table + fragment sketches of one device-resident query sub-batch; the arrays live in the context's buffers
-// (frags, fragOff, fragS, fragGenome, fragQSeq, qPool) and stay valid across the index chunks the sub-batch is mapped against
-struct FragSet {
-  int32_t nFrag = 0, maxS = 0;
-  uint64_t nHashes = 0;
-  std::vector<int32_t> genomeFragments;
-};
-
 int fragment_stage(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, FragSet *qr)
 {
   if (ctx->timerPending.size() > 4096) flush_timers(ctx);      // no stage timer is open here
   const int k = p.kmerSize, w = p.windowSize, L = p.fragLen;
-  // ---- fragment table (computeMap.hpp:132-190) ----
-  // per-contig fragment prefix; fragment descriptors are expanded on the device
-  std::vector<uint32_t> fragStart((size_t)db.nContigs + 1, 0);
-  std::vector<int32_t> cGenome((size_t)db.nContigs + 1, 0), cQBase((size_t)db.nContigs + 1, 0);
-  qr->genomeFragments.assign(db.nGenomes, 0);
-  uint64_t nF64 = 0;
-  for (int32_t g = 0; g < db.nGenomes; g++) {
-    int32_t seqCounter = 0;
-    for (int32_t c = db.genomeContigStart[g]; c < db.genomeContigStart[g + 1]; c++) {
-      fragStart[c] = (uint32_t)nF64; cGenome[c] = g; cQBase[c] = seqCounter;
-      const int32_t len = db.contigLen[c];
-      if (len < w || len < k || len < L) continue;            // :138
-      const int32_t fc = len / L;                              // :152
-      seqCounter += fc; nF64 += (uint64_t)fc;
-      if (nF64 > 0x3fffffffull) return fail(ANI_ERR_LIMIT, "too many fragments in one query batch");
-    }
-    qr->genomeFragments[g] = seqCounter;
-  }
-  fragStart[db.nContigs] = (uint32_t)nF64;
-  const size_t nF = (size_t)nF64;
-  qr->nFrag = (int32_t)nF; qr->maxS = 0; qr->nHashes = 0;
-  ctx->counters.queryGenomes += (uint64_t)db.nGenomes; ctx->counters.queryFragments += nF; ctx->counters.queryBases += db.totalBases;
-  if (nF == 0) return ANI_OK;
-  TRY(ctx->frags.ensure(nF * sizeof(FragDesc))); TRY(ctx->fragOff.ensure(nF * 4)); TRY(ctx->fragS.ensure(nF * 4));
-  TRY(ctx->fragGenome.ensure(nF * 4)); TRY(ctx->fragQSeq.ensure(nF * 4));
+  // worst case sizes are known from the contig lengths: make room before the tables point into the buffers
   {
-    const size_t nc1 = (size_t)db.nContigs + 1;
-    TRY(ctx->unitStart.ensure(nc1 * 4)); TRY(ctx->unitAux.ensure(nc1 * 8));
-    HIP_TRY(hipMemcpyAsync(ctx->unitStart.p, fragStart.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->unitAux.p, cGenome.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->unitAux.as<int32_t>() + nc1, cQBase.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_expand_frags, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), (const int32_t *)ctx->unitAux.as<int32_t>(),
-                       (const int32_t *)(ctx->unitAux.as<int32_t>() + nc1), db.nContigs, (uint32_t)nF, L, ctx->frags.as<FragDesc>(), ctx->fragGenome.as<int32_t>(),
-                       ctx->fragQSeq.as<int32_t>());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    uint64_t nF = 0;
+    for (int32_t c = 0; c < db.nContigs; c++) { const int32_t len = db.contigLen[c]; if (!(len < w || len < k || len < L)) nF += (uint64_t)(len / L); }
+    TRY(ctx->fragOff.ensure((nF + 1) * 4)); TRY(ctx->fragS.ensure((nF + 1) * 4)); TRY(ctx->fragGenome.ensure((nF + 1) * 4)); TRY(ctx->fragQSeq.ensure((nF + 1) * 4));
   }
+  FragArrays fa; fa.fragOff = ctx->fragOff.as<uint32_t>(); fa.fragS = ctx->fragS.as<int32_t>(); fa.fragGenome = ctx->fragGenome.as<int32_t>(); fa.fragQSeq = ctx->fragQSeq.as<int32_t>();
+  std::vector<uint32_t> fragStart;
+  TRY(frag_tables(ctx, p, db, qr, &fragStart, fa, false, nullptr));
+  const size_t nF = (size_t)qr->nFrag;
+  if (nF == 0) return ANI_OK;
 
   unsigned long long host[CNT_N];
   // ---- fragment sketches ----
@@ -930,7 +1008,8 @@ int fragment_stage(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, F
   const int maxS = (int)(uint32_t)host[CNT_MAXS];
   if (maxS >= 0x7fffffff) return fail(ANI_ERR_LIMIT, "a query fragment produced more than %d minimizers", kFragHashCap);
   ctx->counters.querySketchHashes += host[CNT_QPOOL];
-  qr->maxS = maxS; qr->nHashes = host[CNT_QPOOL];
+  qr->maxS = maxS; qr->nHashes = host[CNT_QPOOL]; qr->poolSize = host[CNT_QPOOL];
+  qr->qPool = ctx->qPool.as<uint32_t>();
   return ANI_OK;
 }
 
@@ -952,7 +1031,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // ---- L1 ----
   TRY(ctx->fragCandOff.ensure(nF * 4)); TRY(ctx->fragCandCnt.ensure(nF * 4)); TRY(ctx->fragCandCntClamped.ensure(nF * 4));
   TRY(ctx->fragHits.ensure(nF * 4)); TRY(ctx->fragOrdOff.ensure((nF + 1) * 4));
-  TRY(ctx->probeFirst.ensure((host[CNT_QPOOL] + 1) * 4)); TRY(ctx->probeCnt.ensure((host[CNT_QPOOL] + 1) * 4));
+  TRY(ctx->probeFirst.ensure((fs.poolSize + 1) * 4)); TRY(ctx->probeCnt.ensure((fs.poolSize + 1) * 4));      // indexed like the sketch pool
   uint64_t ccap = (uint64_t)((double)nF * ctx->candPerFrag) + 4096;
   TRY(ctx->l1LargeList.ensure(nF * 4)); TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
   unsigned nLarge = 0, nMid = 0, nBig = 0;
@@ -964,7 +1043,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     if (attempt == 0) TRY(zero_counters(ctx));
     else { HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CAND), 0, 8, ctx->stream)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
     L1Args a;
-    a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>(); a.nFrag = (int32_t)nF;
+    a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS; a.nFrag = (int32_t)nF;
     a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.bucketW = w; a.nIndex = sk->n;
     a.minHitsLUT = set->dMinHits; a.lutMaxS = set->dLutMaxS; a.L = L;
     a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
@@ -989,7 +1068,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
           bigFrags.resize(nBig); bigS.resize(nBig); bigH.resize(nBig);
           HIP_TRY(hipMemcpy(bigFrags.data(), ctx->l1BigList.p, (size_t)nBig * 4, hipMemcpyDeviceToHost));
           for (unsigned i = 0; i < nBig; i++) {
-            HIP_TRY(hipMemcpy(&bigS[i], ctx->fragS.as<int32_t>() + bigFrags[i], 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&bigS[i], fs.fragS + bigFrags[i], 4, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(&bigH[i], ctx->fragHits.as<int32_t>() + bigFrags[i], 4, hipMemcpyDeviceToHost));
           }
         }
@@ -1047,7 +1126,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     TRY(zero_counters(ctx));
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
-    a.nCand = (int32_t)nCand; a.qPool = ctx->qPool.as<uint32_t>(); a.fragOff = ctx->fragOff.as<uint32_t>(); a.fragS = ctx->fragS.as<int32_t>();
+    a.nCand = (int32_t)nCand; a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS;
     a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mWin = sk->mWin; a.posBase = sk->posBase; a.posSample = sk->posSample;
     a.contigFirstMin = sk->contigFirstMin;
     { int lg = 0; while ((2 << lg) <= w) lg++; a.rankShift = 21 - std::max(0, lg - 1); }   // w = 24: 2048 buckets over [0, 2^29)
@@ -1216,7 +1295,7 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &f
   if (nCand) {
     OneWayArgs a;
     a.nCand = nCand; a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.refStart = ctx->refStart.as<int32_t>();
-    a.idBits = ctx->idBits.as<uint32_t>(); a.fragGenome = ctx->fragGenome.as<int32_t>(); a.contigGenome = sk->contigGenome;
+    a.idBits = ctx->idBits.as<uint32_t>(); a.fragGenome = fs.fragGenome; a.genomeBase = fs.genomeBase; a.contigGenome = sk->contigGenome;
     a.contigBinBase = sk->contigBinBase; a.binWidth = set->params.fragLen - 20; a.bins = ctx->bins.as<uint32_t>(); a.binsPerQuery = binsPerQuery;
     hipLaunchKernelGGL(k_oneway_bins, dim3(grid_for((size_t)nCand)), dim3(256), 0, ctx->stream, a);
   }
@@ -1270,6 +1349,108 @@ template <class T> int to_host_malloc(const std::vector<T> &v, T **out, size_t *
 
 }  // namespace
 
+// Fragment sketches of a batch of query genomes, kept on the device (ani_fragset_build / ani_sketch_records_self): mapping them
+// against several reference sets or index chunks — or mapping genomes that were sketched as references — hashes nothing twice.
+struct ani_fragset {
+  ani_ctx *ctx = nullptr; int device = 0;
+  ani_params_t params;
+  FragSet fs;                      // host tables + device pointers into the arrays below
+  FragArrays arr; uint32_t *qPool = nullptr;
+  std::vector<int64_t> genomeFragStart;     // prefix of fs.genomeFragments
+};
+
+namespace {
+void fragset_release(ani_fragset *f)
+{
+  void *ptrs[] = {f->arr.fragOff, f->arr.fragS, f->arr.fragGenome, f->arr.fragQSeq, f->qPool};
+  for (void *q : ptrs) if (q) pool_free(q);
+  delete f;
+}
+void fragset_finish(ani_fragset *f)
+{
+  f->genomeFragStart.assign(f->fs.genomeFragments.size() + 1, 0);
+  for (size_t g = 0; g < f->fs.genomeFragments.size(); g++) f->genomeFragStart[g + 1] = f->genomeFragStart[g] + f->fs.genomeFragments[g];
+}
+// sketch one uploaded batch as references, optionally keeping its fragment sketches
+int records_of_batch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, int32_t seqIdBase, void **devRecords, size_t *n, ani_fragset *keep)
+{
+  // slices of ~2^30 bases keep the temporary pools small; a single slice is handed over as it is.  With `keep` the batch is one slice
+  // (the caller — the command line, the bench — already works in such slices).
+  std::vector<RecordPart> parts;
+  auto cleanup = [&]() { for (auto &q : parts) if (q.rec) pool_free(q.rec); };
+  size_t total = 0;
+  int32_t g0 = 0;
+  while (g0 < refs->nGenomes) {
+    int32_t g1 = g0; uint64_t bases = 0;
+    while (g1 < refs->nGenomes && (g1 == g0 || keep || bases < (1ull << 30))) {
+      for (int32_t c = refs->genomeContigStart[g1]; c < refs->genomeContigStart[g1 + 1]; c++) bases += (uint64_t)refs->contigLen[c];
+      g1++;
+    }
+    DeviceBatch db;
+    int rc = upload_batch(ctx, refs, g0, g1, &db);
+    RecordPart pt; pt.g0 = g0; pt.g1 = g1;
+    if (rc == ANI_OK) {
+      if (keep && fusable(p)) {
+        FusedOut fo{&keep->fs, &keep->arr, &keep->qPool};
+        rc = sketch_records(ctx, p, db, seqIdBase + refs->genomeContigStart[g0], &pt.rec, &pt.n, &fo);
+      } else {
+        rc = sketch_records(ctx, p, db, seqIdBase + refs->genomeContigStart[g0], &pt.rec, &pt.n);
+        if (rc == ANI_OK && keep) {           // fragments that do not fit one tile: the two passes stay separate
+          rc = fragment_stage(ctx, *p, db, &keep->fs);
+          const size_t nF = (size_t)keep->fs.nFrag, nH = (size_t)keep->fs.nHashes;
+          hipError_t e = hipSuccess;
+          if (rc == ANI_OK && nF) {
+            e = pool_malloc((void **)&keep->arr.fragOff, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&keep->arr.fragS, nF * 4);
+            if (e == hipSuccess) e = pool_malloc((void **)&keep->arr.fragGenome, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&keep->arr.fragQSeq, nF * 4);
+            if (e == hipSuccess) e = pool_malloc((void **)&keep->qPool, (nH ? nH : 1) * 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragOff, keep->fs.fragOff, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragS, keep->fs.fragS, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragGenome, keep->fs.fragGenome, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragQSeq, keep->fs.fragQSeq, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess && nH) e = hipMemcpyAsync(keep->qPool, keep->fs.qPool, nH * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "keeping the fragment sketches failed: %s", hipGetErrorString(e));
+            keep->fs.fragOff = keep->arr.fragOff; keep->fs.fragS = keep->arr.fragS; keep->fs.fragGenome = keep->arr.fragGenome; keep->fs.fragQSeq = keep->arr.fragQSeq;
+            keep->fs.qPool = keep->qPool;
+          }
+        }
+      }
+    }
+    if (rc != ANI_OK) { cleanup(); return rc; }
+    parts.push_back(pt); total += pt.n;
+    g0 = g1;
+  }
+  uint32_t *all = nullptr;
+  if (parts.size() == 1) { all = parts[0].rec; parts[0].rec = nullptr; }
+  else if (total) {
+    hipError_t e = pool_malloc((void **)&all, total * 12);
+    size_t o = 0;
+    for (size_t i = 0; i < parts.size() && e == hipSuccess; i++) {
+      if (parts[i].n) e = hipMemcpyAsync(all + 3 * o, parts[i].rec, parts[i].n * 12, hipMemcpyDeviceToDevice, ctx->stream);
+      o += parts[i].n;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { if (all) pool_free(all); cleanup(); return fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "gathering %zu records failed: %s", total, hipGetErrorString(e)); }
+  }
+  cleanup();
+  if (ctx->timerPending.size() > 1024) flush_timers(ctx);
+  *devRecords = all; *n = total;
+  return ANI_OK;
+}
+
+// Map + reduce for the fragments of `fs` (a whole set or a slice of one) against every index chunk; rows appended
+int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows)
+{
+  TRY(upload_luts(sk, fs.maxS));
+  for (IndexChunk *ch : sk->chunks) {
+    int32_t nCand = 0;
+    TRY(map_stage(ctx, sk, ch, fs, &nCand));
+    TRY(reduce_stage(ctx, sk, ch, fs, nCand, nQuery));
+  }
+  return collect_rows(ctx, sk, fs, nQuery, firstQueryId, rows);
+}
+}  // namespace
+
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
@@ -1307,7 +1488,7 @@ void ani_shutdown(ani_ctx *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileMeta, &c->tileCnt,
+  DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileInfo, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
                     &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
@@ -1421,40 +1602,89 @@ int ani_sketch_records(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_
   if (!ctx || !devRecords || !n) return fail(ANI_ERR_ARG, "null argument");
   TRY(check_params(p)); TRY(check_batch(refs));
   HIP_TRY(hipSetDevice(ctx->device));
-  // slices of ~2^30 bases keep the temporary pools small; a single slice is handed over as it is
-  std::vector<RecordPart> parts;
-  auto cleanup = [&]() { for (auto &q : parts) if (q.rec) pool_free(q.rec); };
-  size_t total = 0;
+  return records_of_batch(ctx, p, refs, seqIdBase, devRecords, n, nullptr);
+}
+
+int ani_sketch_records_self(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *genomes, int32_t seqIdBase, void **devRecords, size_t *n, ani_fragset **frags)
+{
+  if (!ctx || !devRecords || !n || !frags) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_params(p)); TRY(check_batch(genomes));
+  HIP_TRY(hipSetDevice(ctx->device));
+  ani_fragset *f = new ani_fragset();
+  f->ctx = ctx; f->device = ctx->device; f->params = *p;
+  const int rc = records_of_batch(ctx, p, genomes, seqIdBase, devRecords, n, f);
+  if (rc != ANI_OK) { fragset_release(f); return rc; }
+  fragset_finish(f);
+  *frags = f;
+  return ANI_OK;
+}
+
+int ani_fragset_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *queries, ani_fragset **out)
+{
+  if (!ctx || !out) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_params(p)); TRY(check_batch(queries));
+  HIP_TRY(hipSetDevice(ctx->device));
+  ani_fragset *f = new ani_fragset();
+  f->ctx = ctx; f->device = ctx->device; f->params = *p;
+  DeviceBatch db;
+  int rc = upload_batch(ctx, queries, 0, queries->nGenomes, &db);
+  if (rc == ANI_OK) rc = fragment_stage(ctx, *p, db, &f->fs);
+  const size_t nF = (size_t)f->fs.nFrag, nH = (size_t)f->fs.nHashes;
+  if (rc == ANI_OK && nF) {
+    hipError_t e = pool_malloc((void **)&f->arr.fragOff, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragS, nF * 4);
+    if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragGenome, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragQSeq, nF * 4);
+    if (e == hipSuccess) e = pool_malloc((void **)&f->qPool, (nH ? nH : 1) * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragOff, f->fs.fragOff, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragS, f->fs.fragS, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragGenome, f->fs.fragGenome, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragQSeq, f->fs.fragQSeq, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && nH) e = hipMemcpyAsync(f->qPool, f->fs.qPool, nH * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "keeping the fragment sketches failed: %s", hipGetErrorString(e));
+    f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq; f->fs.qPool = f->qPool;
+  }
+  if (rc != ANI_OK) { fragset_release(f); return rc; }
+  fragset_finish(f);
+  *out = f;
+  return ANI_OK;
+}
+
+void ani_fragset_free(ani_fragset *f)
+{
+  if (!f) return;
+  (void)hipSetDevice(f->device);
+  fragset_release(f);
+}
+
+int ani_map_cgi_fragset(ani_ctx *ctx, const ani_sketch *skc, const ani_fragset *f, int32_t firstQueryId, ani_cgi_t **out, size_t *m)
+{
+  if (!ctx || !skc || !f || !out || !m) return fail(ANI_ERR_ARG, "null argument");
+  ani_sketch *sk = const_cast<ani_sketch *>(skc);
+  if (f->device != ctx->device) return fail(ANI_ERR_ARG, "fragment set lives on device %d, context on %d", f->device, ctx->device);
+  if (f->params.kmerSize != sk->params.kmerSize || f->params.windowSize != sk->params.windowSize || f->params.fragLen != sk->params.fragLen)
+    return fail(ANI_ERR_ARG, "fragment set and sketch were built with different parameters");
+  HIP_TRY(hipSetDevice(ctx->device));
+  RowBuf rows;
+  const int32_t nG = (int32_t)f->fs.genomeFragments.size();
   int32_t g0 = 0;
-  while (g0 < refs->nGenomes) {
-    int32_t g1 = g0; uint64_t bases = 0;
-    while (g1 < refs->nGenomes && (g1 == g0 || bases < (1ull << 30))) {
-      for (int32_t c = refs->genomeContigStart[g1]; c < refs->genomeContigStart[g1 + 1]; c++) bases += (uint64_t)refs->contigLen[c];
-      g1++;
-    }
-    DeviceBatch db;
-    int rc = upload_batch(ctx, refs, g0, g1, &db);
-    RecordPart pt; pt.g0 = g0; pt.g1 = g1;
-    if (rc == ANI_OK) rc = sketch_records(ctx, p, db, seqIdBase + refs->genomeContigStart[g0], &pt.rec, &pt.n);
-    if (rc != ANI_OK) { cleanup(); return rc; }
-    parts.push_back(pt); total += pt.n;
+  while (g0 < nG) {
+    // the same sub-batch bounds as ani_map_cgi_batch
+    int32_t g1 = g0;
+    const uint64_t maxQ = std::max<uint64_t>(1, std::min<uint64_t>((ctx->subBatchBinBytes) / (4ull * std::max<uint32_t>(sk->maxChunkBins, 1)),
+                                                               ((uint64_t)2 << 30) / (8ull * (uint64_t)std::max<int32_t>(sk->nGenomes, 1))));
+    while (g1 < nG && (g1 == g0 || ((uint64_t)(f->genomeFragStart[g1] - f->genomeFragStart[g0]) < ctx->subBatchFragments && (uint64_t)(g1 - g0) < maxQ))) g1++;
+    const int64_t fA = f->genomeFragStart[g0], fB = f->genomeFragStart[g1];
+    FragSet v;                                              // slice [g0, g1) of the kept set
+    v.nFrag = (int32_t)(fB - fA); v.maxS = f->fs.maxS; v.poolSize = f->fs.poolSize;
+    v.genomeFragments.assign(f->fs.genomeFragments.begin() + g0, f->fs.genomeFragments.begin() + g1);
+    v.qPool = f->fs.qPool; v.genomeBase = g0;
+    if (v.nFrag) { v.fragOff = f->fs.fragOff + fA; v.fragS = f->fs.fragS + fA; v.fragGenome = f->fs.fragGenome + fA; v.fragQSeq = f->fs.fragQSeq + fA; }
+    v.nHashes = f->fs.nFrag ? (uint64_t)((double)f->fs.nHashes * (double)v.nFrag / (double)f->fs.nFrag) : 0;      // statistics only (l1Probes)
+    TRY(map_fragset(ctx, sk, v, g1 - g0, firstQueryId + g0, &rows));
     g0 = g1;
   }
-  uint32_t *all = nullptr;
-  if (parts.size() == 1) { all = parts[0].rec; parts[0].rec = nullptr; }
-  else if (total) {
-    hipError_t e = pool_malloc((void **)&all, total * 12);
-    size_t o = 0;
-    for (size_t i = 0; i < parts.size() && e == hipSuccess; i++) {
-      if (parts[i].n) e = hipMemcpyAsync(all + 3 * o, parts[i].rec, parts[i].n * 12, hipMemcpyDeviceToDevice, ctx->stream);
-      o += parts[i].n;
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { if (all) pool_free(all); cleanup(); return fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "gathering %zu records failed: %s", total, hipGetErrorString(e)); }
-  }
-  cleanup();
-  if (ctx->timerPending.size() > 1024) flush_timers(ctx);
-  *devRecords = all; *n = total;
+  *m = rows.n; *out = rows.release();
+  if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
   return ANI_OK;
 }
 
@@ -1640,8 +1870,8 @@ int ani_map_query(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t *qu
     if (!nKeep) continue;
     TRY(ctx->mapOut.ensure(nKeep * 44));
     hipLaunchKernelGGL(ani::k_emit_mappings, dim3(grid_for(nC)), dim3(256), 0, ctx->stream, (int32_t)nC, ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(),
-                       ctx->refStart.as<int32_t>(), ctx->idBits.as<uint32_t>(), ctx->l2Best.as<int32_t>(), ctx->fragS.as<int32_t>(),
-                       ctx->fragQSeq.as<int32_t>(), ctx->keepOff.as<uint32_t>(), sk->params.fragLen, ch->c0, ctx->mapOut.as<uint32_t>());
+                       ctx->refStart.as<int32_t>(), ctx->idBits.as<uint32_t>(), ctx->l2Best.as<int32_t>(), fs.fragS,
+                       fs.fragQSeq, ctx->keepOff.as<uint32_t>(), sk->params.fragLen, ch->c0, ctx->mapOut.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     const size_t o = maps.size();
     maps.resize(o + nKeep);
@@ -1721,6 +1951,7 @@ int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *skc, const ani_mapping_t *ma
   const size_t nF = (size_t)(f + 1);
   TRY(ctx->fragGenome.ensure((nF ? nF : 1) * 4));
   if (nF) HIP_TRY(hipMemsetAsync(ctx->fragGenome.p, 0, nF * 4, ctx->stream));
+  fs.fragGenome = ctx->fragGenome.as<int32_t>(); fs.genomeBase = 0;
   for (size_t c = 0; c < nCh; c++) {
     const size_t nc = cFrag[c].size();
     if (nc) {

@@ -321,6 +321,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
   __shared__ uint32_t qs[kL2FastMaxS + 2];
   __shared__ uint16_t st[kL2RankBuckets + 2];
+  __shared__ uint32_t st2[kL2RankBuckets];
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive fragments of a query map to overlapping
   // reference ranges, so XCD x takes a contiguous eighth of the chunk's fragments: neighbours share their reference reads in L2.
   const int32_t per = (int32_t)(gridDim.x >> 3);
@@ -343,6 +344,8 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     for (int b = b0; b <= b1; b++) st[b] = (uint16_t)i;
   }
   __syncthreads();
+  for (int b = threadIdx.x; b < kL2RankBuckets; b += kTPB) st2[b] = (uint32_t)st[b] | ((uint32_t)(st[b + 1] - st[b]) << 16);
+  __syncthreads();
   for (int32_t c = cA; c < cB; c++) {
     const int32_t i = c - a.c0;
     if (a.codeCount[i] == 0) continue;
@@ -353,15 +356,18 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     const uint32_t m = (uint32_t)(r.last - r.beg0);
     const int32_t nInit = r.end0 - r.beg0, nInsAll = (int32_t)m - 1;  // inserts (first window included) are the entries [0, m-1)
     const int32_t nDel = r.nEvents - nInsAll;                         // deletes are the entries [0, nDel)
-    for (uint32_t j = 4u * threadIdx.x; j < m; j += 4u * kTPB) {
+    // a thread ranks four entries per pass, kTPB apart: every load is one contiguous 256-byte run per wave, and the event stores of
+    // neighbouring lanes land two or three slots apart
+    for (uint32_t j = threadIdx.x; j < m; j += 4u * kTPB) {
       uint32_t h[4], wl[4], rk[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) { const uint32_t x = j + e < m ? j + e : m - 1; h[e] = hsh[x]; wl[e] = win[x]; }
+      for (int e = 0; e < 4; e++) { const uint32_t x = j + e * kTPB < m ? j + e * kTPB : m - 1; h[e] = hsh[x]; wl[e] = win[x]; }
       bool deep = false;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const int rb = l2_rank_bucket(h[e], sh);
-        const uint32_t lo = st[rb], nb = st[rb + 1] - lo;
+        const uint32_t sp = st2[rb];                                   // first sketch entry of the bucket | entries in it << 16
+        const uint32_t lo = sp & 0xffffu, nb = sp >> 16;
         const uint32_t q0 = qs[lo], q1 = qs[lo + 1];                  // sentinels 0xffffffff behind the sketch
         const uint32_t in0 = nb > 0, in1 = nb > 1;
         const uint32_t lt = (in0 & (q0 < h[e])) + (in1 & (q1 < h[e]));
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
       }
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const int32_t x = (int32_t)(j + e);
+        const int32_t x = (int32_t)(j + e * kTPB);
         if (x >= (int32_t)m) break;
         const uint32_t cd = rk[e] | ((wl[e] & kWinDupBit) ? kL2DupBit : 0u);
         // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B16 - 2

@@ -45,7 +45,8 @@ __global__ void k_finish_candidates(FinishArgs a)
 struct OneWayArgs {
   int32_t nCand;
   const int32_t *candFrag, *candSeq, *refStart; const uint32_t *idBits;
-  const int32_t *fragGenome;        // fragment -> query genome index inside the batch
+  const int32_t *fragGenome;        // fragment -> query genome index inside the set the fragments were cut from
+  int32_t genomeBase;               // ... minus this = query index inside the sub-batch
   const int32_t *contigGenome;      // reference contig -> reference genome
   const uint32_t *contigBinBase;    // reference contig -> first bin
   int32_t binWidth;                 // fragLen - 20
@@ -69,7 +70,7 @@ __global__ void k_oneway_bins(OneWayArgs a)
     if (bits > bBits || (bits == bBits && (sq > bSeq || (sq == bSeq && ps > bPos)))) { bBits = bits; bSeq = sq; bPos = ps; }
   }
   if (bBits) {
-    const size_t bin = (size_t)a.fragGenome[f] * a.binsPerQuery + a.contigBinBase[bSeq] + (uint32_t)(bPos / a.binWidth);
+    const size_t bin = (size_t)(a.fragGenome[f] - a.genomeBase) * a.binsPerQuery + a.contigBinBase[bSeq] + (uint32_t)(bPos / a.binWidth);
     atomicMax(&a.bins[bin], bBits);
   }
 }

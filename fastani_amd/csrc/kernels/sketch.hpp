@@ -116,16 +116,15 @@ __device__ __forceinline__ void hash_positions(const void *seq, int64_t off, int
 //   ws   : LDS scratch, >= kTPB + 8 ints
 // Outputs per thread: em[j] (emit at own position j), W[j] (window-min key), and block-wide first/last P.
 // ------------------------------------------------------------------------------------------------
-template <bool PACKED>
-__device__ __forceinline__ void tile_winnow(const void *seq, int64_t off, int32_t len, int32_t B, int k, int w,
-                                            uint64_t *keys, int *ws,
-                                            uint64_t (&W)[kPer], bool (&em)[kPer], int &tileFirstP, int &tileLastP)
+// key[] = this thread's kPer position keys (hash_positions).  lo = first local position that exists for this pass (keys below
+// it must be kSkipKey: a query fragment is winnowed in isolation), windows are evaluated where they end at local positions in
+// [lo + w - 1, hiEmit) and at k-mer starts below nPos.
+__device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], int32_t B, int32_t nPos, int w, int lo, int hiEmit,
+                                                 uint64_t *keys, int *ws,
+                                                 uint64_t (&W)[kPer], bool (&em)[kPer], int &tileFirstP, int &tileLastP)
 {
   const int t = threadIdx.x;
   const int local0 = t * kPer;
-  const int32_t nPos = len - k + 1;
-  uint64_t key[kPer];
-  hash_positions<PACKED>(seq, off, len, B + local0, local0, k, key);
   bool own_ok[kPer];
 #pragma unroll
   for (int j = 0; j < kPer; j++) { keys[local0 + j] = key[j]; W[j] = key[j]; own_ok[j] = key[j] != kSkipKey; }
@@ -155,7 +154,7 @@ __device__ __forceinline__ void tile_winnow(const void *seq, int64_t off, int32_
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
     const int l = local0 + j;
-    val[j] = own_ok[j] && l >= w - 1 && (B + l) < nPos;
+    val[j] = own_ok[j] && l >= lo + w - 1 && l < hiEmit && (B + l) < nPos;
     P[j] = val[j] ? (kTile - 1 - (int)(uint32_t)W[j]) : -1;
     if (val[j]) { if (myFirst < 0) myFirst = P[j]; myMax = P[j]; }
   }
@@ -180,6 +179,16 @@ __device__ __forceinline__ void tile_winnow(const void *seq, int64_t off, int32_
   tileFirstP = firstAll >= 0 ? B + firstAll : -1;
   tileLastP = lastAll >= 0 ? B + lastAll : -1;
   __syncthreads();
+}
+
+template <bool PACKED>
+__device__ __forceinline__ void tile_winnow(const void *seq, int64_t off, int32_t len, int32_t B, int k, int w,
+                                            uint64_t *keys, int *ws,
+                                            uint64_t (&W)[kPer], bool (&em)[kPer], int &tileFirstP, int &tileLastP)
+{
+  uint64_t key[kPer];
+  hash_positions<PACKED>(seq, off, len, B + (int)threadIdx.x * kPer, (int)threadIdx.x * kPer, k, key);
+  tile_winnow_keys(key, B, len - k + 1, w, 0, kTile, keys, ws, W, em, tileFirstP, tileLastP);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,6 +397,139 @@ __global__ __launch_bounds__(kTPB, SINGLE ? 4 : 3) void k_fragment_sketch(const 
     fragment_sketch_body<true>(packed, contigOff, frags, fragLen, k, w, pool, poolCap, poolCount, fragOff, fragS, maxS, keys, hbuf, ws, &sBase);
   else
     fragment_sketch_body<false>(ascii, contigOff, frags, fragLen, k, w, pool, poolCap, poolCount, fragOff, fragS, maxS, keys, hbuf, ws, &sBase);
+}
+
+// ------------------------------------------------------------------------------------------------
+// All-vs-all: a genome that is reference AND query is hashed once.  One workgroup per fragment-aligned tile: the tile of
+// fragment f of a contig starts w-1 positions before the fragment, so that the same kTile strand hashes give (1) the
+// contig-continuous reference minimizers whose windows end inside the fragment's positions and (2), with the positions outside
+// the fragment masked, the fragment's own sketch (winnowed in isolation, computeMap.hpp:260).  Hashing is ~2/3 of either
+// kernel's instructions; the second window-minimum pass and the sort are what remains of the fragment kernel.  Tiles behind a
+// contig's last whole fragment (and contigs shorter than a fragment) are reference-only.  Needs fragLen + w - 1 <= kTile.
+// ------------------------------------------------------------------------------------------------
+struct FusedInfo {
+  int32_t frag;         // fragment index in the batch, -1 = reference-only tile
+  int32_t emitEnd;      // reference minimizers are emitted for windows ending at local positions < emitEnd
+  int32_t fragLocal0;   // local position of the fragment's first base
+};
+
+__global__ void k_expand_fused(const uint32_t *__restrict__ tileStart, const uint32_t *__restrict__ fragStart, int32_t nContigs, uint32_t nTiles,
+                               int32_t fragLen, int32_t w, int32_t stride, TileDesc *__restrict__ tiles, FusedInfo *__restrict__ info)
+{
+  const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+  if (T >= nTiles) return;
+  const int32_t c = owner_of(tileStart, nContigs, T);
+  const int32_t t = (int32_t)(T - tileStart[c]);
+  const int32_t nFragC = (int32_t)(fragStart[c + 1] - fragStart[c]);
+  if (t < nFragC) {
+    const int32_t B = t == 0 ? 0 : t * fragLen - (w - 1);
+    tiles[T] = TileDesc{c, B};
+    info[T] = FusedInfo{(int32_t)fragStart[c] + t, t * fragLen - B + fragLen, t * fragLen - B};
+  } else {
+    const int32_t base = nFragC > 0 ? nFragC * fragLen - (w - 1) : 0;
+    tiles[T] = TileDesc{c, base + (t - nFragC) * stride};
+    info[T] = FusedInfo{-1, kTile, 0};
+  }
+}
+
+// sorted unique hashes of the n minimizer hashes in hbuf -> pool (computeMap.hpp:268-274); shared by the fragment kernels
+__device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool overflow, int frag, uint32_t *__restrict__ pool, uint32_t poolCap,
+                                                unsigned long long *__restrict__ poolCount, uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS,
+                                                int *__restrict__ maxS, int *ws, unsigned long long *sBasePtr)
+{
+  const int n2 = next_pow2(n > 1 ? n : 1);
+  for (int i = n + threadIdx.x; i < n2; i += kTPB) hbuf[i] = 0xffffffffu;
+  block_bitonic_sort<uint32_t>(hbuf, n2);
+  const int per = (n + kTPB - 1) / kTPB;
+  const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  int cntU = 0;
+  for (int i = lo; i < hi; i++) cntU += (i == 0 || hbuf[i] != hbuf[i - 1]);
+  int s; int r = block_excl_scan(cntU, ws, &s);
+  if (threadIdx.x == 0) {
+    *sBasePtr = s ? atomicAdd(poolCount, (unsigned long long)s) : 0ull;
+    fragOff[frag] = (uint32_t)*sBasePtr;
+    fragS[frag] = overflow ? -1 : s;
+    atomicMax(maxS, overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+  }
+  __syncthreads();
+  const unsigned long long base = *sBasePtr;
+  if (base + (unsigned long long)s <= (unsigned long long)poolCap)
+    for (int i = lo; i < hi; i++)
+      if (i == 0 || hbuf[i] != hbuf[i - 1]) pool[base + r++] = hbuf[i];
+}
+
+template <bool PACKED>
+__device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, int64_t off, int32_t len, const TileDesc td, const FusedInfo fi, int k, int w, int fragLen,
+                                                uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
+                                                TileMeta *__restrict__ meta,
+                                                uint32_t *__restrict__ qPool, uint32_t qCap, unsigned long long *__restrict__ qCount,
+                                                uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS, int *__restrict__ maxS,
+                                                uint64_t *keys, int *ws, unsigned long long *sBasePtr)
+{
+  const int local0 = (int)threadIdx.x * kPer;
+  uint64_t key[kPer];
+  hash_positions<PACKED>(seq, off, len, td.firstPos + local0, local0, k, key);
+  uint64_t W[kPer]; bool em[kPer]; int firstP, lastP;
+  // ---- reference minimizers (as k_sketch_tiles, windows ending below emitEnd) ----
+  tile_winnow_keys(key, td.firstPos, len - k + 1, w, 0, fi.emitEnd, keys, ws, W, em, firstP, lastP);
+  {
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) cnt += em[j];
+    int total; int rank = block_excl_scan(cnt, ws, &total);
+    if (threadIdx.x == 0) *sBasePtr = total ? atomicAdd(poolCount, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    const unsigned long long base = *sBasePtr;
+    if (base + (unsigned long long)total <= (unsigned long long)poolCap) {
+#pragma unroll
+      for (int j = 0; j < kPer; j++)
+        if (em[j]) {
+          poolHash[base + rank] = (uint32_t)(W[j] >> 32);
+          poolWpos[base + rank] = td.firstPos + local0 + j - w + 1;     // currentWindowId, commonFunc.hpp:124
+          rank++;
+        }
+    }
+    if (threadIdx.x == 0) { TileMeta m; m.off = (uint32_t)base; m.cnt = total; m.firstP = firstP; m.lastP = lastP; meta[blockIdx.x] = m; }
+  }
+  if (fi.frag < 0) return;                          // workgroup-uniform
+  // ---- the fragment's own sketch: only k-mers that lie inside the fragment exist ----
+  const int f0 = fi.fragLocal0, fEnd = f0 + fragLen - k;     // last k-mer start inside the fragment (local)
+#pragma unroll
+  for (int j = 0; j < kPer; j++) { const int l = local0 + j; if (l < f0 || l > fEnd) key[j] = kSkipKey; }
+  __syncthreads();                                  // the reference pass is done with keys / ws
+  tile_winnow_keys(key, td.firstPos, 0x7fffffff, w, f0, kTile, keys, ws, W, em, firstP, lastP);
+  uint32_t *hbuf = (uint32_t *)keys;                // dead once the tile is winnowed (kFragHashCap * 4 <= kTile * 8)
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; j++) cnt += em[j];
+  int total; int rank = block_excl_scan(cnt, ws, &total);
+#pragma unroll
+  for (int j = 0; j < kPer; j++)
+    if (em[j]) { if (rank < kFragHashCap) hbuf[rank] = (uint32_t)(W[j] >> 32); rank++; }
+  const bool overflow = total > kFragHashCap;
+  __syncthreads();
+  fragment_finish(hbuf, overflow ? kFragHashCap : total, overflow, fi.frag, qPool, qCap, qCount, fragOff, fragS, maxS, ws, sBasePtr);
+}
+
+__global__ __launch_bounds__(kTPB, 3) void k_sketch_fused(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
+                                                          const int64_t *__restrict__ contigOff, const int32_t *__restrict__ contigLen, const uint8_t *__restrict__ contigMode,
+                                                          const TileDesc *__restrict__ tiles, const FusedInfo *__restrict__ info, int k, int w, int fragLen,
+                                                          uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
+                                                          TileMeta *__restrict__ meta,
+                                                          uint32_t *__restrict__ qPool, uint32_t qCap, unsigned long long *__restrict__ qCount,
+                                                          uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS, int *__restrict__ maxS)
+{
+  __shared__ uint64_t keys[kTile];
+  __shared__ int ws[kTPB + 16];
+  __shared__ unsigned long long sBase;
+  const TileDesc td = tiles[blockIdx.x];
+  const FusedInfo fi = info[blockIdx.x];
+  const int64_t off = contigOff[td.contig];
+  const int32_t len = contigLen[td.contig];
+  if (contigMode[td.contig])
+    fused_tile_body<true>(packed, off, len, td, fi, k, w, fragLen, poolHash, poolWpos, poolCap, poolCount, meta, qPool, qCap, qCount, fragOff, fragS, maxS, keys, ws, &sBase);
+  else
+    fused_tile_body<false>(ascii, off, len, td, fi, k, w, fragLen, poolHash, poolWpos, poolCap, poolCount, meta, qPool, qCap, qCount, fragOff, fragS, maxS, keys, ws, &sBase);
 }
 
 }  // namespace ani

@@ -92,6 +92,7 @@ typedef struct {
 typedef struct ani_ctx ani_ctx;
 typedef struct ani_sketch ani_sketch;
 typedef struct ani_dev_batch ani_dev_batch;
+typedef struct ani_fragset ani_fragset;
 
 /* Run-time counters for the measurement contract: the algorithmic-byte figure of a run is
  * computed from these, never estimated. */
@@ -186,6 +187,21 @@ int ani_map_query(ani_ctx *ctx, const ani_sketch *sk, const ani_seq_batch_t *que
  * unique hashes — for parity tests */
 int ani_query_sketch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *query,
                      uint32_t **hashes, uint64_t **offsets, size_t *nFragments);
+
+/* ---- kept fragment sketches.  Map::Map sketches every 3-kb fragment of a query genome (computeMap.hpp:252-274) each time the
+ * genome is mapped, and the reference driver re-does that per reference split (core_genome_identity.cpp:81-106).  Here the
+ * fragment sketches of a batch of query genomes can be built once and kept on the device:
+ *   ani_fragset_build        from query genomes;
+ *   ani_sketch_records_self  all-vs-all: the genomes are references AND queries — one pass over their k-mer hashes yields both
+ *                            the reference minimizer records (as ani_sketch_records) and the fragment sketches;
+ *   ani_map_cgi_fragset      = ani_map_cgi_batch for the genomes of a kept set (any sketch with the same parameters).
+ * qryGenomeId = firstQueryId + index of the genome in the set. */
+int ani_fragset_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *queries, ani_fragset **out);
+int ani_sketch_records_self(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *genomes, int32_t seqIdBase,
+                            void **devRecords, size_t *n, ani_fragset **frags);
+int ani_map_cgi_fragset(ani_ctx *ctx, const ani_sketch *sk, const ani_fragset *frags, int32_t firstQueryId,
+                        ani_cgi_t **out, size_t *m);
+void ani_fragset_free(ani_fragset *frags);
 
 /* ---- reducer: replaces cgi::computeCGI (computeCoreIdentity.hpp:166-298) for one query genome ---- */
 int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *sk, const ani_mapping_t *mappings, size_t n,

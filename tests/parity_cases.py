@@ -214,6 +214,41 @@ def case_uploaded(engine):
     assert np.array_equal(sk0.minimizers(), osk.minimizers())
 
 
+def case_self(engine):
+    """all-vs-all in one pass over the hashes (ani_sketch_records_self -> k_sketch_fused): reference records and fragment
+    sketches of the same genomes, then ani_map_cgi_fragset; also kept fragment sets of plain queries (ani_fragset_build).
+    Fragment lengths that fit a tile together with their lead-in are fused, longer ones take the two separate kernels."""
+    genomes = [messy_genome(5, 50000), [orc.synth_genome(5, 0, 40000)], [rng_genome(1, 10, b"ACGT")], [orc.synth_genome(5, 3, 35001)], [b""],
+               [orc.synth_genome(5, 1, 2999)], [orc.synth_genome(5, 2, 3000)], [orc.synth_genome(5, 4, 6047), orc.synth_genome(5, 20, 9100)]]
+    contig_len = np.array([len(c) for g in genomes for c in g], dtype=np.int32)
+    gcs = np.cumsum([0] + [len(g) for g in genomes]).astype(np.int32)
+    for k, frag_len in ((16, 3000), (16, 1000), (12, 3000), (16, 3049), (16, 3050), (16, 5000)):
+        p = engine.params(k, frag_len)
+        direct = Sketch(engine, p, genomes)
+        rows0 = direct.map_cgi_batch(genomes, 0)
+        ptr, n, frags = engine.sketch_records_self(p, genomes, 0)
+        sk = Sketch(engine, p, records=(ptr, n, contig_len, gcs))
+        assert np.array_equal(sk.minimizers(), direct.minimizers()), (k, frag_len)
+        rows = sk.map_cgi_fragset(frags, 0)
+        assert np.array_equal(rows, rows0), (k, frag_len)
+        if n:
+            engine.device_free(ptr)
+        frags.close()
+        f2 = engine.fragment_set(p, genomes[3:])
+        assert np.array_equal(direct.map_cgi_fragset(f2, 3), rows0[rows0["qryGenomeId"] >= 3]), (k, frag_len)
+        f2.close()
+    # and against the oracle for the default parameters
+    p = engine.params()
+    osk = orc.Sketch(genomes, 16, p.windowSize)
+    exp = []
+    for qi, g in enumerate(genomes):
+        maps, tot = osk.map_genome(g)
+        exp.append(osk.compute_cgi(maps, tot, qi))
+    ptr, n, frags = engine.sketch_records_self(p, genomes, 0)
+    sk = Sketch(engine, p, records=(ptr, n, contig_len, gcs))
+    assert np.array_equal(sk.map_cgi_fragset(frags, 0), np.concatenate(exp))
+
+
 def case_limits(engine):
     """documented limits fail loudly with ANI_ERR_LIMIT (-4), never silently"""
     from fastani_amd.api import AniError
@@ -237,7 +272,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_sparse_hits, case_empty_and_short, case_uploaded]
+             case_low_complexity_big, case_sparse_hits, case_empty_and_short, case_uploaded, case_self]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):

@@ -40,6 +40,10 @@ if has ab; then
 import json,sys; d=json.loads(sys.stdin.readline()); print('$v', d['value'], d['ms_per_step'], d['stage_ms_per_step_rank0'], d['roofline']['all_kernels_ms_per_step'])" | tee -a "$OUT/ab.txt"
   done
 fi
+if has noself; then
+  echo "== bench (default workload, query role sketched separately)"; timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --no-self 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('no-self', d['value'], d['ms_per_step'], d['stage_ms_per_step_rank0'], d['roofline']['all_kernels_ms_per_step'])" | tee "$OUT/noself.txt"
+fi
 if has c4w; then
   echo "== bench c4 (10000 refs, 300 queries, 1 GPU, warm)"; timeout 900 python bench.py --config c4 --queries 300 --steps 2 --warmup 1 --no-e2e 2> "$OUT/bench_c4.err" | tee "$OUT/bench_c4.json" | cut -c1-400; tail -3 "$OUT/bench_c4.err"
 fi
