@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -327,7 +328,7 @@ std::vector<std::pair<size_t, size_t>> make_slices(const FilePipeline &fp, size_
   return out;
 }
 
-struct Device { int id = 0; ani_ctx *ctx = nullptr; };
+struct Device { int id = 0; ani_ctx *ctx = nullptr, *up = nullptr; };    // compute context + upload context (own stream and staging)
 
 struct RefPart { void *rec = nullptr; uint64_t n = 0; int dev = 0; int32_t g0 = 0, g1 = 0; };
 
@@ -374,7 +375,7 @@ int main(int argc, char **argv)
 
   // ---- devices ----
   std::vector<Device> dev(o.devices.size());
-  for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx)) die("ani_init"); }
+  for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx) || ani_init(dev[d].id, &dev[d].up)) die("ani_init"); }
   const int nDev = (int)dev.size();
   std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
   std::cerr << "INFO [thread 0], skch::main, Count of threads executing parallel_for : " << (o.sanityCheck ? o.threads : nDev) << std::endl;
@@ -392,52 +393,88 @@ int main(int argc, char **argv)
     // reference tables, filled slice by slice
     std::vector<int32_t> contigLenAll, gcsAll{0};
     std::vector<RefPart> parts(refSlices.size());
-    std::vector<ani_dev_batch *> kept(allVsAll ? refSlices.size() : 0, nullptr);
-    std::vector<std::vector<int32_t>> keptLen(kept.size()), keptGcs(kept.size());
-    std::vector<int32_t> sliceSeqBase(refSlices.size() + 1, 0);
+    std::vector<ani_fragset *> kept(allVsAll ? refSlices.size() : 0, nullptr);     // all-vs-all: the slices' fragment sketches stay on their device
     const auto t0 = Clock::now();
-    // Slices are prepared in order (contig numbering is global), the device work of slice k runs on device k % nDev in its own
-    // thread, so that upload + sketching of consecutive slices overlap across devices and with the readers.
-    {
-      std::vector<std::thread> workers;
+    // Two threads per device.  The upload thread takes the device's slices in order (k = d, d + nDev, ...): waits for the readers,
+    // enters the slice into the global contig / genome tables (in slice order: contig numbering is global), packs and copies it to
+    // the device on its own context.  The compute thread sketches the uploaded slices.  So parsing (reader pool), packing + H2D and
+    // the kernels of consecutive slices overlap.  All-vs-all: the fused pass also yields the slice's fragment sketches, which are
+    // what the mapping phase needs; the packed bases are dropped right away.
+    struct Uploaded { ani_dev_batch *b = nullptr; std::vector<int32_t> len, gcs; int32_t seqBase = 0; bool ready = false; };
+    auto run_two_stage = [&](const std::vector<std::pair<size_t, size_t>> &slices, const char *what,
+                             const std::function<bool(int, size_t, SliceBatch &, Uploaded &)> &enter,          // bookkeeping before the upload (upload thread)
+                             const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute) {     // device work on the uploaded slice (compute thread)
+      std::vector<Uploaded> ups(slices.size());
       std::vector<std::string> errs((size_t)nDev);
+      std::mutex mu; std::condition_variable cv;
+      std::vector<size_t> done((size_t)nDev, 0);          // slices the compute thread of device d has finished (bounds the upload thread's lead)
+      std::vector<std::thread> th;
+      for (int d = 0; d < nDev; d++) {
+        th.emplace_back([&, d]() {                        // upload thread
+          size_t mine = 0;
+          for (size_t k = (size_t)d; k < slices.size(); k += (size_t)nDev, mine++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return mine < done[d] + 2 || !errs[d].empty(); }); if (!errs[d].empty()) return; }
+            const size_t a = slices[k].first, b = slices[k].second;
+            if (!fp.wait(a, b)) { std::lock_guard<std::mutex> lk(mu); errs[d] = "input"; cv.notify_all(); return; }
+            SliceBatch sb;
+            for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
+            Uploaded &u = ups[k];
+            bool ok = enter(d, k, sb, u);
+            ani_seq_batch_t hb = sb.batch();
+            if (ok && ani_batch_upload(dev[d].up, &hb, &u.b)) ok = false;
+            std::string msg = ok ? "" : ani_last_error();
+            fp.release(a, b);                               // the host copy is no longer needed
+            u.len = std::move(sb.len); u.gcs = std::move(sb.gcs);
+            { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "upload" : msg; u.ready = true; }
+            cv.notify_all();
+            if (!ok) return;
+          }
+        });
+        th.emplace_back([&, d]() {                        // compute thread
+          for (size_t k = (size_t)d; k < slices.size(); k += (size_t)nDev) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return ups[k].ready || !errs[d].empty(); }); if (!errs[d].empty()) return; }
+            std::string msg;
+            const bool ok = compute(d, k, ups[k], msg);
+            if (ups[k].b) { ani_batch_free(ups[k].b); ups[k].b = nullptr; }
+            { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "device" : msg; done[d]++; }
+            cv.notify_all();
+            if (!ok) return;
+          }
+        });
+      }
+      for (auto &t : th) t.join();
+      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, " << what << ": " << e << std::endl; exit(1); }
+    };
+    auto dev_view = [](const Uploaded &u) {
+      static const int32_t zero = 0;
+      ani_seq_batch_t db; db.layout = ANI_SEQ_DEVICE_BATCH; db.nGenomes = (int32_t)u.gcs.size() - 1; db.nContigs = (int32_t)u.len.size();
+      db.genomeContigStart = u.gcs.data(); db.contigOffset = nullptr; db.contigLen = u.len.empty() ? &zero : u.len.data(); db.data = u.b;
+      return db;
+    };
+    {
       std::mutex orderMu; std::condition_variable orderCv; size_t nextSlice = 0;   // slices enter the tables in order
-      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
-        for (size_t k = (size_t)d; k < refSlices.size(); k += (size_t)nDev) {
-          const size_t a = refSlices[k].first, b = refSlices[k].second;
-          if (!fp.wait(a, b)) { errs[d] = "input"; return; }
-          SliceBatch sb;
-          for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
-          int32_t seqBase;
-          {
-            std::unique_lock<std::mutex> lk(orderMu);
-            orderCv.wait(lk, [&]() { return nextSlice == k; });
-            seqBase = (int32_t)contigLenAll.size();
-            sliceSeqBase[k] = seqBase;
-            const int32_t gBase = (int32_t)gcsAll.size() - 1;
-            contigLenAll.insert(contigLenAll.end(), sb.len.begin(), sb.len.end());
-            for (size_t g = 1; g < sb.gcs.size(); g++) gcsAll.push_back(seqBase + sb.gcs[g]);
-            parts[k].g0 = gBase; parts[k].g1 = gBase + (int32_t)sb.gcs.size() - 1; parts[k].dev = d;
-            nextSlice = k + 1;
-          }
-          orderCv.notify_all();
-          ani_seq_batch_t hb = sb.batch();
+      run_two_stage(refSlices, "reference sketch",
+        [&](int d, size_t k, SliceBatch &sb, Uploaded &u) {
+          std::unique_lock<std::mutex> lk(orderMu);
+          orderCv.wait(lk, [&]() { return nextSlice == k; });
+          u.seqBase = (int32_t)contigLenAll.size();
+          const int32_t gBase = (int32_t)gcsAll.size() - 1;
+          contigLenAll.insert(contigLenAll.end(), sb.len.begin(), sb.len.end());
+          for (size_t g = 1; g < sb.gcs.size(); g++) gcsAll.push_back(u.seqBase + sb.gcs[g]);
+          parts[k].g0 = gBase; parts[k].g1 = gBase + (int32_t)sb.gcs.size() - 1; parts[k].dev = d;
+          nextSlice = k + 1;
+          lk.unlock(); orderCv.notify_all();
+          return true;
+        },
+        [&](int d, size_t k, Uploaded &u, std::string &msg) {
+          ani_seq_batch_t db = dev_view(u);
           size_t n = 0;
-          if (allVsAll) {
-            if (ani_batch_upload(dev[d].ctx, &hb, &kept[k])) { errs[d] = ani_last_error(); return; }
-            keptLen[k] = sb.len; keptGcs[k] = sb.gcs;
-            fp.release(a, b);                                         // host copy no longer needed
-            ani_seq_batch_t db = hb; db.layout = ANI_SEQ_DEVICE_BATCH; db.data = kept[k]; db.contigLen = keptLen[k].data(); db.genomeContigStart = keptGcs[k].data();
-            if (ani_sketch_records(dev[d].ctx, &ap, &db, seqBase, &parts[k].rec, &n)) { errs[d] = ani_last_error(); return; }
-          } else {
-            if (ani_sketch_records(dev[d].ctx, &ap, &hb, seqBase, &parts[k].rec, &n)) { errs[d] = ani_last_error(); return; }
-            fp.release(a, b);
-          }
+          const int rc = allVsAll ? ani_sketch_records_self(dev[d].ctx, &ap, &db, u.seqBase, &parts[k].rec, &n, &kept[k])
+                                  : ani_sketch_records(dev[d].ctx, &ap, &db, u.seqBase, &parts[k].rec, &n);
+          if (rc) { msg = ani_last_error(); return false; }
           parts[k].n = n;
-        }
-      });
-      for (auto &w : workers) w.join();
-      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, reference sketch: " << e << std::endl; exit(1); }
+          return true;
+        });
     }
     // every device gets every part (peer-to-peer pulls), then builds the full index
     std::vector<ani_sketch *> sk((size_t)nDev, nullptr);
@@ -473,43 +510,50 @@ int main(int argc, char **argv)
 
     // ---- queries: slices round-robin over the devices; rows are collected per slice so that the order does not depend on timing ----
     std::vector<std::vector<ani_cgi_t>> sliceRows(qrySlices.size());
-    {
+    std::mutex logMu;
+    auto log_map = [&](int d, int32_t firstQ, size_t nq, double total, double post) {
+      std::lock_guard<std::mutex> lk(logMu);
+      std::cerr << "INFO [thread " << d << "], skch::main, Time spent mapping fragments in query #" << firstQ + 1 << "-#" << firstQ + (int32_t)nq << " : " << std::max(0.0, total - post) << " sec" << std::endl;
+      std::cerr << "INFO [thread " << d << "], skch::main, Time spent post mapping : " << post << " sec" << std::endl;
+    };
+    if (allVsAll) {
+      // slice k's fragment sketches are on device k % nDev already
       std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
-      std::mutex logMu;
       for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
         for (size_t k = (size_t)d; k < qrySlices.size(); k += (size_t)nDev) {
           const size_t a = qrySlices[k].first, b = qrySlices[k].second;
-          const int32_t firstQ = (int32_t)(allVsAll ? a : a - (size_t)nRef);
           const auto tm = Clock::now();
           ani_counters_t c0, c1;
           ani_get_counters(dev[d].ctx, &c0);
           ani_cgi_t *rows = nullptr; size_t m = 0;
-          if (allVsAll) {
-            // slice k was uploaded by device k % nDev = d
-            ani_seq_batch_t db; db.layout = ANI_SEQ_DEVICE_BATCH; db.nGenomes = (int32_t)keptGcs[k].size() - 1; db.nContigs = (int32_t)keptLen[k].size();
-            static const int32_t zero = 0;
-            db.genomeContigStart = keptGcs[k].data(); db.contigOffset = nullptr; db.contigLen = keptLen[k].empty() ? &zero : keptLen[k].data(); db.data = kept[k];
-            if (ani_map_cgi_batch(dev[d].ctx, sk[d], &db, firstQ, &rows, &m)) { errs[d] = ani_last_error(); return; }
-            ani_batch_free(kept[k]); kept[k] = nullptr;
-          } else {
-            if (!fp.wait(a, b)) { errs[d] = "input"; return; }
-            SliceBatch sb;
-            for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
-            ani_seq_batch_t hb = sb.batch();
-            if (ani_map_cgi_batch(dev[d].ctx, sk[d], &hb, firstQ, &rows, &m)) { errs[d] = ani_last_error(); return; }
-            fp.release(a, b);
-          }
+          if (ani_map_cgi_fragset(dev[d].ctx, sk[d], kept[k], (int32_t)a, &rows, &m)) { errs[d] = ani_last_error(); return; }
+          ani_fragset_free(kept[k]); kept[k] = nullptr;
           sliceRows[k].assign(rows, rows + m);
           ani_free(rows);
           ani_get_counters(dev[d].ctx, &c1);
-          const double total = secs_since(tm), post = (c1.msReduce - c0.msReduce) / 1e3;
-          std::lock_guard<std::mutex> lk(logMu);
-          std::cerr << "INFO [thread " << d << "], skch::main, Time spent mapping fragments in query #" << firstQ + 1 << "-#" << firstQ + (int32_t)(b - a) << " : " << std::max(0.0, total - post) << " sec" << std::endl;
-          std::cerr << "INFO [thread " << d << "], skch::main, Time spent post mapping : " << post << " sec" << std::endl;
+          log_map(d, (int32_t)a, b - a, secs_since(tm), (c1.msReduce - c0.msReduce) / 1e3);
         }
       });
       for (auto &w : workers) w.join();
       for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, mapping: " << e << std::endl; exit(1); }
+    } else {
+      run_two_stage(qrySlices, "mapping",
+        [&](int, size_t, SliceBatch &, Uploaded &) { return true; },
+        [&](int d, size_t k, Uploaded &u, std::string &msg) {
+          const size_t a = qrySlices[k].first, b = qrySlices[k].second;
+          const int32_t firstQ = (int32_t)(a - (size_t)nRef);
+          const auto tm = Clock::now();
+          ani_counters_t c0, c1;
+          ani_get_counters(dev[d].ctx, &c0);
+          ani_seq_batch_t db = dev_view(u);
+          ani_cgi_t *rows = nullptr; size_t m = 0;
+          if (ani_map_cgi_batch(dev[d].ctx, sk[d], &db, firstQ, &rows, &m)) { msg = ani_last_error(); return false; }
+          sliceRows[k].assign(rows, rows + m);
+          ani_free(rows);
+          ani_get_counters(dev[d].ctx, &c1);
+          log_map(d, firstQ, b - a, secs_since(tm), (c1.msReduce - c0.msReduce) / 1e3);
+          return true;
+        });
     }
     for (auto &v : sliceRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }
     for (int d = 0; d < nDev; d++) { ani_sketch_destroy(sk[d]); std::cerr << "INFO [thread " << d << "], skch::main, ready to exit the loop" << std::endl; }
@@ -676,6 +720,6 @@ int main(int argc, char **argv)
       out << r.q << "\t" << r.r << "\t" << r.id << "\tNA\tNA\tNA\t" << r.qs << "\t" << r.qe << "\t" << r.rs << "\t" << r.re << "\tNA\tNA\n";
   }
   std::cerr << "INFO, skch::main, Time spent writing the output : " << secs_since(tOut) << " sec; total : " << secs_since(tStart) << " sec" << std::endl;
-  for (auto &d : dev) ani_shutdown(d.ctx);
+  for (auto &d : dev) { ani_shutdown(d.up); ani_shutdown(d.ctx); }
   return 0;
 }
