@@ -261,14 +261,19 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
             e2e_out = os.path.join(td, "e2e.out")
             threads = min(hi["logical_cpus"], 64)
             t0 = time.time()
-            r = subprocess.run([cli, "--ql", lst, "--rl", lst, "-t", str(threads), "-o", e2e_out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            r = subprocess.run([cli, "--ql", lst, "--rl", lst, "-t", str(threads), "-o", e2e_out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                               env=dict(os.environ, ANI_CLI_TRACE="1"))
             t_e2e = time.time() - t0
             e2e = {"seconds": round(t_e2e, 2), "pairs_per_s": round(n_refs * n_refs / t_e2e, 1), "threads": threads, "returncode": r.returncode,
                    "what": "fastani_amd/fastANI --ql all --rl all (%d x %d FASTA files, %.1f GB, local disk) -> output file; first FASTA byte to output closed"
                            % (n_refs, n_refs, out["fasta_set"]["bytes"] / 1e9)}
-            tl = [ln for ln in r.stderr.decode(errors="replace").splitlines() if "Time spent" in ln or "time spent" in ln]
+            err_lines = r.stderr.decode(errors="replace").splitlines()
+            tl = [ln for ln in err_lines if "Time spent sketching" in ln or "Time spent writing" in ln]
             if tl:
-                e2e["stderr_timers"] = tl[-6:]
+                e2e["stderr_timers"] = tl
+            tr = [ln.replace("[fastANI trace]", "").strip() for ln in err_lines if ln.startswith("[fastANI trace]")]
+            if tr:
+                e2e["phases"] = tr
             if r.returncode == 0 and not args.no_verify:
                 printed = read_ref_out(e2e_out, index_of)
                 want = {k: v for k, v in rows_by_pair.items() if trusted(v[1], L)}

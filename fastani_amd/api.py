@@ -84,6 +84,11 @@ def _bind(lib):
         "ani_map_query": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
         "ani_query_sketch": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_compute_cgi": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_sketch_save": (C.c_int, [vp, C.c_char_p, vp]),
+        "ani_sketch_load": (C.c_int, [vp, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]),
+        "ani_sketch_file_info": (C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+        "ani_sketch_genome_name": (C.c_char_p, [vp, C.c_int32]),
+        "ani_sketch_tables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "ani_fragset_build": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp)]),
         "ani_sketch_records_self": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]),
         "ani_map_cgi_fragset": (C.c_int, [vp, vp, vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
@@ -321,14 +326,16 @@ class FragmentSet:
 
 
 class Sketch:
-    def __init__(self, engine, params, genomes=None, records=None, record_parts=None):
+    def __init__(self, engine, params, genomes=None, records=None, record_parts=None, file=None, genome_range=(0, -1)):
         """Either `genomes` (≙ Sketch::Sketch over the reference files), or for the multi-GPU staging path
         records=(dev_ptr, n, contig_len[int32], genome_contig_start[int32]) or
         record_parts=(dev_ptrs, counts, part_genome_start[nParts+1], contig_len, genome_contig_start)."""
         self.e = engine
         self.params = params
         h = C.c_void_p()
-        if record_parts is not None:
+        if file is not None:
+            engine._chk(engine.lib.ani_sketch_load(engine.h, str(file).encode(), genome_range[0], genome_range[1], C.byref(h)))
+        elif record_parts is not None:
             ptrs, counts, pgs, clen, gcs = record_parts
             ptrs = np.ascontiguousarray(ptrs, dtype=np.uint64)
             counts = np.ascontiguousarray(counts, dtype=np.uint64)
@@ -365,6 +372,15 @@ class Sketch:
         p, n = C.c_void_p(), C.c_size_t()
         self.e._chk(self.e.lib.ani_sketch_export(self.h, C.byref(p), C.byref(n)))
         return self.e._take(p, n.value, MINIMIZER_DT)
+
+    def save(self, path, names=None):
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[n.encode() if isinstance(n, str) else n for n in names])
+        self.e._chk(self.e.lib.ani_sketch_save(self.h, str(path).encode(), arr))
+
+    def genome_names(self):
+        return [self.e.lib.ani_sketch_genome_name(self.h, g).decode() for g in range(self.stats()["genomes"])]
 
     def chunks(self):
         """first genome id of every index chunk of the reference set"""

@@ -8,6 +8,11 @@
 // There is no CPU code path behind these entry points: without a usable HIP device every call fails.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -230,6 +235,7 @@ struct ani_sketch {
   uint64_t totalLen = 0;
   uint64_t nUnique = 0; bool uniqueExact = false;   // distinct hashes over all chunks (computed on demand when there are several)
   std::vector<int32_t> contigLen, genomeContigStart;
+  std::vector<std::string> genomeNames;    // optional (ani_sketch_save / _load carry them)
   std::vector<IndexChunk *> chunks;
   uint32_t maxChunkBins = 0;
   // LUTs
@@ -1814,6 +1820,172 @@ int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGeno
   if (!sk || !nChunks) return fail(ANI_ERR_ARG, "null argument");
   *nChunks = (int32_t)sk->chunks.size();
   if (firstGenome) for (int32_t i = 0; i < cap && i < *nChunks; i++) firstGenome[i] = sk->chunks[i]->g0;
+  return ANI_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Persistent sketch file (the reference rebuilds its sketch in every run and every thread).
+//   header (4096 B) : magic "ANISKTCH", version, the parameters the sketch depends on, counts, section offsets
+//   contigLen        int32[nContigs]
+//   genomeContigStart int32[nGenomes + 1]
+//   genomeRecStart   uint64[nGenomes + 1]   first record of every genome: a reader can take any genome range (one rank's shard)
+//   names            nGenomes NUL-terminated strings (may be empty)
+//   records          12-byte (hash, seqId, wpos) minimizer records, position order, global seqIds = skch::MinimizerInfo, the
+//                    layout of ani_sketch_records / ani_sketch_from_records
+// Sections start on 4096-byte boundaries, so the file can be mmap'ed and the record section handed to hipMemcpy as it is.  The
+// hash-ordered index is not stored: rebuilding it on the device (radix sort) is faster than reading it back.
+// -----------------------------------------------------------------------------------------------------
+namespace {
+struct SketchFileHeader {
+  char magic[8]; uint32_t version, headerBytes;
+  int32_t kmerSize, windowSize, fragLen; float percentageIdentity;
+  int32_t nContigs, nGenomes; uint64_t nRecords;
+  uint64_t offContigLen, offGcs, offGenomeRec, offNames, namesBytes, offRecords;
+};
+constexpr uint64_t kFileAlign = 4096;
+inline uint64_t align_up(uint64_t x) { return (x + kFileAlign - 1) / kFileAlign * kFileAlign; }
+bool write_all(int fd, const void *p, size_t n) { const char *c = (const char *)p; while (n) { const ssize_t w = ::write(fd, c, n); if (w <= 0) return false; c += w; n -= (size_t)w; } return true; }
+bool pad_to(int fd, uint64_t *pos, uint64_t target) { static const char z[4096] = {0}; while (*pos < target) { const size_t n = (size_t)std::min<uint64_t>(4096, target - *pos); if (!write_all(fd, z, n)) return false; *pos += n; } return true; }
+}  // namespace
+
+int ani_sketch_save(const ani_sketch *sk, const char *path, const char *const *genomeNames)
+{
+  if (!sk || !path) return fail(ANI_ERR_ARG, "null argument");
+  ani_ctx *ctx = sk->ctx;
+  HIP_TRY(hipSetDevice(sk->device));
+  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return fail(ANI_ERR_ARG, "cannot create %s", path);
+  std::string names;
+  for (int32_t g = 0; g < sk->nGenomes; g++) { names += genomeNames && genomeNames[g] ? genomeNames[g] : (g < (int32_t)sk->genomeNames.size() ? sk->genomeNames[g].c_str() : ""); names.push_back('\0'); }
+  // records per genome: chunk by chunk (contigFirstMin of the chunk's genomes' first contigs)
+  std::vector<uint64_t> genomeRec((size_t)sk->nGenomes + 1, 0);
+  {
+    uint64_t base = 0;
+    for (const IndexChunk *ch : sk->chunks) {
+      std::vector<int32_t> cfm((size_t)ch->nContigs + 1);
+      if (hipMemcpy(cfm.data(), ch->contigFirstMin, cfm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { ::close(fd); return fail(ANI_ERR_DEVICE, "reading the index failed"); }
+      for (int32_t g = 0; g < ch->nGenomes; g++) genomeRec[ch->g0 + g] = base + (uint64_t)cfm[sk->genomeContigStart[ch->g0 + g] - ch->c0];
+      base += ch->n;
+    }
+    genomeRec[sk->nGenomes] = base;
+  }
+  SketchFileHeader h; memset(&h, 0, sizeof h);
+  memcpy(h.magic, "ANISKTCH", 8); h.version = 1; h.headerBytes = (uint32_t)kFileAlign;
+  h.kmerSize = sk->params.kmerSize; h.windowSize = sk->params.windowSize; h.fragLen = sk->params.fragLen; h.percentageIdentity = sk->params.percentageIdentity;
+  h.nContigs = sk->nContigs; h.nGenomes = sk->nGenomes; h.nRecords = sk->n;
+  h.offContigLen = kFileAlign;
+  h.offGcs = align_up(h.offContigLen + (uint64_t)sk->nContigs * 4);
+  h.offGenomeRec = align_up(h.offGcs + ((uint64_t)sk->nGenomes + 1) * 4);
+  h.offNames = align_up(h.offGenomeRec + ((uint64_t)sk->nGenomes + 1) * 8);
+  h.namesBytes = names.size();
+  h.offRecords = align_up(h.offNames + names.size());
+  uint64_t pos = 0;
+  bool ok = write_all(fd, &h, sizeof h); pos += sizeof h;
+  ok = ok && pad_to(fd, &pos, h.offContigLen) && write_all(fd, sk->contigLen.data(), (size_t)sk->nContigs * 4); pos += (uint64_t)sk->nContigs * 4;
+  ok = ok && pad_to(fd, &pos, h.offGcs) && write_all(fd, sk->genomeContigStart.data(), ((size_t)sk->nGenomes + 1) * 4); pos += ((uint64_t)sk->nGenomes + 1) * 4;
+  ok = ok && pad_to(fd, &pos, h.offGenomeRec) && write_all(fd, genomeRec.data(), genomeRec.size() * 8); pos += genomeRec.size() * 8;
+  ok = ok && pad_to(fd, &pos, h.offNames) && write_all(fd, names.data(), names.size()); pos += names.size();
+  ok = ok && pad_to(fd, &pos, h.offRecords);
+  // records: joined on the device into 12-byte records, through page-locked staging, 64 M records at a time
+  const size_t kPiece = (size_t)64 << 20;
+  for (const IndexChunk *ch : sk->chunks) {
+    for (size_t o = 0; ok && o < ch->n; o += kPiece) {
+      const size_t m = std::min<size_t>(kPiece, ch->n - o);
+      uint32_t *tmp = nullptr; void *host = nullptr;
+      if (pool_malloc((void **)&tmp, m * 12) != hipSuccess || pinned_buffer(ctx, 0, m * 12, &host) != ANI_OK) { if (tmp) pool_free(tmp); ok = false; break; }
+      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(m, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash + o, ch->mSeq + o, ch->mWpos + o, (uint32_t)m, (uint32_t)ch->c0, tmp);
+      hipError_t e = hipMemcpyAsync(host, tmp, m * 12, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      pool_free(tmp);
+      ok = e == hipSuccess && write_all(fd, host, m * 12);
+    }
+  }
+  if (::close(fd) != 0) ok = false;
+  if (!ok) { ::unlink(path); return fail(ANI_ERR_DEVICE, "writing %s failed", path); }
+  return ANI_OK;
+}
+
+// genomes [g0, g1) of a sketch file (g1 < 0: to the end) -> a sketch on this context; seqIds / genome ids are renumbered from 0
+int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_sketch **out)
+{
+  if (!ctx || !path || !out) return fail(ANI_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) return fail(ANI_ERR_ARG, "cannot open %s", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < sizeof(SketchFileHeader)) { ::close(fd); return fail(ANI_ERR_ARG, "%s is not a sketch file", path); }
+  const size_t fileBytes = (size_t)st.st_size;
+  const uint8_t *base = (const uint8_t *)mmap(nullptr, fileBytes, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (base == MAP_FAILED) return fail(ANI_ERR_NOMEM, "mmap of %s failed", path);
+  struct Unmap { const uint8_t *p; size_t n; ~Unmap() { munmap((void *)p, n); } } unmap{base, fileBytes};
+  SketchFileHeader h; memcpy(&h, base, sizeof h);
+  if (memcmp(h.magic, "ANISKTCH", 8) != 0 || h.version != 1) return fail(ANI_ERR_ARG, "%s is not a version-1 sketch file", path);
+  if (h.nContigs < 0 || h.nGenomes < 0 || h.offRecords + h.nRecords * 12 > fileBytes || h.offNames + h.namesBytes > fileBytes ||
+      h.offGenomeRec + ((uint64_t)h.nGenomes + 1) * 8 > fileBytes || h.offGcs + ((uint64_t)h.nGenomes + 1) * 4 > fileBytes || h.offContigLen + (uint64_t)h.nContigs * 4 > fileBytes)
+    return fail(ANI_ERR_ARG, "%s is truncated", path);
+  if (g1 < 0) g1 = h.nGenomes;
+  if (g0 < 0 || g0 > g1 || g1 > h.nGenomes) return fail(ANI_ERR_ARG, "genome range [%d, %d) outside the file's %d genomes", g0, g1, h.nGenomes);
+  ani_params_t p; p.kmerSize = h.kmerSize; p.windowSize = h.windowSize; p.fragLen = h.fragLen; p.percentageIdentity = h.percentageIdentity;
+  TRY(check_params(&p));
+  const int32_t *gcsF = (const int32_t *)(base + h.offGcs), *clenF = (const int32_t *)(base + h.offContigLen);
+  const uint64_t *grec = (const uint64_t *)(base + h.offGenomeRec);
+  const int32_t c0 = gcsF[g0], c1 = gcsF[g1], nG = g1 - g0;
+  std::vector<int32_t> gcs((size_t)nG + 1);
+  for (int32_t g = 0; g <= nG; g++) gcs[g] = gcsF[g0 + g] - c0;
+  ani_sketch *sk = new_sketch(ctx, &p, clenF + c0, c1 - c0, gcs.data(), nG);
+  { const char *nm = (const char *)(base + h.offNames), *end = nm + h.namesBytes;
+    for (int32_t g = 0; g < h.nGenomes && nm < end; g++) { const size_t l = strnlen(nm, (size_t)(end - nm)); if (g >= g0 && g < g1) sk->genomeNames.emplace_back(nm, l); nm += l + 1; } }
+  // records to the device in pieces of whole genomes (<= 64 M records), seqIds rebased to the range's first contig
+  std::vector<RecordPart> parts;
+  auto bail = [&](int rc) { for (auto &q : parts) if (q.rec) pool_free(q.rec); free_sketch_device(sk); delete sk; return rc; };
+  const uint64_t kPiece = (uint64_t)64 << 20;
+  int32_t ga = g0;
+  while (ga < g1) {
+    int32_t gb = ga + 1;
+    while (gb < g1 && grec[gb + 1] - grec[ga] <= kPiece) gb++;
+    RecordPart pt; pt.g0 = ga - g0; pt.g1 = gb - g0; pt.n = (size_t)(grec[gb] - grec[ga]);
+    if (pt.n) {
+      if (pool_malloc((void **)&pt.rec, pt.n * 12) != hipSuccess) return bail(fail(ANI_ERR_NOMEM, "device allocation of %zu records failed", pt.n));
+      parts.push_back(pt);
+      hipError_t e = hipMemcpyAsync(pt.rec, base + h.offRecords + grec[ga] * 12, pt.n * 12, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess && c0) hipLaunchKernelGGL(ani::k_records_rebase, dim3(grid_for(pt.n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, pt.rec, (uint64_t)pt.n, c0);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "copying records to the device failed: %s", hipGetErrorString(e)));
+    } else parts.push_back(pt);
+    ga = gb;
+  }
+  if (parts.empty()) { RecordPart pt; pt.g0 = 0; pt.g1 = nG; parts.push_back(pt); }
+  const int rc = add_chunks(ctx, sk, parts);
+  for (auto &q : parts) if (q.rec) { pool_free(q.rec); q.rec = nullptr; }
+  if (rc != ANI_OK) return bail(rc);
+  *out = sk;
+  return ANI_OK;
+}
+
+int ani_sketch_file_info(const char *path, ani_params_t *p, int32_t *nContigs, int32_t *nGenomes, uint64_t *nMinimizers)
+{
+  if (!path) return fail(ANI_ERR_ARG, "null argument");
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(ANI_ERR_ARG, "cannot open %s", path);
+  SketchFileHeader h;
+  const size_t got = fread(&h, 1, sizeof h, f);
+  fclose(f);
+  if (got != sizeof h || memcmp(h.magic, "ANISKTCH", 8) != 0 || h.version != 1) return fail(ANI_ERR_ARG, "%s is not a version-1 sketch file", path);
+  if (p) { p->kmerSize = h.kmerSize; p->windowSize = h.windowSize; p->fragLen = h.fragLen; p->percentageIdentity = h.percentageIdentity; }
+  if (nContigs) *nContigs = h.nContigs;
+  if (nGenomes) *nGenomes = h.nGenomes;
+  if (nMinimizers) *nMinimizers = h.nRecords;
+  return ANI_OK;
+}
+
+// genome name / contig lengths of a (loaded) sketch: what the command line needs to print results without the FASTA files
+const char *ani_sketch_genome_name(const ani_sketch *sk, int32_t g) { return (sk && g >= 0 && g < (int32_t)sk->genomeNames.size()) ? sk->genomeNames[g].c_str() : ""; }
+int ani_sketch_tables(const ani_sketch *sk, const int32_t **contigLen, const int32_t **genomeContigStart)
+{
+  if (!sk) return fail(ANI_ERR_ARG, "null sketch");
+  if (contigLen) *contigLen = sk->contigLen.data();
+  if (genomeContigStart) *genomeContigStart = sk->genomeContigStart.data();
   return ANI_OK;
 }
 

@@ -56,7 +56,7 @@ struct Options {
   bool visualize = false, matrix = false, sanityCheck = false;
   std::vector<std::string> refs, queries;
   std::vector<int> devices{0};
-  std::string out;
+  std::string out, saveSketch, refSketch;
 };
 
 [[noreturn]] void usage(const char *argv0, int code)
@@ -86,7 +86,9 @@ struct Options {
     "     -o, --output <value>  output file name\n"
     "     -s, --sanityCheck  run sanity check\n"
     "     -v, --version  show version\n"
-    "     --gpus <value>  number of GPUs to use [default : 1] (--devices a,b,.. names them)\n" << std::endl;
+    "     --gpus <value>  number of GPUs to use [default : 1] (--devices a,b,.. names them)\n"
+    "     --saveSketch <value>  write the reference sketch (minimizer records, contig tables, genome names) to this file\n"
+    "     --refSketch <value>  use a saved reference sketch instead of -r / --rl\n" << std::endl;
   exit(code);
 }
 
@@ -134,15 +136,22 @@ Options parse(int argc, char **argv)
     else if (a == "-o" || a == "--output") o.out = need(i);
     else if (a == "-s" || a == "--sanityCheck") o.sanityCheck = true;
     else if (a == "-v" || a == "--version") version = true;
+    else if (a == "--saveSketch") o.saveSketch = need(i);
+    else if (a == "--refSketch") o.refSketch = need(i);
     else if (a == "--gpus") { const int n = atoi(need(i)); o.devices.clear(); for (int d = 0; d < std::max(1, n); d++) o.devices.push_back(d); }
     else if (a == "--devices") { o.devices.clear(); std::stringstream ss(need(i)); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (o.devices.empty()) o.devices.push_back(0); }
     else usage(argv[0], 1);
   }
   if (help) usage(argv[0], 0);
   if (version) { std::cerr << "version 1.33\n\n"; exit(0); }                         // parseCmdArgs.hpp:194-198
-  if (refName.empty() && refList.empty()) { std::cerr << "Provide reference file (s)\n"; exit(1); }
+  if (refName.empty() && refList.empty() && o.refSketch.empty()) { std::cerr << "Provide reference file (s)\n"; exit(1); }
   if (qryName.empty() && qryList.empty()) { std::cerr << "Provide query file (s)\n"; exit(1); }
-  if (!refName.empty()) o.refs.push_back(refName); else parseFileList(refList, o.refs);
+  if (!o.refSketch.empty()) {
+    // reference names come from the sketch file; its genome count is needed before the sketch is loaded
+    int32_t ng = 0;
+    if (ani_sketch_file_info(o.refSketch.c_str(), nullptr, nullptr, &ng, nullptr)) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << o.refSketch << std::endl; exit(1); }
+    o.refs.assign((size_t)ng, std::string());
+  } else if (!refName.empty()) o.refs.push_back(refName); else parseFileList(refList, o.refs);
   if (!qryName.empty()) o.queries.push_back(qryName); else parseFileList(qryList, o.queries);
   if (o.threads < 1) o.threads = 1;
   return o;
@@ -310,6 +319,10 @@ struct SliceBatch {
   }
 };
 
+// ANI_CLI_TRACE=1: wall-clock marks of the phases on stderr (where does an end-to-end run spend its time?)
+Clock::time_point g_t0;
+void trace(const char *what) { static const bool on = getenv("ANI_CLI_TRACE") != nullptr; if (on) fprintf(stderr, "[fastANI trace] %8.3f s  %s\n", secs_since(g_t0), what); }
+
 void die(const char *what) { std::cerr << "ERROR, " << what << ": " << ani_last_error() << std::endl; exit(1); }
 
 struct VisRow { std::string q, r; float id; int64_t qs, qe, rs, re; };
@@ -337,6 +350,7 @@ struct RefPart { void *rec = nullptr; uint64_t n = 0; int dev = 0; int32_t g0 = 
 int main(int argc, char **argv)
 {
   const auto tStart = Clock::now();
+  g_t0 = tStart;
   Options o = parse(argc, argv);
   ani_params_t ap;
   if (ani_params_default(&ap, o.kmerSize, o.fragLen)) die("parameters");
@@ -353,11 +367,19 @@ int main(int argc, char **argv)
   // validateInputFiles, parseCmdArgs.hpp:59-88
   if (o.queries.empty() || o.refs.empty()) { std::cerr << "ERROR, skch::validateInputFiles, Count of query and ref genomes should be non-zero" << std::endl; exit(1); }
   for (auto &e : o.queries) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
-  for (auto &e : o.refs) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
+  if (o.refSketch.empty()) for (auto &e : o.refs) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
+  if (!o.refSketch.empty()) {
+    ani_params_t fp_;
+    ani_sketch_file_info(o.refSketch.c_str(), &fp_, nullptr, nullptr, nullptr);
+    if (fp_.kmerSize != ap.kmerSize || fp_.fragLen != ap.fragLen || fp_.windowSize != ap.windowSize) {
+      std::cerr << "ERROR, the sketch file was built with -k " << fp_.kmerSize << " --fragLen " << fp_.fragLen << ", this run uses -k " << ap.kmerSize << " --fragLen " << ap.fragLen << std::endl; exit(1); }
+  }
 
   const uint64_t kSliceBytes = getenv("ANI_SLICE_BYTES") ? (uint64_t)atoll(getenv("ANI_SLICE_BYTES")) : (1ull << 30);
   const int nRef = (int)o.refs.size(), nQry = (int)o.queries.size();
-  const bool allVsAll = (o.queries == o.refs) && !o.visualize && !o.sanityCheck;
+  const bool fromFile = !o.refSketch.empty();
+  if (fromFile && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --refSketch cannot be combined with --visualize or -s" << std::endl; exit(1); }
+  const bool allVsAll = !fromFile && (o.queries == o.refs) && !o.visualize && !o.sanityCheck;
   if (o.visualize || o.sanityCheck) o.devices.resize(1);            // the per-split / per-mapping paths are single-device
 
   std::unordered_map<std::string, uint64_t> genomeLengths;          // computeCoreIdentity.hpp:48-92, filled while the files pass through
@@ -373,10 +395,20 @@ int main(int argc, char **argv)
   std::vector<VisRow> vis;
   std::vector<int> failedSplits; std::vector<float> failedRatio;
 
+  // the readers start before the devices are initialised (HIP start-up is a few hundred milliseconds)
+  std::vector<std::string> files;
+  std::unique_ptr<FilePipeline> fpPtr;
+  if (!o.visualize && !o.sanityCheck) {
+    if (!fromFile) files = o.refs;
+    if (!allVsAll) files.insert(files.end(), o.queries.begin(), o.queries.end());
+    fpPtr.reset(new FilePipeline(files, o.threads, 3 * kSliceBytes));
+  }
+  trace("options parsed, readers started");
   // ---- devices ----
   std::vector<Device> dev(o.devices.size());
   for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx) || ani_init(dev[d].id, &dev[d].up)) die("ani_init"); }
   const int nDev = (int)dev.size();
+  trace("devices initialised");
   std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
   std::cerr << "INFO [thread 0], skch::main, Count of threads executing parallel_for : " << (o.sanityCheck ? o.threads : nDev) << std::endl;
 
@@ -384,11 +416,10 @@ int main(int argc, char **argv)
     // =================================================================================================================
     // Streaming path.  File order: references, then (unless all-vs-all) queries; one reader pool over all of them.
     // =================================================================================================================
-    std::vector<std::string> files = o.refs;
-    if (!allVsAll) files.insert(files.end(), o.queries.begin(), o.queries.end());
-    FilePipeline fp(files, o.threads, 3 * kSliceBytes);
-    const auto refSlices = make_slices(fp, 0, (size_t)nRef, kSliceBytes);
-    const auto qrySlices = allVsAll ? refSlices : make_slices(fp, (size_t)nRef, files.size(), kSliceBytes);
+    FilePipeline &fp = *fpPtr;
+    const size_t nRefFiles = fromFile ? 0 : (size_t)nRef;
+    const auto refSlices = make_slices(fp, 0, nRefFiles, kSliceBytes);
+    const auto qrySlices = allVsAll ? refSlices : make_slices(fp, nRefFiles, files.size(), kSliceBytes);
 
     // reference tables, filled slice by slice
     std::vector<int32_t> contigLenAll, gcsAll{0};
@@ -476,9 +507,22 @@ int main(int argc, char **argv)
           return true;
         });
     }
+    trace("reference slices sketched");
     // every device gets every part (peer-to-peer pulls), then builds the full index
     std::vector<ani_sketch *> sk((size_t)nDev, nullptr);
-    {
+    if (fromFile) {
+      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
+      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() { if (ani_sketch_load(dev[d].ctx, o.refSketch.c_str(), 0, -1, &sk[d])) errs[d] = ani_last_error(); });
+      for (auto &w : workers) w.join();
+      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, reference sketch file: " << e << std::endl; exit(1); }
+      const int32_t *cl = nullptr, *gcs = nullptr;
+      ani_sketch_tables(sk[0], &cl, &gcs);
+      for (int g = 0; g < nRef; g++) {
+        o.refs[g] = ani_sketch_genome_name(sk[0], g);
+        Genome gm; gm.lens.assign(cl + gcs[g], cl + gcs[g + 1]);
+        noteLength(o.refs[g], gm);
+      }
+    } else {
       std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
       for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
         std::vector<const void *> recs(parts.size()); std::vector<uint64_t> ns(parts.size()); std::vector<int32_t> pgs(parts.size() + 1, 0);
@@ -508,6 +552,12 @@ int main(int argc, char **argv)
       std::cerr << "INFO [thread 0], skch::main, Time spent sketching the reference : " << secs_since(t0) << " sec" << std::endl;
     }
 
+    if (!o.saveSketch.empty()) {
+      std::vector<const char *> nm; for (auto &r : o.refs) nm.push_back(r.c_str());
+      if (ani_sketch_save(sk[0], o.saveSketch.c_str(), nm.data())) die("ani_sketch_save");
+      trace("sketch file written");
+    }
+    trace("index built");
     // ---- queries: slices round-robin over the devices; rows are collected per slice so that the order does not depend on timing ----
     std::vector<std::vector<ani_cgi_t>> sliceRows(qrySlices.size());
     std::mutex logMu;
@@ -541,7 +591,7 @@ int main(int argc, char **argv)
         [&](int, size_t, SliceBatch &, Uploaded &) { return true; },
         [&](int d, size_t k, Uploaded &u, std::string &msg) {
           const size_t a = qrySlices[k].first, b = qrySlices[k].second;
-          const int32_t firstQ = (int32_t)(a - (size_t)nRef);
+          const int32_t firstQ = (int32_t)(a - nRefFiles);
           const auto tm = Clock::now();
           ani_counters_t c0, c1;
           ani_get_counters(dev[d].ctx, &c0);
@@ -555,6 +605,7 @@ int main(int argc, char **argv)
           return true;
         });
     }
+    trace("queries mapped");
     for (auto &v : sliceRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }
     for (int d = 0; d < nDev; d++) { ani_sketch_destroy(sk[d]); std::cerr << "INFO [thread " << d << "], skch::main, ready to exit the loop" << std::endl; }
   } else {
@@ -720,6 +771,9 @@ int main(int argc, char **argv)
       out << r.q << "\t" << r.r << "\t" << r.id << "\tNA\tNA\tNA\t" << r.qs << "\t" << r.qe << "\t" << r.rs << "\t" << r.re << "\tNA\tNA\n";
   }
   std::cerr << "INFO, skch::main, Time spent writing the output : " << secs_since(tOut) << " sec; total : " << secs_since(tStart) << " sec" << std::endl;
+  trace("output written");
+  fpPtr.reset();
   for (auto &d : dev) { ani_shutdown(d.up); ani_shutdown(d.ctx); }
+  trace("contexts shut down");
   return 0;
 }

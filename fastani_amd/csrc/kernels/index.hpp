@@ -175,6 +175,12 @@ __global__ void k_records_contig_first(const uint32_t *__restrict__ records, uin
   }
 }
 
+// records read from a sketch file for a genome range that does not start at contig 0: seqIds relative to the range
+__global__ void k_records_rebase(uint32_t *__restrict__ records, uint64_t n, int32_t c0)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) records[3 * i + 1] -= (uint32_t)c0;
+}
+
 // Exact number of distinct hashes over several index chunks (Sketch::sanityCheck needs it, winSketch.hpp:298-318): every
 // distinct hash of chunk C (its first entry in hash order) is looked up in one earlier chunk E; seen[r] is set when found.
 __global__ void k_index_mark_shared(const uint32_t *__restrict__ sHashC, uint32_t nC, const uint32_t *__restrict__ sHashE,

@@ -178,6 +178,16 @@ int ani_sketch_from_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nP
                                  const int32_t *contigLen, int32_t nContigs,
                                  const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out);
 
+/* ---- persistent sketch file: the position-ordered minimizer records + contig / genome tables + genome names,
+ * sections 4096-byte aligned (mmap-able); the reference has nothing like it (every run and every thread re-sketches).  Saving
+ * costs one pass over the index; loading is an mmap, one host-to-device copy of the records and the device-side index build.
+ * ani_sketch_load takes a genome range [g0, g1) (g1 < 0: all), so every rank of a multi-GPU job can read its own share. */
+int ani_sketch_save(const ani_sketch *sk, const char *path, const char *const *genomeNames /* [nGenomes] or NULL */);
+int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_sketch **out);
+int ani_sketch_file_info(const char *path, ani_params_t *p, int32_t *nContigs, int32_t *nGenomes, uint64_t *nMinimizers);
+const char *ani_sketch_genome_name(const ani_sketch *sk, int32_t genome);
+int ani_sketch_tables(const ani_sketch *sk, const int32_t **contigLen, const int32_t **genomeContigStart);
+
 /* ---- mapping: replaces skch::Map::Map + callback (computeMap.hpp:93-102, mapQuery :112) for ONE query genome.
  * Mappings are returned in the reference's callback order (fragment, then candidate).  *totalQueryFragments is
  * set (not accumulated). */

@@ -249,6 +249,39 @@ def case_self(engine):
     assert np.array_equal(sk.map_cgi_fragset(frags, 0), np.concatenate(exp))
 
 
+def case_sketch_file(engine, tmpdir):
+    """persistent sketch file: save -> load gives the same minimizers, mappings and rows; a genome sub-range loads as a sketch of
+    its own with ids renumbered from 0 (what a rank of a multi-GPU job reads); the header is readable without a device"""
+    import os
+    from fastani_amd.api import AniError, Params
+    import ctypes as C
+    genomes = [messy_genome(5, 50000), [orc.synth_genome(5, 0, 40000)], [rng_genome(1, 10, b"ACGT")], [orc.synth_genome(5, 3, 35001)], [b""],
+               [orc.synth_genome(5, 4, 6047), orc.synth_genome(5, 20, 9100)]]
+    names = ["genome_%d.fa" % i for i in range(len(genomes))]
+    p = engine.params()
+    sk = Sketch(engine, p, genomes)
+    path = os.path.join(str(tmpdir), "refs.anisk")
+    sk.save(path, names)
+    hp, nc, ng, nm = Params(), C.c_int32(), C.c_int32(), C.c_uint64()
+    engine._chk(engine.lib.ani_sketch_file_info(path.encode(), C.byref(hp), C.byref(nc), C.byref(ng), C.byref(nm)))
+    assert (hp.kmerSize, hp.windowSize, hp.fragLen, ng.value, nm.value) == (16, p.windowSize, 3000, len(genomes), len(sk.minimizers()))
+    sk2 = Sketch(engine, p, file=path)
+    assert np.array_equal(sk2.minimizers(), sk.minimizers()) and sk2.stats() == sk.stats() and sk2.genome_names() == names
+    assert np.array_equal(sk2.map_cgi_batch(genomes, 0), sk.map_cgi_batch(genomes, 0))
+    m1, t1 = sk.map_query(genomes[1]); m2, t2 = sk2.map_query(genomes[1])
+    assert t1 == t2 and np.array_equal(m1, m2)
+    part = Sketch(engine, p, file=path, genome_range=(1, 4))
+    ref = Sketch(engine, p, genomes[1:4])
+    assert np.array_equal(part.minimizers(), ref.minimizers()) and part.genome_names() == names[1:4]
+    assert np.array_equal(part.map_cgi_batch(genomes, 0), ref.map_cgi_batch(genomes, 0))
+    open(path, "r+b").write(b"XXXX")
+    try:
+        Sketch(engine, p, file=path)
+        raise AssertionError("a damaged file must be rejected")
+    except AniError as e:
+        assert e.code == -1
+
+
 def case_limits(engine):
     """documented limits fail loudly with ANI_ERR_LIMIT (-4), never silently"""
     from fastani_amd.api import AniError

@@ -83,6 +83,19 @@ def _run_streaming_variants(binary, tmp):
                 assert open(rout + ".matrix").read() == open(out + ".matrix").read(), (env, extra)
             err = rb.stderr.decode()
             assert "Time spent sketching the reference" in err and "Time spent mapping fragments in query" in err and "Time spent post mapping" in err
+    # persistent reference sketch: written by one run, used instead of --rl by the next (same rows, file names from the sketch)
+    skf = os.path.join(tmp, "refs.anisk")
+    args, rout = ref["qr"]
+    out = os.path.join(tmp, "sk1.out")
+    rb = subprocess.run([binary] + args + ["-o", out, "--saveSketch", skf], capture_output=True, env=dict(os.environ, ANI_MAX_INDEX_MINIMIZERS="7000"))
+    assert rb.returncode == 0 and os.path.getsize(skf) > 4096 and _lines(rout) == _lines(out), rb.stderr.decode()[-1500:]
+    for extra in ([], ["--devices", "0,0"]):
+        out = os.path.join(tmp, "sk2.out")
+        rb = subprocess.run([binary, "--ql", ql, "--refSketch", skf, "-t", "2", "-o", out, "--matrix"] + extra, capture_output=True)
+        assert rb.returncode == 0, rb.stderr.decode()[-1500:]
+        assert _lines(rout) == _lines(out), extra
+    rb = subprocess.run([binary, "--ql", ql, "--refSketch", skf, "-k", "14", "-o", out], capture_output=True)
+    assert rb.returncode == 1 and b"sketch file was built with" in rb.stderr
 
 
 @pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")

@@ -66,6 +66,16 @@ def test_chunked_with_small_batches(monkeypatch):
     e.close()
 
 
+def test_sketch_file(emu_engine, tmp_path):
+    pc.case_sketch_file(emu_engine, tmp_path)
+
+
+def test_sketch_file_chunked(monkeypatch, tmp_path):
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=6000)
+    pc.case_sketch_file(e, tmp_path)
+    e.close()
+
+
 def test_limits(emu_engine):
     pc.case_limits(emu_engine)
 

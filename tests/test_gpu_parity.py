@@ -182,6 +182,16 @@ def test_chunked_full_size_equals_unchunked(gpu_engine, monkeypatch):
     e.close()
 
 
+def test_sketch_file(gpu_engine, tmp_path):
+    pc.case_sketch_file(gpu_engine, tmp_path)
+
+
+def test_sketch_file_chunked(monkeypatch, tmp_path):
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=6000)
+    pc.case_sketch_file(e, tmp_path)
+    e.close()
+
+
 def test_limits(gpu_engine):
     pc.case_limits(gpu_engine)
 
