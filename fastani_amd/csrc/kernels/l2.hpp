@@ -20,6 +20,7 @@
 // parallelism); state words live in a lane-interleaved scratch array so that lane l touches
 // scratch[word * laneStride + l].
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "index.hpp"
 
@@ -493,22 +494,25 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   const int nBlk = (n + 7) >> 3;
   int best = 0, begAtBest = -1, begAtLast = -1, steps = 0, delCount = 0;
   uint4 cur = p[0];
-  for (int blk = 0; __any(blk < nBlk); blk++) {
-    const int nb = blk + 1 < nBlk ? blk + 1 : blk;                     // never beyond the lane's own stream
-    const uint4 nxt = p[nb];
-    const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+  // one block = 8 events.  PLAIN: every lane of the wave has all 8 events and none of them is flagged nearDup (two wave votes per
+  // block decide) — then an event needs no bounds test and no look-up path; otherwise the block takes the general form.
+  auto run_block = [&](auto plainTag, int blk, const uint4 &blkWords) {
+    constexpr bool PLAIN = decltype(plainTag)::value;
+    const uint32_t wd[4] = {blkWords.x, blkWords.y, blkWords.z, blkWords.w};
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const uint32_t code = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffffu);
       const int ev = 8 * blk + e;                                     // events applied so far
-      const bool on = ev < n;
+      const bool on = PLAIN ? true : ev < n;
       const bool INS = (code & kL2InsBit) != 0;
       bool eff = on;
-      if (__any(on && (code & kL2DupBit) != 0)) {
-        if (on && (code & kL2DupBit)) {
-          const int insCount = ev - delCount;                         // entries [delCount, insCount) are in the window
-          if (INS) eff = a.g.prevSame[r.beg0 + insCount] < r.beg0 + delCount;            // new iff no same-hash entry in [beg, end)
-          else { const int32_t nx = a.g.nextSame[r.beg0 + delCount]; eff = !(nx >= 0 && nx < r.beg0 + insCount); }   // stays iff a later same-hash entry is in the window
+      if (!PLAIN) {
+        if (__any(on && (code & kL2DupBit) != 0)) {
+          if (on && (code & kL2DupBit)) {
+            const int insCount = ev - delCount;                       // entries [delCount, insCount) are in the window
+            if (INS) eff = a.g.prevSame[r.beg0 + insCount] < r.beg0 + delCount;            // new iff no same-hash entry in [beg, end)
+            else { const int32_t nx = a.g.nextSame[r.beg0 + delCount]; eff = !(nx >= 0 && nx < r.beg0 + insCount); }   // stays iff a later same-hash entry is in the window
+          }
         }
       }
       l2_apply(F, R, code, INS, eff);
@@ -521,6 +525,14 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
       begAtLast = tieOrBetter ? delCount : begAtLast;
       steps += evl ? 1 : 0;
     }
+  };
+  for (int blk = 0; __any(blk < nBlk); blk++) {
+    const int nb = blk + 1 < nBlk ? blk + 1 : blk;                     // never beyond the lane's own stream
+    const uint4 nxt = p[nb];
+    const uint32_t orw = cur.x | cur.y | cur.z | cur.w;
+    const bool plain = 8 * blk + 8 <= n && (orw & (kL2DupBit | (kL2DupBit << 16))) == 0;
+    if (__all(plain)) run_block(std::true_type(), blk, cur);
+    else run_block(std::false_type(), blk, cur);
     cur = nxt;
   }
   if (mine) {

@@ -40,6 +40,16 @@ if has ab; then
 import json,sys; d=json.loads(sys.stdin.readline()); print('$v', d['value'], d['ms_per_step'], d['stage_ms_per_step_rank0'], d['roofline']['all_kernels_ms_per_step'])" | tee -a "$OUT/ab.txt"
   done
 fi
+if has e2e; then
+  # the command line alone, twice, with allocation and phase traces (FASTA set in /tmp/ani_fa from benchfast)
+  ls /tmp/ani_fa/g*.fa | head -1000 > /tmp/ani_fa/all.txt
+  for i in 1 2; do
+    TIMEFORMAT=%R; w=$( { time ANI_POOL_TRACE=1 ANI_CLI_TRACE=1 fastani_amd/fastANI --ql /tmp/ani_fa/all.txt --rl /tmp/ani_fa/all.txt -t 64 -o /tmp/ani_fa/e2e.out > /dev/null 2> "$OUT/e2e_$i.err"; } 2>&1 )
+    echo "fastANI 1000x1000 run $i: wall $w s" | tee -a "$OUT/e2e.txt"
+    grep "fastANI trace" "$OUT/e2e_$i.err" | tee -a "$OUT/e2e.txt"
+    grep "ani pool" "$OUT/e2e_$i.err" | awk '{mb+=$4; ms+=$6} END {print "hipMalloc calls", NR, "MB", mb, "ms", ms}' | tee -a "$OUT/e2e.txt"
+  done
+fi
 if has noself; then
   echo "== bench (default workload, query role sketched separately)"; timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-verify --no-self 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.readline()); print('no-self', d['value'], d['ms_per_step'], d['stage_ms_per_step_rank0'], d['roofline']['all_kernels_ms_per_step'])" | tee "$OUT/noself.txt"
