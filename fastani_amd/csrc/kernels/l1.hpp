@@ -254,31 +254,35 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
     }
     __syncthreads();
     if (sKeep == 0) {
-      // groups in seqId order: thread = slot; rank among the used slots by counting, then the start = hits in lower-ranked groups
+      // groups in seqId order.  The used slots (a few dozen of the 256) are compacted first; slot t then counts the hits of the groups
+      // with a smaller seqId over that short list = where its own group starts.
       const int myKey = slotKey[t], myCnt = slotCnt[t];          // kTPB == kSlots
-      int before = 0;
-      if (myKey >= 0)
-        for (int u = 0; u < kSlots; u++) { const int ku = slotKey[u]; before += (ku >= 0 && ku < myKey) ? slotCnt[u] : 0; }
-      slotStart[t] = before;
+      int nUsed; const int ci = block_excl_scan(myKey >= 0 ? 1 : 0, ws, &nUsed);
+      int *usedKey = slotFill + kSlots, *usedCnt = usedKey + kSlots;      // 2 x 256 more ints of the free half
+      if (myKey >= 0) { usedKey[ci] = myKey; usedCnt[ci] = myCnt; }
+      __syncthreads();
+      if (myKey >= 0) {
+        int before = 0;
+        for (int u = 0; u < nUsed; u++) before += usedKey[u] < myKey ? usedCnt[u] : 0;
+        slotStart[t] = before;
+      }
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < PER2; j++)
         if (sl[j] >= 0) dst[slotStart[sl[j]] + atomicAdd(&slotFill[sl[j]], 1)] = hv[j];
       __syncthreads();
-      // place inside the group (positions are distinct: one index entry per (contig, position))
+      // place inside the group = number of members with a smaller position (positions are distinct: one index entry per (contig,
+      // position); the members share the seqId, so the low words decide).  The thread still knows its hits' slots.
+      const uint32_t *dlo = (const uint32_t *)dst;
 #pragma unroll
       for (int j = 0; j < PER2; j++) {
         const int x = t + j * kTPB;
         if (x < n) {
-          const uint64_t me = dst[x];
-          // the group of dst[x]: its slot is found again through the table (one or two probes)
-          const int sq = (int)(me >> 32);
-          int h = (int)(((uint32_t)sq * 0x9E3779B1u) >> 24);
-          while (slotKey[h] != sq) h = (h + 1) & (kSlots - 1);
-          const int g0 = slotStart[h], g1 = g0 + slotCnt[h];
+          const uint32_t me = (uint32_t)hv[j];
+          const int g0 = slotStart[sl[j]], g1 = g0 + slotCnt[sl[j]];
           int r = 0;
-          for (int y = g0; y < g1; y++) r += dst[y] < me;
-          hits[g0 + r] = me;
+          for (int y = g0; y < g1; y++) r += dlo[2 * y] < me;
+          hits[g0 + r] = hv[j];
         }
       }
       sorted = true;
