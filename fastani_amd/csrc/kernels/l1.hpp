@@ -218,82 +218,9 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
     __syncthreads();
     n = sKeep;
   }
-  // Sort (:320).  The kept hits of a fragment sit on a few dozen contigs, a few dozen hits each: instead of one bitonic network over
-  // everything (n log^2 n compare-exchanges on 64-bit keys — more than half of this kernel's instructions), the hits are grouped
-  // by contig through a small hash table, the groups are put in seqId order, and a hit's place inside its group is the number of
-  // group members with a smaller position.  Same sorted array, about a fifth of the work.  Fragments whose hits do not fit the
-  // scheme (too many hits, contigs or hits on one contig) take the network.
-  bool sorted = false;
-  if (n > 64 && n <= HCAP / 2) {
-    constexpr int kSlots = 256, kMaxGroup = 160;
-    int *slotKey = (int *)(hits + HCAP / 2);        // the upper half of `hits` is free (n <= HCAP / 2): 4 x 256 ints
-    int *slotCnt = slotKey + kSlots, *slotStart = slotCnt + kSlots, *slotFill = slotStart + kSlots;
-    uint64_t *dst = (uint64_t *)V;                   // HCAP ints = HCAP / 2 keys
-    __syncthreads();                                 // compaction / gather complete
-    for (int i = t; i < kSlots; i += kTPB) { slotKey[i] = -1; slotCnt[i] = 0; slotFill[i] = 0; }
-    if (t == 0) sKeep = 0;                           // becomes the failure flag
-    __syncthreads();
-    constexpr int PER2 = HCAP / 2 / kTPB;
-    uint64_t hv[PER2]; int sl[PER2];
-#pragma unroll
-    for (int j = 0; j < PER2; j++) {
-      const int x = t + j * kTPB;
-      sl[j] = -1;
-      if (x < n) {
-        hv[j] = hits[x];
-        const int sq = (int)(hv[j] >> 32);
-        int h = (int)(((uint32_t)sq * 0x9E3779B1u) >> 24);
-        for (int tries = 0; tries < kSlots; tries++) {
-          const int old = atomicCAS(&slotKey[h], -1, sq);
-          if (old == -1 || old == sq) { sl[j] = h; break; }
-          h = (h + 1) & (kSlots - 1);
-        }
-        if (sl[j] < 0) sKeep = 1;                    // more than 256 contigs
-        else if (atomicAdd(&slotCnt[sl[j]], 1) >= kMaxGroup) sKeep = 1;
-      }
-    }
-    __syncthreads();
-    if (sKeep == 0) {
-      // groups in seqId order.  The used slots (a few dozen of the 256) are compacted first; slot t then counts the hits of the groups
-      // with a smaller seqId over that short list = where its own group starts.
-      const int myKey = slotKey[t], myCnt = slotCnt[t];          // kTPB == kSlots
-      int nUsed; const int ci = block_excl_scan(myKey >= 0 ? 1 : 0, ws, &nUsed);
-      int *usedKey = slotFill + kSlots, *usedCnt = usedKey + kSlots;      // 2 x 256 more ints of the free half
-      if (myKey >= 0) { usedKey[ci] = myKey; usedCnt[ci] = myCnt; }
-      __syncthreads();
-      if (myKey >= 0) {
-        int before = 0;
-        for (int u = 0; u < nUsed; u++) before += usedKey[u] < myKey ? usedCnt[u] : 0;
-        slotStart[t] = before;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < PER2; j++)
-        if (sl[j] >= 0) dst[slotStart[sl[j]] + atomicAdd(&slotFill[sl[j]], 1)] = hv[j];
-      __syncthreads();
-      // place inside the group = number of members with a smaller position (positions are distinct: one index entry per (contig,
-      // position); the members share the seqId, so the low words decide).  The thread still knows its hits' slots.
-      const uint32_t *dlo = (const uint32_t *)dst;
-#pragma unroll
-      for (int j = 0; j < PER2; j++) {
-        const int x = t + j * kTPB;
-        if (x < n) {
-          const uint32_t me = (uint32_t)hv[j];
-          const int g0 = slotStart[sl[j]], g1 = g0 + slotCnt[sl[j]];
-          int r = 0;
-          for (int y = g0; y < g1; y++) r += dlo[2 * y] < me;
-          hits[g0 + r] = hv[j];
-        }
-      }
-      sorted = true;
-    }
-    __syncthreads();
-  }
-  if (!sorted) {
-    const int n2 = next_pow2(n);
-    for (int i = n + t; i < n2; i += kTPB) hits[i] = ~0ull;
-    block_bitonic_sort<uint64_t>(hits, n2);         // starts with a barrier: the gather is complete
-  }
+  const int n2 = next_pow2(n);
+  for (int i = n + t; i < n2; i += kTPB) hits[i] = ~0ull;
+  block_bitonic_sort<uint64_t>(hits, n2);           // :320 (starts with a barrier: the gather is complete)
 
   l1_emit_candidates(a, f, s, n, hits, V, ws, &sBase);
 }
