@@ -440,11 +440,13 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
   const int t = (act && lt) ? sg : 0;
   r.shared += isQ ? t : 0;
   r.cStar += isQ ? 0 : t;
-  // insert: q_iStar leaves the s smallest;  delete: q_{iStar+1} joins them
+  // insert: q_iStar leaves the s smallest iff rank idx+1 <= iStar and iStar + cStar > s;
+  // delete: q_{iStar+1} joins them iff iStar < s and iStar + cStar + 1 + n[iStar] <= s.  One comparison against s serves both.
   const int tot = r.iStar + r.cStar;
-  const bool condI = lt & (tot > r.s), condD = (r.iStar < r.s) & (tot + 1 + cntj <= r.s);      // both sides, no control flow
-  const bool cond = INS ? condI : condD;
-  const bool mv = act && !isQ && cond;
+  const int reach = INS ? tot : tot + 1 + cntj;
+  const bool over = reach > r.s;
+  const bool room = INS ? lt : (r.iStar < r.s);
+  const bool mv = act && !isQ && room && (over == INS);
   const int mone = mv ? sg : 0;                                      // insert: -1 on everything, delete: +1
   const int cm = mv ? cntj : 0;
   r.iStar -= mone;

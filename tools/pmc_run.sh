@@ -3,7 +3,7 @@
 TAG=$1; CTRS=$2; shift 2
 REPO=$(pwd); OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-cd /tmp && timeout 900 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/pmc -o pmc --output-format csv -- python $REPO/bench.py --no-cpu-baseline "$@" > $OUT/pmc.log 2>&1
+cd /tmp && timeout 900 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/pmc -o pmc --output-format csv -- python $REPO/bench.py --no-cpu-baseline --no-e2e --no-verify "$@" > $OUT/pmc.log 2>&1
 cd $REPO
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections
