@@ -45,10 +45,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# VALU integer ceiling for the MurmurHash3 kernels (tools/ubench_valu.hip on MI355X, profiles/r02_ubench_valu.txt):
-# a 64x64->64 multiply costs 3 quarter-rate multiplier instructions; one hash = 8 of them + >= 57 full-rate instructions
-# (rotates, xors, 64-bit adds).  Rates in wave64-instructions per cycle per SIMD; 1024 SIMDs at 2.4 GHz.
-UBENCH = {"full_rate_cyc": 2.0, "mul32_cyc": 8.0, "clock_ghz": 2.4, "simds": 1024,
+# VALU integer ceiling for the MurmurHash3 kernels, from the instruction costs measured on MI355X (tools/ubench/valu.hip,
+# profiles/r02_ubench_valu.txt): every wave64 VALU instruction issues in ~4 SIMD cycles (v_add/v_xor 4.0, v_mul_lo/hi_u32 and
+# v_mad_u64_u32 4.4-4.6: 32-bit integer multiplies are NOT quarter-rate on this part).  One hash = 8 64-bit multiplies = 24
+# multiplier instructions + >= 57 others (rotates, xors, 64-bit adds).  1024 SIMDs at 2.4 GHz.
+UBENCH = {"full_rate_cyc": 4.06, "mul32_cyc": 4.5, "clock_ghz": 2.4, "simds": 1024,
           "mul_instr_per_hash": 24, "other_instr_per_hash": 57}
 
 
@@ -290,15 +291,16 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
     return out
 
 
-def int_ops_block(c, steps):
+def int_ops_block(c, steps, fused=False):
     """MurmurHash3 kernels against the VALU integer ceiling: 2 hashes (both strands) per k-mer start position."""
     u = UBENCH
     cyc_per_hash = u["mul_instr_per_hash"] * u["mul32_cyc"] + u["other_instr_per_hash"] * u["full_rate_cyc"]     # per wave of 64 hashes
     ceiling = u["simds"] * u["clock_ghz"] * 1e9 * 64.0 / cyc_per_hash
     out = {"ceiling_hashes_per_s": round(ceiling, 1),
-           "ceiling_model": "per 64 hashes: %d quarter-rate 32-bit multiplier instr x %.0f cyc + %d full-rate instr x %.0f cyc on 1 of %d SIMDs at %.1f GHz (hash arithmetic only: no base decoding, no winnowing)"
+           "ceiling_model": "per 64 hashes: %d 32-bit multiplier instr x %.2f cyc + %d other VALU instr x %.2f cyc (measured issue costs, tools/ubench/valu.hip) on 1 of %d SIMDs at %.1f GHz; hash arithmetic only: no base decoding, no winnowing, no sort"
                             % (u["mul_instr_per_hash"], u["mul32_cyc"], u["other_instr_per_hash"], u["full_rate_cyc"], u["simds"], u["clock_ghz"])}
-    for name, ms, bases in (("ani::k_sketch_tiles", c["msSketch"], c["refBases"]), ("ani::k_fragment_sketch", c["msFragSketch"], c["queryBases"])):
+    for name, ms, bases in (("ani::k_sketch_fused (hashes each genome once for both roles)" if fused else "ani::k_sketch_tiles", c["msSketch"], c["refBases"]),
+                            ("ani::k_fragment_sketch", c["msFragSketch"], c["queryBases"])):
         if ms > 0:
             hps = 2.0 * bases / (ms / 1e3)
             out[name] = {"hashes_per_s": round(hps, 1), "mul64_per_s": round(8 * hps, 1), "frac_of_valu_ceiling": round(hps / ceiling, 4),
@@ -484,8 +486,11 @@ def main():
                               "class-A launches (k_l2_sim<L2Geom<255>>): 12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per class-A candidate"),
             "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate (the SAME bytes as k_l2_sim: the two kernels share one set of algorithmic bytes, see roofline.stage)"),
             "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
-            "ani::k_l1": (c["msL1"], 4.0 * c["l1Probes"] + 8.0 * c["seedHits"], "4 B x fragment sketch hashes probed (per index chunk) + 8 B x seed hits"),
-            "ani::k_sketch_tiles": (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"], "G/4 packed bases + 12 B x minimizers"),
+            "ani::k_l1_probe": (c["msL1Probe"], 4.0 * c["l1Probes"], "4 B x fragment sketch hashes probed (per index chunk)"),
+            "ani::k_l1<0,2048>": (c["msL1Main"], 8.0 * c["seedHits"], "8 B x seed hits (all LDS classes; the small class handles nearly all fragments)"),
+            ("ani::k_sketch_fused" if self_mode else "ani::k_sketch_tiles"):
+                (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"] + (4.0 * c["querySketchHashes"] if self_mode else 0.0),
+                 "G/4 packed bases + 12 B x minimizers" + (" + 4 B x fragment sketch hashes (fused all-vs-all pass)" if self_mode else "")),
             "ani::k_fragment_sketch": (c["msFragSketch"], c["queryBases"] / 4.0 + 4.0 * c["querySketchHashes"], "G/4 packed bases + 4 B x sketch hashes"),
         }
         # whole-job figure of SURVEY.md §8d: B_total = N_r (G/4 + 36 M) + N_q (G/4 + 8 F s) + 8 H + sum(12 m_c + 4 s) + 112 #mappings
@@ -508,7 +513,7 @@ def main():
             st = l2_bytes / (c["msL2"] / 1e3) / 1e9
             roof["stage"] = {"stage": "L2 (k_l2_ranges + k_l2_len_* + k_l2_codes + k_l2_sim<A,B> + k_l2)", "ms_per_step": round(c["msL2"] / args.steps, 3),
                              "algorithmic_bytes_per_step": round(l2_bytes / args.steps, 1), "achieved": round(st, 2), "unit": "GB/s", "frac": round(st / HBM_PEAK_GBS, 5)}
-        roof["int_ops"] = int_ops_block(c, args.steps)
+        roof["int_ops"] = int_ops_block(c, args.steps, self_mode)
         # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
         # + WRITE_SIZE, per launch) — only quoted when it is this default workload
         try:

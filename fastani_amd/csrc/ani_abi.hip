@@ -800,7 +800,7 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
       const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
       if (n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask)        // otherwise the L2 fast path is off (map_stage) and the links are never read
         hipLaunchKernelGGL(k_index_window_links, dim3(grid_for(n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
-                           (const int32_t *)sk->contigFirstMin, (const uint8_t *)sk->mDelta, (uint32_t)n, cmw - 1, sk->mWin);
+                           (const int32_t *)sk->contigFirstMin, (const uint8_t *)sk->mDelta, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
     }
     // bucket table over the top bits of the (density-flattened) bucket key: about one bucket per entry, between 2^10 and 2^28 buckets
     int bits = 10;
@@ -1063,8 +1063,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
-      if (attempt == 0) hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a);
-      hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr);
+      if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a); }
+      { StageTimer tk(ctx, &ctx->counters.msL1Main, 1); hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr); }
       if (attempt == 0) {
         unsigned long long nl[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(nl, cnt_ptr(ctx, CNT_LISTM), 24, hipMemcpyDeviceToHost, ctx->stream));

@@ -139,19 +139,32 @@ __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t 
 constexpr uint32_t kWinMask = 0x3fffu, kWinMoreBit = 1u << 30, kWinDupBit = 1u << 31;
 constexpr int kWinShiftA = 14;
 __global__ void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
-                                     const uint8_t *__restrict__ mDelta, uint32_t n, int32_t cmw1, uint32_t *__restrict__ mWin)
+                                     const uint8_t *__restrict__ mDelta, uint32_t n, int32_t cmw1, int32_t expect /* entries per cmw positions */,
+                                     uint32_t *__restrict__ mWin)
 {
   for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int32_t sq = mSeq[j], wj = mWpos[j];
     const int32_t cLo = contigFirstMin[sq], cHi = contigFirstMin[sq + 1];
+    // Both answers lie about `expect` entries away; a 64-entry bracket around that guess is tried first (two loads + 6 steps
+    // instead of 12 steps over the whole super-window), the full range only where the local density is unusual.
     // u = first x in [max(cLo, j - cmw1), j] with wpos[x] > wj - cmw1   (wpos is strictly increasing: at most one entry per position)
     int32_t lo = (int32_t)j - cmw1 > cLo ? (int32_t)j - cmw1 : cLo, hi = (int32_t)j;
+    {
+      const int32_t g0 = (int32_t)j - expect - 32, g1 = (int32_t)j - expect + 32;
+      if (g0 >= lo && mWpos[g0] <= wj - cmw1) lo = g0 + 1;
+      if (g1 >= lo && g1 < hi && mWpos[g1] > wj - cmw1) hi = g1;
+    }
     while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] <= wj - cmw1) lo = mid + 1; else hi = mid; }
     const uint32_t b = (uint32_t)((int32_t)j - lo);
     uint32_t a = 0, more = 0;
     if ((int32_t)j + 1 < cHi) {
       const int32_t tgt = mWpos[j + 1] + cmw1;
       lo = (int32_t)j + 1; hi = (int32_t)j + 2 + cmw1 < cHi ? (int32_t)j + 2 + cmw1 : cHi;
+      {
+        const int32_t g0 = (int32_t)j + expect - 32, g1 = (int32_t)j + expect + 32;
+        if (g0 >= lo && g0 < hi && mWpos[g0] < tgt) lo = g0 + 1;
+        if (g1 >= lo && g1 < hi && mWpos[g1] >= tgt) hi = g1;
+      }
       while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < tgt) lo = mid + 1; else hi = mid; }
       a = (uint32_t)(lo - (int32_t)j);
       more = (lo < cHi && mWpos[lo] == tgt) ? kWinMoreBit : 0u;
@@ -208,8 +221,9 @@ __global__ void k_count_flags(const uint8_t *__restrict__ flags, uint32_t n, uns
 
 // Sampled position index for the three searchIndex() calls of every L2 candidate (computeMap.hpp:424-436): posSample[posBase[c] + b]
 // = first position-ordered entry of contig c with wpos >= b << kPosSampleShift.  A search then is one table read plus a binary
-// search inside one 1024-position bin (<= ~80 entries) instead of over the whole contig.
-constexpr int kPosSampleShift = 10;
+// search inside one 256-position bin (~20 entries = one or two cache lines; k_l2_ranges is HBM-bound on exactly these lines)
+// instead of over the whole contig.
+constexpr int kPosSampleShift = 8;
 __global__ void k_index_pos_sample(const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
                                    const uint32_t *__restrict__ posBase, int32_t nContigs, uint32_t totalBins, uint32_t n,
                                    uint32_t *__restrict__ posSample)

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
     a.codeCount[i] = 0; a.slowFlag[i] = 16;          // done
     return;
   }
-  a.codeCount[i] = fast ? ((nEv + 7) & ~7) : 0;      // 16-bit events, padded to 16-byte blocks
+  a.codeCount[i] = fast ? ((nEv + 8) & ~7) : 0;      // 16-bit events, padded to 16-byte blocks with at least one pad slot (k_l2_codes)
   a.slowFlag[i] = fast ? ((s <= L2GeomA::kMaxS && a.allowFast != 2) ? 0 : 4) : 1;
 }
 
@@ -355,8 +355,9 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     const uint32_t *__restrict__ hsh = a.g.mHash + r.beg0;            // unsigned 32-bit offsets from per-candidate bases:
     const uint32_t *__restrict__ win = a.g.mWin + r.beg0;             // scalar base + vector offset addressing, no 64-bit index math
     const uint32_t m = (uint32_t)(r.last - r.beg0);
-    const int32_t nInit = r.end0 - r.beg0, nInsAll = (int32_t)m - 1;  // inserts (first window included) are the entries [0, m-1)
-    const int32_t nDel = r.nEvents - nInsAll;                         // deletes are the entries [0, nDel)
+    const uint32_t nInit = (uint32_t)(r.end0 - r.beg0), nInsAll = m - 1;      // inserts (first window included) are the entries [0, m-1)
+    const uint32_t nDel = (uint32_t)r.nEvents - nInsAll;                      // deletes are the entries [0, nDel)
+    const uint32_t dump = (uint32_t)r.nEvents;                                // pad slot
     // a thread ranks four entries per pass, kTPB apart: every load is one contiguous 256-byte run per wave, and the event stores of
     // neighbouring lanes land two or three slots apart
     for (uint32_t j = threadIdx.x; j < m; j += 4u * kTPB) {
@@ -387,24 +388,21 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
           }
         }
       }
+      // Two events per entry, stored without control flow: an event that does not exist (entries beyond the range, the never-inserted
+      // last entry, entries that never leave) goes to the pad slot behind the stream (k_l2_ranges reserves at least one).
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const int32_t x = (int32_t)(j + e * kTPB);
-        if (x >= (int32_t)m) break;
+        const uint32_t x = j + e * kTPB;
         const uint32_t cd = rk[e] | ((wl[e] & kWinDupBit) ? kL2DupBit : 0u);
-        // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B16 - 2
-        if (x < nInsAll) {
-          int32_t db = x - (int32_t)(wl[e] & kWinMask) - 1;           // deletes that precede it
-          db = db < 0 ? 0 : db;
-          out[x + db] = (uint16_t)(cd | kL2InsBit | (x < nInit - 1 ? kL2NoEvalBit : 0u));
-        }
-        // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A16 (at least the
-        // first window's)
-        if (x < nDel) {
-          int32_t ib = x + (int32_t)((wl[e] >> kWinShiftA) & kWinMask);
-          ib = ib < nInit ? nInit : ib;
-          out[x + ib] = (uint16_t)(cd | ((wl[e] & kWinMoreBit) ? kL2NoEvalBit : 0u));
-        }
+        // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
+        const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
+        const uint32_t pi = x < nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dump;
+        out[pi] = (uint16_t)(cd | kL2InsBit | (x + 1 < nInit ? kL2NoEvalBit : 0u));
+        // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
+        // window's)
+        const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
+        const uint32_t pd = x < nDel ? x + (ib < nInit ? nInit : ib) : dump;
+        out[pd] = (uint16_t)(cd | ((wl[e] & kWinMoreBit) ? kL2NoEvalBit : 0u));
       }
     }
   }

@@ -118,6 +118,7 @@ typedef struct {
   double msL2Kernel;          /* HIP-event time of the class-A ani::k_l2_sim launches alone (on the launch stream) */
   double msL2Ranges, msL2Codes, msL2Slow;   /* ani::k_l2_ranges, ani::k_l2_codes, ani::k_l2 */
   double msL2SimB;            /* class-B simulation launches (ani::k_l2_sim<L2Geom<319>> + its list compaction) */
+  double msL1Probe, msL1Main; /* ani::k_l1_probe; ani::k_l1<0, 2048> (the small-class gather + filter + sort + candidate kernel) */
 } ani_counters_t;
 
 /* ---- life cycle ---- */
