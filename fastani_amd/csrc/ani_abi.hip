@@ -218,9 +218,9 @@ struct IndexChunk {
   uint64_t nUnique = 0;
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
-  uint32_t *sHash = nullptr, *bucketStart = nullptr, *mWin = nullptr; uint8_t *mDelta = nullptr;
+  uint32_t *sHash = nullptr, *mWin = nullptr; uint8_t *mDelta = nullptr;
   uint64_t *sSW = nullptr;
-  int bucketShift = 0; uint32_t nBuckets = 0;
+  ani::TableSlot *table = nullptr; uint32_t tableSlots = 0;     // order-preserving probe table over the distinct hashes (index.hpp)
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
   uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr, *posBase = nullptr, *posSample = nullptr;
   uint32_t totalBins = 0;
@@ -720,7 +720,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 void free_chunk(IndexChunk *ch)
 {
   if (!ch) return;
-  void *ptrs[] = {ch->mWin, ch->sSW, ch->mDelta, ch->mHash, ch->mSeq, ch->mWpos, ch->prevSame, ch->nextSame, ch->sHash, ch->bucketStart, ch->contigFirstMin,
+  void *ptrs[] = {ch->mWin, ch->sSW, ch->mDelta, ch->mHash, ch->mSeq, ch->mWpos, ch->prevSame, ch->nextSame, ch->sHash, ch->table, ch->contigFirstMin,
                   ch->contigGenome, ch->contigBinBase, ch->genomeBinStart, ch->posBase, ch->posSample};
   for (void *q : ptrs) if (q) pool_free(q);
   delete ch;
@@ -802,13 +802,42 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
         hipLaunchKernelGGL(k_index_window_links, dim3(grid_for(n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
                            (const int32_t *)sk->contigFirstMin, (const uint8_t *)sk->mDelta, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
     }
-    // bucket table over the top bits of the (density-flattened) bucket key: about one bucket per entry, between 2^10 and 2^28 buckets
-    int bits = 10;
-    while (bits < 28 && (1ull << bits) < n) bits++;
-    sk->bucketShift = 32 - bits; sk->nBuckets = 1u << bits;
-    SK_HIP(pool_malloc((void **)&sk->bucketStart, ((size_t)sk->nBuckets + 1) * 4));
-    if (n) hipLaunchKernelGGL(k_index_buckets, dim3(grid_for(n, 256, 65535)), dim3(256), 0, ctx->stream, sk->sHash, (uint32_t)n, sk->bucketShift, p->windowSize, sk->nBuckets, sk->bucketStart);
-    else SK_HIP(hipMemsetAsync(sk->bucketStart, 0, ((size_t)sk->nBuckets + 1) * 4, ctx->stream));
+    // probe table: the distinct hashes in an order-preserving open-addressing table, load ~0.7 (index.hpp)
+    {
+      const uint32_t nSlots = (uint32_t)std::min<uint64_t>(0x7ffffff0ull, std::max<uint64_t>(1024, (uint64_t)((double)n / 0.7)));
+      const uint32_t nb = (uint32_t)((n + kTableBlock - 1) / kTableBlock);
+      std::vector<int32_t> cnt(nb ? nb : 1), best(nb ? nb : 1);
+      int64_t lastP = -1;
+      if (n) {
+        SK_TRY(ctx->scanTmpA.ensure((size_t)nb * 4)); SK_TRY(ctx->scanTmpB.ensure((size_t)nb * 4));
+        hipLaunchKernelGGL(k_table_block_totals, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize, nSlots,
+                           ctx->scanTmpA.as<int32_t>(), ctx->scanTmpB.as<int32_t>());
+        SK_HIP(hipMemcpyAsync(cnt.data(), ctx->scanTmpA.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIP(hipMemcpyAsync(best.data(), ctx->scanTmpB.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIP(hipStreamSynchronize(ctx->stream));
+        int64_t before = 0, run = INT32_MIN;                              // distinct hashes before the block; max(slot - global index) over them
+        for (uint32_t b = 0; b < nb; b++) {
+          const int32_t c = cnt[b], bb = best[b];
+          cnt[b] = (int32_t)before; best[b] = (int32_t)std::max<int64_t>(run, INT32_MIN);
+          if (c > 0) { run = std::max<int64_t>(run, (int64_t)bb - before); lastP = before + c - 1 + run; }
+          before += c;
+        }
+      }
+      const uint64_t alloc = std::max<uint64_t>(nSlots, (uint64_t)(lastP + 1)) + 2;        // the clusters at the end may run past nSlots
+      if (alloc > 0x7ffffff0ull) return bail(fail(ANI_ERR_LIMIT, "probe table of %llu slots", (unsigned long long)alloc));
+      SK_HIP(pool_malloc((void **)&sk->table, alloc * sizeof(TableSlot)));
+      SK_HIP(hipMemsetAsync(sk->table, 0xff, alloc * sizeof(TableSlot), ctx->stream));
+      if (n) {
+        SK_HIP(hipMemcpyAsync(ctx->scanTmpA.p, cnt.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        SK_HIP(hipMemcpyAsync(ctx->scanTmpB.p, best.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_table_scatter, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize, nSlots,
+                           (const int32_t *)ctx->scanTmpA.as<int32_t>(), (const int32_t *)ctx->scanTmpB.as<int32_t>(), sk->table);
+      }
+      const TableSlot sentinel{0xffffffffu, (uint32_t)n | 0x80000000u};
+      SK_HIP(hipMemcpyAsync(sk->table + (alloc - 2), &sentinel, sizeof sentinel, hipMemcpyHostToDevice, ctx->stream));
+      SK_HIP(hipStreamSynchronize(ctx->stream));                             // cnt / best / sentinel are host memory
+      sk->tableSlots = nSlots;
+    }
     SK_HIP(hipGetLastError());
     unsigned long long host[CNT_N];
     SK_TRY(read_counters(ctx, host));
@@ -951,8 +980,8 @@ int exact_unique(ani_sketch *sk)
     for (size_t x = 0; x < c && e == hipSuccess; x++) {
       IndexChunk *E = sk->chunks[x];
       if (!E->n) continue;
-      hipLaunchKernelGGL(k_index_mark_shared, dim3(grid_for(C->n, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)C->sHash, C->n, (const uint32_t *)E->sHash,
-                         (const uint32_t *)E->bucketStart, E->bucketShift, sk->params.windowSize, seen);
+      hipLaunchKernelGGL(k_index_mark_shared, dim3(grid_for(C->n, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)C->sHash, C->n, (const TableSlot *)E->table,
+                         E->tableSlots, sk->params.windowSize, seen);
     }
     int rc = e == hipSuccess ? zero_counters(ctx) : fail(ANI_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     unsigned long long host[CNT_N];
@@ -1050,7 +1079,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     else { HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CAND), 0, 8, ctx->stream)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
     L1Args a;
     a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS; a.nFrag = (int32_t)nF;
-    a.sHash = sk->sHash; a.sSW = sk->sSW; a.bucketStart = sk->bucketStart; a.bucketShift = sk->bucketShift; a.bucketW = w; a.nIndex = sk->n;
+    a.table = sk->table; a.tableSlots = sk->tableSlots; a.sSW = sk->sSW; a.bucketW = w; a.nIndex = sk->n;
     a.minHitsLUT = set->dMinHits; a.lutMaxS = set->dLutMaxS; a.L = L;
     a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
     a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);

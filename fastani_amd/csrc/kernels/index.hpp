@@ -5,7 +5,7 @@
 //   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n], mDelta[n] (flag byte), mWin[n] (window links of the L2 event stream) + contigFirstMin[nContigs+1]
 //   hash order    (≙ minimizerPosLookupIndex)  sHash[n] (sorted), sSW[n] = seqId<<32|wpos carried through the stable sort, so
 //                                              every hash's occurrence list is one contiguous run in (seqId,wpos) order (:186-190)
-//   bucket table  bucketStart[2^bits + 1]      lower bounds of the top `bits` bits of bucket_key(hash) inside sHash
+//   probe table   table[~n / 0.7]              order-preserving open-addressing table {hash, first} over the distinct hashes (below)
 //   same-hash links (for the L2 set semantics) prevSame[n], nextSame[n]: neighbouring NEAR occurrence of the same hash in
 //                                              position order (one that can share a super-window), -1 otherwise
 #pragma once
@@ -98,17 +98,98 @@ __host__ __device__ __forceinline__ uint32_t bucket_key(uint32_t h, int w)
   return ~r;
 }
 
-// bucketStart[b] = first r with (bucket_key(sHash[r]) >> shift) >= b, for b = 0..nBuckets (inclusive).  Entry-driven: entry r
-// fills the buckets between its predecessor's and its own (about one per entry), the last entry also the tail.  n >= 1.
-__global__ void k_index_buckets(const uint32_t *__restrict__ sHash, uint32_t n, int shift, int w, uint32_t nBuckets,
-                                uint32_t *__restrict__ bucketStart)
+// ------------------------------------------------------------------------------------------------
+// Probe table (≙ minimizerPosLookupIndex.find, winSketch.hpp:181-193): an order-preserving open-addressing table of the distinct
+// hashes.  Slot of a hash = its (monotone) bucket key scaled to the table size; the distinct hashes are inserted in sorted order
+// with linear probing, so a cluster stays sorted and the i-th distinct hash lands at
+//     p_i = max(slot_i, p_(i-1) + 1) = i + max_(j <= i) (slot_j - j),
+// a running maximum — no atomics, no collisions to resolve.  A slot is 8 bytes {hash, first} (first = start of the hash's run in
+// sSW); the run's length is the next occupied slot's `first` minus this one's (a sentinel {~0, n | 2^31} closes the table).  A probe reads
+// the slot of the hash and walks forward while the entries are smaller: one 128-byte line in nearly all cases, where the bucket
+// table + hash array cost three (k_l1_probe was HBM-bound on exactly those lines: 161 GB per 1000 x 1000 step).
+// ------------------------------------------------------------------------------------------------
+struct TableSlot { uint32_t hash, first; };
+constexpr uint32_t kSlotEmpty = 0xffffffffu;
+constexpr int kTableBlock = kTPB * 8;
+__host__ __device__ __forceinline__ uint32_t table_slot(uint32_t h, int w, uint32_t nSlots) { return (uint32_t)(((uint64_t)bucket_key(h, w) * nSlots) >> 32); }
+
+// pass 1: per block of kTableBlock entries of the hash-sorted index: number of distinct hashes that start in it, and
+// max(slot - index inside the block) over them (INT_MIN if none)
+__global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__restrict__ sHash, uint32_t n, int w, uint32_t nSlots,
+                                                             int32_t *__restrict__ blockCnt, int32_t *__restrict__ blockBest)
 {
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-    const int64_t k1 = (int64_t)(bucket_key(sHash[r], w) >> shift);
-    const int64_t k0 = r ? (int64_t)(bucket_key(sHash[r - 1], w) >> shift) : -1;
-    for (int64_t b = k0 + 1; b <= k1; b++) bucketStart[b] = r;
-    if (r == n - 1) for (int64_t b = k1 + 1; b <= (int64_t)nBuckets; b++) bucketStart[b] = n;
+  __shared__ int ws[16];
+  const uint32_t r0 = blockIdx.x * (uint32_t)kTableBlock + threadIdx.x * 8u;
+  int cnt = 0;
+  uint32_t h[8]; bool head[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t r = r0 + k;
+    h[k] = r < n ? sHash[r] : 0u;
+    head[k] = r < n && (r == 0 || sHash[r - 1] != h[k]);
+    cnt += head[k];
   }
+  int total; int idx = block_excl_scan(cnt, ws, &total);
+  int best = INT32_MIN;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (head[k]) { const int v = (int)table_slot(h[k], w, nSlots) - idx; best = v > best ? v : best; idx++; }
+  const int inc = block_incl_maxscan(best, ws);
+  if (threadIdx.x == kTPB - 1) { blockCnt[blockIdx.x] = total; blockBest[blockIdx.x] = inc; }
+}
+
+// pass 2: the distinct hashes into their slots.  carryCnt[b] = distinct hashes before block b, carryBest[b] = max(slot - global
+// index) over them (both finished on the host from pass 1)
+__global__ __launch_bounds__(kTPB) void k_table_scatter(const uint32_t *__restrict__ sHash, uint32_t n, int w, uint32_t nSlots,
+                                                        const int32_t *__restrict__ carryCnt, const int32_t *__restrict__ carryBest,
+                                                        TableSlot *__restrict__ table)
+{
+  __shared__ int ws[kTPB + 16];
+  const uint32_t r0 = blockIdx.x * (uint32_t)kTableBlock + threadIdx.x * 8u;
+  int cnt = 0;
+  uint32_t h[8]; bool head[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t r = r0 + k;
+    h[k] = r < n ? sHash[r] : 0u;
+    head[k] = r < n && (r == 0 || sHash[r - 1] != h[k]);
+    cnt += head[k];
+  }
+  int total; const int excl = block_excl_scan(cnt, ws, &total);
+  const int g0 = carryCnt[blockIdx.x] + excl;       // global index of my first distinct hash
+  int slot[8]; int best = INT32_MIN, g = g0;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (head[k]) { slot[k] = (int)table_slot(h[k], w, nSlots); const int v = slot[k] - g; best = v > best ? v : best; g++; }
+  const int inc = block_incl_maxscan(best, ws);
+  __syncthreads();
+  ws[8 + threadIdx.x] = inc;
+  __syncthreads();
+  int run = carryBest[blockIdx.x];
+  if (threadIdx.x > 0) { const int pv = ws[8 + threadIdx.x - 1]; run = pv > run ? pv : run; }
+  g = g0;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (head[k]) {
+      const int v = slot[k] - g; run = v > run ? v : run;
+      TableSlot e; e.hash = h[k]; e.first = r0 + k;
+      table[(uint32_t)(g + run)] = e;
+      g++;
+    }
+}
+
+// occurrences of hash h in the hash-ordered payload array: [first, first + cnt)
+__device__ __forceinline__ void table_probe(const TableSlot *__restrict__ table, int w, uint32_t nSlots, uint32_t h, uint32_t &first, uint32_t &cnt)
+{
+  uint32_t s = table_slot(h, w, nSlots);
+  TableSlot e = table[s];
+  while (e.first != kSlotEmpty && e.hash < h) e = table[++s];        // the sentinel {~0, n} stops the walk at the latest
+  first = 0; cnt = 0;
+  if ((e.first & 0x80000000u) || e.hash != h) return;                 // empty slot, the sentinel, or a larger hash: not in the index
+  first = e.first;
+  TableSlot nx = table[++s];
+  while (nx.first == kSlotEmpty) nx = table[++s];
+  cnt = (nx.first & 0x7fffffffu) - first;
 }
 
 // contigFirstMin[c] = first position-ordered entry with seqId >= c, for c = 0..nContigs
@@ -196,18 +277,16 @@ __global__ void k_records_rebase(uint32_t *__restrict__ records, uint64_t n, int
 
 // Exact number of distinct hashes over several index chunks (Sketch::sanityCheck needs it, winSketch.hpp:298-318): every
 // distinct hash of chunk C (its first entry in hash order) is looked up in one earlier chunk E; seen[r] is set when found.
-__global__ void k_index_mark_shared(const uint32_t *__restrict__ sHashC, uint32_t nC, const uint32_t *__restrict__ sHashE,
-                                    const uint32_t *__restrict__ bucketStartE, int shiftE, int w, uint8_t *__restrict__ seen)
+__global__ void k_index_mark_shared(const uint32_t *__restrict__ sHashC, uint32_t nC, const TableSlot *__restrict__ tableE, uint32_t nSlotsE, int w,
+                                    uint8_t *__restrict__ seen)
 {
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nC; r += gridDim.x * blockDim.x) {
     const uint32_t h = sHashC[r];
     if (r > 0 && sHashC[r - 1] == h) continue;
     if (seen[r]) continue;
-    const uint32_t b = bucket_key(h, w) >> shiftE;
-    uint32_t lo = bucketStartE[b], hi = bucketStartE[b + 1];
-    const uint32_t bhi = hi;
-    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (sHashE[mid] < h) lo = mid + 1; else hi = mid; }
-    if (lo < bhi && sHashE[lo] == h) seen[r] = 1;
+    uint32_t first, cnt;
+    table_probe(tableE, w, nSlotsE, h, first, cnt);
+    if (cnt) seen[r] = 1;
   }
 }
 __global__ void k_count_flags(const uint8_t *__restrict__ flags, uint32_t n, unsigned long long *__restrict__ total)

@@ -26,7 +26,7 @@ template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return H
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
-  const uint32_t *sHash; const uint64_t *sSW; const uint32_t *bucketStart; int bucketShift, bucketW; uint32_t nIndex;
+  const TableSlot *table; uint32_t tableSlots; const uint64_t *sSW; int bucketW; uint32_t nIndex;
   const int32_t *minHitsLUT; int32_t lutMaxS;
   int L;
   int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
@@ -39,23 +39,8 @@ struct L1Args {
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
 };
 
-// occurrences of hash h in the hash-sorted index: [first, first+cnt)
-__device__ __forceinline__ void l1_probe(const L1Args &a, uint32_t h, uint32_t &first, uint32_t &cnt)
-{
-  const uint32_t b = bucket_key(h, a.bucketW) >> a.bucketShift;
-  uint32_t lo = a.bucketStart[b], hi = a.bucketStart[b + 1];
-  const uint32_t bhi = hi;
-  while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (a.sHash[mid] < h) lo = mid + 1; else hi = mid; }
-  first = lo;
-  // upper bound inside the bucket (occurrence lists are short except for low-complexity repeats)
-  uint32_t e = lo;
-  if (e < bhi && a.sHash[e] == h) {
-    uint32_t l2 = e + 1, h2 = bhi;
-    while (l2 < h2) { uint32_t mid = l2 + ((h2 - l2) >> 1); if (a.sHash[mid] <= h) l2 = mid + 1; else h2 = mid; }
-    e = l2;
-  }
-  cnt = e - lo;
-}
+// occurrences of hash h in the hash-ordered payload array: [first, first+cnt)
+__device__ __forceinline__ void l1_probe(const L1Args &a, uint32_t h, uint32_t &first, uint32_t &cnt) { table_probe(a.table, a.bucketW, a.tableSlots, h, first, cnt); }
 
 __device__ __forceinline__ int32_t hit_seq(uint64_t h) { return (int32_t)(h >> 32); }
 __device__ __forceinline__ int32_t hit_wpos(uint64_t h) { return (int32_t)(uint32_t)h; }

@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
 }
 
 constexpr uint32_t kL2DupBit = 1u << 10, kL2InsBit = 1u << 11, kL2NoEvalBit = 1u << 12;
+static_assert((kWinDupBit >> 21) == kL2DupBit && (kWinMoreBit >> 18) == kL2NoEvalBit, "flag bits of the window links shift into the event code");
 constexpr int kL2RankBuckets = 2048;
 // rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
 __device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh; return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
@@ -351,9 +352,10 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     const int32_t i = c - a.c0;
     if (a.codeCount[i] == 0) continue;
     const L2Range r = a.ranges[i];
-    uint16_t *out = (uint16_t *)a.codes + a.codeOff[i];
-    const uint32_t *__restrict__ hsh = a.g.mHash + r.beg0;            // unsigned 32-bit offsets from per-candidate bases:
-    const uint32_t *__restrict__ win = a.g.mWin + r.beg0;             // scalar base + vector offset addressing, no 64-bit index math
+    // wave-uniform base pointers + 32-bit byte offsets per lane (scalar base + vector offset addressing, no 64-bit index math)
+    char *__restrict__ ob = (char *)((uint16_t *)a.codes + a.codeOff[i]);
+    const char *__restrict__ hb = (const char *)(a.g.mHash + r.beg0);
+    const char *__restrict__ wb = (const char *)(a.g.mWin + r.beg0);
     const uint32_t m = (uint32_t)(r.last - r.beg0);
     const uint32_t nInit = (uint32_t)(r.end0 - r.beg0), nInsAll = m - 1;      // inserts (first window included) are the entries [0, m-1)
     const uint32_t nDel = (uint32_t)r.nEvents - nInsAll;                      // deletes are the entries [0, nDel)
@@ -363,25 +365,28 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     for (uint32_t j = threadIdx.x; j < m; j += 4u * kTPB) {
       uint32_t h[4], wl[4], rk[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) { const uint32_t x = j + e * kTPB < m ? j + e * kTPB : m - 1; h[e] = hsh[x]; wl[e] = win[x]; }
-      bool deep = false;
+      for (int e = 0; e < 4; e++) {
+        const uint32_t x = j + e * kTPB;
+        const uint32_t off = (x < m ? x : m - 1) * 4u;
+        h[e] = *(const uint32_t *)(hb + off); wl[e] = *(const uint32_t *)(wb + off);
+      }
+      // Rank = entries of the sketch below h.  The two sketch entries at the bucket's start decide it unless the bucket holds more
+      // than two and both are below h: entries behind the bucket's own belong to later buckets, i.e. are larger than any hash of
+      // this bucket, so they need no "is it in the bucket" test (the sketch is followed by two 0xffffffff sentinels).
+      uint32_t deep = 0;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const int rb = l2_rank_bucket(h[e], sh);
-        const uint32_t sp = st2[rb];                                   // first sketch entry of the bucket | entries in it << 16
-        const uint32_t lo = sp & 0xffffu, nb = sp >> 16;
-        const uint32_t q0 = qs[lo], q1 = qs[lo + 1];                  // sentinels 0xffffffff behind the sketch
-        const uint32_t in0 = nb > 0, in1 = nb > 1;
-        const uint32_t lt = (in0 & (q0 < h[e])) + (in1 & (q1 < h[e]));
-        const uint32_t eq = (in0 & (q0 == h[e])) | (in1 & (q1 == h[e]));
-        rk[e] = ((lo + lt) << 1) | eq;
-        deep |= nb > 2 && q1 < h[e];                                  // more than two sketch hashes in the bucket and the answer lies beyond them
+        const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];            // first sketch entry of the bucket | entries in it << 16
+        const uint32_t lo = sp & 0xffffu;
+        const uint32_t q0 = qs[lo], q1 = qs[lo + 1];
+        rk[e] = ((lo + (uint32_t)(q0 < h[e]) + (uint32_t)(q1 < h[e])) << 1) | (uint32_t)((q0 == h[e]) | (q1 == h[e]));
+        deep |= (uint32_t)(q1 < h[e]) & (uint32_t)(sp > 0x2ffffu);
       }
-      if (__any(deep)) {
+      if (__any(deep != 0)) {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const int rb = l2_rank_bucket(h[e], sh);
-          int lo = st[rb], hi = st[rb + 1];
+          const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];
+          int lo = (int)(sp & 0xffffu), hi = lo + (int)(sp >> 16);
           if (hi - lo > 2) {
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h[e]) lo = mid + 1; else hi = mid; }
             rk[e] = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h[e]);    // == q_rank(qs, s, h)
@@ -393,16 +398,16 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const uint32_t x = j + e * kTPB;
-        const uint32_t cd = rk[e] | ((wl[e] & kWinDupBit) ? kL2DupBit : 0u);
+        const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
         // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
         const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
         const uint32_t pi = x < nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dump;
-        out[pi] = (uint16_t)(cd | kL2InsBit | (x + 1 < nInit ? kL2NoEvalBit : 0u));
+        *(uint16_t *)(ob + pi * 2u) = (uint16_t)(cd | kL2InsBit | (x + 1 < nInit ? kL2NoEvalBit : 0u));
         // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
         // window's)
         const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
         const uint32_t pd = x < nDel ? x + (ib < nInit ? nInit : ib) : dump;
-        out[pd] = (uint16_t)(cd | ((wl[e] & kWinMoreBit) ? kL2NoEvalBit : 0u));
+        *(uint16_t *)(ob + pd * 2u) = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit));    // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
       }
     }
   }
