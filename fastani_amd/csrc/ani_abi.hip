@@ -1092,7 +1092,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
-      if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a); }
+      if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
       { StageTimer tk(ctx, &ctx->counters.msL1Main, 1); hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr); }
       if (attempt == 0) {
         unsigned long long nl[3] = {0, 0, 0};

@@ -103,30 +103,51 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
   if (t == 0) a.fragCandCnt[f] = nG;
 }
 
-// Pass 1: probes only.  No LDS, one lane per query hash: the dependent loads of a probe (bucket table -> hash-sorted index)
-// are covered by occupancy instead of stalling the LDS-heavy sort kernel.  Writes (first, cnt) per sketch hash and H per fragment.
+// Pass 1: probes only.  No LDS, one lane per query hash.  A probe is a chain of dependent loads (sketch hash -> table slot), and
+// the kernel is bound by that latency, not by bandwidth: measured, one cache line per probe instead of three bought nothing as long
+// as a lane had a single probe in flight.  So a workgroup takes kL1ProbeFrags fragments at once and every lane runs that many
+// independent chains side by side.  Writes (first, cnt) per sketch hash and H per fragment.
+constexpr int kL1ProbeFrags = 4;
 __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
 {
   __shared__ int ws[16];
-  const int f = blockIdx.x;
-  const int s = a.fragS[f];
-  if (s <= 0) { if (threadIdx.x == 0) a.fragHits[f] = 0; return; }
-  const uint32_t off = a.fragOff[f];
-  int c = 0;
-  for (int i = threadIdx.x; i < s; i += kTPB) {
-    uint32_t fi, cn; l1_probe(a, a.qPool[off + i], fi, cn);
-    a.probeFirst[off + i] = fi; a.probeCnt[off + i] = cn;
-    c += (int)cn;
+  const int f0 = blockIdx.x * kL1ProbeFrags;
+  int s[kL1ProbeFrags]; uint32_t off[kL1ProbeFrags]; int c[kL1ProbeFrags];
+  int smax = 0;
+#pragma unroll
+  for (int q = 0; q < kL1ProbeFrags; q++) {
+    const int f = f0 + q;
+    s[q] = f < a.nFrag ? a.fragS[f] : 0; if (s[q] < 0) s[q] = 0;
+    off[q] = f < a.nFrag ? a.fragOff[f] : 0u;
+    c[q] = 0;
+    smax = s[q] > smax ? s[q] : smax;
   }
-  int H; block_excl_scan(c, ws, &H);
-  if (threadIdx.x == 0) {
-    a.fragHits[f] = H;
-    if (H) atomicAdd(stat_slot(a.sumHits), (unsigned long long)H);
-    // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
-    if (s <= kL1MaxS && H <= kL1HitCapMax) {
-      if (H > kL1HitCapSmall && H <= kL1HitCapMid) a.midList[atomicAdd(a.midCount, 1u)] = f;
-      else if (H > kL1HitCapMid) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
-    } else a.bigList[atomicAdd(a.bigCount, 1u)] = f;           // beyond every LDS class: global-memory path
+  for (int i = threadIdx.x; i < smax; i += kTPB) {
+    uint32_t h[kL1ProbeFrags], fi[kL1ProbeFrags], cn[kL1ProbeFrags];
+#pragma unroll
+    for (int q = 0; q < kL1ProbeFrags; q++) h[q] = i < s[q] ? a.qPool[off[q] + i] : 0u;
+#pragma unroll
+    for (int q = 0; q < kL1ProbeFrags; q++) { fi[q] = 0; cn[q] = 0; if (i < s[q]) l1_probe(a, h[q], fi[q], cn[q]); }
+#pragma unroll
+    for (int q = 0; q < kL1ProbeFrags; q++)
+      if (i < s[q]) { a.probeFirst[off[q] + i] = fi[q]; a.probeCnt[off[q] + i] = cn[q]; c[q] += (int)cn[q]; }
+  }
+#pragma unroll
+  for (int q = 0; q < kL1ProbeFrags; q++) {
+    const int f = f0 + q;
+    if (f >= a.nFrag) break;                        // workgroup-uniform
+    int H; block_excl_scan(c[q], ws, &H);
+    if (threadIdx.x == 0) {
+      a.fragHits[f] = H;
+      if (H) atomicAdd(stat_slot(a.sumHits), (unsigned long long)H);
+      if (s[q] > 0) {
+        // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
+        if (s[q] <= kL1MaxS && H <= kL1HitCapMax) {
+          if (H > kL1HitCapSmall && H <= kL1HitCapMid) a.midList[atomicAdd(a.midCount, 1u)] = f;
+          else if (H > kL1HitCapMid) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
+        } else a.bigList[atomicAdd(a.bigCount, 1u)] = f;         // beyond every LDS class: global-memory path
+      }
+    }
   }
 }
 
@@ -158,7 +179,14 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   for (int i = t; i < s; i += kTPB) {
     const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H;
     const uint32_t fi = a.probeFirst[off + i];
-    for (int c = 0; c < e - o; c++) hits[o + c] = a.sSW[fi + c];
+    // four loads in flight per lane (the run of a hash is contiguous; the kernel waits on these random reads)
+    for (int c = 0; c < e - o; c += 4) {
+      uint64_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = a.sSW[fi + (c + u < e - o ? c + u : c)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (c + u < e - o) hits[o + c + u] = v[u];
+    }
   }
   // Noise filter.  Minimizer hashes are minima over w k-mers, so they crowd the low end of the 32-bit range and most seed hits of
   // a fragment against a large reference set are chance collisions: isolated hits (measured on 1000 x 5 Mbp: ~1300 hits per
