@@ -311,7 +311,6 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
 constexpr uint32_t kL2DupBit = 1u << 10, kL2InsBit = 1u << 11, kL2NoEvalBit = 1u << 12;
 static_assert((kWinDupBit >> 21) == kL2DupBit && (kWinMoreBit >> 18) == kL2NoEvalBit, "flag bits of the window links shift into the event code");
 constexpr int kL2RankBuckets = 2048;
-constexpr int kL2StageEvents = 6144;       // events of one candidate staged in LDS before they are written out (12 KiB)
 // rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
 __device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh; return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
 
@@ -325,7 +324,6 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   __shared__ uint32_t qs[kL2FastMaxS + 2];
   __shared__ uint16_t st[kL2RankBuckets + 2];
   __shared__ uint32_t st2[kL2RankBuckets];
-  __shared__ __attribute__((aligned(16))) uint16_t stage[kL2StageEvents];
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive fragments of a query map to overlapping
   // reference ranges, so XCD x takes a contiguous eighth of the chunk's fragments: neighbours share their reference reads in L2.
   const int32_t per = (int32_t)(gridDim.x >> 3);
@@ -350,83 +348,95 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   __syncthreads();
   for (int b = threadIdx.x; b < kL2RankBuckets; b += kTPB) st2[b] = (uint32_t)st[b] | ((uint32_t)(st[b + 1] - st[b]) << 16);
   __syncthreads();
-  for (int32_t c = cA; c < cB; c++) {
-    const int32_t i = c - a.c0;
-    if (a.codeCount[i] == 0) continue;
-    const L2Range r = a.ranges[i];
-    // wave-uniform base pointers + 32-bit byte offsets per lane (scalar base + vector offset addressing, no 64-bit index math)
-    char *__restrict__ ob = (char *)((uint16_t *)a.codes + a.codeOff[i]);
-    const char *__restrict__ hb = (const char *)(a.g.mHash + r.beg0);
-    const char *__restrict__ wb = (const char *)(a.g.mWin + r.beg0);
-    const uint32_t m = (uint32_t)(r.last - r.beg0);
-    const uint32_t nInit = (uint32_t)(r.end0 - r.beg0), nInsAll = m - 1;      // inserts (first window included) are the entries [0, m-1)
-    const uint32_t nDel = (uint32_t)r.nEvents - nInsAll;                      // deletes are the entries [0, nDel)
-    const uint32_t dump = (uint32_t)r.nEvents;                                // pad slot
-    // The events of one entry land hundreds of slots apart, so direct 2-byte stores reach HBM as partial lines.  A stream that fits
-    // the staging buffer (all but pathological candidates) is assembled in LDS and written out in 16-byte pieces.
-    const bool staged = (uint32_t)r.nEvents < (uint32_t)kL2StageEvents;
-    auto emit = [&](auto stagedTag) {
-      constexpr bool STAGED = decltype(stagedTag)::value;
-      // a thread ranks four entries per pass, kTPB apart: every load is one contiguous 256-byte run per wave
-      for (uint32_t jb = 0; jb < m; jb += 4u * kTPB) {                 // workgroup-uniform trip count (entries beyond m are clamped / dumped)
-        const uint32_t j = jb + threadIdx.x;
-        uint32_t h[4], wl[4], rk[4];
+  // Work items = (candidate, pass of 4 * kTPB entries), in order.  The loads of the next item are issued before the current one is
+  // ranked: a pass is "load 8 words per thread, rank, store", and with one candidate after the other the workgroup spent most of
+  // its time waiting for those loads (the kernel was latency-bound: neither fewer instructions nor fewer bytes moved its time).
+  struct Item {
+    int32_t c; uint32_t jb;                          // candidate, first entry of the pass
+    char *ob; const char *hb, *wb;                   // wave-uniform bases: event stream, hashes, window links (32-bit byte offsets per lane)
+    uint32_t m, nInit, nInsAll, nDel, dump;
+  };
+  auto open_cand = [&](int32_t c, Item &it) -> bool {          // first candidate >= c of this fragment that has a stream
+    for (; c < cB; c++) {
+      const int32_t i = c - a.c0;
+      if (a.codeCount[i] == 0) continue;
+      const L2Range r = a.ranges[i];
+      it.c = c; it.jb = 0;
+      it.ob = (char *)((uint16_t *)a.codes + a.codeOff[i]);
+      it.hb = (const char *)(a.g.mHash + r.beg0); it.wb = (const char *)(a.g.mWin + r.beg0);
+      it.m = (uint32_t)(r.last - r.beg0);
+      it.nInit = (uint32_t)(r.end0 - r.beg0); it.nInsAll = it.m - 1;          // inserts (first window included) are the entries [0, m-1)
+      it.nDel = (uint32_t)r.nEvents - it.nInsAll;                             // deletes are the entries [0, nDel)
+      it.dump = (uint32_t)r.nEvents;                                          // pad slot
+      return true;
+    }
+    return false;
+  };
+  auto next_item = [&](const Item &cur, Item &nx) -> bool {
+    if (cur.jb + 4u * kTPB < cur.m) { nx = cur; nx.jb = cur.jb + 4u * kTPB; return true; }
+    return open_cand(cur.c + 1, nx);
+  };
+  auto load_item = [&](const Item &it, uint32_t (&h)[4], uint32_t (&wl)[4]) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const uint32_t x = j + e * kTPB;
-          const uint32_t off = (x < m ? x : m - 1) * 4u;
-          h[e] = *(const uint32_t *)(hb + off); wl[e] = *(const uint32_t *)(wb + off);
-        }
-        // Rank = entries of the sketch below h.  The two sketch entries at the bucket's start decide it unless the bucket holds more
-        // than two and both are below h: entries behind the bucket's own belong to later buckets, i.e. are larger than any hash of
-        // this bucket, so they need no "is it in the bucket" test (the sketch is followed by two 0xffffffff sentinels).
-        uint32_t deep = 0;
+    for (int e = 0; e < 4; e++) {
+      const uint32_t x = it.jb + threadIdx.x + e * kTPB;                       // kTPB apart: every load is one contiguous run per wave
+      const uint32_t off = (x < it.m ? x : it.m - 1) * 4u;
+      h[e] = *(const uint32_t *)(it.hb + off); wl[e] = *(const uint32_t *)(it.wb + off);
+    }
+  };
+  Item cur, nxt;
+  bool have = open_cand(cA, cur);
+  uint32_t h[4], wl[4], hn[4], wn[4];
+  if (have) load_item(cur, h, wl);
+  while (have) {
+    const bool haveNext = next_item(cur, nxt);
+    if (haveNext) load_item(nxt, hn, wn);
+    // Rank = entries of the sketch below h.  The two sketch entries at the bucket's start decide it unless the bucket holds more
+    // than two and both are below h: entries behind the bucket's own belong to later buckets, i.e. are larger than any hash of
+    // this bucket, so they need no "is it in the bucket" test (the sketch is followed by two 0xffffffff sentinels).
+    uint32_t rk[4];
+    uint32_t deep = 0;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];            // first sketch entry of the bucket | entries in it << 16
-          const uint32_t lo = sp & 0xffffu;
-          const uint32_t q0 = qs[lo], q1 = qs[lo + 1];
-          rk[e] = ((lo + (uint32_t)(q0 < h[e]) + (uint32_t)(q1 < h[e])) << 1) | (uint32_t)((q0 == h[e]) | (q1 == h[e]));
-          deep |= (uint32_t)(q1 < h[e]) & (uint32_t)(sp > 0x2ffffu);
-        }
-        if (__any(deep != 0)) {
+    for (int e = 0; e < 4; e++) {
+      const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];            // first sketch entry of the bucket | entries in it << 16
+      const uint32_t lo = sp & 0xffffu;
+      const uint32_t q0 = qs[lo], q1 = qs[lo + 1];
+      rk[e] = ((lo + (uint32_t)(q0 < h[e]) + (uint32_t)(q1 < h[e])) << 1) | (uint32_t)((q0 == h[e]) | (q1 == h[e]));
+      deep |= (uint32_t)(q1 < h[e]) & (uint32_t)(sp > 0x2ffffu);
+    }
+    if (__any(deep != 0)) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];
-            int lo = (int)(sp & 0xffffu), hi = lo + (int)(sp >> 16);
-            if (hi - lo > 2) {
-              while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h[e]) lo = mid + 1; else hi = mid; }
-              rk[e] = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h[e]);    // == q_rank(qs, s, h)
-            }
-          }
-        }
-        // Two events per entry, stored without control flow: an event that does not exist (entries beyond the range, the
-        // never-inserted last entry, entries that never leave) goes to the pad slot behind the stream (k_l2_ranges reserves one).
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const uint32_t x = j + e * kTPB;
-          const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
-          // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
-          const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
-          const uint32_t pi = x < nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dump;
-          const uint16_t ci = (uint16_t)(cd | kL2InsBit | (x + 1 < nInit ? kL2NoEvalBit : 0u));
-          // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the
-          // first window's)
-          const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
-          const uint32_t pd = x < nDel ? x + (ib < nInit ? nInit : ib) : dump;
-          const uint16_t cdl = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit));             // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
-          if (STAGED) { stage[pi] = ci; stage[pd] = cdl; }
-          else { *(uint16_t *)(ob + pi * 2u) = ci; *(uint16_t *)(ob + pd * 2u) = cdl; }
+      for (int e = 0; e < 4; e++) {
+        const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];
+        int lo = (int)(sp & 0xffffu), hi = lo + (int)(sp >> 16);
+        if (hi - lo > 2) {
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h[e]) lo = mid + 1; else hi = mid; }
+          rk[e] = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h[e]);    // == q_rank(qs, s, h)
         }
       }
-      if (STAGED) {
-        __syncthreads();
-        const uint32_t nOut = ((uint32_t)r.nEvents + 8u) & ~7u;                            // = codeCount: the stream and its pad, whole 16-byte pieces
-        for (uint32_t o = threadIdx.x * 8u; o < nOut; o += kTPB * 8u) *(uint4 *)(ob + o * 2u) = *(const uint4 *)(stage + o);
-        __syncthreads();
-      }
-    };
-    if (staged) emit(std::true_type()); else emit(std::false_type());
+    }
+    // Two events per entry, stored without control flow: an event that does not exist (entries beyond the range, the never-inserted
+    // last entry, entries that never leave) goes to the pad slot behind the stream (k_l2_ranges reserves one).
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t x = cur.jb + threadIdx.x + e * kTPB;
+      const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
+      // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
+      const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
+      const uint32_t pi = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : cur.dump;
+      *(uint16_t *)(cur.ob + pi * 2u) = (uint16_t)(cd | kL2InsBit | (x + 1 < cur.nInit ? kL2NoEvalBit : 0u));
+      // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
+      // window's)
+      const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
+      const uint32_t pd = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : cur.dump;
+      *(uint16_t *)(cur.ob + pd * 2u) = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit));    // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+    }
+    have = haveNext;
+    if (have) {
+      cur = nxt;
+#pragma unroll
+      for (int e = 0; e < 4; e++) { h[e] = hn[e]; wl[e] = wn[e]; }
+    }
   }
 }
 
