@@ -760,7 +760,8 @@ int upload_luts(ani_sketch *sk, int maxS)
 // chunk's genomes [g0, g0 + nGenomes) = contigs [c0, c0 + nContigs), position order, GLOBAL seqIds; contigLen / genomeContigStart
 // are the whole reference set's tables.
 // -----------------------------------------------------------------------------------------------------
-int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, size_t n, const int32_t *contigLenAll, const int32_t *gcsAll,
+struct RecordPiece { const uint32_t *rec; size_t n; };
+int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPiece> &pieces, size_t n, const int32_t *contigLenAll, const int32_t *gcsAll,
                 int32_t g0, int32_t nGenomes, IndexChunk **out)
 {
   if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "index chunk of %zu minimizers exceeds 2^31", n);
@@ -782,8 +783,13 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const uint32_t *dRecords, s
     SK_HIP(pool_malloc((void **)&tmpK, n4));
     { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
     if (n) {
-      hipLaunchKernelGGL(k_index_split, dim3(grid_for(n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, dRecords, (uint32_t)n, (uint32_t)c0, sk->mHash, sk->mSeq, sk->mWpos, sk->mDelta,
-                         sk->prevSame, sk->nextSame, tmpK, tmpV);
+      size_t o = 0;                                 // the pieces (slices of record parts, in order) go straight into the chunk's arrays: no concatenated copy
+      for (const RecordPiece &pc : pieces) {
+        if (!pc.n) continue;
+        hipLaunchKernelGGL(k_index_split, dim3(grid_for(pc.n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, pc.rec, (uint32_t)pc.n, (uint32_t)c0, sk->mHash + o, sk->mSeq + o, sk->mWpos + o,
+                           sk->mDelta + o, sk->prevSame + o, sk->nextSame + o, tmpK + o, tmpV + o);
+        o += pc.n;
+      }
       size_t tb = 0;
       int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, nullptr, &tb, ctx->stream);
       if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 16); if (rc == ANI_OK) rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, ctx->sortTmp.p, &tb, ctx->stream); }
@@ -929,28 +935,16 @@ int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
     int32_t g1 = g0; uint64_t n = 0;
     while (g1 < sk->nGenomes && (g1 == g0 || n + genomeRecs[g1] <= target)) { n += genomeRecs[g1]; g1++; }
     if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "reference genome %d alone yields %llu minimizers (>= 2^31)", g0, (unsigned long long)n);
-    // the chunk's records: one part's slice as it is, or a copy of several slices
-    const uint32_t *rec = nullptr; uint32_t *tmp = nullptr;
-    if (n) {
-      const int32_t pa = genomePart[g0], pb = genomePart[g1 - 1];
-      if (pa == pb) rec = parts[pa].rec + 3 * genomeOffInPart[g0];
-      else {
-        HIP_TRY(pool_malloc((void **)&tmp, n * 12));
-        size_t o = 0;
-        for (int32_t g = g0; g < g1;) {             // runs of genomes inside one part
-          const int32_t pi = genomePart[g]; int32_t h = g; uint64_t m = 0;
-          while (h < g1 && genomePart[h] == pi) { m += genomeRecs[h]; h++; }
-          if (m) { hipError_t e = hipMemcpyAsync(tmp + 3 * o, parts[pi].rec + 3 * genomeOffInPart[g], m * 12, hipMemcpyDeviceToDevice, ctx->stream);
-                   if (e != hipSuccess) { pool_free(tmp); HIP_TRY(e); } }
-          o += m; g = h;
-        }
-        rec = tmp;
-      }
+    // the chunk's records: slices of the parts its genomes come from, in order
+    std::vector<RecordPiece> pieces;
+    for (int32_t g = g0; g < g1;) {                 // runs of genomes inside one part
+      const int32_t pi = genomePart[g]; int32_t h = g; uint64_t m = 0;
+      while (h < g1 && genomePart[h] == pi) { m += genomeRecs[h]; h++; }
+      if (m) pieces.push_back(RecordPiece{parts[pi].rec + 3 * genomeOffInPart[g], (size_t)m});
+      g = h;
     }
     IndexChunk *ch = nullptr;
-    const int rc = build_chunk(ctx, &sk->params, rec, (size_t)n, sk->contigLen.data(), gcs, g0, g1 - g0, &ch);
-    if (tmp) pool_free(tmp);
-    TRY(rc);
+    TRY(build_chunk(ctx, &sk->params, pieces, (size_t)n, sk->contigLen.data(), gcs, g0, g1 - g0, &ch));
     sk->chunks.push_back(ch); ctx->counters.indexChunks++;
     sk->n += n; sk->maxChunkBins = std::max(sk->maxChunkBins, ch->totalBins);
     for (size_t pi = 0; pi < parts.size(); pi++)
