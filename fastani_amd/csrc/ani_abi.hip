@@ -808,9 +808,12 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPie
         hipLaunchKernelGGL(k_index_window_links, dim3(grid_for(n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
                            (const int32_t *)sk->contigFirstMin, (const uint8_t *)sk->mDelta, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
     }
-    // probe table: the distinct hashes in an order-preserving open-addressing table, load ~0.7 (index.hpp)
+    // probe table: the distinct hashes in an order-preserving open-addressing table, load 0.5 (index.hpp)
     {
-      const uint32_t nSlots = (uint32_t)std::min<uint64_t>(0x7ffffff0ull, std::max<uint64_t>(1024, (uint64_t)((double)n / 0.7)));
+      unsigned long long host[CNT_N];
+      SK_TRY(read_counters(ctx, host));                       // k_index_links counted the distinct hashes
+      sk->nUnique = host[CNT_UNIQ];
+      const uint32_t nSlots = (uint32_t)std::min<uint64_t>(0x7ffffff0ull, std::max<uint64_t>(1024, (uint64_t)sk->nUnique * 2));
       const uint32_t nb = (uint32_t)((n + kTableBlock - 1) / kTableBlock);
       std::vector<int32_t> cnt(nb ? nb : 1), best(nb ? nb : 1);
       int64_t lastP = -1;
@@ -839,15 +842,12 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPie
         hipLaunchKernelGGL(k_table_scatter, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize, nSlots,
                            (const int32_t *)ctx->scanTmpA.as<int32_t>(), (const int32_t *)ctx->scanTmpB.as<int32_t>(), sk->table);
       }
-      const TableSlot sentinel{0xffffffffu, (uint32_t)n | 0x80000000u};
+      const TableSlot sentinel{0xffffffffu, (uint32_t)n | 0x80000000u, 0u};
       SK_HIP(hipMemcpyAsync(sk->table + (alloc - 2), &sentinel, sizeof sentinel, hipMemcpyHostToDevice, ctx->stream));
       SK_HIP(hipStreamSynchronize(ctx->stream));                             // cnt / best / sentinel are host memory
       sk->tableSlots = nSlots;
     }
     SK_HIP(hipGetLastError());
-    unsigned long long host[CNT_N];
-    SK_TRY(read_counters(ctx, host));
-    sk->nUnique = host[CNT_UNIQ];
   }
   // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194); all chunk-local
   std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);

@@ -103,12 +103,12 @@ __host__ __device__ __forceinline__ uint32_t bucket_key(uint32_t h, int w)
 // hashes.  Slot of a hash = its (monotone) bucket key scaled to the table size; the distinct hashes are inserted in sorted order
 // with linear probing, so a cluster stays sorted and the i-th distinct hash lands at
 //     p_i = max(slot_i, p_(i-1) + 1) = i + max_(j <= i) (slot_j - j),
-// a running maximum — no atomics, no collisions to resolve.  A slot is 8 bytes {hash, first} (first = start of the hash's run in
-// sSW); the run's length is the next occupied slot's `first` minus this one's (a sentinel {~0, n | 2^31} closes the table).  A probe reads
-// the slot of the hash and walks forward while the entries are smaller: one 128-byte line in nearly all cases, where the bucket
-// table + hash array cost three (k_l1_probe was HBM-bound on exactly those lines: 161 GB per 1000 x 1000 step).
+// a running maximum — no atomics, no collisions to resolve.  A slot is 12 bytes {hash, first, cnt}: the hash's run in sSW (a
+// sentinel {~0, n | 2^31, 0} closes the table).  A probe reads the slot of the hash and walks forward while the entries are
+// smaller: one dependent load in most cases.  (With 8-byte slots the run length was the next occupied slot's `first` minus this
+// one's — at load 0.25 that was four more dependent loads per probe, and the probe kernel does nothing but wait for its loads.)
 // ------------------------------------------------------------------------------------------------
-struct TableSlot { uint32_t hash, first; };
+struct TableSlot { uint32_t hash, first, cnt; };
 constexpr uint32_t kSlotEmpty = 0xffffffffu;
 constexpr int kTableBlock = kTPB * 8;
 __host__ __device__ __forceinline__ uint32_t table_slot(uint32_t h, int w, uint32_t nSlots) { return (uint32_t)(((uint64_t)bucket_key(h, w) * nSlots) >> 32); }
@@ -173,6 +173,9 @@ __global__ __launch_bounds__(kTPB) void k_table_scatter(const uint32_t *__restri
     if (head[k]) {
       const int v = slot[k] - g; run = v > run ? v : run;
       TableSlot e; e.hash = h[k]; e.first = r0 + k;
+      uint32_t c = 1;                                                // runs are short (a hash occurs a few times) and the entries cached
+      while (r0 + k + c < n && sHash[r0 + k + c] == h[k]) c++;
+      e.cnt = c;
       table[(uint32_t)(g + run)] = e;
       g++;
     }
@@ -183,13 +186,10 @@ __device__ __forceinline__ void table_probe(const TableSlot *__restrict__ table,
 {
   uint32_t s = table_slot(h, w, nSlots);
   TableSlot e = table[s];
-  while (e.first != kSlotEmpty && e.hash < h) e = table[++s];        // the sentinel {~0, n} stops the walk at the latest
+  while (e.first != kSlotEmpty && e.hash < h) e = table[++s];        // the sentinel {~0, n | 2^31} stops the walk at the latest
   first = 0; cnt = 0;
   if ((e.first & 0x80000000u) || e.hash != h) return;                 // empty slot, the sentinel, or a larger hash: not in the index
-  first = e.first;
-  TableSlot nx = table[++s];
-  while (nx.first == kSlotEmpty) nx = table[++s];
-  cnt = (nx.first & 0x7fffffffu) - first;
+  first = e.first; cnt = e.cnt;
 }
 
 // contigFirstMin[c] = first position-ordered entry with seqId >= c, for c = 0..nContigs

@@ -314,16 +314,31 @@ constexpr int kL2RankBuckets = 2048;
 // rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
 __device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh; return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
 
-// One workgroup per fragment.  The kernel is instruction-issue-bound (every wave instruction, vector or scalar, costs about four
-// SIMD cycles on MI355X: tools/ubench/valu.hip), so the loop is built for few instructions per entry: a thread ranks four
-// consecutive entries per pass (one address computation, one 8-byte store), and the rank lookup has no loop — the rank table has
-// 2048 buckets for ~240 sketch hashes, so a bucket holds at most two of them except in rare cases, which a wave vote sends to a
-// binary search.
+// One workgroup per fragment: the fragment sketch and its rank table sit in LDS; each of the four waves takes every fourth
+// candidate of the fragment and works on its own from there (no workgroup barrier after the set-up).
+// What bounds it (SQ counters, profiles/r02s_sq_wait.txt): the two events of an entry land hundreds of slots apart, and a scattered
+// 2-byte global store costs the memory pipeline about one cycle per lane — 8 such stores per lane and pass were the kernel's time,
+// whatever its instruction count or the bytes moved.  So a wave assembles its candidate's stream in a private LDS window (scattered
+// LDS writes cost a few cycles per wave) and writes it out in 16-byte pieces, 1 KiB per wave instruction; only streams beyond the
+// window (ranges of thousands of entries) are stored directly.
+// A lane ranks four entries per pass, 64 apart (every load is one contiguous 256-byte run per wave); the loads of the next pass or
+// candidate are in flight while the current one is ranked.  The rank lookup has no loop: 2048 buckets for ~240 sketch hashes, so a
+// bucket holds at most two of them except in rare cases, which a wave vote sends to a binary search.
+constexpr int kL2StageEvents = 2048;        // events per wave window (4 KiB)
+constexpr int kL2CandBatch = 40;            // candidates whose descriptors are fetched at once
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ANI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define ANI_WAVE_SYNC() (void)__ballot(1)   /* CPU stand-in: lanes are fibers, a wave collective is the rendezvous */
+#endif
 __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
   __shared__ uint32_t qs[kL2FastMaxS + 2];
-  __shared__ uint16_t st[kL2RankBuckets + 2];
   __shared__ uint32_t st2[kL2RankBuckets];
+  __shared__ __attribute__((aligned(16))) uint16_t stageAll[(kTPB / kWave) * kL2StageEvents];
+  __shared__ L2Range cRange[kL2CandBatch];         // the candidates' descriptors, fetched side by side (nEvents < 0: no stream)
+  __shared__ uint64_t cOff[kL2CandBatch];
+  uint16_t *st = stageAll;                         // the plain rank table is only needed to build st2 (2050 of the 8192 entries)
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive fragments of a query map to overlapping
   // reference ranges, so XCD x takes a contiguous eighth of the chunk's fragments: neighbours share their reference reads in L2.
   const int32_t per = (int32_t)(gridDim.x >> 3);
@@ -336,9 +351,22 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   if (cB > a.c1) cB = a.c1;
   if (cA >= cB || s < 1 || s > kL2FastMaxS) return;
   const uint32_t *q = a.g.qPool + a.g.fragOff[f];
+  // A candidate's descriptor is three dependent memory round trips away from its first hash (count -> range -> hashes); walked
+  // candidate by candidate that chain was most of a workgroup's life.  All descriptors of the fragment are fetched here, together
+  // with the sketch.
+  auto fetch_cands = [&](int32_t base) {
+    const int32_t c = base + (int32_t)threadIdx.x;
+    if ((int)threadIdx.x < kL2CandBatch && c < cB) {
+      const int32_t i = c - a.c0;
+      L2Range r = a.ranges[i];
+      if (a.codeCount[i] == 0) r.nEvents = -1;
+      cRange[threadIdx.x] = r; cOff[threadIdx.x] = a.codeOff[i];
+    }
+  };
+  fetch_cands(cA);
   for (int i = threadIdx.x; i < s; i += kTPB) qs[i] = q[i];
   if (threadIdx.x < 2) qs[s + threadIdx.x] = 0xffffffffu;             // the two-entry probe may read one or two slots past the sketch
-  // rank table: st[b] = #{q : bucket(q) < b}; a lookup then looks at the (at most two, as a rule) sketch entries of the hash's bucket
+  // rank table: st[b] = #{q : bucket(q) < b}; st2[b] = st[b] | entries of bucket b << 16
   const int sh = a.g.rankShift;
   for (int i = threadIdx.x; i <= s; i += kTPB) {
     const int b0 = i > 0 ? l2_rank_bucket(q[i - 1], sh) + 1 : 0;
@@ -347,45 +375,50 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kL2RankBuckets; b += kTPB) st2[b] = (uint32_t)st[b] | ((uint32_t)(st[b + 1] - st[b]) << 16);
-  __syncthreads();
-  // Work items = (candidate, pass of 4 * kTPB entries), in order.  The loads of the next item are issued before the current one is
-  // ranked: a pass is "load 8 words per thread, rank, store", and with one candidate after the other the workgroup spent most of
-  // its time waiting for those loads (the kernel was latency-bound: neither fewer instructions nor fewer bytes moved its time).
+  __syncthreads();                                 // from here on the waves go their own ways; `st` is dead, the windows are free
+
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  uint16_t *stage = stageAll + wv * kL2StageEvents;
+  // Work items of this wave = (candidate, pass of 4 * 64 entries), in order.
   struct Item {
     int32_t c; uint32_t jb;                          // candidate, first entry of the pass
     char *ob; const char *hb, *wb;                   // wave-uniform bases: event stream, hashes, window links (32-bit byte offsets per lane)
-    uint32_t m, nInit, nInsAll, nDel, dump;
+    uint32_t m, nInit, nInsAll, nDel, dump; bool staged, lastPass;
   };
-  auto open_cand = [&](int32_t c, Item &it) -> bool {          // first candidate >= c of this fragment that has a stream
-    for (; c < cB; c++) {
-      const int32_t i = c - a.c0;
-      if (a.codeCount[i] == 0) continue;
-      const L2Range r = a.ranges[i];
+  constexpr uint32_t kPass = 4u * kWave;
+  int32_t batch0 = cA, batch1 = cA + kL2CandBatch < cB ? cA + kL2CandBatch : cB;      // candidates whose descriptors are in LDS
+  auto open_cand = [&](int32_t c, Item &it) -> bool {          // first candidate >= c of this wave (within the batch) that has a stream
+    for (; c < batch1; c += kTPB / kWave) {
+      const L2Range r = cRange[c - batch0];
+      if (r.nEvents < 0) continue;
       it.c = c; it.jb = 0;
-      it.ob = (char *)((uint16_t *)a.codes + a.codeOff[i]);
+      it.ob = (char *)((uint16_t *)a.codes + cOff[c - batch0]);
       it.hb = (const char *)(a.g.mHash + r.beg0); it.wb = (const char *)(a.g.mWin + r.beg0);
       it.m = (uint32_t)(r.last - r.beg0);
       it.nInit = (uint32_t)(r.end0 - r.beg0); it.nInsAll = it.m - 1;          // inserts (first window included) are the entries [0, m-1)
       it.nDel = (uint32_t)r.nEvents - it.nInsAll;                             // deletes are the entries [0, nDel)
       it.dump = (uint32_t)r.nEvents;                                          // pad slot
+      it.staged = (uint32_t)r.nEvents < (uint32_t)kL2StageEvents;
+      it.lastPass = kPass >= it.m;
       return true;
     }
     return false;
   };
   auto next_item = [&](const Item &cur, Item &nx) -> bool {
-    if (cur.jb + 4u * kTPB < cur.m) { nx = cur; nx.jb = cur.jb + 4u * kTPB; return true; }
-    return open_cand(cur.c + 1, nx);
+    if (!cur.lastPass) { nx = cur; nx.jb = cur.jb + kPass; nx.lastPass = nx.jb + kPass >= nx.m; return true; }
+    return open_cand(cur.c + kTPB / kWave, nx);
   };
   auto load_item = [&](const Item &it, uint32_t (&h)[4], uint32_t (&wl)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const uint32_t x = it.jb + threadIdx.x + e * kTPB;                       // kTPB apart: every load is one contiguous run per wave
+      const uint32_t x = it.jb + lane + e * kWave;
       const uint32_t off = (x < it.m ? x : it.m - 1) * 4u;
       h[e] = *(const uint32_t *)(it.hb + off); wl[e] = *(const uint32_t *)(it.wb + off);
     }
   };
   Item cur, nxt;
-  bool have = open_cand(cA, cur);
+  for (;;) {
+  bool have = open_cand(batch0 + wv, cur);
   uint32_t h[4], wl[4], hn[4], wn[4];
   if (have) load_item(cur, h, wl);
   while (have) {
@@ -419,17 +452,25 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     // last entry, entries that never leave) goes to the pad slot behind the stream (k_l2_ranges reserves one).
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const uint32_t x = cur.jb + threadIdx.x + e * kTPB;
+      const uint32_t x = cur.jb + lane + e * kWave;
       const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
       // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
       const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
       const uint32_t pi = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : cur.dump;
-      *(uint16_t *)(cur.ob + pi * 2u) = (uint16_t)(cd | kL2InsBit | (x + 1 < cur.nInit ? kL2NoEvalBit : 0u));
+      const uint16_t ci = (uint16_t)(cd | kL2InsBit | (x + 1 < cur.nInit ? kL2NoEvalBit : 0u));
       // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
       // window's)
       const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
       const uint32_t pd = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : cur.dump;
-      *(uint16_t *)(cur.ob + pd * 2u) = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit));    // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+      const uint16_t cdl = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit));             // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+      if (cur.staged) { stage[pi] = ci; stage[pd] = cdl; }                              // wave-uniform choice
+      else { *(uint16_t *)(cur.ob + pi * 2u) = ci; *(uint16_t *)(cur.ob + pd * 2u) = cdl; }
+    }
+    if (cur.staged && cur.lastPass) {                // the candidate's stream is complete in the window: write it out
+      ANI_WAVE_SYNC();
+      const uint32_t nOut = (cur.dump + 8u) & ~7u;   // = codeCount: the stream and its pad, whole 16-byte pieces
+      for (uint32_t o = (uint32_t)lane * 8u; o < nOut; o += kWave * 8u) *(uint4 *)(cur.ob + o * 2u) = *(const uint4 *)(stage + o);
+      ANI_WAVE_SYNC();                               // the window is reused by the next candidate
     }
     have = haveNext;
     if (have) {
@@ -437,6 +478,12 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 #pragma unroll
       for (int e = 0; e < 4; e++) { h[e] = hn[e]; wl[e] = wn[e]; }
     }
+  }
+  if (batch1 >= cB) break;                         // workgroup-uniform; fragments with more candidates than a batch are rare
+  __syncthreads();
+  fetch_cands(batch1);
+  batch0 = batch1; batch1 = batch0 + kL2CandBatch < cB ? batch0 + kL2CandBatch : cB;
+  __syncthreads();
   }
 }
 
