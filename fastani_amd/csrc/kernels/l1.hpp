@@ -175,18 +175,12 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   for (int i = t; i < s; i += kTPB) pOff[i] = (int)a.probeCnt[off + i];
   __syncthreads();
   block_array_excl_scan(pOff, s, ws);
-  // gather (computeMap.hpp:283-299)
+  // gather (computeMap.hpp:283-299).  (Tried and measured equal: four loads in flight per lane; one lane per hit instead of per
+  // sketch hash.  The kernel's time is in the barrier-separated LDS phases below, not here.)
   for (int i = t; i < s; i += kTPB) {
     const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H;
     const uint32_t fi = a.probeFirst[off + i];
-    // four loads in flight per lane (the run of a hash is contiguous; the kernel waits on these random reads)
-    for (int c = 0; c < e - o; c += 4) {
-      uint64_t v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = a.sSW[fi + (c + u < e - o ? c + u : c)];
-#pragma unroll
-      for (int u = 0; u < 4; u++) if (c + u < e - o) hits[o + c + u] = v[u];
-    }
+    for (int c = 0; c < e - o; c++) hits[o + c] = a.sSW[fi + c];
   }
   // Noise filter.  Minimizer hashes are minima over w k-mers, so they crowd the low end of the 32-bit range and most seed hits of
   // a fragment against a large reference set are chance collisions: isolated hits (measured on 1000 x 5 Mbp: ~1300 hits per

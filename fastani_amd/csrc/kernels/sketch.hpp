@@ -126,6 +126,38 @@ __device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], in
   const int t = threadIdx.x;
   const int local0 = t * kPer;
   bool own_ok[kPer];
+  if (t == 0) ws[kTPB + 8] = -1;                   // slot of the tile's first valid P (read after the barriers below)
+  if (w >= kPer && w <= 4 * kPer) {
+    // ---- window minimum over (i-w, i], w >= kPer: the window of own position j is the own prefix [0, j], a whole number of
+    // earlier threads' blocks and a suffix of one more block.  Prefix minima stay in registers, every thread publishes its suffix
+    // minima (suffix 0 = its whole block): one barrier and ~16 LDS reads, where doubling the span takes log2(w) rounds of two
+    // barriers and 2 * kPer LDS accesses each (the sketch kernels spent nearly half their wave cycles parked at barriers).
+    uint64_t suf = kSkipKey, pre = kSkipKey;
+#pragma unroll
+    for (int j = kPer - 1; j >= 0; j--) { suf = key[j] < suf ? key[j] : suf; keys[local0 + j] = suf; }
+#pragma unroll
+    for (int j = 0; j < kPer; j++) { own_ok[j] = key[j] != kSkipKey; pre = key[j] < pre ? key[j] : pre; W[j] = pre; }
+    __syncthreads();
+    const int aHi = (w - 1) / kPer;                // whole blocks before the own one that position 0 needs (1..3); position j: aHi or aHi - 1
+    uint64_t allHi = kSkipKey, allLo = kSkipKey;   // minimum over the aHi / aHi - 1 preceding blocks
+#pragma unroll
+    for (int x = 1; x <= 3; x++) {
+      if (x <= aHi) {
+        const uint64_t v = t - x >= 0 ? keys[(t - x) * kPer] : kSkipKey;
+        allLo = allHi; allHi = v < allHi ? v : allHi;
+      }
+    }
+    int a = aHi, b = (w - 1) - aHi * kPer;         // position j needs w - 1 - j earlier positions = a blocks + the last b of one more
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const uint64_t whole = a == aHi ? allHi : allLo;
+      const int tb = t - a - 1;
+      const uint64_t part = (b > 0 && tb >= 0) ? keys[tb * kPer + kPer - b] : kSkipKey;
+      uint64_t m = whole < part ? whole : part;
+      W[j] = m < W[j] ? m : W[j];
+      if (b == 0) { a--; b = kPer - 1; } else b--;
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < kPer; j++) { keys[local0 + j] = key[j]; W[j] = key[j]; own_ok[j] = key[j] != kSkipKey; }
 
@@ -147,6 +179,7 @@ __device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], in
 #pragma unroll
     for (int j = 0; j < kPer; j++) { int q = local0 + j - d; uint64_t r = q >= 0 ? keys[q] : kSkipKey; W[j] = r < W[j] ? r : W[j]; }
   }
+  }
 
   // ---- emission: argmin positions are monotone, so "previous P" is a running maximum ----
   int P[kPer]; bool val[kPer];
@@ -158,19 +191,21 @@ __device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], in
     P[j] = val[j] ? (kTile - 1 - (int)(uint32_t)W[j]) : -1;
     if (val[j]) { if (myFirst < 0) myFirst = P[j]; myMax = P[j]; }
   }
-  int incl = block_incl_maxscan(myMax, ws);        // max P over threads 0..t
+  // max P over all earlier threads: wave scan by shuffles, one barrier for the wave totals
+  const int lane = t & (kWave - 1), wv = t >> 6;
+  int v = myMax;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v = o > v ? o : v; }
+  int prev = __shfl_up(v, 1); if (lane == 0) prev = -1;
+  if (lane == kWave - 1) ws[wv] = v;
   __syncthreads();
-  ws[8 + t] = incl;
+  int lastAll = -1;
+#pragma unroll
+  for (int i = 0; i < kTPB / kWave; i++) { const int x = ws[i]; if (i < wv) prev = x > prev ? x : prev; lastAll = x > lastAll ? x : lastAll; }
+  // first valid P in the tile: the thread whose predecessor max is -1 and that has a valid position (exactly one, if any)
+  if (myFirst >= 0 && prev < 0) ws[kTPB + 8] = myFirst;
   __syncthreads();
-  int prev = t > 0 ? ws[8 + t - 1] : -1;           // max P over all earlier threads
-  const int lastAll = ws[8 + kTPB - 1];
-  // first valid P in the tile: the thread whose predecessor max is -1 and that has a valid position
-  __syncthreads();
-  if (t == 0) ws[0] = -1;
-  __syncthreads();
-  if (myFirst >= 0 && prev < 0) ws[0] = myFirst;   // exactly one thread satisfies this
-  __syncthreads();
-  const int firstAll = ws[0];
+  const int firstAll = ws[kTPB + 8];
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
     em[j] = val[j] && P[j] != prev;

@@ -282,6 +282,33 @@ def case_sketch_file(engine, tmpdir):
         assert e.code == -1
 
 
+def case_window_sizes(engine):
+    """explicit window sizes around the borders of the winnowing kernel's two forms (prefix/suffix decomposition for
+    kPer = 12 <= w <= 48, span doubling otherwise): reference minimizers, fragment sketches and the fused all-vs-all pass"""
+    genomes = [messy_genome(6, 30000), [orc.synth_genome(6, 0, 20000)], [orc.synth_genome(6, 2, 9000), rng_genome(3, 7000, b"ACGTN")]]
+    contig_len = np.array([len(c) for g in genomes for c in g], dtype=np.int32)
+    gcs = np.cumsum([0] + [len(g) for g in genomes]).astype(np.int32)
+    for w in (2, 11, 12, 13, 23, 25, 35, 36, 37, 47, 48, 49, 97):
+        p = engine.params(16, 3000)
+        p.windowSize = w
+        sk = Sketch(engine, p, genomes)
+        osk = orc.Sketch(genomes, 16, w)
+        assert np.array_equal(sk.minimizers(), osk.minimizers()), w
+        for q in genomes:
+            fr = engine.query_sketch(p, [q])
+            exp_fr = [orc.fragment_sketch(orc.upper(c)[i * 3000:(i + 1) * 3000], 16, w) for c in q if len(c) >= 3000 for i in range(len(c) // 3000)]
+            assert len(fr) == len(exp_fr), w
+            for a, b in zip(fr, exp_fr):
+                assert np.array_equal(a, b), w
+        ptr, n, frags = engine.sketch_records_self(p, genomes, 0)
+        sk2 = Sketch(engine, p, records=(ptr, n, contig_len, gcs))
+        assert np.array_equal(sk2.minimizers(), osk.minimizers()), w
+        assert np.array_equal(sk2.map_cgi_fragset(frags, 0), sk.map_cgi_batch(genomes, 0)), w
+        if n:
+            engine.device_free(ptr)
+        frags.close()
+
+
 def case_limits(engine):
     """documented limits fail loudly with ANI_ERR_LIMIT (-4), never silently"""
     from fastani_amd.api import AniError
@@ -305,7 +332,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_sparse_hits, case_empty_and_short, case_uploaded, case_self]
+             case_low_complexity_big, case_sparse_hits, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):
