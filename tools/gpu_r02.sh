@@ -78,8 +78,9 @@ if has pmc; then
   bash tools/pmc_run.sh ${TAG}_pmc_fetch FETCH_SIZE --steps 1 --warmup 0 > /dev/null 2>&1; tail -3 gpurun_out/${TAG}_pmc_fetch/pmc.log | cut -c1-200
   bash tools/pmc_run.sh ${TAG}_pmc_write WRITE_SIZE --steps 1 --warmup 0 > /dev/null 2>&1
   bash tools/pmc_run.sh ${TAG}_pmc_sq "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT" --steps 1 --warmup 0 --genomes 200 > /dev/null 2>&1
+  bash tools/pmc_run.sh ${TAG}_pmc_sqwait "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" --steps 1 --warmup 0 --genomes 200 > /dev/null 2>&1
   python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch/pmc_summary.txt gpurun_out/${TAG}_pmc_write/pmc_summary.txt gpurun_out/${TAG}_pmc_traffic.json
   head -12 gpurun_out/${TAG}_pmc_sq/pmc_summary.txt | cut -c1-330
-  rm -rf gpurun_out/${TAG}_pmc_fetch/pmc gpurun_out/${TAG}_pmc_write/pmc gpurun_out/${TAG}_pmc_sq/pmc
+  rm -rf gpurun_out/${TAG}_pmc_fetch/pmc gpurun_out/${TAG}_pmc_write/pmc gpurun_out/${TAG}_pmc_sq/pmc gpurun_out/${TAG}_pmc_sqwait/pmc
 fi
 du -sh "$OUT" | tail -1
