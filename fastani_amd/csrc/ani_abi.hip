@@ -200,7 +200,7 @@ struct ani_ctx {
   DevBuf sortTmp, unitStart, unitAux, tiles, tileInfo, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
-  DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff;
+  DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
   DevBuf l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
@@ -1057,6 +1057,27 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   host[CNT_QPOOL] = fs.nHashes;
   ctx->counters.l1Probes += fs.nHashes;
 
+  // ---- processing order ----
+  // Fragments are numbered genome by genome.  The genomes of a batch are often close relatives (an all-vs-all run over a species, a
+  // database sorted by taxonomy): fragment k of genome A and fragment k of its neighbour B then probe the same index entries, get the
+  // same candidates and re-read the same reference ranges.  Processed in fragment order they are a whole genome (1666 workgroups,
+  // 200 MB of traffic) apart; processed "k-th fragments of all genomes, then the (k+1)-th" they are neighbours and meet in one L2
+  // (kernels map an XCD to a contiguous run of the order, xcd_item).  Results do not depend on the order: every kernel writes through
+  // the fragment id, the candidates of a fragment stay contiguous, and single-genome calls (ani_map_query, whose mappings are
+  // returned in callback order) keep the ascending order.
+  const int32_t *fragOrder = nullptr;
+  { const char *ev = getenv("ANI_FRAG_ORDER");
+    if (fs.genomeFragments.size() >= 2 && fs.fragQSeq && !(ev && !strcmp(ev, "plain"))) {
+      TRY(ctx->fragOrder.ensure(nF * 4)); TRY(ctx->fragOrderTmp.ensure(nF * 20));
+      uint64_t *keyIn = ctx->fragOrderTmp.as<uint64_t>(), *keyOut = keyIn + nF; uint32_t *idxIn = (uint32_t *)(keyOut + nF);
+      hipLaunchKernelGGL(k_frag_order_keys, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, fs.fragQSeq, (int32_t)nF, keyIn, idxIn);
+      size_t tb = 0;
+      int rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, nullptr, &tb, ctx->stream);
+      if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 16)); rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, ctx->sortTmp.p, &tb, ctx->stream); }
+      if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of the fragment order failed (%d)", rc);
+      fragOrder = ctx->fragOrder.as<int32_t>();
+    } }
+
   // ---- L1 ----
   TRY(ctx->fragCandOff.ensure(nF * 4)); TRY(ctx->fragCandCnt.ensure(nF * 4)); TRY(ctx->fragCandCntClamped.ensure(nF * 4));
   TRY(ctx->fragHits.ensure(nF * 4)); TRY(ctx->fragOrdOff.ensure((nF + 1) * 4));
@@ -1080,14 +1101,15 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
     a.filterShift = 1; while (a.filterShift < 30 && (1 << a.filterShift) < 2 * L) a.filterShift++;
+    a.fragOrder = fragOrder;
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
     a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTL);
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
-      if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3((unsigned)((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
-      { StageTimer tk(ctx, &ctx->counters.msL1Main, 1); hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr); }
+      if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
+      { StageTimer tk(ctx, &ctx->counters.msL1Main, 1); hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3(pad8(nF)), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr); }
       if (attempt == 0) {
         unsigned long long nl[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(nl, cnt_ptr(ctx, CNT_LISTM), 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -1115,7 +1137,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of seed hits failed (%d)", rc);
         hipLaunchKernelGGL(k_l1_big_candidates, dim3(1), dim3(kTPB), 0, ctx->stream, a, bigFrags[i], (const uint64_t *)ctx->l1BigHitsB.as<uint64_t>(), ctx->l1BigV.as<int>());
       }
-      hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, ctx->fragCandCnt.as<int32_t>(),
+      hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, ctx->fragCandCnt.as<int32_t>(), fragOrder,
                          ctx->fragCandCntClamped.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG));
     }
     HIP_TRY(hipGetLastError());
@@ -1138,7 +1160,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     if (nCand) {
       TRY(ctx->ocFrag.ensure(nCand * 4)); TRY(ctx->ocSeq.ensure(nCand * 4)); TRY(ctx->ocStart.ensure(nCand * 4)); TRY(ctx->ocEnd.ensure(nCand * 4));
       hipLaunchKernelGGL(k_l1_order, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, ctx->fragCandOff.as<uint32_t>(), ctx->fragCandCntClamped.as<int32_t>(),
-                         ctx->fragOrdOff.as<uint32_t>(), (int32_t)nF, ctx->candSeq.as<int32_t>(), ctx->candStart.as<int32_t>(), ctx->candEnd.as<int32_t>(),
+                         ctx->fragOrdOff.as<uint32_t>(), fragOrder, (int32_t)nF, ctx->candSeq.as<int32_t>(), ctx->candStart.as<int32_t>(), ctx->candEnd.as<int32_t>(),
                          ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(), ctx->ocStart.as<int32_t>(), ctx->ocEnd.as<int32_t>());
       HIP_TRY(hipGetLastError());
     }
@@ -1195,7 +1217,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       L2FastArgs fa;
       fa.g = a; fa.c0 = (int32_t)c0; fa.c1 = (int32_t)c1;
       fa.ranges = ctx->l2Ranges[p].as<L2Range>(); fa.codeCount = ctx->l2CodeCount[p].as<int32_t>(); fa.codeOff = ctx->l2CodeOff[p].as<uint32_t>();
-      fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag[p].as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.nFrag = (int32_t)nF;
+      fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag[p].as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.fragOrder = fragOrder; fa.nFrag = (int32_t)nF;
       // fragments that own candidates c0 and c1-1 (ordOff is non-decreasing; fragments without candidates repeat a value)
       const int32_t fA = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)c0) - ordOff) - 1;
       const int32_t fB = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)(c1 - 1)) - ordOff) - 1;
@@ -1520,7 +1542,7 @@ void ani_shutdown(ani_ctx *c)
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileInfo, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
                     &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
-                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
+                    &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->fragOrder, &c->fragOrderTmp, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
                     &c->l2Ranges[1], &c->l2CodeCount[1], &c->l2CodeOff[1], &c->l2Codes[1], &c->l2SlowFlag[1], &c->l2ClassList[1], &c->l2Order[1], &c->l2LenHist[1], &c->l2SlowList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();

@@ -201,6 +201,12 @@ __device__ inline void block_bitonic_sort(K *a, int n2)
   __syncthreads();
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A grid padded to a multiple of 8 is turned inside out:
+// XCD x works through the x-th eighth of the items in order, so items that are neighbours in the list (and share data) meet in
+// one L2 at about the same time.  The caller drops indices >= its item count.
+__device__ __forceinline__ int xcd_item(int block, int gridBlocks) { return (block & 7) * (gridBlocks >> 3) + (block >> 3); }
+__host__ __device__ __forceinline__ unsigned pad8(size_t n) { return (unsigned)((n + 7) / 8 * 8); }
+
 __host__ __device__ __forceinline__ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace ani

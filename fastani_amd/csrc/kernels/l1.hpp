@@ -37,6 +37,7 @@ struct L1Args {
   int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
   unsigned long long *sumHits;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
+  const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
 };
 
 // occurrences of hash h in the hash-ordered payload array: [first, first+cnt)
@@ -111,14 +112,15 @@ constexpr int kL1ProbeFrags = 4;
 __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
 {
   __shared__ int ws[16];
-  const int f0 = blockIdx.x * kL1ProbeFrags;
-  int s[kL1ProbeFrags]; uint32_t off[kL1ProbeFrags]; int c[kL1ProbeFrags];
+  const int i0 = xcd_item(blockIdx.x, gridDim.x) * kL1ProbeFrags;
+  if (i0 >= a.nFrag) return;
+  int fq[kL1ProbeFrags], s[kL1ProbeFrags]; uint32_t off[kL1ProbeFrags]; int c[kL1ProbeFrags];
   int smax = 0;
 #pragma unroll
   for (int q = 0; q < kL1ProbeFrags; q++) {
-    const int f = f0 + q;
-    s[q] = f < a.nFrag ? a.fragS[f] : 0; if (s[q] < 0) s[q] = 0;
-    off[q] = f < a.nFrag ? a.fragOff[f] : 0u;
+    fq[q] = i0 + q < a.nFrag ? (a.fragOrder ? a.fragOrder[i0 + q] : i0 + q) : -1;
+    s[q] = fq[q] >= 0 ? a.fragS[fq[q]] : 0; if (s[q] < 0) s[q] = 0;
+    off[q] = fq[q] >= 0 ? a.fragOff[fq[q]] : 0u;
     c[q] = 0;
     smax = s[q] > smax ? s[q] : smax;
   }
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
   }
 #pragma unroll
   for (int q = 0; q < kL1ProbeFrags; q++) {
-    const int f = f0 + q;
-    if (f >= a.nFrag) break;                        // workgroup-uniform
+    const int f = fq[q];
+    if (f < 0) break;                               // workgroup-uniform
     int H; block_excl_scan(c[q], ws, &H);
     if (threadIdx.x == 0) {
       a.fragHits[f] = H;
@@ -160,7 +162,13 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
   __shared__ int sKeep;
-  const int f = list ? list[blockIdx.x] : (int)blockIdx.x;
+  int f;
+  if (list) f = list[blockIdx.x];
+  else {
+    const int i = xcd_item(blockIdx.x, gridDim.x);
+    if (i >= a.nFrag) return;
+    f = a.fragOrder ? a.fragOrder[i] : i;
+  }
   const int t = threadIdx.x;
   const int s = a.fragS[f];
   const int H = a.fragHits[f];
@@ -257,19 +265,22 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, int f, con
   l1_emit_candidates(a, f, a.fragS[f], a.fragHits[f], hitsSorted, V, ws, &sBase);
 }
 
-// reorder candidates into the reference's callback order: fragment ascending, then (seqId, start) as produced
+// Reorder candidates into the reference's callback order — fragment ascending, then (seqId, start) as produced — or, for a batch
+// of several genomes, into the fragments' processing order (`order`; the candidates of one fragment stay together either way).
+// fragCandCnt and orderedOff are indexed by position in that order.
 __global__ void k_l1_order(const uint32_t *__restrict__ fragCandOff, const int32_t *__restrict__ fragCandCnt,
-                           const uint32_t *__restrict__ orderedOff, int32_t nFrag,
+                           const uint32_t *__restrict__ orderedOff, const int32_t *__restrict__ order, int32_t nFrag,
                            const int32_t *__restrict__ inSeq, const int32_t *__restrict__ inStart, const int32_t *__restrict__ inEnd,
                            int32_t *__restrict__ outFrag, int32_t *__restrict__ outSeq, int32_t *__restrict__ outStart,
                            int32_t *__restrict__ outEnd)
 {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nFrag) return;
-  const int n = fragCandCnt[f];
-  const uint32_t src = fragCandOff[f], dst = orderedOff[f];
-  for (int i = 0; i < n; i++) {
-    outFrag[dst + i] = f; outSeq[dst + i] = inSeq[src + i]; outStart[dst + i] = inStart[src + i]; outEnd[dst + i] = inEnd[src + i];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nFrag) return;
+  const int f = order ? order[i] : i;
+  const int n = fragCandCnt[i];
+  const uint32_t src = fragCandOff[f], dst = orderedOff[i];
+  for (int j = 0; j < n; j++) {
+    outFrag[dst + j] = f; outSeq[dst + j] = inSeq[src + j]; outStart[dst + j] = inStart[src + j]; outEnd[dst + j] = inEnd[src + j];
   }
 }
 

@@ -260,7 +260,8 @@ struct L2FastArgs {
   const uint32_t *codeOff;         // [c1-c0] exclusive scan of codeCount (in entries)
   uint32_t *codes;
   int32_t *slowFlag;               // [c1-c0] 1 = take the general kernel
-  const uint32_t *fragCandOff;     // ordered candidate offset per fragment [nFrag]
+  const uint32_t *fragCandOff;     // ordered candidate offset per position in the fragments' processing order [nFrag]
+  const int32_t *fragOrder;        // processing order (nullptr: fragment ascending)
   int32_t nFrag, fragBase, nFragChunk;   // first fragment of the chunk, fragments that own its candidates
   int32_t allowFast;               // test knob ANI_L2_PATH: 0 = everything to the general kernel, 2 = everything to class B
 };
@@ -344,9 +345,10 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   const int32_t per = (int32_t)(gridDim.x >> 3);
   const int32_t fl = (int32_t)(blockIdx.x & 7) * per + (int32_t)(blockIdx.x >> 3);
   if (fl >= a.nFragChunk) return;
-  const int32_t f = a.fragBase + fl;
+  const int32_t fi = a.fragBase + fl;              // position in the processing order
+  const int32_t f = a.fragOrder ? a.fragOrder[fi] : fi;
   const int32_t s = a.g.fragS[f];
-  int32_t cA = (int32_t)a.fragCandOff[f], cB = (f + 1 < a.nFrag) ? (int32_t)a.fragCandOff[f + 1] : a.g.nCand;
+  int32_t cA = (int32_t)a.fragCandOff[fi], cB = (fi + 1 < a.nFrag) ? (int32_t)a.fragCandOff[fi + 1] : a.g.nCand;
   if (cA < a.c0) cA = a.c0;
   if (cB > a.c1) cB = a.c1;
   if (cA >= cB || s < 1 || s > kL2FastMaxS) return;

@@ -137,13 +137,22 @@ __global__ void k_keep_flags(int32_t n, const uint32_t *__restrict__ idBits, int
   if (c < n) flags[c] = idBits[c] != 0;
 }
 
-__global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, int32_t *__restrict__ out, unsigned int *__restrict__ nNeg)
+// out[i] = candidates of the i-th fragment in processing order (order == nullptr: fragment i)
+__global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ order, int32_t *__restrict__ out,
+                               unsigned int *__restrict__ nNeg)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int v = in[i];
+  const int v = in[order ? order[i] : i];
   out[i] = v > 0 ? v : 0;
   if (v < 0) atomicAdd(nNeg, 1u);
+}
+
+// Processing order of the fragments of a multi-genome batch (see map_stage): sort key = running fragment id inside the genome
+__global__ void k_frag_order_keys(const int32_t *__restrict__ fragQSeq, int32_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n) { key[f] = (uint64_t)(uint32_t)fragQSeq[f]; idx[f] = (uint32_t)f; }
 }
 
 }  // namespace ani
