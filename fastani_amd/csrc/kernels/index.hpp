@@ -173,8 +173,12 @@ __global__ __launch_bounds__(kTPB) void k_table_scatter(const uint32_t *__restri
     if (head[k]) {
       const int v = slot[k] - g; run = v > run ? v : run;
       TableSlot e; e.hash = h[k]; e.first = r0 + k;
-      uint32_t c = 1;                                                // runs are short (a hash occurs a few times) and the entries cached
-      while (r0 + k + c < n && sHash[r0 + k + c] == h[k]) c++;
+      // run length: the thread's own eight entries are in registers (h[] is 0 beyond n, and a hash of 0 cannot follow a larger one
+      // in sorted order unless the run is over); only a run that reaches the end of the eight continues in memory
+      uint32_t c = 1; bool open = true;
+#pragma unroll
+      for (int j = 1; j < 8; j++) if (k + j < 8) { open = open && r0 + k + j < n && h[k + j] == h[k]; c += open ? 1u : 0u; }
+      if (open) { uint32_t r = r0 + 8; while (r < n && sHash[r] == h[k]) { c++; r++; } }
       e.cnt = c;
       table[(uint32_t)(g + run)] = e;
       g++;
@@ -219,12 +223,25 @@ __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t 
 // coalesce.
 constexpr uint32_t kWinMask = 0x3fffu, kWinMoreBit = 1u << 30, kWinDupBit = 1u << 31;
 constexpr int kWinShiftA = 14;
-__global__ void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
-                                     const uint8_t *__restrict__ mDelta, uint32_t n, int32_t cmw1, int32_t expect /* entries per cmw positions */,
-                                     uint32_t *__restrict__ mWin)
+constexpr int kWinHalo = 768;             // positions staged in LDS on either side of a workgroup's 256 entries (~3 typical spans)
+__global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
+                                                            const int32_t *__restrict__ contigFirstMin, const uint8_t *__restrict__ mDelta, uint32_t n,
+                                                            int32_t cmw1, int32_t expect /* entries per cmw positions */, uint32_t *__restrict__ mWin)
 {
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const int32_t sq = mSeq[j], wj = mWpos[j];
+  // The searches of 256 neighbouring entries touch the same few hundred positions on either side: staged once (coalesced), searched
+  // in LDS — the kernel was nothing but chains of dependent global loads.  A search that leaves the staged range (unusually sparse
+  // stretches) reads global memory as before.
+  __shared__ int32_t sw[256 + 2 * kWinHalo];
+  const int64_t j0 = (int64_t)blockIdx.x * 256;
+  const int64_t w0 = j0 - kWinHalo > 0 ? j0 - kWinHalo : 0, w1 = j0 + 256 + kWinHalo < (int64_t)n ? j0 + 256 + kWinHalo : (int64_t)n;
+  for (int64_t x = w0 + threadIdx.x; x < w1; x += 256) sw[x - w0] = mWpos[x];
+  __syncthreads();
+  auto wpos_at = [&](int32_t x) -> int32_t { return ((int64_t)x >= w0 && (int64_t)x < w1) ? sw[x - w0] : mWpos[x]; };
+  const int64_t jj = j0 + threadIdx.x;
+  if (jj >= (int64_t)n) return;
+  const uint32_t j = (uint32_t)jj;
+  {
+    const int32_t sq = mSeq[j], wj = wpos_at((int32_t)j);
     const int32_t cLo = contigFirstMin[sq], cHi = contigFirstMin[sq + 1];
     // Both answers lie about `expect` entries away; a 64-entry bracket around that guess is tried first (two loads + 6 steps
     // instead of 12 steps over the whole super-window), the full range only where the local density is unusual.
@@ -232,23 +249,23 @@ __global__ void k_index_window_links(const int32_t *__restrict__ mSeq, const int
     int32_t lo = (int32_t)j - cmw1 > cLo ? (int32_t)j - cmw1 : cLo, hi = (int32_t)j;
     {
       const int32_t g0 = (int32_t)j - expect - 32, g1 = (int32_t)j - expect + 32;
-      if (g0 >= lo && mWpos[g0] <= wj - cmw1) lo = g0 + 1;
-      if (g1 >= lo && g1 < hi && mWpos[g1] > wj - cmw1) hi = g1;
+      if (g0 >= lo && wpos_at(g0) <= wj - cmw1) lo = g0 + 1;
+      if (g1 >= lo && g1 < hi && wpos_at(g1) > wj - cmw1) hi = g1;
     }
-    while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] <= wj - cmw1) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (wpos_at(mid) <= wj - cmw1) lo = mid + 1; else hi = mid; }
     const uint32_t b = (uint32_t)((int32_t)j - lo);
     uint32_t a = 0, more = 0;
     if ((int32_t)j + 1 < cHi) {
-      const int32_t tgt = mWpos[j + 1] + cmw1;
+      const int32_t tgt = wpos_at((int32_t)j + 1) + cmw1;
       lo = (int32_t)j + 1; hi = (int32_t)j + 2 + cmw1 < cHi ? (int32_t)j + 2 + cmw1 : cHi;
       {
         const int32_t g0 = (int32_t)j + expect - 32, g1 = (int32_t)j + expect + 32;
-        if (g0 >= lo && g0 < hi && mWpos[g0] < tgt) lo = g0 + 1;
-        if (g1 >= lo && g1 < hi && mWpos[g1] >= tgt) hi = g1;
+        if (g0 >= lo && g0 < hi && wpos_at(g0) < tgt) lo = g0 + 1;
+        if (g1 >= lo && g1 < hi && wpos_at(g1) >= tgt) hi = g1;
       }
-      while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < tgt) lo = mid + 1; else hi = mid; }
+      while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (wpos_at(mid) < tgt) lo = mid + 1; else hi = mid; }
       a = (uint32_t)(lo - (int32_t)j);
-      more = (lo < cHi && mWpos[lo] == tgt) ? kWinMoreBit : 0u;
+      more = (lo < cHi && wpos_at(lo) == tgt) ? kWinMoreBit : 0u;
     }
     mWin[j] = (a > kWinMask ? kWinMask : a) << kWinShiftA | (b > kWinMask ? kWinMask : b) | more | ((mDelta[j] & 0x20u) ? kWinDupBit : 0u);
   }
