@@ -142,6 +142,17 @@ def case_sparse_hits(engine):
     check_queries(engine, p, sk, osk, [[base], genomes[3]])
 
 
+def case_l1_class_overflow(engine):
+    """N near-identical copies of one 6-kb region: N x ~240 seed hits per query fragment, nearly all of them with neighbours, so the
+    noise filter keeps them and the fragment overflows the LDS of its hit-count class — 7 copies: class S -> M, 14: M -> L,
+    25: L -> the global-memory path, 40: global path directly"""
+    base = rng_genome(77, 6000)
+    for copies in (7, 14, 25, 40):
+        genomes = [[np.concatenate([rng_genome(900 + i, 300 + 7 * i), mutate(base, 0.002 * (i % 5), 4100 + i), rng_genome(1900 + i, 500)])] for i in range(copies)]
+        p, sk, osk = check_sketch(engine, genomes)
+        check_queries(engine, p, sk, osk, [[base], genomes[copies // 2]])
+
+
 def case_empty_and_short(engine):
     genomes = [[b"ACGT" * 3], [orc.synth_genome(2, 0, 30000)], [b""], [orc.synth_genome(2, 1, 2999)]]
     p, sk, osk = check_sketch(engine, genomes)
@@ -332,7 +343,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_sparse_hits, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
+             case_low_complexity_big, case_sparse_hits, case_l1_class_overflow, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):
