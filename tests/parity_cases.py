@@ -225,7 +225,7 @@ def case_uploaded(engine):
     assert np.array_equal(sk0.minimizers(), osk.minimizers())
 
 
-def case_self(engine):
+def case_self(engine, combos=((16, 3000), (16, 1000), (12, 3000), (16, 3049), (16, 3050), (16, 5000))):
     """all-vs-all in one pass over the hashes (ani_sketch_records_self -> k_sketch_fused): reference records and fragment
     sketches of the same genomes, then ani_map_cgi_fragset; also kept fragment sets of plain queries (ani_fragset_build).
     Fragment lengths that fit a tile together with their lead-in are fused, longer ones take the two separate kernels."""
@@ -233,7 +233,7 @@ def case_self(engine):
                [orc.synth_genome(5, 1, 2999)], [orc.synth_genome(5, 2, 3000)], [orc.synth_genome(5, 4, 6047), orc.synth_genome(5, 20, 9100)]]
     contig_len = np.array([len(c) for g in genomes for c in g], dtype=np.int32)
     gcs = np.cumsum([0] + [len(g) for g in genomes]).astype(np.int32)
-    for k, frag_len in ((16, 3000), (16, 1000), (12, 3000), (16, 3049), (16, 3050), (16, 5000)):
+    for k, frag_len in combos:
         p = engine.params(k, frag_len)
         direct = Sketch(engine, p, genomes)
         rows0 = direct.map_cgi_batch(genomes, 0)

@@ -62,7 +62,7 @@ def test_chunked_with_small_batches(monkeypatch):
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_L2_CHUNK=11)
     pc.case_synthetic_cluster(e, 30000)
     pc.case_sparse_hits(e)
-    pc.case_self(e)
+    pc.case_self(e, combos=((16, 3000), (16, 3050)))
     e.close()
 
 
