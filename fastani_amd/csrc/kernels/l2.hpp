@@ -310,6 +310,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
 }
 
 constexpr uint32_t kL2DupBit = 1u << 10, kL2InsBit = 1u << 11, kL2NoEvalBit = 1u << 12;
+constexpr int kL2DeltaShift = 13;         // bits 13..15: the event's signed change of its field (+2 / +1 insert, -1 / -2 delete; query hash = 1)
 static_assert((kWinDupBit >> 21) == kL2DupBit && (kWinMoreBit >> 18) == kL2NoEvalBit, "flag bits of the window links shift into the event code");
 constexpr int kL2RankBuckets = 2048;
 // rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
@@ -456,15 +457,16 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     for (int e = 0; e < 4; e++) {
       const uint32_t x = cur.jb + lane + e * kWave;
       const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
+      const uint32_t dIns = 2u - (rk[e] & 1u);                                          // field change of the insert; the delete's is its negative (3-bit two's complement)
       // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
       const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
       const uint32_t pi = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : cur.dump;
-      const uint16_t ci = (uint16_t)(cd | kL2InsBit | (x + 1 < cur.nInit ? kL2NoEvalBit : 0u));
+      const uint16_t ci = (uint16_t)(cd | kL2InsBit | (x + 1 < cur.nInit ? kL2NoEvalBit : 0u) | (dIns << kL2DeltaShift));
       // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
       // window's)
       const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
       const uint32_t pd = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : cur.dump;
-      const uint16_t cdl = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit));             // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+      const uint16_t cdl = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (((8u - dIns) & 7u) << kL2DeltaShift));   // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
       if (cur.staged) { stage[pi] = ci; stage[pd] = cdl; }                              // wave-uniform choice
       else { *(uint16_t *)(cur.ob + pi * 2u) = ci; *(uint16_t *)(cur.ob + pd * 2u) = cdl; }
     }
@@ -494,43 +496,44 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 // pivot) are issued up front; `on` = false turns the event into a no-op.  Field g of this lane sits at F[g << 6]
 // (byte-interleaved over the wave: one shift to address it; the only bank conflicts are between the four lanes of a dword
 // column whose g differ by a multiple of 4 — the LDS pipe has an order of magnitude of slack under the VALU work of a step).
-struct L2Regs { int s, iStar, cStar, shared; bool ovf; };
+struct L2Regs { int s, iStar, tot, shared; uint32_t ovfAcc; };   // tot = iStar + (non-query hashes below the pivot) = rank of q_iStar in the union
 constexpr bool kL2ByteInterleave = true;
 __device__ __forceinline__ int l2_field_off(int g) { return kL2ByteInterleave ? (g << 6) : (((g >> 2) << 8) + (g & 3)); }
 
+// The kernel is VALU-bound, so the event is applied with as few vector instructions as the arithmetic allows: the field change comes
+// ready-made in the event code; a counter that passes 127 is not intercepted but noticed afterwards (every new field value is OR-ed
+// into ovfAcc; bit 8 = a byte overflowed — the lane then computes garbage, harmlessly: iStar stays in [0, s] by construction, and the
+// candidate is redone by the general kernel); tot is carried instead of being re-added from two registers.
 __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, bool INS, bool on)
 {
   const bool isQ = (code & 1u) != 0;
   const int idx = (int)((code >> 1) & 0x1ffu);
+  const int d0 = ((int)(code << (32 - kL2DeltaShift - 3))) >> 29;     // sign-extended 3-bit field
+  const int d = on ? d0 : 0;
   const int sg = INS ? 1 : -1;
   int j = r.iStar - (INS ? 1 : 0); j = j < 0 ? 0 : j;               // pivot-adjacent field: n[j], b[j+1]
   uint8_t *pOwn = F + l2_field_off(idx);
   const int own = *pOwn;
   int fj = F[l2_field_off(j)];
-  const int delta = isQ ? 1 : 2;                                     // counter lives in bits 1..7, presence in bit 0
-  const bool full = INS && !isQ && own >= 254;
-  r.ovf = r.ovf || (on && full);
-  const bool act = on && !full;
-  const int d = act ? (INS ? delta : -delta) : 0;
-  *pOwn = (uint8_t)(own + d);
+  const int nw = own + d;                                            // counter lives in bits 1..7, presence in bit 0
+  r.ovfAcc |= (uint32_t)nw;
+  *pOwn = (uint8_t)nw;
   fj += (idx == j) ? d : 0;                                          // the event itself changed field[j]
-  const int cntj = fj >> 1;
+  const int c1 = (fj >> 1) + 1;
   const bool lt = idx < r.iStar;                                     // rank idx+1 <= iStar  <=>  gap idx < iStar
-  const int t = (act && lt) ? sg : 0;
+  const int t = (on && lt) ? sg : 0;
   r.shared += isQ ? t : 0;
-  r.cStar += isQ ? 0 : t;
+  r.tot += isQ ? 0 : t;
   // insert: q_iStar leaves the s smallest iff rank idx+1 <= iStar and iStar + cStar > s;
   // delete: q_{iStar+1} joins them iff iStar < s and iStar + cStar + 1 + n[iStar] <= s.  One comparison against s serves both.
-  const int tot = r.iStar + r.cStar;
-  const int reach = INS ? tot : tot + 1 + cntj;
+  const int reach = INS ? r.tot : r.tot + c1;
   const bool over = reach > r.s;
   const bool room = INS ? lt : (r.iStar < r.s);
-  const bool mv = act && !isQ && room && (over == INS);
+  const bool mv = on && !isQ && room && (over == INS);
   const int mone = mv ? sg : 0;                                      // insert: -1 on everything, delete: +1
-  const int cm = mv ? cntj : 0;
   r.iStar -= mone;
   r.shared -= (fj & 1) ? mone : 0;
-  r.cStar -= INS ? cm : -cm;
+  r.tot -= mv ? (INS ? c1 : -c1) : 0;                               // the pivot moved over q and the n[] non-query hashes next to it
 }
 
 // slowFlag protocol: 0 = class A (pending or done), 4 = class B pending (s in 256..319), 8 = class B done, 16 = done without a
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   L2Range r; r.beg0 = 0; r.end0 = 0; r.last = 0; r.nEvents = 0;
   if (mine) r = a.ranges[i];
   const int n = r.nEvents;                                            // 0 for a lane without a candidate: it idles
-  L2Regs R; R.s = mine ? a.g.fragS[a.g.candFrag[c]] : 1; R.iStar = R.s; R.cStar = 0; R.shared = 0; R.ovf = false;
+  L2Regs R; R.s = mine ? a.g.fragS[a.g.candFrag[c]] : 1; R.iStar = R.s; R.tot = R.s; R.shared = 0; R.ovfAcc = 0;
   const uint4 *p = (const uint4 *)((const uint16_t *)a.codes + (mine ? a.codeOff[i] : 0u));      // idle lanes read the head of the buffer
   const int nBlk = (n + 7) >> 3;
   int best = 0, begAtBest = -1, begAtLast = -1, steps = 0, delCount = 0;
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
     cur = nxt;
   }
   if (mine) {
-    if (R.ovf) a.slowFlag[i] = 3;
+    if (R.ovfAcc & 0x100u) a.slowFlag[i] = 3;
     else {
       a.slowFlag[i] = (G::kMaxS == 255) ? 0 : 8;     // class B runs concurrently with class A: its "done" must not read as class A
       a.g.outBest[c] = best;
