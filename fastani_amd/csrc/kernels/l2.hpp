@@ -528,12 +528,13 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
   // delete: q_{iStar+1} joins them iff iStar < s and iStar + cStar + 1 + n[iStar] <= s.  One comparison against s serves both.
   const int reach = INS ? r.tot : r.tot + c1;
   const bool over = reach > r.s;
-  const bool room = INS ? lt : (r.iStar < r.s);
+  const bool room = (INS ? idx : r.iStar) < (INS ? r.iStar : r.s);   // insert: lt; delete: iStar < s (two selects and one comparison: cheaper than selecting between two flags)
   const bool mv = on && !isQ && room && (over == INS);
-  const int mone = mv ? sg : 0;                                      // insert: -1 on everything, delete: +1
+  const int mvm = -(int)mv;                                          // all ones if the pivot moves (masks, not selects: no branch around the rest)
+  const int mone = sg & mvm;                                         // insert: -1 on everything, delete: +1
   r.iStar -= mone;
-  r.shared -= (fj & 1) ? mone : 0;
-  r.tot -= mv ? (INS ? c1 : -c1) : 0;                               // the pivot moved over q and the n[] non-query hashes next to it
+  r.shared -= mone & -(fj & 1);
+  r.tot -= (INS ? c1 : -c1) & mvm;                                   // the pivot moved over q and the n[] non-query hashes next to it
 }
 
 // slowFlag protocol: 0 = class A (pending or done), 4 = class B pending (s in 256..319), 8 = class B done, 16 = done without a
@@ -603,7 +604,8 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
       delCount += (on && !INS) ? 1 : 0;
       // evaluate (computeMap.hpp:468-476) with the window starting at entry number delCount
       const bool evl = on && (code & kL2NoEvalBit) == 0;
-      const bool better = evl && R.shared > best, tieOrBetter = evl && R.shared >= best;
+      const int se = evl ? R.shared : -1;                             // best >= 0: an event without evaluation never compares
+      const bool better = se > best, tieOrBetter = se >= best;
       best = better ? R.shared : best;
       begAtBest = better ? delCount : begAtBest;
       begAtLast = tieOrBetter ? delCount : begAtLast;
