@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 if has tests; then
   { echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-    echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12; } | tee "$OUT/tests.log"
+    echo "== pytest -m gpu"; timeout 1500 python -X faulthandler -m pytest tests -m gpu -x -q > "$OUT/tests_full.log" 2>&1; echo "rc=$?"; grep -v "^  File" "$OUT/tests_full.log" | tail -12; } | tee "$OUT/tests.log"
 fi
 if has ubench; then timeout 300 tools/ubench/valu > "$OUT/ubench_valu.txt" 2>&1; tail -22 "$OUT/ubench_valu.txt"; fi
 if has bench; then
