@@ -1252,9 +1252,21 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
           fa.nFragChunk = fB - fA + 1;
           hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)((fa.nFragChunk + 7) / 8 * 8)), dim3(kTPB), 0, ctx->stream, fa);
         }
+        // ANI_L2_OVERLAP=1 puts the simulation (VALU-bound) on the side stream so that the next chunk's ranges / codes kernels
+        // (memory- and latency-bound) can run beside it.  Measured: the L2 stage 94.7 -> 91.2 ms, all of it from the tails — a codes
+        // workgroup (25 KiB of LDS) does not fit the 16 KiB slot a retiring simulation workgroup frees, and a 128-thread variant that
+        // does (14.5 KiB) shares the CUs for real but wins nothing (95.5 ms: the two kernels compete for the same issue slots).  Off
+        // by default: the per-kernel times of the bench line and of rocprofv3 stay those of kernels that run alone.
+        static const bool overlap = getenv("ANI_L2_OVERLAP") && !strcmp(getenv("ANI_L2_OVERLAP"), "1");
+        hipStream_t simStream = ctx->stream;
+        if (overlap) {
+          HIP_TRY(hipEventRecord(ctx->evSimA[p], ctx->stream));            // codes of this chunk are written
+          HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->evSimA[p], 0));
+          simStream = ctx->stream2;
+        }
         {
-          StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
+          StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1, simStream);
+          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
                              (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
         }
         ctx->counters.l2Launches++;
