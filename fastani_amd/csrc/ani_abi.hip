@@ -76,8 +76,12 @@ struct DevicePool {
     auto it = cache.lower_bound(bytes);
     // reuse only a closely fitting block: a looser fit lets a long-lived buffer capture the block a per-sketch array of a
     // different size will ask for again, and that array then needs fresh memory in the middle of a later step
+    // ANI_POOL_POISON=<byte> (tests): every block handed out is filled with that byte first, so that a kernel which reads memory
+    // it (or an earlier kernel) has not written sees the same garbage every time instead of whatever the previous owner left
+    static const int poison = getenv("ANI_POOL_POISON") ? (int)strtol(getenv("ANI_POOL_POISON"), nullptr, 0) : -1;
     if (it != cache.end() && it->first <= bytes + bytes / 16 + (1u << 20)) {
       *out = it->second; live[*out] = it->first; cachedBytes -= it->first; cache.erase(it);
+      if (poison >= 0) { (void)hipDeviceSynchronize(); (void)hipMemset(*out, poison, bytes); (void)hipDeviceSynchronize(); }
       return hipSuccess;
     }
     static const bool trace = getenv("ANI_POOL_TRACE") != nullptr;
@@ -87,6 +91,7 @@ struct DevicePool {
     if (trace) fprintf(stderr, "[ani pool] hipMalloc %.1f MB: %.2f ms (cache %.1f MB in %zu blocks)\n", bytes / 1048576.0,
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), cachedBytes / 1048576.0, cache.size());
     if (e == hipSuccess) live[*out] = bytes;
+    if (e == hipSuccess && poison >= 0) { (void)hipDeviceSynchronize(); (void)hipMemset(*out, poison, bytes); (void)hipDeviceSynchronize(); }
     return e;
   }
   void release(void *p)
@@ -1102,6 +1107,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
     a.filterShift = 1; while (a.filterShift < 30 && (1 << a.filterShift) < 2 * L) a.filterShift++;
     a.fragOrder = fragOrder;
+    { static const int fm = getenv("ANI_L1_FILTER_MIN") ? atoi(getenv("ANI_L1_FILTER_MIN")) : kL1FilterMinHits; a.filterMinHits = fm; }
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
     a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTL);
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);

@@ -111,15 +111,28 @@ __device__ __forceinline__ int wave_incl_scan(int v)
   return v;
 }
 
+// Workgroup barrier.  HIP's __syncthreads() is fence(release) + s_barrier + fence(acquire), and the compiler of ROCm 7.2 was seen
+// to drop the s_waitcnt lgkmcnt(0) that the release fence needs in front of a barrier at a loop header (the back edge of the bitonic
+// sort's pass loop: four ds_write_b64 in flight, then s_barrier): a wave then passes the barrier with its LDS writes still queued
+// and another wave reads the old values — about one mis-sorted fragment in 10^6, different ones in every run.  The wait is
+// therefore spelled out: every kernel of this library synchronises through block_barrier().
+__device__ __forceinline__ void block_barrier()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt / expcnt untouched
+#endif
+  __syncthreads();
+}
+
 // exclusive scan of one int per thread across the workgroup; *total = sum over all threads.
 // `ws` = LDS scratch of at least 8 ints.  Contains barriers: every thread of the block must call it.
 __device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total)
 {
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   int incl = wave_incl_scan(v);
-  __syncthreads();                       // protect ws against a previous use
+  block_barrier();                       // protect ws against a previous use
   if (lane == kWave - 1) ws[wv] = incl;
-  __syncthreads();
+  block_barrier();
   int base = 0, tot = 0;
 #pragma unroll
   for (int i = 0; i < kTPB / kWave; i++) { int x = ws[i]; if (i < wv) base += x; tot += x; }
@@ -136,9 +149,9 @@ __device__ __forceinline__ int block_incl_maxscan(int v, int *ws)
     int o = __shfl_up(v, d);
     if (lane >= d) v = o > v ? o : v;
   }
-  __syncthreads();
+  block_barrier();
   if (lane == kWave - 1) ws[wv] = v;
-  __syncthreads();
+  block_barrier();
 #pragma unroll
   for (int i = 0; i < kTPB / kWave; i++) { int x = ws[i]; if (i < wv) v = x > v ? x : v; }
   return v;
@@ -160,7 +173,7 @@ __device__ inline int block_array_excl_scan(int *a, int n, int *ws)
     for (int j = 0; j < 8; j++) { int idx = first + j; if (idx < n) a[idx] = carry + off + loc[j]; }
     carry += tot;
   }
-  __syncthreads();
+  block_barrier();
   return carry;
 }
 
@@ -177,7 +190,7 @@ __device__ inline void block_bitonic_sort(K *a, int n2)
     int stride = size >> 1;
     while (stride >= 2) {
       const int h = stride >> 1;
-      __syncthreads();
+      block_barrier();
       for (int q = threadIdx.x; q < (n2 >> 2); q += kTPB) {
         const int i0 = ((q & ~(h - 1)) << 2) | (q & (h - 1));      // index with the `h` and `stride` bits cleared
         const bool up = ((i0 & size) == 0);
@@ -189,7 +202,7 @@ __device__ inline void block_bitonic_sort(K *a, int n2)
       stride >>= 2;
     }
     if (stride == 1) {
-      __syncthreads();
+      block_barrier();
       for (int t = threadIdx.x; t < (n2 >> 1); t += kTPB) {
         const int lo = 2 * t;
         const bool up = ((lo & size) == 0);
@@ -198,7 +211,7 @@ __device__ inline void block_bitonic_sort(K *a, int n2)
       }
     }
   }
-  __syncthreads();
+  block_barrier();
 }
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A grid padded to a multiple of 8 is turned inside out:

@@ -75,7 +75,7 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) uniq += __shfl_down(uniq, d);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = uniq;
-  __syncthreads();
+  block_barrier();
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
     for (unsigned w = 0; w < (blockDim.x >> 6); w++) t += part[w];
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(kTPB) void k_table_scatter(const uint32_t *__restri
   for (int k = 0; k < 8; k++)
     if (head[k]) { slot[k] = (int)table_slot(h[k], w, nSlots); const int v = slot[k] - g; best = v > best ? v : best; g++; }
   const int inc = block_incl_maxscan(best, ws);
-  __syncthreads();
+  block_barrier();
   ws[8 + threadIdx.x] = inc;
-  __syncthreads();
+  block_barrier();
   int run = carryBest[blockIdx.x];
   if (threadIdx.x > 0) { const int pv = ws[8 + threadIdx.x - 1]; run = pv > run ? pv : run; }
   g = g0;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__res
   const int64_t j0 = (int64_t)blockIdx.x * 256;
   const int64_t w0 = j0 - kWinHalo > 0 ? j0 - kWinHalo : 0, w1 = j0 + 256 + kWinHalo < (int64_t)n ? j0 + 256 + kWinHalo : (int64_t)n;
   for (int64_t x = w0 + threadIdx.x; x < w1; x += 256) sw[x - w0] = mWpos[x];
-  __syncthreads();
+  block_barrier();
   auto wpos_at = [&](int32_t x) -> int32_t { return ((int64_t)x >= w0 && (int64_t)x < w1) ? sw[x - w0] : mWpos[x]; };
   const int64_t jj = j0 + threadIdx.x;
   if (jj >= (int64_t)n) return;

@@ -38,6 +38,7 @@ struct L1Args {
   unsigned long long *sumHits;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
+  int filterMinHits;                    // kL1FilterMinHits (ANI_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
 };
 
 // occurrences of hash h in the hash-ordered payload array: [first, first+cnt)
@@ -77,7 +78,7 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
     for (int x = lo; x < hi; x++) c += l1_valid(hits, x, m, a.L);
     int nv; int r = block_excl_scan(c, ws, &nv);
     for (int x = lo; x < hi; x++) if (l1_valid(hits, x, m, a.L)) V[r++] = x;
-    __syncthreads();
+    block_barrier();
     // candidate heads
     per = (nv + kTPB - 1) / kTPB;
     lo = t * per; hi = lo + per < nv ? lo + per : nv;
@@ -85,7 +86,7 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
     for (int j = lo; j < hi; j++) c += l1_head(hits, V, j, m, a.L);
     int g = block_excl_scan(c, ws, &nG);
     if (t == 0) *sBasePtr = nG ? atomicAdd(a.candCount, (unsigned long long)nG) : 0ull;
-    __syncthreads();
+    block_barrier();
     const unsigned long long base = *sBasePtr;
     if (base + (unsigned long long)nG <= (unsigned long long)a.candCap) {
       for (int j = lo; j < hi; j++) {
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   const uint32_t off = a.fragOff[f];
   int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)
   for (int i = t; i < s; i += kTPB) pOff[i] = (int)a.probeCnt[off + i];
-  __syncthreads();
+  block_barrier();
   block_array_excl_scan(pOff, s, ws);
   // gather (computeMap.hpp:283-299).  (Tried and measured equal: four loads in flight per lane; one lane per hit instead of per
   // sketch hash.  The kernel's time is in the barrier-separated LDS phases below, not here.)
@@ -199,13 +200,13 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   // tile in one of them) hashed into 2-bit occupancy counters: a collision only keeps a hit that could have been dropped.
   int n = H;
   int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;
-  if (m >= 2 && H > kL1FilterMinHits) {
+  if (m >= 2 && H > a.filterMinHits) {
     constexpr int NBW = HCAP / 4;                    // words per bit array; V holds {seenA, twiceA, seenB, twiceB}
     uint32_t *bits = (uint32_t *)V;
-    __syncthreads();                                 // the gather is complete
+    block_barrier();                                 // the gather is complete
     for (int i = t; i < HCAP; i += kTPB) bits[i] = 0u;
     if (t == 0) sKeep = 0;
-    __syncthreads();
+    block_barrier();
     constexpr int PER = HCAP / kTPB;
     uint64_t hv[PER]; uint32_t ia[PER], ib[PER];
 #pragma unroll
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
         if (atomicOr(&bits[2 * NBW + (ib[j] >> 5)], bb) & bb) atomicOr(&bits[3 * NBW + (ib[j] >> 5)], bb);
       }
     }
-    __syncthreads();
+    block_barrier();
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const int x = t + j * kTPB;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
         if (keep) hits[atomicAdd(&sKeep, 1)] = hv[j];      // every lane has read its hits: compaction in place, order irrelevant
       }
     }
-    __syncthreads();
+    block_barrier();
     n = sKeep;
   }
   const int n2 = next_pow2(n);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, int f, int *__
   const int H = a.fragHits[f];
   const uint32_t off = a.fragOff[f];
   for (int i = threadIdx.x; i < s; i += kTPB) offTmp[i] = (int)a.probeCnt[off + i];
-  __syncthreads();
+  block_barrier();
   block_array_excl_scan(offTmp, s, ws);
   for (int i = threadIdx.x; i < s; i += kTPB) {
     const int o = offTmp[i], e = (i + 1 < s) ? offTmp[i + 1] : H;

@@ -376,9 +376,9 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     const int b1 = i < s ? l2_rank_bucket(q[i], sh) : kL2RankBuckets;
     for (int b = b0; b <= b1; b++) st[b] = (uint16_t)i;
   }
-  __syncthreads();
+  block_barrier();
   for (int b = threadIdx.x; b < kL2RankBuckets; b += kTPB) st2[b] = (uint32_t)st[b] | ((uint32_t)(st[b + 1] - st[b]) << 16);
-  __syncthreads();                                 // from here on the waves go their own ways; `st` is dead, the windows are free
+  block_barrier();                                 // from here on the waves go their own ways; `st` is dead, the windows are free
 
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
   uint16_t *stage = stageAll + wv * kL2StageEvents;
@@ -484,10 +484,10 @@ __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     }
   }
   if (batch1 >= cB) break;                         // workgroup-uniform; fragments with more candidates than a batch are rare
-  __syncthreads();
+  block_barrier();
   fetch_cands(batch1);
   batch0 = batch1; batch1 = batch0 + kL2CandBatch < cB ? batch0 + kL2CandBatch : cB;
-  __syncthreads();
+  block_barrier();
   }
 }
 
@@ -652,12 +652,12 @@ __global__ __launch_bounds__(kTPB) void k_l2_len_hist(const int32_t *__restrict_
 {
   __shared__ unsigned int h[kL2LenBuckets];
   for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) h[i] = 0;
-  __syncthreads();
+  block_barrier();
   for (int i = blockIdx.x * kTPB + threadIdx.x; i < n; i += gridDim.x * kTPB) {
     int b = codeCount[i] >> 5; b = b >= kL2LenBuckets ? kL2LenBuckets - 1 : b;
     atomicAdd(&h[kL2LenBuckets - 1 - b], 1u);                  // longest first
   }
-  __syncthreads();
+  block_barrier();
   for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 __global__ __launch_bounds__(kTPB) void k_l2_len_scan(unsigned int *__restrict__ hist)     // one workgroup: exclusive scan in place
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_len_scatter(const int32_t *__restri
   // one global atomic per (workgroup, bucket): ranks inside the workgroup come from LDS atomics
   __shared__ unsigned int cnt[kL2LenBuckets], base[kL2LenBuckets];
   for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) cnt[i] = 0;
-  __syncthreads();
+  block_barrier();
   const int i = blockIdx.x * kTPB + threadIdx.x;
   int b = 0; unsigned int r = 0;
   if (i < n) {
@@ -679,9 +679,9 @@ __global__ __launch_bounds__(kTPB) void k_l2_len_scatter(const int32_t *__restri
     b = kL2LenBuckets - 1 - b;
     r = atomicAdd(&cnt[b], 1u);
   }
-  __syncthreads();
+  block_barrier();
   for (int j = threadIdx.x; j < kL2LenBuckets; j += kTPB) if (cnt[j]) base[j] = atomicAdd(&cursor[j], cnt[j]);
-  __syncthreads();
+  block_barrier();
   if (i < n) order[base[b] + r] = c0 + i;
 }
 

@@ -137,7 +137,7 @@ __device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], in
     for (int j = kPer - 1; j >= 0; j--) { suf = key[j] < suf ? key[j] : suf; keys[local0 + j] = suf; }
 #pragma unroll
     for (int j = 0; j < kPer; j++) { own_ok[j] = key[j] != kSkipKey; pre = key[j] < pre ? key[j] : pre; W[j] = pre; }
-    __syncthreads();
+    block_barrier();
     const int aHi = (w - 1) / kPer;                // whole blocks before the own one that position 0 needs (1..3); position j: aHi or aHi - 1
     uint64_t allHi = kSkipKey, allLo = kSkipKey;   // minimum over the aHi / aHi - 1 preceding blocks
 #pragma unroll
@@ -164,16 +164,16 @@ __device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], in
   // ---- window minimum over (i-w, i] by doubling: after the loop W = min over the last p positions ----
   int p = 1;
   while (2 * p <= w) {
-    __syncthreads();
+    block_barrier();
     uint64_t r[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; j++) { int q = local0 + j - p; r[j] = q >= 0 ? keys[q] : kSkipKey; }
-    __syncthreads();
+    block_barrier();
 #pragma unroll
     for (int j = 0; j < kPer; j++) { W[j] = r[j] < W[j] ? r[j] : W[j]; keys[local0 + j] = W[j]; }
     p <<= 1;
   }
-  __syncthreads();
+  block_barrier();
   if (w > p) {
     const int d = w - p;
 #pragma unroll
@@ -198,13 +198,13 @@ __device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], in
   for (int d = 1; d < kWave; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v = o > v ? o : v; }
   int prev = __shfl_up(v, 1); if (lane == 0) prev = -1;
   if (lane == kWave - 1) ws[wv] = v;
-  __syncthreads();
+  block_barrier();
   int lastAll = -1;
 #pragma unroll
   for (int i = 0; i < kTPB / kWave; i++) { const int x = ws[i]; if (i < wv) prev = x > prev ? x : prev; lastAll = x > lastAll ? x : lastAll; }
   // first valid P in the tile: the thread whose predecessor max is -1 and that has a valid position (exactly one, if any)
   if (myFirst >= 0 && prev < 0) ws[kTPB + 8] = myFirst;
-  __syncthreads();
+  block_barrier();
   const int firstAll = ws[kTPB + 8];
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
@@ -213,7 +213,7 @@ __device__ __forceinline__ void tile_winnow_keys(const uint64_t (&key)[kPer], in
   }
   tileFirstP = firstAll >= 0 ? B + firstAll : -1;
   tileLastP = lastAll >= 0 ? B + lastAll : -1;
-  __syncthreads();
+  block_barrier();
 }
 
 template <bool PACKED>
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kTPB) void k_sketch_tiles(const uint32_t *__restric
   for (int j = 0; j < kPer; j++) cnt += em[j];
   int total; int rank = block_excl_scan(cnt, ws, &total);
   if (threadIdx.x == 0) sBase = total ? atomicAdd(poolCount, (unsigned long long)total) : 0ull;
-  __syncthreads();
+  block_barrier();
   const unsigned long long base = sBase;
   if (base + (unsigned long long)total <= (unsigned long long)poolCap) {
 #pragma unroll
@@ -388,7 +388,7 @@ __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ se
     produced += total - drop;
     if (produced > kFragHashCap) { overflow = true; produced = kFragHashCap; }
     if (lastP >= 0) prevLastP = lastP;
-    __syncthreads();
+    block_barrier();
   }
   // ---- sort + unique (computeMap.hpp:268-274) ----
   const int n = produced;
@@ -406,7 +406,7 @@ __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ se
     fragS[blockIdx.x] = overflow ? -1 : s;
     atomicMax(maxS, overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
   }
-  __syncthreads();
+  block_barrier();
   const unsigned long long base = *sBasePtr;
   if (base + (unsigned long long)s <= (unsigned long long)poolCap)
     for (int i = lo; i < hi; i++)
@@ -486,7 +486,7 @@ __device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool over
     fragS[frag] = overflow ? -1 : s;
     atomicMax(maxS, overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
   }
-  __syncthreads();
+  block_barrier();
   const unsigned long long base = *sBasePtr;
   if (base + (unsigned long long)s <= (unsigned long long)poolCap)
     for (int i = lo; i < hi; i++)
@@ -513,7 +513,7 @@ __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, in
     for (int j = 0; j < kPer; j++) cnt += em[j];
     int total; int rank = block_excl_scan(cnt, ws, &total);
     if (threadIdx.x == 0) *sBasePtr = total ? atomicAdd(poolCount, (unsigned long long)total) : 0ull;
-    __syncthreads();
+    block_barrier();
     const unsigned long long base = *sBasePtr;
     if (base + (unsigned long long)total <= (unsigned long long)poolCap) {
 #pragma unroll
@@ -531,7 +531,7 @@ __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, in
   const int f0 = fi.fragLocal0, fEnd = f0 + fragLen - k;     // last k-mer start inside the fragment (local)
 #pragma unroll
   for (int j = 0; j < kPer; j++) { const int l = local0 + j; if (l < f0 || l > fEnd) key[j] = kSkipKey; }
-  __syncthreads();                                  // the reference pass is done with keys / ws
+  block_barrier();                                  // the reference pass is done with keys / ws
   tile_winnow_keys(key, td.firstPos, 0x7fffffff, w, f0, kTile, keys, ws, W, em, firstP, lastP);
   uint32_t *hbuf = (uint32_t *)keys;                // dead once the tile is winnowed (kFragHashCap * 4 <= kTile * 8)
   int cnt = 0;
@@ -542,7 +542,7 @@ __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, in
   for (int j = 0; j < kPer; j++)
     if (em[j]) { if (rank < kFragHashCap) hbuf[rank] = (uint32_t)(W[j] >> 32); rank++; }
   const bool overflow = total > kFragHashCap;
-  __syncthreads();
+  block_barrier();
   fragment_finish(hbuf, overflow ? kFragHashCap : total, overflow, fi.frag, qPool, qCap, qCount, fragOff, fragS, maxS, ws, sBasePtr);
 }
 

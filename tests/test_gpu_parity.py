@@ -138,10 +138,10 @@ def test_sharded_sketch_records_on_device(gpu_engine):
 
 
 def _engine_with(monkeypatch, **env):
-    import fastani_amd
+    from fastani_amd import _lib, api
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
-    return fastani_amd.api.Engine(fastani_amd._lib.load(), 0)
+    return api.Engine(_lib.load(), 0)
 
 
 def test_chunked_reference_set(monkeypatch):
@@ -179,6 +179,33 @@ def test_chunked_full_size_equals_unchunked(gpu_engine, monkeypatch):
     assert len(sk2.chunks()) >= 5
     assert sk2.stats() == st
     assert np.array_equal(sk2.map_cgi_batch(dg, 0), rows)
+    e.close()
+
+
+def test_repeated_runs_are_identical(monkeypatch):
+    """24 x 5 Mbp mapped 25 times with the L1 noise filter forced on for every fragment (its compaction hands the sort a different
+    permutation every time): rows, candidate and window counters must not move.  Regression test for a barrier without its LDS
+    wait at the back edge of the sort's pass loop (a mis-sorted fragment in about 10^6, 2-5 % of such runs differed)."""
+    import torch
+    from fastani_amd.api import DeviceGenomes, Sketch
+    e = _engine_with(monkeypatch, ANI_L1_FILTER_MIN=0)
+    n, L = 24, 5_000_000
+    words = (L + 15) // 16
+    buf = torch.zeros(n * words + 64, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    e.synth_packed(99, 0, n, L, buf.data_ptr())
+    dg = DeviceGenomes(buf.data_ptr(), n, L)
+    sk = Sketch(e, e.params(), dg)
+    keys = ("seedHits", "l1Candidates", "l2WindowEntries", "l2Steps", "cgiRows")
+    e.reset_counters()
+    first = sk.map_cgi_batch(dg, 0)
+    c0 = {k: e.counters()[k] for k in keys}
+    for i in range(25):
+        e.reset_counters()
+        rows = sk.map_cgi_batch(dg, 0)
+        assert {k: e.counters()[k] for k in keys} == c0, i
+        assert np.array_equal(rows, first), i
+    sk.close()
     e.close()
 
 
