@@ -123,6 +123,15 @@ __device__ __forceinline__ void block_barrier()
 #endif
   __syncthreads();
 }
+// ... and the same with the wave's global stores drained too, for code that runs over LDS or global memory alike (the global-memory
+// L1 path of fragments beyond the LDS classes): one thread's stores are read by another thread after the barrier.
+__device__ __forceinline__ void block_barrier_mem()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+#endif
+  __syncthreads();
+}
 
 // exclusive scan of one int per thread across the workgroup; *total = sum over all threads.
 // `ws` = LDS scratch of at least 8 ints.  Contains barriers: every thread of the block must call it.
@@ -173,7 +182,7 @@ __device__ inline int block_array_excl_scan(int *a, int n, int *ws)
     for (int j = 0; j < 8; j++) { int idx = first + j; if (idx < n) a[idx] = carry + off + loc[j]; }
     carry += tot;
   }
-  block_barrier();
+  block_barrier_mem();
   return carry;
 }
 

@@ -78,7 +78,7 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
     for (int x = lo; x < hi; x++) c += l1_valid(hits, x, m, a.L);
     int nv; int r = block_excl_scan(c, ws, &nv);
     for (int x = lo; x < hi; x++) if (l1_valid(hits, x, m, a.L)) V[r++] = x;
-    block_barrier();
+    block_barrier_mem();
     // candidate heads
     per = (nv + kTPB - 1) / kTPB;
     lo = t * per; hi = lo + per < nv ? lo + per : nv;
@@ -86,7 +86,7 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
     for (int j = lo; j < hi; j++) c += l1_head(hits, V, j, m, a.L);
     int g = block_excl_scan(c, ws, &nG);
     if (t == 0) *sBasePtr = nG ? atomicAdd(a.candCount, (unsigned long long)nG) : 0ull;
-    block_barrier();
+    block_barrier_mem();
     const unsigned long long base = *sBasePtr;
     if (base + (unsigned long long)nG <= (unsigned long long)a.candCap) {
       for (int j = lo; j < hi; j++) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, int f, int *__
   const int H = a.fragHits[f];
   const uint32_t off = a.fragOff[f];
   for (int i = threadIdx.x; i < s; i += kTPB) offTmp[i] = (int)a.probeCnt[off + i];
-  block_barrier();
+  block_barrier_mem();
   block_array_excl_scan(offTmp, s, ws);
   for (int i = threadIdx.x; i < s; i += kTPB) {
     const int o = offTmp[i], e = (i + 1 < s) ? offTmp[i + 1] : H;
