@@ -436,6 +436,7 @@ def main():
     t0 = time.perf_counter()
     rows = None
     step_ms = []
+    rows_all = []
     trace = bool(os.environ.get("ANI_POOL_TRACE"))
     for i in range(args.steps):
         if trace:
@@ -443,8 +444,13 @@ def main():
         ts = time.perf_counter()
         rows = step()                                        # returns with the rows on the host: the step's device work is done
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
+        rows_all.append(rows)
     sync()
     dt_local = time.perf_counter() - t0
+    # outside the timed region: every step must have produced the same rows (run-to-run determinism)
+    import zlib
+    rows_crc = [zlib.crc32(np.ascontiguousarray(r).tobytes()) & 0xffffffff for r in rows_all]
+    del rows_all
     dt = dt_local
     rank_info = None
     if dist is not None:
@@ -545,7 +551,7 @@ def main():
                                       % (wl, L, p.windowSize, "" if world == 1 else "; queries sharded %d ways, reference sketch all-gathered over RCCL" % world),
                           "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM", "all_vs_all_single_hash_pass": bool(self_mode),
                           "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
-               "rows_last_step": int(len(rows)), "step_ms_rank0": step_ms,
+               "rows_last_step": int(len(rows)), "rows_identical_across_steps": len(set(rows_crc)) == 1, "step_ms_rank0": step_ms,
                "stage_ms_per_step_rank0": stages,
                "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                               "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
