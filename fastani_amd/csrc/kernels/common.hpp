@@ -186,37 +186,68 @@ __device__ inline int block_array_excl_scan(int *a, int n, int *ws)
   return carry;
 }
 
-// Bitonic sort of n2 (power of two) keys, ascending, by the whole workgroup.  Works on LDS or global pointers.
+// Wave-level rendezvous for data exchanged through LDS inside ONE wave: the LDS performs a wave's operations in order, so no
+// counter wait is needed, only that the compiler keeps the order (and, in the CPU stand-in where lanes are fibers, a real rendezvous).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ANI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define ANI_WAVE_SYNC() (void)__ballot(1)
+#endif
+
+// Bitonic sort of n2 (power of two) keys in LDS, ascending, by the whole workgroup.
 // Two consecutive stages (strides 2h and h) are fused: a thread loads the four elements i0 + {0, h, 2h, 3h}, runs the four
-// compare-exchanges of both stages in registers and stores them back — half the LDS passes and barriers of the plain network.
+// compare-exchanges of both stages in registers and stores them back — half the LDS passes of the plain network.
+// Each wave owns a segment of n2 / 4 keys (one wave all of them if n2 <= 256): a pass whose stride stays inside a segment touches no other
+// wave's keys, and because one wave's LDS operations are performed in order such passes follow each other with a wave-level
+// rendezvous only.  Workgroup barriers remain around the few passes that cross segments (3 of the 55 stages at n2 = 1024).
 template <class K>
 __device__ __forceinline__ void bitonic_ce(K &x, K &y, bool up) { if ((x > y) == up) { const K t = x; x = y; y = t; } }
 
 template <class K>
+__device__ __forceinline__ void bitonic_quad(K *a, int q, int h, int stride, int size)
+{
+  const int i0 = ((q & ~(h - 1)) << 2) | (q & (h - 1));      // index with the `h` and `stride` bits cleared
+  const bool up = ((i0 & size) == 0);
+  K x0 = a[i0], x1 = a[i0 + h], x2 = a[i0 + stride], x3 = a[i0 + stride + h];
+  bitonic_ce(x0, x2, up); bitonic_ce(x1, x3, up);            // stage `stride`
+  bitonic_ce(x0, x1, up); bitonic_ce(x2, x3, up);            // stage `h`
+  a[i0] = x0; a[i0 + h] = x1; a[i0 + stride] = x2; a[i0 + stride + h] = x3;
+}
+
+template <class K>
 __device__ inline void block_bitonic_sort(K *a, int n2)
 {
+  constexpr int kWaves = kTPB / kWave;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int seg = n2 > kWaves * kWave ? n2 / kWaves : n2;           // keys per wave segment (up to 256 keys: one wave sorts alone, a quad per lane)
+  const bool mine = wv * seg < n2;                                  // this wave has a segment (wave-uniform)
+  block_barrier();                                                  // the keys are complete
   for (int size = 2; size <= n2; size <<= 1) {
     int stride = size >> 1;
     while (stride >= 2) {
       const int h = stride >> 1;
-      block_barrier();
-      for (int q = threadIdx.x; q < (n2 >> 2); q += kTPB) {
-        const int i0 = ((q & ~(h - 1)) << 2) | (q & (h - 1));      // index with the `h` and `stride` bits cleared
-        const bool up = ((i0 & size) == 0);
-        K x0 = a[i0], x1 = a[i0 + h], x2 = a[i0 + stride], x3 = a[i0 + stride + h];
-        bitonic_ce(x0, x2, up); bitonic_ce(x1, x3, up);            // stage `stride`
-        bitonic_ce(x0, x1, up); bitonic_ce(x2, x3, up);            // stage `h`
-        a[i0] = x0; a[i0 + h] = x1; a[i0 + stride] = x2; a[i0 + stride + h] = x3;
+      if (stride >= seg) {                                          // the quads span segments: all waves, barriers around the pass
+        block_barrier();
+        for (int q = threadIdx.x; q < (n2 >> 2); q += kTPB) bitonic_quad(a, q, h, stride, size);
+        block_barrier();
+      } else if (mine) {
+        ANI_WAVE_SYNC();
+        for (int q = wv * (seg >> 2) + lane; q < (wv + 1) * (seg >> 2); q += kWave) bitonic_quad(a, q, h, stride, size);
       }
       stride >>= 2;
     }
     if (stride == 1) {
-      block_barrier();
-      for (int t = threadIdx.x; t < (n2 >> 1); t += kTPB) {
-        const int lo = 2 * t;
-        const bool up = ((lo & size) == 0);
-        K x = a[lo], y = a[lo + 1];
-        if ((x > y) == up) { a[lo] = y; a[lo + 1] = x; }
+      if (seg < 2) {                                                // n2 == 1 never gets here; kept for completeness
+        block_barrier();
+      }
+      if (mine) {
+        ANI_WAVE_SYNC();
+        for (int t = wv * (seg >> 1) + lane; t < (wv + 1) * (seg >> 1); t += kWave) {
+          const int lo = 2 * t;
+          const bool up = ((lo & size) == 0);
+          K x = a[lo], y = a[lo + 1];
+          if ((x > y) == up) { a[lo] = y; a[lo + 1] = x; }
+        }
       }
     }
   }

@@ -328,11 +328,6 @@ __device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32
 // bucket holds at most two of them except in rare cases, which a wave vote sends to a binary search.
 constexpr int kL2StageEvents = 2048;        // events per wave window (4 KiB)
 constexpr int kL2CandBatch = 40;            // candidates whose descriptors are fetched at once
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ANI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#else
-#define ANI_WAVE_SYNC() (void)__ballot(1)   /* CPU stand-in: lanes are fibers, a wave collective is the rendezvous */
-#endif
 __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
   __shared__ uint32_t qs[kL2FastMaxS + 2];
