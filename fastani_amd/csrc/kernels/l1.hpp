@@ -63,11 +63,11 @@ __device__ __forceinline__ bool l1_head(const uint64_t *hits, const int *V, int 
 }
 
 // Sorted hits -> candidate regions of one fragment (computeMap.hpp:313-354).  hits/V may live in LDS or in global memory.
-__device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, const uint64_t *hits, int *V, int *ws,
-                                          unsigned long long *sBasePtr)
+__device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, int m /* minimumHits of s, :301 */, const uint64_t *hits, int *V,
+                                          int *ws, unsigned long long *sBasePtr)
 {
   const int t = threadIdx.x;
-  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1; if (m < 1) m = 1;      // :301, :316
+  if (m < 1) m = 1;                                                     // :316
   const int nA = H - m + 1;
   int nG = 0;
   if (nA > 0) {
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   if (HLO == 0 && (s > kL1MaxS || H > kL1HitCapMax)) return;       // beyond every LDS class: k_l1_big_* below
   if (H <= HLO || H > HCAP || s <= 0 || s > kL1MaxS) return;     // another class handles it
   const uint32_t off = a.fragOff[f];
+  const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather
   int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)
   for (int i = t; i < s; i += kTPB) pOff[i] = (int)a.probeCnt[off + i];
   block_barrier();
@@ -199,7 +200,6 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   // "Has a neighbour" is tested conservatively with two offset tilings of width W >= 2 fragLen (two points closer than W/2 share a
   // tile in one of them) hashed into 2-bit occupancy counters: a collision only keeps a hit that could have been dropped.
   int n = H;
-  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;
   if (m >= 2 && H > a.filterMinHits) {
     constexpr int NBW = HCAP / 4;                    // words per bit array; V holds {seenA, twiceA, seenB, twiceB}
     uint32_t *bits = (uint32_t *)V;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   for (int i = n + t; i < n2; i += kTPB) hits[i] = ~0ull;
   block_bitonic_sort<uint64_t>(hits, n2);           // :320 (starts with a barrier: the gather is complete)
 
-  l1_emit_candidates(a, f, s, n, hits, V, ws, &sBase);
+  l1_emit_candidates(a, f, s, n, m, hits, V, ws, &sBase);
 }
 
 // Fragments beyond the LDS classes (low-complexity / highly repetitive references): same algorithm over global memory,
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, int f, con
 {
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
-  l1_emit_candidates(a, f, a.fragS[f], a.fragHits[f], hitsSorted, V, ws, &sBase);
+  const int s = a.fragS[f];
+  l1_emit_candidates(a, f, s, a.fragHits[f], s <= a.lutMaxS ? a.minHitsLUT[s] : 1, hitsSorted, V, ws, &sBase);
 }
 
 // Reorder candidates into the reference's callback order — fragment ascending, then (seqId, start) as produced — or, for a batch
