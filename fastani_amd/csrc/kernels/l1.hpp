@@ -182,15 +182,25 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   const uint32_t off = a.fragOff[f];
   const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather
   int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)
-  for (int i = t; i < s; i += kTPB) pOff[i] = (int)a.probeCnt[off + i];
+  constexpr int kPerS = kL1MaxS / kTPB;              // sketch hashes per thread at most
+  uint32_t pFirst[kPerS];                           // the runs' starts travel with the counts: one round trip to memory instead of two
+#pragma unroll
+  for (int j = 0; j < kPerS; j++) {
+    const int i = t + j * kTPB;
+    if (i < s) { pOff[i] = (int)a.probeCnt[off + i]; pFirst[j] = a.probeFirst[off + i]; }
+  }
   block_barrier();
   block_array_excl_scan(pOff, s, ws);
   // gather (computeMap.hpp:283-299).  (Tried and measured equal: four loads in flight per lane; one lane per hit instead of per
   // sketch hash.  The kernel's time is in the barrier-separated LDS phases below, not here.)
-  for (int i = t; i < s; i += kTPB) {
-    const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H;
-    const uint32_t fi = a.probeFirst[off + i];
-    for (int c = 0; c < e - o; c++) hits[o + c] = a.sSW[fi + c];
+#pragma unroll
+  for (int j = 0; j < kPerS; j++) {
+    const int i = t + j * kTPB;
+    if (i < s) {
+      const int o = pOff[i], e = (i + 1 < s) ? pOff[i + 1] : H;
+      const uint32_t fi = pFirst[j];
+      for (int c = 0; c < e - o; c++) hits[o + c] = a.sSW[fi + c];
+    }
   }
   // Noise filter.  Minimizer hashes are minima over w k-mers, so they crowd the low end of the 32-bit range and most seed hits of
   // a fragment against a large reference set are chance collisions: isolated hits (measured on 1000 x 5 Mbp: ~1300 hits per
