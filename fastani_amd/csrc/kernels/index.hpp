@@ -5,7 +5,7 @@
 //   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n], mDelta[n] (flag byte), mWin[n] (window links of the L2 event stream) + contigFirstMin[nContigs+1]
 //   hash order    (≙ minimizerPosLookupIndex)  sHash[n] (sorted), sSW[n] = seqId<<32|wpos carried through the stable sort, so
 //                                              every hash's occurrence list is one contiguous run in (seqId,wpos) order (:186-190)
-//   probe table   table[~n / 0.7]              order-preserving open-addressing table {hash, first} over the distinct hashes (below)
+//   probe table   table[2 x distinct]          order-preserving open-addressing table {hash, first, count} over the distinct hashes (below)
 //   same-hash links (for the L2 set semantics) prevSame[n], nextSame[n]: neighbouring NEAR occurrence of the same hash in
 //                                              position order (one that can share a super-window), -1 otherwise
 #pragma once

@@ -5,8 +5,7 @@
 // slide a run of `minimumHits` consecutive hits, keep runs that stay on one contig and span < fragLen, merge
 // overlapping candidates).  Stateless form, SURVEY.md App. A.3.
 //
-// Two passes.  k_l1_probe: one lane per sketch hash, bucket table + binary search in the hash-sorted index, no LDS, so the
-// dependent loads are hidden by occupancy.  k_l1<HLO,HCAP>: one workgroup per fragment with HLO < H <= HCAP seed hits,
+// Two passes.  k_l1_probe: one lane per sketch hash, the index chunk's probe table (index.hpp), no LDS.  k_l1<HLO,HCAP>: one workgroup per fragment with HLO < H <= HCAP seed hits,
 // everything in LDS: gather the hit runs as 64-bit (seqId<<32 | wpos) keys, bitonic sort, flag valid runs, compact, flag
 // group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous candidate" only needs
 // the previous valid run), scan, emit.  Three LDS classes (<= 2048 hits: 6 workgroups per CU; <= 4096; <= 8192), the larger two driven by fragment lists.  Larger
