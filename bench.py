@@ -520,6 +520,9 @@ def main():
             roof["stage"] = {"stage": "L2 (k_l2_ranges + k_l2_len_* + k_l2_codes + k_l2_sim<A,B> + k_l2)", "ms_per_step": round(c["msL2"] / args.steps, 3),
                              "algorithmic_bytes_per_step": round(l2_bytes / args.steps, 1), "achieved": round(st, 2), "unit": "GB/s", "frac": round(st / HBM_PEAK_GBS, 5)}
         roof["int_ops"] = int_ops_block(c, args.steps, self_mode)
+        roof["bound_note"] = ("'hbm' by the algorithmic-byte accounting of SURVEY.md section 8d (12 B per reference minimizer in a candidate range); what "
+                              "limits k_l2_sim is vector instruction issue: its VALU wave-instructions x 4 cycles are 86 % of the kernel's SIMD cycles at 2.5 "
+                              "waves per SIMD (LDS-bound occupancy), profiles/r02X_pmc_sq_summary.txt; its HBM traffic is roofline.traffic, a third of the algorithmic bytes")
         # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
         # + WRITE_SIZE, per launch) — only quoted when it is this default workload
         try:
