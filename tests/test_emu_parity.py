@@ -53,7 +53,7 @@ def _emu_engine_with(monkeypatch, **env):
 def test_chunked_reference_set(monkeypatch):
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=8000)
     pc.case_chunked(e)
-    assert pc.fuzz(e, seed=23, iterations=5) == 5
+    assert pc.fuzz(e, seed=23, iterations=3) == 3
     e.close()
 
 
