@@ -393,6 +393,7 @@ int main(int argc, char **argv)
 
   std::vector<ani_cgi_t> finalResults;
   std::vector<VisRow> vis;
+  bool visWritten = false;           // a query went through computeCGI with --visualize (the reference creates the .visual file there)
   std::vector<int> failedSplits; std::vector<float> failedRatio;
 
   // the readers start before the devices are initialised (HIP start-up is a few hundred milliseconds)
@@ -624,7 +625,9 @@ int main(int argc, char **argv)
     loadAll(o.queries, Q); loadAll(o.refs, R);
     SliceBatch qbAll; for (auto &fd : Q) qbAll.add(fd);
     ani_seq_batch_t qb = qbAll.batch();
-    const int nSplits = o.sanityCheck ? o.threads : 1;
+    // the reference splits its references round-robin over the -t threads whatever the mode; the split only shows in the -s check
+    // (per split) and in the order of the .visual rows (thread 0's queries first, core_genome_identity.cpp:142-163)
+    const int nSplits = o.threads;
     for (int sp = 0; sp < nSplits; sp++) {
       std::vector<int> refIdx;
       for (int j = 0; j < nRef; j++) if (nSplits == 1 || j % nSplits == sp) refIdx.push_back(j);   // computeCoreIdentity.hpp:467-472
@@ -664,10 +667,10 @@ int main(int argc, char **argv)
           SliceBatch one; one.add(Q[qi]);
           ani_seq_batch_t ob = one.batch();
           auto tm = Clock::now();
-          std::cerr << "INFO [thread 0], skch::main, Start Map " << qi + 1 << std::endl;
+          if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Start Map " << qi + 1 << std::endl;
           ani_mapping_t *maps = nullptr; size_t n = 0; uint64_t totalFr = 0;
           if (ani_map_query(ctx, sk, &ob, &maps, &n, &totalFr)) die("ani_map_query");
-          std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #" << qi + 1 << " : " << secs_since(tm) << " sec" << std::endl;
+          if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #" << qi + 1 << " : " << secs_since(tm) << " sec" << std::endl;
           tm = Clock::now();
           ani_cgi_t *rows = nullptr; size_t m = 0;
           if (ani_compute_cgi(ctx, sk, maps, n, totalFr, (int32_t)qi, &rows, &m)) die("ani_compute_cgi");
@@ -692,18 +695,23 @@ int main(int argc, char **argv)
             return std::tie(x.genome, x.qSeq, x.id, x.refSeq, x.refStart) < std::tie(y.genome, y.qSeq, y.id, y.refSeq, y.refStart); });
           std::vector<M> one_way;
           for (auto &e : v) { if (!one_way.empty() && one_way.back().genome == e.genome && one_way.back().qSeq == e.qSeq) one_way.back() = e; else one_way.push_back(e); }
-          std::stable_sort(one_way.begin(), one_way.end(), [](const M &x, const M &y) { return std::tie(x.refSeq, x.bin, x.id) < std::tie(y.refSeq, y.bin, y.id); });
+          // Which of several equal-identity mappings of one reference bin survives is decided by the order std::sort leaves equal
+          // elements in (computeCoreIdentity.hpp:240: cmp_refbin_bucket compares (contig, bin, identity) only).  That order is a
+          // deterministic function of the input sequence and the comparator, so the same call on the same sequence — the 1-way list,
+          // which the total order above fixes — keeps the same mapping as the reference (same libstdc++ algorithm), row for row.
+          std::sort(one_way.begin(), one_way.end(), [](const M &x, const M &y) { return std::tie(x.refSeq, x.bin, x.id) < std::tie(y.refSeq, y.bin, y.id); });
+          visWritten = true;                                                // outputVisualizationFile opens (creates) the file per query
           std::vector<M> two_way;
           for (auto &e : one_way) { if (!two_way.empty() && two_way.back().refSeq == e.refSeq && two_way.back().bin == e.bin) two_way.back() = e; else two_way.push_back(e); }
           for (auto &e : two_way)
             vis.push_back(VisRow{o.queries[qi], o.refs[refIdx[e.genome]], e.id, 0 + qOff[e.qSeq], 0 + ap.fragLen - 1 + qOff[e.qSeq],
                                  e.refStart + refOff[e.refSeq], e.refStart + ap.fragLen - 1 + refOff[e.refSeq]});
-          std::cerr << "INFO [thread 0], skch::main, Time spent post mapping : " << secs_since(tm) << " sec" << std::endl;
+          if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Time spent post mapping : " << secs_since(tm) << " sec" << std::endl;
         }
       }
       ani_sketch_destroy(sk);
     }
-    std::cerr << "INFO [thread 0], skch::main, ready to exit the loop" << std::endl;
+    for (int sp = 0; sp < nSplits; sp++) std::cerr << "INFO [thread " << sp << "], skch::main, ready to exit the loop" << std::endl;
   }
   std::cerr << "INFO, skch::main, parallel_for execution finished" << std::endl;
   for (size_t i = 0; i < failedSplits.size(); i++)
@@ -711,9 +719,18 @@ int main(int argc, char **argv)
 
   // ---- outputCGI (computeCoreIdentity.hpp:307-344): query ascending, identity descending ----
   const auto tOut = Clock::now();
-  std::stable_sort(finalResults.begin(), finalResults.end(), [](const ani_cgi_t &x, const ani_cgi_t &y) {
-    if (x.qryGenomeId != y.qryGenomeId) return x.qryGenomeId < y.qryGenomeId;
-    return x.identity > y.identity; });
+  // The reference sorts with std::sort over reverse iterators and CGI_Results::operator< (cgid_types.hpp:76-79), which leaves rows of
+  // one query with equal identity in an order that depends on the sequence it is given.  That sequence is: thread (= reference
+  // split) tid appends, query by query, the rows of its references j = tid, tid + T, ... in ascending order
+  // (core_genome_identity.cpp:55-121; with T > 1 the threads append in completion order — thread order is taken here).  The same
+  // call on the same sequence gives the reference's row order, ties included.
+  {
+    const int T = std::max(1, o.threads);
+    std::stable_sort(finalResults.begin(), finalResults.end(), [T](const ani_cgi_t &x, const ani_cgi_t &y) {
+      return std::make_tuple(x.refGenomeId % T, x.qryGenomeId, x.refGenomeId) < std::make_tuple(y.refGenomeId % T, y.qryGenomeId, y.refGenomeId); });
+    std::sort(finalResults.rbegin(), finalResults.rend(), [](const ani_cgi_t &a, const ani_cgi_t &b) {
+      return std::tie(b.qryGenomeId, a.identity) < std::tie(a.qryGenomeId, b.identity); });
+  }
   std::vector<uint64_t> qLen((size_t)nQry), rLen((size_t)nRef);
   for (int i = 0; i < nQry; i++) qLen[i] = genomeLengths[o.queries[i]];
   for (int i = 0; i < nRef; i++) rLen[i] = genomeLengths[o.refs[i]];
@@ -765,8 +782,11 @@ int main(int argc, char **argv)
       out << "\n";
     }
   }
-  if (o.visualize) {
-    std::ofstream out(o.out + ".visual");
+  // .visual: with one thread the reference appends to the file from inside computeCGI (computeCoreIdentity.hpp:110-113,
+  // std::ios::app: an existing file is kept, no file at all if no query was mapped, e.g. when the -s check rejects the only split);
+  // with several threads the per-thread files are merged into a freshly created one (core_genome_identity.cpp:142-163)
+  if (o.visualize && (o.threads > 1 || visWritten)) {
+    std::ofstream out(o.out + ".visual", o.threads > 1 ? std::ios::out : std::ios::app);
     for (auto &r : vis)
       out << r.q << "\t" << r.r << "\t" << r.id << "\tNA\tNA\tNA\t" << r.qs << "\t" << r.qe << "\t" << r.rs << "\t" << r.re << "\tNA\tNA\n";
   }

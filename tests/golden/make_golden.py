@@ -30,7 +30,10 @@ REF_DATA = "/root/reference/tests/data"
 
 def main():
     assert orc.have_ref(), "build oracle/_ref first (make -C oracle)"
+    only = set(sys.argv[1:])                       # optional: regenerate only the named cases
     for name, (refs, qrys, k, L) in golden_cases.cases().items():
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as td:
             d = orc.run_ref_dump(td, refs, qrys, k=k, frag_len=L)
         out = {"k": d["k"], "w": d["w"], "L": d["L"], "minimizers": d["minimizers"], "cgi": d["cgi"],
@@ -42,6 +45,8 @@ def main():
             out["fragH%d" % qi] = np.concatenate(fr) if fr else np.zeros(0, dtype=np.uint32)
         np.savez_compressed(os.path.join(HERE, "case_%s.npz" % name), **out)
         print(name, len(d["minimizers"]), [len(m) for m in d["maps"]], len(d["cgi"]))
+    if only:
+        return
     # statistics LUTs from the reference's own functions
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call([orc.REF_DUMP, "--stats", "16", "400", os.path.join(td, "s")])

@@ -45,4 +45,94 @@ def cases():
     ref = np.concatenate([flank[:10000], rep, flank[10000:]])
     qry = np.concatenate([flank[:10000], noise, flank[10000:]])
     c["tandem"] = ([[ref], [qry]], [[qry], [ref]], 16, 3000)
+    fam = evolved_family(3, 60000, 6, seg=(800, 6000))
+    c["evolved"] = (fam, [fam[0], fam[2], fam[4], fam[5]], 16, 3000)
     return c
+
+
+# ---------------------------------------------------------------------------------------------
+# Evolved genomes: what real relatives differ by besides substitutions.  With substitutions only, fragment i of a query always
+# lands at i * fragLen in its relative, candidate ranges are maximally regular and the reducer's bins never have two claimants
+# (computeCoreIdentity.hpp:237-254); indels shift the frame, inversions give reverse-strand matches, duplications / translocations
+# give several placements per fragment and several fragments per reference bin.
+# ---------------------------------------------------------------------------------------------
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgt", b"TGCAtgca"):
+    _COMP[_a] = _b
+
+
+def revcomp(a):
+    return _COMP[np.asarray(a, dtype=np.uint8)[::-1]]
+
+
+def evolve(g, seed, sub=0.03, indel=0.002, inversions=2, duplications=1, translocations=1, seg=(1000, 20000)):
+    """g after `inversions` inversions (reverse complement in place), `duplications` segmental duplications (a copy of a segment
+    inserted elsewhere), `translocations` (a segment cut out and re-inserted elsewhere) — segment lengths uniform in `seg`, capped
+    at a quarter of the genome — then i.i.d. substitutions at rate `sub` and indel events at rate `indel` per base (half deletions,
+    half insertions of random bases; lengths geometric with mean ~3, one event in twenty 50 times longer)."""
+    r = np.random.default_rng(seed)
+    g = np.asarray(g, dtype=np.uint8).copy()
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def segment(n):
+        hi = max(2, min(seg[1], n // 4))
+        lo = max(1, min(seg[0], hi - 1))
+        ln = int(r.integers(lo, hi + 1))
+        a = int(r.integers(0, max(1, n - ln)))
+        return a, min(n, a + ln)
+
+    for _ in range(inversions):
+        a, b = segment(len(g))
+        g[a:b] = revcomp(g[a:b])
+    for _ in range(duplications):
+        a, b = segment(len(g))
+        at = int(r.integers(0, len(g) + 1))
+        g = np.concatenate([g[:at], g[a:b], g[at:]])
+    for _ in range(translocations):
+        a, b = segment(len(g))
+        piece, rest = g[a:b].copy(), np.concatenate([g[:a], g[b:]])
+        at = int(r.integers(0, len(rest) + 1))
+        g = np.concatenate([rest[:at], piece, rest[at:]])
+    if sub > 0:
+        m = r.random(len(g)) < sub
+        g[m] = acgt[r.integers(0, 4, int(m.sum()))]
+    n_ev = int(r.binomial(len(g), indel)) if indel > 0 else 0
+    if n_ev:
+        pos = np.sort(r.choice(len(g), size=n_ev, replace=False))
+        lens = r.geometric(0.3, n_ev) * np.where(r.random(n_ev) < 0.05, 50, 1)
+        dele = r.random(n_ev) < 0.5
+        out, last = [], 0
+        for p, ln, d in zip(pos.tolist(), lens.tolist(), dele.tolist()):
+            if p < last:
+                continue                      # swallowed by the previous deletion
+            out.append(g[last:p])
+            if d:
+                last = min(len(g), p + ln)
+            else:
+                out.append(acgt[r.integers(0, 4, ln)])
+                last = p
+        out.append(g[last:])
+        g = np.concatenate(out)
+    return g
+
+
+def evolved_family(seed, n, members, contig_games=True, seg=(1000, 20000)):
+    """`members` genomes derived from one random ancestor of n bases: member 0 is the ancestor; the others differ by growing amounts
+    of substitutions, indels and rearrangements; with `contig_games` some come as several contigs in shuffled order, and some carry
+    a second, plasmid-like contig that is a diverged copy of part of the chromosome."""
+    r = np.random.default_rng(seed)
+    anc = _rng(seed + 1, n)
+    fam = [[anc]]
+    for m in range(1, members):
+        g = evolve(anc, 1000 * seed + m, sub=float(r.choice([0.0, 0.005, 0.02, 0.05, 0.08, 0.12, 0.16])), indel=float(r.choice([0.0005, 0.002, 0.005, 0.01])),
+                   inversions=int(r.integers(0, 4)), duplications=int(r.integers(0, 3)), translocations=int(r.integers(0, 3)), seg=seg)
+        contigs = [g]
+        if contig_games and m % 3 == 1:
+            cuts = [0] + sorted(r.integers(0, len(g), int(r.integers(1, 3))).tolist()) + [len(g)]
+            contigs = [g[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+            contigs = [contigs[i] for i in r.permutation(len(contigs))]
+        if contig_games and m % 3 == 2:
+            a = int(r.integers(0, max(1, len(anc) - n // 8)))
+            contigs.append(evolve(anc[a:a + n // 8], 7000 * seed + m, sub=0.04, indel=0.003, inversions=1, duplications=0, translocations=0, seg=seg))
+        fam.append(contigs)
+    return fam

@@ -3,6 +3,7 @@ Each case drives the engine through the C-ABI and compares with the CPU oracle (
 Bars: minimizers, fragment sketches, mapping records (incl. float fields) and CGI rows BIT-EXACT."""
 import numpy as np
 
+import golden_cases
 import orc
 from fastani_amd.api import DeviceGenomes, Sketch
 
@@ -151,6 +152,19 @@ def case_l1_class_overflow(engine):
         genomes = [[np.concatenate([rng_genome(900 + i, 300 + 7 * i), mutate(base, 0.002 * (i % 5), 4100 + i), rng_genome(1900 + i, 500)])] for i in range(copies)]
         p, sk, osk = check_sketch(engine, genomes)
         check_queries(engine, p, sk, osk, [[base], genomes[copies // 2]])
+
+
+def case_evolved(engine, n=60000, members=7):
+    """relatives that differ by more than substitutions (golden_cases.evolve): indels shift the fragment frame, inversions map
+    fragments to the reverse strand, duplications / translocations give a fragment several placements in one reference and several
+    fragments one reference bin (the 2-way competition, computeCoreIdentity.hpp:237-254), contigs in shuffled order, a plasmid-like
+    second contig that is a diverged copy of part of the chromosome"""
+    fam = golden_cases.evolved_family(3, n, members, seg=(800, max(1000, n // 10)))
+    other = golden_cases.evolved_family(8, n // 2, 2, seg=(800, max(1000, n // 20)))
+    genomes = fam + other
+    p, sk, osk = check_sketch(engine, genomes)
+    rows = check_queries(engine, p, sk, osk, [genomes[0], genomes[2], genomes[4], genomes[5], genomes[-1]])
+    assert len(rows) >= 3 * (members - 1)
 
 
 def case_empty_and_short(engine):
@@ -343,11 +357,12 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_sparse_hits, case_l1_class_overflow, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
+             case_low_complexity_big, case_sparse_hits, case_l1_class_overflow, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):
-    """random genomes (alphabets with N / IUPAC / lower case, tandem repeats, A-rich), random contig splits, k in {8..16},
+    """random genomes (alphabets with N / IUPAC / lower case, tandem repeats, A-rich), relatives by substitution or by
+    golden_cases.evolve (indels, inversions, duplications, translocations), random contig splits, k in {8..16},
     fragLen in {500..3000}: sketch, fragment sketches, mappings and CGI rows all bit-exact against the oracle"""
     import time
     rng = np.random.default_rng(seed)
@@ -384,13 +399,19 @@ def fuzz(engine, seed, seconds=None, iterations=None):
             for _ in range(int(rng.integers(20, 70))):
                 flank = rng_genome(int(rng.integers(1e9)), int(rng.integers(0, 1500)))
                 genomes.append([np.concatenate([flank, mutate(base, float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.25])), int(rng.integers(1e9)))])])
+        def relative(rate):
+            if rng.random() < 0.5:
+                return mutate(base, rate, int(rng.integers(1e9)))
+            return golden_cases.evolve(base, int(rng.integers(1e9)), sub=rate, indel=float(rng.choice([0.0, 0.001, 0.005, 0.02])), inversions=int(rng.integers(0, 3)),
+                                       duplications=int(rng.integers(0, 3)), translocations=int(rng.integers(0, 3)), seg=(max(50, L // 4), 3 * L))
+
         for _ in range(int(rng.integers(1, 5))):
             if rng.random() < 0.6:
-                g = mutate(base, float(rng.choice([0, 0.01, 0.05, 0.1, 0.2])), int(rng.integers(1e9)))
+                g = relative(float(rng.choice([0, 0.01, 0.05, 0.1, 0.2])))
             else:
                 g = rand_genome(int(rng.integers(10, 10 * L)))
             genomes.append(contigs(g))
-        qs = [genomes[int(rng.integers(len(genomes)))] for _ in range(2)] + [contigs(mutate(base, 0.03, int(rng.integers(1e9))))]
+        qs = [genomes[int(rng.integers(len(genomes)))] for _ in range(2)] + [contigs(relative(0.03))]
         p, sk, osk = check_sketch(engine, genomes, k=k, frag_len=L)
         check_queries(engine, p, sk, osk, qs, k=k, frag_len=L)
     return it

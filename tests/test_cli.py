@@ -18,7 +18,7 @@ def _lines(path):
 
 
 def _run_both(binary, tmp):
-    gs = [[orc.synth_genome(7, i, 45000)] for i in (0, 3, 11, 20)] + [golden_cases.messy(5, 40000)]
+    gs = [[orc.synth_genome(7, i, 45000)] for i in (0, 3, 11, 20)] + [golden_cases.messy(5, 40000)] + [[orc.synth_genome(7, 3, 45000)]]   # the last = genome 1 again: rows with equal identity
     paths = []
     for i, g in enumerate(gs):
         p = os.path.join(tmp, "g%d.fa" % i)
@@ -34,6 +34,8 @@ def _run_both(binary, tmp):
         assert ra.returncode == 0 and rb.returncode == 0, rb.stderr.decode()[-2000:]
         assert _lines(os.path.join(tmp, "ref.out")) == _lines(os.path.join(tmp, "new.out")), extra
         assert len(_lines(os.path.join(tmp, "ref.out"))) > 0
+        if "-t" not in extra:      # one thread: the reference's row order is deterministic, ties included (std::sort on a fixed sequence)
+            assert open(os.path.join(tmp, "ref.out")).read() == open(os.path.join(tmp, "new.out")).read(), extra
         if "--matrix" in extra:
             assert open(os.path.join(tmp, "ref.out.matrix")).read() == open(os.path.join(tmp, "new.out.matrix")).read()
     # one-to-one with --visualize
@@ -48,6 +50,49 @@ def _run_both(binary, tmp):
         ra = subprocess.run([orc.REF_BIN] + args, capture_output=True)
         rb = subprocess.run([binary] + args, capture_output=True)
         assert ra.returncode == rb.returncode == 1 and msg in ra.stderr and msg in rb.stderr
+
+
+def _run_evolved(binary, tmp, n=45000):
+    """relatives with indels / inversions / duplications / translocations / shuffled contigs / a plasmid-like copy: all-vs-all with
+    --matrix, and many-to-many --visualize on two threads (the .visual rows come from the 2-way selection, the only place where two
+    fragments compete for one reference bin)"""
+    fam = golden_cases.evolved_family(5, n, 6, seg=(800, max(1000, n // 8))) + golden_cases.evolved_family(6, n, 2, seg=(800, 4000))
+    paths = []
+    for i, g in enumerate(fam):
+        p = os.path.join(tmp, "e%d.fa" % i)
+        orc.write_fasta(p, g, names=["e%d_%d" % (i, j) for j in range(len(g))])
+        paths.append(p)
+    lst = os.path.join(tmp, "e.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    for extra in (["--matrix"], ["-t", "2", "--visualize"], ["-t", "3", "--visualize", "--matrix", "--fragLen", "1500"]):
+        ra = subprocess.run([orc.REF_BIN, "--ql", lst, "--rl", lst, "-o", os.path.join(tmp, "eref.out")] + extra, capture_output=True)
+        rb = subprocess.run([binary, "--ql", lst, "--rl", lst, "-o", os.path.join(tmp, "enew.out")] + extra, capture_output=True)
+        assert ra.returncode == 0 and rb.returncode == 0, rb.stderr.decode()[-2000:]
+        assert _lines(os.path.join(tmp, "eref.out")) == _lines(os.path.join(tmp, "enew.out")), extra
+        assert len(_lines(os.path.join(tmp, "eref.out"))) >= 30
+        if "-t" not in extra:
+            assert open(os.path.join(tmp, "eref.out")).read() == open(os.path.join(tmp, "enew.out")).read(), extra
+        if "--matrix" in extra:
+            assert open(os.path.join(tmp, "eref.out.matrix")).read() == open(os.path.join(tmp, "enew.out.matrix")).read()
+        if "--visualize" in extra:
+            # byte for byte, not just as a set of lines: which of several equal-identity mappings of a reference bin is reported,
+            # and in which order (thread 0's queries first), is reproduced
+            assert open(os.path.join(tmp, "eref.out.visual")).read() == open(os.path.join(tmp, "enew.out.visual")).read(), extra
+            os.unlink(os.path.join(tmp, "enew.out.visual")); os.unlink(os.path.join(tmp, "eref.out.visual"))
+
+
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")
+def test_cli_evolved_cpu_build(tmp_path):
+    emu = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "all"])
+    _run_evolved(os.path.join(emu, "fastANI_emu"), str(tmp_path), n=30000)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not shipped")
+def test_cli_evolved_gpu(tmp_path):
+    _run_evolved(os.path.join(ROOT, "fastani_amd", "fastANI"), str(tmp_path))
+    _run_evolved(os.path.join(ROOT, "fastani_amd", "fastANI"), str(tmp_path), n=400000)
 
 
 def _run_streaming_variants(binary, tmp):

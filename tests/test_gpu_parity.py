@@ -80,6 +80,30 @@ def test_full_size_properties(gpu_engine):
     assert r["identity"] == o["identity"]
 
 
+def test_evolved_full_size(gpu_engine):
+    """24 genomes of ~5 Mbp in two families whose members differ by substitutions, indels, inversions, segmental duplications and
+    translocations, some as several shuffled contigs, some with a plasmid-like diverged copy (golden_cases.evolved_family):
+    the minimizer stream of all 24 and the CGI rows of six queries against all 24, bit-exact against the oracle"""
+    import golden_cases
+    import orc
+    from fastani_amd.api import Sketch
+    fam = golden_cases.evolved_family(21, 5_000_000, 12) + golden_cases.evolved_family(22, 5_000_000, 12)
+    p = gpu_engine.params()
+    sk = Sketch(gpu_engine, p, fam)
+    osk = orc.Sketch(fam, 16, p.windowSize)
+    assert np.array_equal(sk.minimizers(), osk.minimizers())
+    rows = sk.map_cgi_batch(fam, 0)
+    for q in (0, 2, 5, 13, 16, 22):
+        maps, tot = osk.map_genome(fam[q])
+        exp = osk.compute_cgi(maps, tot, q)
+        got = rows[rows["qryGenomeId"] == q]
+        assert len(exp) >= 12 and np.array_equal(got, exp), q
+    # one of them through the per-mapping interface as well (all 11 fields of every mapping record)
+    m, tot = sk.map_query(fam[5])
+    om, otot = osk.map_genome(fam[5])
+    assert tot == otot and np.array_equal(m, om)
+
+
 def test_fuzz(gpu_engine):
     assert pc.fuzz(gpu_engine, seed=11, iterations=150) == 150
 
