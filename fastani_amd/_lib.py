@@ -3,7 +3,14 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("ANI_LIB_PATH") or os.path.join(HERE, "csrc", "libfastani_amd.so")   # ANI_LIB_PATH: A/B builds of the same sources (profiling)
+LIB_PATH = os.path.join(HERE, "csrc", "libfastani_amd.so")
+# ANI_LIB_VARIANT=<tag>: an A/B build of the same sources for profiling, csrc/libfastani_amd.<tag>.so — a file name inside the
+# package only, never an arbitrary path
+_variant = os.environ.get("ANI_LIB_VARIANT", "")
+if _variant:
+    if not _variant.replace("_", "").replace("-", "").isalnum():
+        raise ImportError("fastani_amd: ANI_LIB_VARIANT must be a plain tag")
+    LIB_PATH = os.path.join(HERE, "csrc", "libfastani_amd.%s.so" % _variant)
 
 _lib = None
 

@@ -1527,7 +1527,12 @@ extern "C" {
 
 const char *ani_last_error(void) { return g_err.c_str(); }
 void ani_free(void *p) { free(p); }
-void ani_device_free(ani_ctx *ctx, void *p) { (void)ctx; if (p) pool_free(p); }
+void ani_device_free(ani_ctx *ctx, void *p)
+{
+  if (!p) return;
+  if (ctx) (void)hipSetDevice(ctx->device);      // the pools are per device: the block goes back to the pool of the context that owns it
+  pool_free(p);
+}
 
 int ani_init(int device, ani_ctx **out)
 {
@@ -1984,9 +1989,21 @@ int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_
   struct Unmap { const uint8_t *p; size_t n; ~Unmap() { munmap((void *)p, n); } } unmap{base, fileBytes};
   SketchFileHeader h; memcpy(&h, base, sizeof h);
   if (memcmp(h.magic, "ANISKTCH", 8) != 0 || h.version != 1) return fail(ANI_ERR_ARG, "%s is not a version-1 sketch file", path);
-  if (h.nContigs < 0 || h.nGenomes < 0 || h.offRecords + h.nRecords * 12 > fileBytes || h.offNames + h.namesBytes > fileBytes ||
-      h.offGenomeRec + ((uint64_t)h.nGenomes + 1) * 8 > fileBytes || h.offGcs + ((uint64_t)h.nGenomes + 1) * 4 > fileBytes || h.offContigLen + (uint64_t)h.nContigs * 4 > fileBytes)
+  // section extents without overflow: a section [off, off + count * size) lies inside the file iff off <= fileBytes and count <= (fileBytes - off) / size
+  auto inside = [&](uint64_t off, uint64_t count, uint64_t size) { return off <= fileBytes && count <= (fileBytes - off) / size; };
+  if (h.nContigs < 0 || h.nGenomes < 0 || !inside(h.offRecords, h.nRecords, 12) || !inside(h.offNames, h.namesBytes, 1) ||
+      !inside(h.offGenomeRec, (uint64_t)h.nGenomes + 1, 8) || !inside(h.offGcs, (uint64_t)h.nGenomes + 1, 4) || !inside(h.offContigLen, (uint64_t)h.nContigs, 4) ||
+      (h.offRecords | h.offGenomeRec | h.offGcs | h.offContigLen) % 4 != 0 || h.offGenomeRec % 8 != 0)
     return fail(ANI_ERR_ARG, "%s is truncated", path);
+  {
+    // the tables are used as copy offsets and sizes below: validate them instead of trusting the file
+    const int32_t *gcsT = (const int32_t *)(base + h.offGcs), *clenT = (const int32_t *)(base + h.offContigLen);
+    const uint64_t *grecT = (const uint64_t *)(base + h.offGenomeRec);
+    bool ok = gcsT[0] == 0 && gcsT[h.nGenomes] == h.nContigs && grecT[0] == 0 && grecT[h.nGenomes] == h.nRecords;
+    for (int32_t g = 0; ok && g < h.nGenomes; g++) ok = gcsT[g] <= gcsT[g + 1] && grecT[g] <= grecT[g + 1];
+    for (int32_t c = 0; ok && c < h.nContigs; c++) ok = clenT[c] >= 0;
+    if (!ok) return fail(ANI_ERR_ARG, "%s has inconsistent genome / contig tables", path);
+  }
   if (g1 < 0) g1 = h.nGenomes;
   if (g0 < 0 || g0 > g1 || g1 > h.nGenomes) return fail(ANI_ERR_ARG, "genome range [%d, %d) outside the file's %d genomes", g0, g1, h.nGenomes);
   ani_params_t p; p.kmerSize = h.kmerSize; p.windowSize = h.windowSize; p.fragLen = h.fragLen; p.percentageIdentity = h.percentageIdentity;

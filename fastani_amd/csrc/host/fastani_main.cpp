@@ -81,10 +81,10 @@ struct Options {
     "     --fragLen <value>  fragment length [default : 3,000]\n"
     "     --minFraction <value>  minimum fraction of genome that must be shared for trusting ANI. [default : 0.2]\n"
     "     --maxRatioDiff <value>  maximum difference between (Total Ref. Length/Total Occ. Hashes) and (Total Ref. Length/Total No. Hashes). [default : 10.0]\n"
-    "     --visualize  output mappings for visualization [disabled by default]\n"
+    "     --visualize  output mappings for visualization [disabled by default] (small-input mode: whole sets in host memory, one GPU)\n"
     "     --matrix    also output ANI values as lower triangular matrix (.matrix) [disabled by default]\n"
     "     -o, --output <value>  output file name\n"
-    "     -s, --sanityCheck  run sanity check\n"
+    "     -s, --sanityCheck  run sanity check (small-input mode: whole sets in host memory, one GPU, one index per -t split)\n"
     "     -v, --version  show version\n"
     "     --gpus <value>  number of GPUs to use [default : 1] (--devices a,b,.. names them)\n"
     "     --saveSketch <value>  write the reference sketch (minimizer records, contig tables, genome names) to this file\n"
@@ -176,7 +176,7 @@ struct BlockReader {
   }
   int getc() { if (p >= n && !fill()) return -1; return buf[p++]; }
   // appends the rest of the current line to `dst` (without the '\n'); returns false if the input ended before a '\n'
-  template <class V> bool rest_of_line(V *dst, size_t *count)
+  template <class V> bool rest_of_line(V *dst, size_t *count, int *lastByte = nullptr)
   {
     for (;;) {
       if (p >= n && !fill()) return false;
@@ -185,6 +185,7 @@ struct BlockReader {
       const size_t len = nl ? (size_t)(nl - s) : n - p;
       if (dst) dst->insert(dst->end(), s, s + len);
       if (count) *count += len;
+      if (lastByte && len) *lastByte = s[len - 1];
       p += len + (nl ? 1 : 0);
       if (nl) return true;
     }
@@ -226,7 +227,7 @@ bool readFile(const std::string &path, FileData &fd)
       if (c == '\n') continue;
       fd.data.push_back((uint8_t)c);
       rd.rest_of_line(&fd.data, nullptr);
-      if (fd.data.size() > start && fd.data.back() == '\r') fd.data.pop_back();
+      if (fd.data.size() - start > 1 && fd.data.back() == '\r') fd.data.pop_back();    // KS_SEP_LINE: a trailing '\r' goes once the sequence so far has more than one byte (kseq.h:141)
     }
     const size_t len = fd.data.size() - start;
     bool ok = true;
@@ -235,7 +236,13 @@ bool readFile(const std::string &path, FileData &fd)
     if (c == '+') {                                                   // FASTQ: skip the quality block (kseq.h:204-213)
       rd.rest_of_line((std::vector<uint8_t> *)nullptr, nullptr);
       size_t q = 0;
-      while (q < len) { size_t line = 0; const bool more = rd.rest_of_line((std::vector<uint8_t> *)nullptr, &line); q += line; if (!more) break; }
+      while (q < len) {                                              // quality lines are appended like sequence lines, '\r' stripped the same way (kseq.h:213, :141)
+        size_t line = 0; int lastB = -1;
+        const bool more = rd.rest_of_line((std::vector<uint8_t> *)nullptr, &line, &lastB);
+        q += line;
+        if (line && lastB == '\r' && q > 1) q--;
+        if (!more) break;
+      }
       last = 0;
       ok = (q == len);                                                // kseq_read < 0: truncated quality string ends the file
     }
@@ -370,7 +377,7 @@ int main(int argc, char **argv)
   if (o.refSketch.empty()) for (auto &e : o.refs) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
   if (!o.refSketch.empty()) {
     ani_params_t fp_;
-    ani_sketch_file_info(o.refSketch.c_str(), &fp_, nullptr, nullptr, nullptr);
+    if (ani_sketch_file_info(o.refSketch.c_str(), &fp_, nullptr, nullptr, nullptr)) die("reference sketch file");
     if (fp_.kmerSize != ap.kmerSize || fp_.fragLen != ap.fragLen || fp_.windowSize != ap.windowSize) {
       std::cerr << "ERROR, the sketch file was built with -k " << fp_.kmerSize << " --fragLen " << fp_.fragLen << ", this run uses -k " << ap.kmerSize << " --fragLen " << ap.fragLen << std::endl; exit(1); }
   }
@@ -379,6 +386,7 @@ int main(int argc, char **argv)
   const int nRef = (int)o.refs.size(), nQry = (int)o.queries.size();
   const bool fromFile = !o.refSketch.empty();
   if (fromFile && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --refSketch cannot be combined with --visualize or -s" << std::endl; exit(1); }
+  if (!o.saveSketch.empty() && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --saveSketch cannot be combined with --visualize or -s (those modes sketch per reference split)" << std::endl; exit(1); }
   const bool allVsAll = !fromFile && (o.queries == o.refs) && !o.visualize && !o.sanityCheck;
   if (o.visualize || o.sanityCheck) o.devices.resize(1);            // the per-split / per-mapping paths are single-device
 
@@ -435,7 +443,8 @@ int main(int argc, char **argv)
     struct Uploaded { ani_dev_batch *b = nullptr; std::vector<int32_t> len, gcs; int32_t seqBase = 0; bool ready = false; };
     auto run_two_stage = [&](const std::vector<std::pair<size_t, size_t>> &slices, const char *what,
                              const std::function<bool(int, size_t, SliceBatch &, Uploaded &)> &enter,          // bookkeeping before the upload (upload thread)
-                             const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute) {     // device work on the uploaded slice (compute thread)
+                             const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute,       // device work on the uploaded slice (compute thread)
+                             const std::function<void()> &onAbort = std::function<void()>()) {                 // called by a thread that gives up (error on its device or in its input)
       std::vector<Uploaded> ups(slices.size());
       std::vector<std::string> errs((size_t)nDev);
       std::mutex mu; std::condition_variable cv;
@@ -445,9 +454,9 @@ int main(int argc, char **argv)
         th.emplace_back([&, d]() {                        // upload thread
           size_t mine = 0;
           for (size_t k = (size_t)d; k < slices.size(); k += (size_t)nDev, mine++) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return mine < done[d] + 2 || !errs[d].empty(); }); if (!errs[d].empty()) return; }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return mine < done[d] + 2 || !errs[d].empty(); }); if (!errs[d].empty()) { lk.unlock(); if (onAbort) onAbort(); return; } }
             const size_t a = slices[k].first, b = slices[k].second;
-            if (!fp.wait(a, b)) { std::lock_guard<std::mutex> lk(mu); errs[d] = "input"; cv.notify_all(); return; }
+            if (!fp.wait(a, b)) { { std::lock_guard<std::mutex> lk(mu); errs[d] = "input"; } cv.notify_all(); if (onAbort) onAbort(); return; }
             SliceBatch sb;
             for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
             Uploaded &u = ups[k];
@@ -459,7 +468,7 @@ int main(int argc, char **argv)
             u.len = std::move(sb.len); u.gcs = std::move(sb.gcs);
             { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "upload" : msg; u.ready = true; }
             cv.notify_all();
-            if (!ok) return;
+            if (!ok) { if (onAbort) onAbort(); return; }
           }
         });
         th.emplace_back([&, d]() {                        // compute thread
@@ -470,7 +479,7 @@ int main(int argc, char **argv)
             if (ups[k].b) { ani_batch_free(ups[k].b); ups[k].b = nullptr; }
             { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "device" : msg; done[d]++; }
             cv.notify_all();
-            if (!ok) return;
+            if (!ok) { if (onAbort) onAbort(); return; }
           }
         });
       }
@@ -485,10 +494,12 @@ int main(int argc, char **argv)
     };
     {
       std::mutex orderMu; std::condition_variable orderCv; size_t nextSlice = 0;   // slices enter the tables in order
+      bool orderAbort = false;        // a device's threads gave up: the slices they would have entered never come, nobody may wait for them
       run_two_stage(refSlices, "reference sketch",
         [&](int d, size_t k, SliceBatch &sb, Uploaded &u) {
           std::unique_lock<std::mutex> lk(orderMu);
-          orderCv.wait(lk, [&]() { return nextSlice == k; });
+          orderCv.wait(lk, [&]() { return nextSlice == k || orderAbort; });
+          if (orderAbort) return false;
           u.seqBase = (int32_t)contigLenAll.size();
           const int32_t gBase = (int32_t)gcsAll.size() - 1;
           contigLenAll.insert(contigLenAll.end(), sb.len.begin(), sb.len.end());
@@ -506,7 +517,8 @@ int main(int argc, char **argv)
           if (rc) { msg = ani_last_error(); return false; }
           parts[k].n = n;
           return true;
-        });
+        },
+        [&]() { { std::lock_guard<std::mutex> lk(orderMu); orderAbort = true; } orderCv.notify_all(); });
     }
     trace("reference slices sketched");
     // every device gets every part (peer-to-peer pulls), then builds the full index

@@ -119,7 +119,9 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 __device__ __forceinline__ void block_barrier()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt / expcnt untouched
+  // asm volatile with a memory clobber: the compiler may not move an LDS store below the wait (the builtin form carries no
+  // ordering against memory operations in the IR)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
   __syncthreads();
 }
@@ -128,7 +130,7 @@ __device__ __forceinline__ void block_barrier()
 __device__ __forceinline__ void block_barrier_mem()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
   __syncthreads();
 }
