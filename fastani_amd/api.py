@@ -46,8 +46,8 @@ class SeqBatch(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
                                           "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
-                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "indexChunks", "l1Probes", "l2ChunkHalvings")] + \
-               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main")]
+                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "indexChunks", "l1Probes", "l2ChunkHalvings", "indexChunkBuilds", "l1BigFragments")] + \
+               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main", "msL1Big")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -93,6 +93,12 @@ def _bind(lib):
         "ani_sketch_records_self": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]),
         "ani_map_cgi_fragset": (C.c_int, [vp, vp, vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_fragset_free": (None, [vp]),
+        "ani_map_cgi_fragsets": (C.c_int, [vp, vp, C.c_int32, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "ani_fragset_info": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
+        "ani_fragset_pack_bytes": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+        "ani_fragset_pack": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "ani_fragset_unpack": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(vp)]),
+        "ani_sketch_residency": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "ani_map_cgi_batch": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
     }
@@ -309,9 +315,33 @@ class Engine:
 class FragmentSet:
     """Fragment sketches of a batch of query genomes kept on the device (ani_fragset)."""
 
-    def __init__(self, engine, handle):
+    def __init__(self, engine, handle, keepalive=None):
         self.e = engine
         self.h = handle
+        self._keepalive = keepalive          # the buffer a view (unpack) points into
+
+    def info(self):
+        g, f, h = C.c_int32(), C.c_int64(), C.c_uint64()
+        self.e._chk(self.e.lib.ani_fragset_info(self.h, C.byref(g), C.byref(f), C.byref(h)))
+        return dict(genomes=g.value, fragments=f.value, hashes=h.value)
+
+    def packed_bytes(self):
+        n = C.c_size_t()
+        self.e._chk(self.e.lib.ani_fragset_pack_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def pack_into(self, dev_ptr, cap):
+        """the set as one device buffer (header + tables + hash pool) at dev_ptr; returns the bytes used"""
+        n = C.c_size_t()
+        self.e._chk(self.e.lib.ani_fragset_pack(self.e.h, self.h, dev_ptr, cap, C.byref(n)))
+        return n.value
+
+    @staticmethod
+    def unpack(engine, dev_ptr, nbytes, keepalive=None):
+        """view of a packed set at dev_ptr (the arrays stay in that buffer: pass its owner as keepalive)"""
+        h = C.c_void_p()
+        engine._chk(engine.lib.ani_fragset_unpack(engine.h, dev_ptr, nbytes, C.byref(h)))
+        return FragmentSet(engine, h, keepalive)
 
     def close(self):
         if getattr(self, "h", None):
@@ -415,6 +445,19 @@ class Sketch:
         p, n = C.c_void_p(), C.c_size_t()
         self.e._chk(self.e.lib.ani_map_cgi_fragset(self.e.h, self.h, fragset.h, first_query_id, C.byref(p), C.byref(n)))
         return self.e._take(p, n.value, CGI_DT)
+
+    def map_cgi_fragsets(self, fragsets, first_query_ids):
+        """several kept sets in one call (a streamed reference set builds each index chunk once per call)"""
+        hs = (C.c_void_p * len(fragsets))(*[f.h for f in fragsets])
+        ids = np.ascontiguousarray(first_query_ids, dtype=np.int32)
+        p, n = C.c_void_p(), C.c_size_t()
+        self.e._chk(self.e.lib.ani_map_cgi_fragsets(self.e.h, self.h, len(fragsets), hs, ids.ctypes.data, C.byref(p), C.byref(n)))
+        return self.e._take(p, n.value, CGI_DT)
+
+    def residency(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.e._chk(self.e.lib.ani_sketch_residency(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(streaming=bool(a.value), max_resident=b.value, resident_now=c.value)
 
     def map_cgi_batch(self, genomes, first_query_id=0):
         g = _as_batch(genomes)

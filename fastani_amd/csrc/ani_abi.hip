@@ -188,6 +188,8 @@ struct ani_ctx {
   size_t l2ChunkCandidates = (size_t)1 << 21;                                      // L2 chunk size (env ANI_L2_CHUNK, tests)
   uint64_t l2CodeLimit = 0xfffffff0ull;                                             // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_L2_CODE_LIMIT, tests)
   uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
+  int32_t maxResidentChunks = 0;                                                    // index chunks of one reference set kept on the device (env ANI_MAX_RESIDENT_CHUNKS; 0 = decide from the free memory)
+  uint64_t streamChunkMinimizers = 1000000000ull;                                   // chunk size once a set is streamed (env ANI_STREAM_CHUNK_MINIMIZERS): the build's transient arrays must fit beside the records
   std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
   void *pinned[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t pinnedCap[5] = {0, 0, 0, 0, 0};   // page-locked staging: 0/1 result reads, 2 prefix-sum block totals, 3/4 ingest (packed / raw bytes)
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
@@ -217,10 +219,16 @@ struct ani_ctx {
 // larger than that is a list of chunks (the reference's own answer to big databases is the same split, per OpenMP thread:
 // computeCoreIdentity.hpp:457-487, scripts/splitDatabase.sh) — exact, because a (query, reference) result does not depend on
 // what else is in the index.
+struct RecordPiece { const uint32_t *rec; size_t n; };   // n 12-byte records on the device
 struct IndexChunk {
   uint32_t n = 0;
   int32_t c0 = 0, nContigs = 0, g0 = 0, nGenomes = 0;   // global ids of the first contig / genome, and counts
   uint64_t nUnique = 0;
+  // The index arrays proper (everything but the small reducer tables at the end) can be dropped and rebuilt from the records
+  // (`pieces`, slices of the record parts the sketch keeps) when the reference set is larger than the device memory: see ensure_chunk.
+  bool resident = false, everBuilt = false;
+  uint64_t lastUse = 0;
+  std::vector<RecordPiece> pieces;
   // device arrays
   uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
   uint32_t *sHash = nullptr, *mWin = nullptr; uint8_t *mDelta = nullptr;
@@ -228,7 +236,7 @@ struct IndexChunk {
   ani::TableSlot *table = nullptr; uint32_t tableSlots = 0;     // order-preserving probe table over the distinct hashes (index.hpp)
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
   uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr, *posBase = nullptr, *posSample = nullptr;
-  uint32_t totalBins = 0;
+  uint32_t totalBins = 0, totalPosBins = 0;
 };
 
 struct ani_sketch {
@@ -243,6 +251,12 @@ struct ani_sketch {
   std::vector<std::string> genomeNames;    // optional (ani_sketch_save / _load carry them)
   std::vector<IndexChunk *> chunks;
   uint32_t maxChunkBins = 0;
+  // Streaming mode (reference sets whose index does not fit the device: BASELINE configs[4]; the reference's answer is the same
+  // split-and-loop, computeCoreIdentity.hpp:457-487 / scripts/splitDatabase.sh): the sketch keeps the 12-byte records (`kept`,
+  // a quarter of the index's size) and at most `maxResident` chunks' index arrays; the others are rebuilt on demand (ensure_chunk).
+  bool streaming = false; int32_t maxResident = 0; uint64_t useClock = 0;
+  std::vector<void *> kept;                // record buffers owned by the sketch (streaming mode)
+  std::vector<uint64_t> genomeRecStart;    // first record of every genome in the position-ordered stream (nGenomes + 1)
   // LUTs
   ani::stat::Luts *luts = nullptr;        // host LUTs, shared by every sketch of the context with the same (k, identity cutoff)
   int32_t *dMinHits = nullptr, *dMinShared = nullptr; uint32_t *dIdLUT = nullptr; int dLutMaxS = 0;
@@ -722,11 +736,19 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
   return ANI_OK;
 }
 
+// the index arrays of a chunk (not its reducer tables): dropped when the chunk is evicted in streaming mode
+void free_chunk_index(IndexChunk *ch)
+{
+  void **ptrs[] = {(void **)&ch->mWin, (void **)&ch->sSW, (void **)&ch->mDelta, (void **)&ch->mHash, (void **)&ch->mSeq, (void **)&ch->mWpos, (void **)&ch->prevSame,
+                   (void **)&ch->nextSame, (void **)&ch->sHash, (void **)&ch->table, (void **)&ch->contigFirstMin, (void **)&ch->posSample};
+  for (void **q : ptrs) if (*q) { pool_free(*q); *q = nullptr; }
+  ch->resident = false;
+}
 void free_chunk(IndexChunk *ch)
 {
   if (!ch) return;
-  void *ptrs[] = {ch->mWin, ch->sSW, ch->mDelta, ch->mHash, ch->mSeq, ch->mWpos, ch->prevSame, ch->nextSame, ch->sHash, ch->table, ch->contigFirstMin,
-                  ch->contigGenome, ch->contigBinBase, ch->genomeBinStart, ch->posBase, ch->posSample};
+  free_chunk_index(ch);
+  void *ptrs[] = {ch->contigGenome, ch->contigBinBase, ch->genomeBinStart, ch->posBase};
   for (void *q : ptrs) if (q) pool_free(q);
   delete ch;
 }
@@ -734,6 +756,8 @@ void free_sketch_device(ani_sketch *sk)
 {
   for (IndexChunk *ch : sk->chunks) free_chunk(ch);
   sk->chunks.clear();
+  for (void *q : sk->kept) if (q) pool_free(q);
+  sk->kept.clear();
   void *ptrs[] = {sk->dMinHits, sk->dMinShared, sk->dIdLUT};
   for (void *q : ptrs) if (q) pool_free(q);
   sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr;
@@ -761,13 +785,12 @@ int upload_luts(ani_sketch *sk, int maxS)
 }
 
 // -----------------------------------------------------------------------------------------------------
-// one index chunk over device-resident records (≙ Sketch::index, winSketch.hpp:181-193).  `dRecords` = the n records of the
-// chunk's genomes [g0, g0 + nGenomes) = contigs [c0, c0 + nContigs), position order, GLOBAL seqIds; contigLen / genomeContigStart
-// are the whole reference set's tables.
+// One index chunk (≙ Sketch::index, winSketch.hpp:181-193) over the genomes [g0, g0 + nGenomes) = contigs [c0, c0 + nContigs) of
+// a reference set.  new_chunk fills the small tables that depend on the contig lengths only (reducer bins, sampled-position
+// bins); build_chunk_index builds the index arrays from the chunk's records (`pieces`: position order, set-global seqIds) and can
+// be repeated after free_chunk_index.
 // -----------------------------------------------------------------------------------------------------
-struct RecordPiece { const uint32_t *rec; size_t n; };
-int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPiece> &pieces, size_t n, const int32_t *contigLenAll, const int32_t *gcsAll,
-                int32_t g0, int32_t nGenomes, IndexChunk **out)
+int new_chunk(ani_ctx *ctx, const ani_params_t *p, size_t n, const int32_t *contigLenAll, const int32_t *gcsAll, int32_t g0, int32_t nGenomes, IndexChunk **out)
 {
   if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "index chunk of %zu minimizers exceeds 2^31", n);
   IndexChunk *sk = new IndexChunk();
@@ -775,6 +798,39 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPie
   const int32_t *contigLen = contigLenAll + c0;
   sk->n = (uint32_t)n; sk->c0 = c0; sk->nContigs = nContigs; sk->g0 = g0; sk->nGenomes = nGenomes;
   auto bail = [&](int rc) { free_chunk(sk); return rc; };
+#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194); all chunk-local
+  std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);
+  std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1), posBase((size_t)nContigs + 1);
+  const int32_t binW = p->fragLen - 20;
+  uint64_t run = 0, runPos = 0;
+  for (int32_t g = 0; g < nGenomes; g++) {
+    gBin[g] = (uint32_t)run;
+    for (int32_t c = gcsAll[g0 + g] - c0; c < gcsAll[g0 + g + 1] - c0; c++) {
+      cg[c] = g; binBase[c] = (uint32_t)run; run += (uint64_t)(contigLen[c] / binW) + 1;
+      posBase[c] = (uint32_t)runPos; runPos += ((uint64_t)contigLen[c] >> ani::kPosSampleShift) + 1;      // bins of the sampled position index
+      if (run > 0xfffffff0ull || runPos > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "index chunk has more than 2^32 position bins"));
+    }
+  }
+  gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run; posBase[nContigs] = (uint32_t)runPos;
+  sk->totalBins = (uint32_t)run; sk->totalPosBins = (uint32_t)runPos;
+  SK_HIP(pool_malloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
+  SK_HIP(pool_malloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->posBase, ((size_t)nContigs + 1) * 4));
+  SK_HIP(hipMemcpyAsync(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->posBase, posBase.data(), posBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipStreamSynchronize(ctx->stream));      // the host tables above die at scope exit
+#undef SK_HIP
+  *out = sk;
+  return ANI_OK;
+}
+
+int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
+{
+  const size_t n = sk->n;
+  const int32_t c0 = sk->c0, nContigs = sk->nContigs;
+  auto bail = [&](int rc) { free_chunk_index(sk); return rc; };
 #define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
 #define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const size_t n4 = (n ? n : 1) * 4;
@@ -789,7 +845,7 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPie
     { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
     if (n) {
       size_t o = 0;                                 // the pieces (slices of record parts, in order) go straight into the chunk's arrays: no concatenated copy
-      for (const RecordPiece &pc : pieces) {
+      for (const RecordPiece &pc : sk->pieces) {
         if (!pc.n) continue;
         hipLaunchKernelGGL(k_index_split, dim3(grid_for(pc.n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, pc.rec, (uint32_t)pc.n, (uint32_t)c0, sk->mHash + o, sk->mSeq + o, sk->mWpos + o,
                            sk->mDelta + o, sk->prevSame + o, sk->nextSame + o, tmpK + o, tmpV + o);
@@ -798,7 +854,7 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPie
       size_t tb = 0;
       int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, nullptr, &tb, ctx->stream);
       if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 16); if (rc == ANI_OK) rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, ctx->sortTmp.p, &tb, ctx->stream); }
-      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
+      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
     }
     pool_free(tmpK); pool_free(tmpV);
     SK_TRY(zero_counters(ctx));
@@ -853,37 +909,17 @@ int build_chunk(ani_ctx *ctx, const ani_params_t *p, const std::vector<RecordPie
       sk->tableSlots = nSlots;
     }
     SK_HIP(hipGetLastError());
+    SK_HIP(pool_malloc((void **)&sk->posSample, ((size_t)sk->totalPosBins + 1) * 4));
+    if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
+                                    sk->totalPosBins, (uint32_t)n, sk->posSample);
+    SK_HIP(hipGetLastError());
   }
-  // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194); all chunk-local
-  std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);
-  std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1), posBase((size_t)nContigs + 1);
-  const int32_t binW = p->fragLen - 20;
-  uint64_t run = 0, runPos = 0;
-  for (int32_t g = 0; g < nGenomes; g++) {
-    gBin[g] = (uint32_t)run;
-    for (int32_t c = gcsAll[g0 + g] - c0; c < gcsAll[g0 + g + 1] - c0; c++) {
-      cg[c] = g; binBase[c] = (uint32_t)run; run += (uint64_t)(contigLen[c] / binW) + 1;
-      posBase[c] = (uint32_t)runPos; runPos += ((uint64_t)contigLen[c] >> ani::kPosSampleShift) + 1;      // bins of the sampled position index
-      if (run > 0xfffffff0ull || runPos > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "index chunk has more than 2^32 position bins"));
-    }
-  }
-  gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run; posBase[nContigs] = (uint32_t)runPos;
-  sk->totalBins = (uint32_t)run;
-  SK_HIP(pool_malloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
-  SK_HIP(pool_malloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4));
-  SK_HIP(hipMemcpyAsync(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  SK_HIP(hipMemcpyAsync(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  SK_HIP(hipMemcpyAsync(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  SK_HIP(pool_malloc((void **)&sk->posBase, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->posSample, ((size_t)runPos + 1) * 4));
-  SK_HIP(hipMemcpyAsync(sk->posBase, posBase.data(), posBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)runPos + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
-                                  (uint32_t)runPos, (uint32_t)n, sk->posSample);
-  SK_HIP(hipGetLastError());
-  SK_HIP(hipStreamSynchronize(ctx->stream));      // the host tables above die at scope exit
-  ctx->counters.refMinimizers += n;
+  SK_HIP(hipStreamSynchronize(ctx->stream));
+  if (!sk->everBuilt) ctx->counters.refMinimizers += n;
+  ctx->counters.indexChunkBuilds++;
+  sk->resident = true; sk->everBuilt = true;
 #undef SK_TRY
 #undef SK_HIP
-  *out = sk;
   return ANI_OK;
 }
 
@@ -898,11 +934,42 @@ ani_sketch *new_sketch(ani_ctx *ctx, const ani_params_t *p, const int32_t *conti
   return sk;
 }
 
+// Streaming mode: make chunk i's index arrays resident, evicting the least recently used ones beyond the set's limit (`pin`, if
+// >= 0, is never evicted and raises the limit to two: exact_unique compares pairs of chunks).
+int ensure_chunk(ani_sketch *sk, size_t i, int pin = -1)
+{
+  IndexChunk *ch = sk->chunks[i];
+  ch->lastUse = ++sk->useClock;
+  if (ch->resident) return ANI_OK;
+  auto evict_one = [&]() -> bool {
+    IndexChunk *victim = nullptr;
+    for (size_t x = 0; x < sk->chunks.size(); x++) {
+      IndexChunk *c = sk->chunks[x];
+      if (!c->resident || x == i || (int)x == pin) continue;
+      if (!victim || c->lastUse < victim->lastUse) victim = c;
+    }
+    if (!victim) return false;
+    (void)hipStreamSynchronize(sk->ctx->stream); (void)hipStreamSynchronize(sk->ctx->stream2);   // nothing in flight reads the arrays that go back to the pool
+    free_chunk_index(victim);
+    return true;
+  };
+  const int limit = std::max<int>(sk->maxResident > 0 ? sk->maxResident : (int)sk->chunks.size(), pin >= 0 ? 2 : 1);
+  for (;;) {
+    int res = 0;
+    for (IndexChunk *c : sk->chunks) res += c->resident;
+    if (res < limit || !evict_one()) break;
+  }
+  int rc = build_chunk_index(sk->ctx, &sk->params, ch);
+  while (rc == ANI_ERR_NOMEM && evict_one()) rc = build_chunk_index(sk->ctx, &sk->params, ch);     // estimate too optimistic: make room, try again
+  return rc;
+}
+
 // A piece of a position-ordered record stream with global seqIds: n records on the device that belong to genomes [g0, g1).
 struct RecordPart { uint32_t *rec = nullptr; size_t n = 0; int32_t g0 = 0, g1 = 0; bool owned = true; };
 
 // Cut the record parts into index chunks at genome borders (each chunk <= ctx->maxIndexMinimizers records, balanced) and build
-// them.  Owned parts are released as soon as the chunks that need them exist.
+// them.  Owned parts are released as soon as the chunks that need them exist — unless the set is streamed: then the sketch takes
+// the records over (unowned parts are copied) and builds index arrays on demand.
 int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
 {
   const int32_t *gcs = sk->genomeContigStart.data();
@@ -929,37 +996,74 @@ int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
     total += pt.n;
   }
   for (int32_t g = 0; g < sk->nGenomes; g++) if (genomePart[g] < 0) return fail(ANI_ERR_INTERNAL, "genome %d is in no record part", g);
+  sk->genomeRecStart.assign((size_t)sk->nGenomes + 1, 0);
+  for (int32_t g = 0; g < sk->nGenomes; g++) sk->genomeRecStart[g + 1] = sk->genomeRecStart[g] + genomeRecs[g];
+  // Resident or streamed?  The index takes ~45 bytes per minimizer and its build another ~25 of transient
+  // arrays; a set that does not fit beside a working-set reserve keeps its 12-byte records instead and at most `maxResident`
+  // chunks' arrays (ANI_MAX_RESIDENT_CHUNKS forces a limit: the tests stream tiny sets that way).
+  uint64_t maxN = std::min<uint64_t>(ctx->maxIndexMinimizers, 0x7fffffe0ull);
+  int32_t resident = ctx->maxResidentChunks;
+  if (resident == 0) {
+    size_t freeB = 0, totB = 0;
+    if (hipMemGetInfo(&freeB, &totB) == hipSuccess) {
+      uint64_t cached = 0;
+      for (int cls = 0; cls < 2; cls++) { DevicePool &pl = cur_pool(cls); std::lock_guard<std::mutex> g(pl.mu); cached += pl.cachedBytes; }
+      const uint64_t avail = (uint64_t)freeB + cached, reserve = std::min<uint64_t>((uint64_t)32 << 30, (uint64_t)totB / 8);
+      const uint64_t largest = std::min<uint64_t>(total, maxN);
+      if (45 * total + 25 * largest + reserve > avail) { resident = 1; maxN = std::min<uint64_t>(maxN, ctx->streamChunkMinimizers); }
+    }
+  }
   // balanced chunk sizes: ceil(total / max) chunks of about total / that
-  const uint64_t maxN = std::min<uint64_t>(ctx->maxIndexMinimizers, 0x7fffffe0ull);
   const uint64_t nCh = std::max<uint64_t>(1, (total + maxN - 1) / maxN);
   const uint64_t target = std::min<uint64_t>(maxN, (total + nCh - 1) / nCh + (total / nCh) / 50 + 1);
+  // the plan: genome ranges and the record slices they are built from
   int32_t g0 = 0;
-  std::vector<int32_t> partLastUse(parts.size(), -1);
-  for (int32_t g = 0; g < sk->nGenomes; g++) partLastUse[genomePart[g]] = g;
   while (g0 < sk->nGenomes || (sk->nGenomes == 0 && sk->chunks.empty())) {
     int32_t g1 = g0; uint64_t n = 0;
     while (g1 < sk->nGenomes && (g1 == g0 || n + genomeRecs[g1] <= target)) { n += genomeRecs[g1]; g1++; }
     if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "reference genome %d alone yields %llu minimizers (>= 2^31)", g0, (unsigned long long)n);
-    // the chunk's records: slices of the parts its genomes come from, in order
-    std::vector<RecordPiece> pieces;
+    IndexChunk *ch = nullptr;
+    TRY(new_chunk(ctx, &sk->params, (size_t)n, sk->contigLen.data(), gcs, g0, g1 - g0, &ch));
     for (int32_t g = g0; g < g1;) {                 // runs of genomes inside one part
       const int32_t pi = genomePart[g]; int32_t h = g; uint64_t m = 0;
       while (h < g1 && genomePart[h] == pi) { m += genomeRecs[h]; h++; }
-      if (m) pieces.push_back(RecordPiece{parts[pi].rec + 3 * genomeOffInPart[g], (size_t)m});
+      if (m) ch->pieces.push_back(RecordPiece{parts[pi].rec + 3 * genomeOffInPart[g], (size_t)m});
       g = h;
     }
-    IndexChunk *ch = nullptr;
-    TRY(build_chunk(ctx, &sk->params, pieces, (size_t)n, sk->contigLen.data(), gcs, g0, g1 - g0, &ch));
     sk->chunks.push_back(ch); ctx->counters.indexChunks++;
     sk->n += n; sk->maxChunkBins = std::max(sk->maxChunkBins, ch->totalBins);
-    for (size_t pi = 0; pi < parts.size(); pi++)
-      if (parts[pi].owned && parts[pi].rec && partLastUse[pi] < g1) { pool_free(parts[pi].rec); parts[pi].rec = nullptr; }
     g0 = g1;
     if (sk->nGenomes == 0) break;
   }
+  sk->streaming = resident > 0 && (size_t)resident < sk->chunks.size();
+  sk->maxResident = sk->streaming ? resident : 0;
+  if (sk->streaming) {
+    // the sketch takes the records over: owned parts as they are, the others copied (the chunks' pieces point into them)
+    for (RecordPart &pt : parts) {
+      if (!pt.rec || !pt.n) continue;
+      if (pt.owned) { sk->kept.push_back(pt.rec); pt.rec = nullptr; continue; }     // taken over: the caller's cleanup finds nothing to free
+      uint32_t *cp = nullptr;
+      HIP_TRY(pool_malloc((void **)&cp, pt.n * 12));
+      sk->kept.push_back(cp);
+      HIP_TRY(hipMemcpyAsync(cp, pt.rec, pt.n * 12, hipMemcpyDeviceToDevice, ctx->stream));
+      for (IndexChunk *ch : sk->chunks) for (RecordPiece &pc : ch->pieces)
+        if (pc.rec >= pt.rec && pc.rec < pt.rec + 3 * pt.n) pc.rec = cp + (pc.rec - pt.rec);
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  } else {
+    std::vector<int32_t> partLastUse(parts.size(), -1);
+    for (int32_t g = 0; g < sk->nGenomes; g++) partLastUse[genomePart[g]] = g;
+    for (size_t c = 0; c < sk->chunks.size(); c++) {
+      IndexChunk *ch = sk->chunks[c];
+      TRY(build_chunk_index(ctx, &sk->params, ch));
+      ch->pieces.clear();                              // the records may go away now
+      for (size_t pi = 0; pi < parts.size(); pi++)
+        if (parts[pi].owned && parts[pi].rec && partLastUse[pi] < ch->g0 + ch->nGenomes) { pool_free(parts[pi].rec); parts[pi].rec = nullptr; }
+    }
+  }
   sk->nUnique = 0;
   for (IndexChunk *ch : sk->chunks) sk->nUnique += ch->nUnique;
-  sk->uniqueExact = sk->chunks.size() <= 1;
+  sk->uniqueExact = sk->chunks.size() <= 1 && !sk->streaming;
   ctx->counters.refBases += sk->totalLen; ctx->counters.refUniqueHashes += sk->nUnique;
   return upload_luts(sk, 512);
 }
@@ -973,12 +1077,14 @@ int exact_unique(ani_sketch *sk)
   for (size_t c = 1; c < sk->chunks.size(); c++) {
     IndexChunk *C = sk->chunks[c];
     if (!C->n) continue;
+    TRY(ensure_chunk(sk, c));
     uint8_t *seen = nullptr;
     HIP_TRY(pool_malloc((void **)&seen, C->n));
     hipError_t e = hipMemsetAsync(seen, 0, C->n, ctx->stream);
     for (size_t x = 0; x < c && e == hipSuccess; x++) {
       IndexChunk *E = sk->chunks[x];
       if (!E->n) continue;
+      { const int rcE = ensure_chunk(sk, x, (int)c); if (rcE != ANI_OK) { pool_free(seen); return rcE; } }
       hipLaunchKernelGGL(k_index_mark_shared, dim3(grid_for(C->n, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)C->sHash, C->n, (const TableSlot *)E->table,
                          E->tableSlots, sk->params.windowSize, seen);
     }
@@ -992,6 +1098,8 @@ int exact_unique(ani_sketch *sk)
     TRY(rc);
     dup += host[CNT_UNIQ];
   }
+  sk->nUnique = 0;                 // (a streamed set knows a chunk's own count only once the chunk has been built: every chunk has been, above)
+  for (IndexChunk *ch : sk->chunks) { if (!ch->everBuilt && ch->n) return fail(ANI_ERR_INTERNAL, "index chunk never built"); sk->nUnique += ch->nUnique; }
   sk->nUnique -= dup; sk->uniqueExact = true;
   return ANI_OK;
 }
@@ -1349,13 +1457,14 @@ struct RowBuf {
 
 // 1-way / 2-way / mean (computeCoreIdentity.hpp:214-297) for the candidates map_stage left in the context's buffers, against one
 // index chunk; the (count, identity) results go to the chunk's column block of the dense [nQuery][nRefGenomes] table in ctx->rows.
-int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, int32_t nCand, int32_t nQuery)
+// `compact`: the table holds this chunk's genomes only ([nQuery][chunk genomes]; a streamed set is reduced and read back chunk by chunk)
+int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, int32_t nCand, int32_t nQuery, bool compact = false)
 {
   if (nQuery == 0 || sk->nGenomes == 0) return ANI_OK;
   const size_t binsPerQuery = sk->totalBins;
   const size_t nBins = binsPerQuery * (size_t)nQuery;
   TRY(ctx->bins.ensure((nBins ? nBins : 1) * 4));
-  const size_t nPairsAll = (size_t)nQuery * (size_t)set->nGenomes;
+  const size_t nPairsAll = (size_t)nQuery * (size_t)(compact ? sk->nGenomes : set->nGenomes);
   TRY(ctx->rows.ensure((nPairsAll ? nPairsAll : 1) * 8));
   hipError_t e1;
   {
@@ -1371,7 +1480,7 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &f
   PairArgs pa;
   pa.nQuery = nQuery; pa.nRefGenomes = sk->nGenomes; pa.bins = ctx->bins.as<uint32_t>(); pa.binsPerQuery = binsPerQuery;
   pa.genomeBinStart = sk->genomeBinStart; pa.pairCount = ctx->rows.as<uint32_t>(); pa.pairIdentity = ctx->rows.as<uint32_t>() + nPairsAll;
-  pa.outStride = set->nGenomes; pa.outCol0 = sk->g0;
+  pa.outStride = compact ? sk->nGenomes : set->nGenomes; pa.outCol0 = compact ? 0 : sk->g0;
   const size_t nPairs = (size_t)nQuery * (size_t)sk->nGenomes;
   hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)((nPairs + 3) / 4)), dim3(256), 0, ctx->stream, pa);   // one wave per pair
   }
@@ -1380,9 +1489,11 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &f
 }
 
 // the dense table of a sub-batch (all chunks reduced) -> rows in (query, reference genome) order, appended to `rows`
-int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows)
+// (`block`: the table is the compact one of that chunk — reference genome = block->g0 + column)
+int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows, const IndexChunk *block = nullptr)
 {
-  const size_t nPairs = (size_t)nQuery * (size_t)set->nGenomes;
+  const int32_t nCols = block ? block->nGenomes : set->nGenomes, col0 = block ? block->g0 : 0;
+  const size_t nPairs = (size_t)nQuery * (size_t)nCols;
   if (nPairs == 0) return ANI_OK;
   uint32_t *dense = nullptr;
   TRY(pinned_buffer(ctx, 1, nPairs * 8 + 8, (void **)&dense));
@@ -1394,10 +1505,10 @@ int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuer
   if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", m);
   rows->n += m;
   for (int32_t qi = 0; qi < nQuery; qi++) {                         // query ascending, reference ascending
-    const uint32_t *cnt = dense + (size_t)qi * (size_t)set->nGenomes, *idb = cnt + nPairs;
-    for (int32_t g = 0; g < set->nGenomes; g++) {
+    const uint32_t *cnt = dense + (size_t)qi * (size_t)nCols, *idb = cnt + nPairs;
+    for (int32_t g = 0; g < nCols; g++) {
       if (!cnt[g]) continue;
-      ani_cgi_t r; r.refGenomeId = g; r.qryGenomeId = firstQueryId + qi; r.countSeq = (int32_t)cnt[g];
+      ani_cgi_t r; r.refGenomeId = col0 + g; r.qryGenomeId = firstQueryId + qi; r.countSeq = (int32_t)cnt[g];
       r.totalQueryFragments = fs.genomeFragments[qi];
       memcpy(&r.identity, &idb[g], 4);
       *out++ = r;
@@ -1425,6 +1536,7 @@ struct ani_fragset {
   ani_params_t params;
   FragSet fs;                      // host tables + device pointers into the arrays below
   FragArrays arr; uint32_t *qPool = nullptr;
+  bool borrowed = false;           // the arrays live in a caller's buffer (ani_fragset_unpack): not freed with the set
   std::vector<int64_t> genomeFragStart;     // prefix of fs.genomeFragments
 };
 
@@ -1432,7 +1544,7 @@ namespace {
 void fragset_release(ani_fragset *f)
 {
   void *ptrs[] = {f->arr.fragOff, f->arr.fragS, f->arr.fragGenome, f->arr.fragQSeq, f->qPool};
-  for (void *q : ptrs) if (q) pool_free(q);
+  if (!f->borrowed) for (void *q : ptrs) if (q) pool_free(q);
   delete f;
 }
 void fragset_finish(ani_fragset *f)
@@ -1507,7 +1619,7 @@ int records_of_batch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
   return ANI_OK;
 }
 
-// Map + reduce for the fragments of `fs` (a whole set or a slice of one) against every index chunk; rows appended
+// Map + reduce for the fragments of `fs` (a whole set or a slice of one) against every index chunk (all resident); rows appended
 int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows)
 {
   TRY(upload_luts(sk, fs.maxS));
@@ -1517,6 +1629,73 @@ int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery,
     TRY(reduce_stage(ctx, sk, ch, fs, nCand, nQuery));
   }
   return collect_rows(ctx, sk, fs, nQuery, firstQueryId, rows);
+}
+
+// Sub-batches of kept fragment sets, mapped against a whole reference set.  A resident set is walked sub-batch by sub-batch (every
+// chunk per sub-batch, one dense result table per sub-batch).  A streamed set is walked CHUNK by chunk — build the chunk's index,
+// map every sub-batch of every set against it, drop it — so that each chunk is built once per call however many query genomes
+// there are (the reference's own loop has the same shape: per reference split, all queries; core_genome_identity.cpp:55-106);
+// the rows of a sub-batch then come chunk by chunk and are put back into (query, reference) order at the end.
+struct SubBatch { const ani_fragset *set; int32_t g0, g1, firstQueryId; FragSet v; };
+int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_fragset *> &sets, const std::vector<int32_t> &firstQueryIds, RowBuf *rows)
+{
+  std::vector<SubBatch> sub;
+  int maxS = 0;
+  for (size_t si = 0; si < sets.size(); si++) {
+    const ani_fragset *f = sets[si];
+    if (f->device != ctx->device) return fail(ANI_ERR_ARG, "fragment set lives on device %d, context on %d", f->device, ctx->device);
+    if (f->params.kmerSize != sk->params.kmerSize || f->params.windowSize != sk->params.windowSize || f->params.fragLen != sk->params.fragLen)
+      return fail(ANI_ERR_ARG, "fragment set and sketch were built with different parameters");
+    maxS = std::max(maxS, f->fs.maxS);
+    const int32_t nG = (int32_t)f->fs.genomeFragments.size();
+    int32_t g0 = 0;
+    while (g0 < nG) {
+      // sub-batches bounded by fragments (2^20), by the bin table of the largest index chunk (8 GiB) and by the dense result table
+      int32_t g1 = g0;
+      const uint64_t maxQ = std::max<uint64_t>(1, std::min<uint64_t>((ctx->subBatchBinBytes) / (4ull * std::max<uint32_t>(sk->maxChunkBins, 1)),
+                                                                 ((uint64_t)2 << 30) / (8ull * (uint64_t)std::max<int32_t>(sk->nGenomes, 1))));
+      while (g1 < nG && (g1 == g0 || ((uint64_t)(f->genomeFragStart[g1] - f->genomeFragStart[g0]) < ctx->subBatchFragments && (uint64_t)(g1 - g0) < maxQ))) g1++;
+      const int64_t fA = f->genomeFragStart[g0], fB = f->genomeFragStart[g1];
+      SubBatch sb; sb.set = f; sb.g0 = g0; sb.g1 = g1; sb.firstQueryId = firstQueryIds[si] + g0;
+      FragSet &v = sb.v;                                       // slice [g0, g1) of the kept set
+      v.nFrag = (int32_t)(fB - fA); v.maxS = f->fs.maxS; v.poolSize = f->fs.poolSize;
+      v.genomeFragments.assign(f->fs.genomeFragments.begin() + g0, f->fs.genomeFragments.begin() + g1);
+      v.qPool = f->fs.qPool; v.genomeBase = g0;
+      if (v.nFrag) { v.fragOff = f->fs.fragOff + fA; v.fragS = f->fs.fragS + fA; v.fragGenome = f->fs.fragGenome + fA; v.fragQSeq = f->fs.fragQSeq + fA; }
+      v.nHashes = f->fs.nFrag ? (uint64_t)((double)f->fs.nHashes * (double)v.nFrag / (double)f->fs.nFrag) : 0;      // statistics only (l1Probes)
+      sub.push_back(std::move(sb));
+      g0 = g1;
+    }
+  }
+  if (!sk->streaming) {
+    for (const SubBatch &sb : sub) TRY(map_fragset(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, rows));
+    return ANI_OK;
+  }
+  TRY(upload_luts(sk, maxS));
+  std::vector<RowBuf> part(sub.size());
+  for (size_t c = 0; c < sk->chunks.size(); c++) {
+    TRY(ensure_chunk(sk, c));
+    IndexChunk *ch = sk->chunks[c];
+    for (size_t i = 0; i < sub.size(); i++) {
+      const SubBatch &sb = sub[i];
+      int32_t nCand = 0;
+      TRY(map_stage(ctx, sk, ch, sb.v, &nCand));
+      TRY(reduce_stage(ctx, sk, ch, sb.v, nCand, sb.g1 - sb.g0, true));
+      TRY(collect_rows(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, &part[i], ch));
+    }
+  }
+  // a sub-batch's rows are (chunk, query, reference)-ordered and a chunk's references all precede the next chunk's: a stable sort by
+  // query restores (query, reference) order
+  for (size_t i = 0; i < sub.size(); i++) {
+    RowBuf &pb = part[i];
+    if (!pb.n) continue;
+    std::stable_sort(pb.p, pb.p + pb.n, [](const ani_cgi_t &a, const ani_cgi_t &b) { return a.qryGenomeId < b.qryGenomeId; });
+    ani_cgi_t *out = rows->grow(pb.n);
+    if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", pb.n);
+    memcpy(out, pb.p, pb.n * sizeof(ani_cgi_t));
+    rows->n += pb.n;
+  }
+  return ANI_OK;
 }
 }  // namespace
 
@@ -1551,6 +1730,8 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
   if (const char *ev = getenv("ANI_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_INDEX_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->maxIndexMinimizers = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev); if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
+  if (const char *ev = getenv("ANI_STREAM_CHUNK_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->streamChunkMinimizers = (uint64_t)v; }
   for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
   int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
   if (rc != ANI_OK) { delete c; return rc; }
@@ -1730,33 +1911,128 @@ void ani_fragset_free(ani_fragset *f)
   fragset_release(f);
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Wire format of a kept fragment set: ONE device buffer = 256-byte header, genome -> fragment counts, the four per-fragment arrays
+// and the hash pool, every section 256-byte aligned.  A multi-GPU run moves query fragment sketches between the GPUs in this form
+// (RCCL send/recv or all-gather of plain bytes; a third of the size of the minimizer records) and maps them where they arrive.
+// -----------------------------------------------------------------------------------------------------
+namespace {
+struct FragWireHeader {
+  char magic[8]; uint32_t version; int32_t kmerSize, windowSize, fragLen; float percentageIdentity;
+  int32_t nFrag, nGenomes, maxS; uint64_t nHashes, poolSize;
+  uint64_t offGenomeFragments, offFragOff, offFragS, offFragGenome, offFragQSeq, offPool, totalBytes;
+};
+static_assert(sizeof(FragWireHeader) <= 256, "wire header fits its slot");
+inline uint64_t wire_align(uint64_t x) { return (x + 255) / 256 * 256; }
+FragWireHeader wire_header(const ani_fragset *f)
+{
+  FragWireHeader h; memset(&h, 0, sizeof h);
+  memcpy(h.magic, "ANIFRAGS", 8); h.version = 1;
+  h.kmerSize = f->params.kmerSize; h.windowSize = f->params.windowSize; h.fragLen = f->params.fragLen; h.percentageIdentity = f->params.percentageIdentity;
+  h.nFrag = f->fs.nFrag; h.nGenomes = (int32_t)f->fs.genomeFragments.size(); h.maxS = f->fs.maxS; h.nHashes = f->fs.nHashes; h.poolSize = f->fs.poolSize;
+  const uint64_t nF = (uint64_t)h.nFrag;
+  h.offGenomeFragments = 256;
+  h.offFragOff = wire_align(h.offGenomeFragments + (uint64_t)h.nGenomes * 4);
+  h.offFragS = wire_align(h.offFragOff + nF * 4);
+  h.offFragGenome = wire_align(h.offFragS + nF * 4);
+  h.offFragQSeq = wire_align(h.offFragGenome + nF * 4);
+  h.offPool = wire_align(h.offFragQSeq + nF * 4);
+  h.totalBytes = wire_align(h.offPool + h.poolSize * 4);
+  return h;
+}
+}  // namespace
+
+int ani_fragset_pack_bytes(const ani_fragset *f, size_t *bytes)
+{
+  if (!f || !bytes) return fail(ANI_ERR_ARG, "null argument");
+  *bytes = (size_t)wire_header(f).totalBytes;
+  return ANI_OK;
+}
+
+int ani_fragset_pack(ani_ctx *ctx, const ani_fragset *f, void *devBuf, size_t cap, size_t *bytes)
+{
+  if (!ctx || !f || !devBuf) return fail(ANI_ERR_ARG, "null argument");
+  if (f->device != ctx->device) return fail(ANI_ERR_ARG, "fragment set lives on device %d, context on %d", f->device, ctx->device);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const FragWireHeader h = wire_header(f);
+  if (h.totalBytes > cap) return fail(ANI_ERR_ARG, "buffer of %zu bytes is too small for a fragment set of %llu bytes", cap, (unsigned long long)h.totalBytes);
+  uint8_t *b = (uint8_t *)devBuf;
+  const size_t nF = (size_t)h.nFrag;
+  HIP_TRY(hipMemcpyAsync(b, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+  if (h.nGenomes) HIP_TRY(hipMemcpyAsync(b + h.offGenomeFragments, f->fs.genomeFragments.data(), (size_t)h.nGenomes * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (nF) {
+    HIP_TRY(hipMemcpyAsync(b + h.offFragOff, f->fs.fragOff, nF * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(b + h.offFragS, f->fs.fragS, nF * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(b + h.offFragGenome, f->fs.fragGenome, nF * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(b + h.offFragQSeq, f->fs.fragQSeq, nF * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (h.poolSize) HIP_TRY(hipMemcpyAsync(b + h.offPool, f->fs.qPool, (size_t)h.poolSize * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));          // the header and the table are host memory of this call
+  if (bytes) *bytes = (size_t)h.totalBytes;
+  return ANI_OK;
+}
+
+// A view of a packed set: the arrays stay in devBuf (which the caller keeps alive until the set is freed)
+int ani_fragset_unpack(ani_ctx *ctx, const void *devBuf, size_t bytes, ani_fragset **out)
+{
+  if (!ctx || !devBuf || !out) return fail(ANI_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (bytes < 256) return fail(ANI_ERR_ARG, "not a packed fragment set");
+  FragWireHeader h;
+  HIP_TRY(hipMemcpy(&h, devBuf, sizeof h, hipMemcpyDeviceToHost));
+  if (memcmp(h.magic, "ANIFRAGS", 8) != 0 || h.version != 1) return fail(ANI_ERR_ARG, "not a packed fragment set");
+  ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen; tmp.params.percentageIdentity = h.percentageIdentity;
+  TRY(check_params(&tmp.params));
+  if (h.nFrag < 0 || h.nGenomes < 0 || h.maxS < 0 || h.poolSize > 0xfffffff0ull || h.nHashes > h.poolSize) return fail(ANI_ERR_ARG, "packed fragment set with inconsistent counts");
+  tmp.fs.nFrag = h.nFrag; tmp.fs.maxS = h.maxS; tmp.fs.nHashes = h.nHashes; tmp.fs.poolSize = h.poolSize; tmp.fs.genomeFragments.assign((size_t)h.nGenomes, 0);
+  const FragWireHeader want = wire_header(&tmp);       // the layout follows from the counts: the offsets in the buffer must be these
+  if (want.offFragOff != h.offFragOff || want.offFragS != h.offFragS || want.offFragGenome != h.offFragGenome || want.offFragQSeq != h.offFragQSeq ||
+      want.offPool != h.offPool || want.totalBytes != h.totalBytes || h.totalBytes > bytes)
+    return fail(ANI_ERR_ARG, "packed fragment set is truncated or malformed");
+  ani_fragset *f = new ani_fragset();
+  f->ctx = ctx; f->device = ctx->device; f->params = tmp.params; f->borrowed = true;
+  f->fs = tmp.fs;
+  if (h.nGenomes) {
+    const hipError_t e = hipMemcpy(f->fs.genomeFragments.data(), (const uint8_t *)devBuf + h.offGenomeFragments, (size_t)h.nGenomes * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { delete f; HIP_TRY(e); }
+  }
+  int64_t sum = 0;
+  for (int32_t v : f->fs.genomeFragments) { if (v < 0) { sum = -1; break; } sum += v; }
+  if (sum != (int64_t)h.nFrag) { delete f; return fail(ANI_ERR_ARG, "packed fragment set: genome table does not add up to the fragment count"); }
+  uint8_t *b = (uint8_t *)const_cast<void *>(devBuf);
+  f->arr.fragOff = (uint32_t *)(b + h.offFragOff); f->arr.fragS = (int32_t *)(b + h.offFragS);
+  f->arr.fragGenome = (int32_t *)(b + h.offFragGenome); f->arr.fragQSeq = (int32_t *)(b + h.offFragQSeq);
+  f->qPool = (uint32_t *)(b + h.offPool);
+  f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq; f->fs.qPool = f->qPool; f->fs.genomeBase = 0;
+  fragset_finish(f);
+  *out = f;
+  return ANI_OK;
+}
+
+int ani_fragset_info(const ani_fragset *f, int32_t *nGenomes, int64_t *nFragments, uint64_t *nHashes)
+{
+  if (!f) return fail(ANI_ERR_ARG, "null argument");
+  if (nGenomes) *nGenomes = (int32_t)f->fs.genomeFragments.size();
+  if (nFragments) *nFragments = f->fs.nFrag;
+  if (nHashes) *nHashes = f->fs.nHashes;
+  return ANI_OK;
+}
+
 int ani_map_cgi_fragset(ani_ctx *ctx, const ani_sketch *skc, const ani_fragset *f, int32_t firstQueryId, ani_cgi_t **out, size_t *m)
 {
-  if (!ctx || !skc || !f || !out || !m) return fail(ANI_ERR_ARG, "null argument");
+  return ani_map_cgi_fragsets(ctx, skc, 1, &f, &firstQueryId, out, m);
+}
+
+int ani_map_cgi_fragsets(ani_ctx *ctx, const ani_sketch *skc, int32_t nSets, const ani_fragset *const *frags, const int32_t *firstQueryIds, ani_cgi_t **out, size_t *m)
+{
+  if (!ctx || !skc || nSets < 0 || (nSets && (!frags || !firstQueryIds)) || !out || !m) return fail(ANI_ERR_ARG, "null argument");
+  for (int32_t i = 0; i < nSets; i++) if (!frags[i]) return fail(ANI_ERR_ARG, "null fragment set %d", i);
   ani_sketch *sk = const_cast<ani_sketch *>(skc);
-  if (f->device != ctx->device) return fail(ANI_ERR_ARG, "fragment set lives on device %d, context on %d", f->device, ctx->device);
-  if (f->params.kmerSize != sk->params.kmerSize || f->params.windowSize != sk->params.windowSize || f->params.fragLen != sk->params.fragLen)
-    return fail(ANI_ERR_ARG, "fragment set and sketch were built with different parameters");
   HIP_TRY(hipSetDevice(ctx->device));
   RowBuf rows;
-  const int32_t nG = (int32_t)f->fs.genomeFragments.size();
-  int32_t g0 = 0;
-  while (g0 < nG) {
-    // the same sub-batch bounds as ani_map_cgi_batch
-    int32_t g1 = g0;
-    const uint64_t maxQ = std::max<uint64_t>(1, std::min<uint64_t>((ctx->subBatchBinBytes) / (4ull * std::max<uint32_t>(sk->maxChunkBins, 1)),
-                                                               ((uint64_t)2 << 30) / (8ull * (uint64_t)std::max<int32_t>(sk->nGenomes, 1))));
-    while (g1 < nG && (g1 == g0 || ((uint64_t)(f->genomeFragStart[g1] - f->genomeFragStart[g0]) < ctx->subBatchFragments && (uint64_t)(g1 - g0) < maxQ))) g1++;
-    const int64_t fA = f->genomeFragStart[g0], fB = f->genomeFragStart[g1];
-    FragSet v;                                              // slice [g0, g1) of the kept set
-    v.nFrag = (int32_t)(fB - fA); v.maxS = f->fs.maxS; v.poolSize = f->fs.poolSize;
-    v.genomeFragments.assign(f->fs.genomeFragments.begin() + g0, f->fs.genomeFragments.begin() + g1);
-    v.qPool = f->fs.qPool; v.genomeBase = g0;
-    if (v.nFrag) { v.fragOff = f->fs.fragOff + fA; v.fragS = f->fs.fragS + fA; v.fragGenome = f->fs.fragGenome + fA; v.fragQSeq = f->fs.fragQSeq + fA; }
-    v.nHashes = f->fs.nFrag ? (uint64_t)((double)f->fs.nHashes * (double)v.nFrag / (double)f->fs.nFrag) : 0;      // statistics only (l1Probes)
-    TRY(map_fragset(ctx, sk, v, g1 - g0, firstQueryId + g0, &rows));
-    g0 = g1;
-  }
+  std::vector<const ani_fragset *> sets(frags, frags + nSets);
+  std::vector<int32_t> firsts(firstQueryIds, firstQueryIds + nSets);
+  TRY(map_fragsets(ctx, sk, sets, firsts, &rows));
   *m = rows.n; *out = rows.release();
   if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
   return ANI_OK;
@@ -1853,6 +2129,14 @@ int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n)
   size_t o = 0;
   for (const IndexChunk *ch : sk->chunks) {
     if (ch->n == 0) continue;
+    if (!ch->resident) {                     // streamed set: the chunk's records are at hand in the export layout already
+      for (const RecordPiece &pc : ch->pieces) {
+        const hipError_t ec = hipMemcpy(*out + o, pc.rec, pc.n * 12, hipMemcpyDeviceToHost);
+        if (ec != hipSuccess) { free(*out); *out = nullptr; HIP_TRY(ec); }
+        o += pc.n;
+      }
+      continue;
+    }
     uint32_t *tmp = nullptr;
     hipError_t e = pool_malloc((void **)&tmp, (size_t)ch->n * 12);
     if (e == hipSuccess) {
@@ -1891,6 +2175,15 @@ int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGeno
   return ANI_OK;
 }
 
+int ani_sketch_residency(const ani_sketch *sk, int32_t *streaming, int32_t *maxResident, int32_t *residentNow)
+{
+  if (!sk) return fail(ANI_ERR_ARG, "null sketch");
+  if (streaming) *streaming = sk->streaming ? 1 : 0;
+  if (maxResident) *maxResident = sk->streaming ? sk->maxResident : (int32_t)sk->chunks.size();
+  if (residentNow) { int32_t r = 0; for (const IndexChunk *ch : sk->chunks) r += ch->resident; *residentNow = r; }
+  return ANI_OK;
+}
+
 // -----------------------------------------------------------------------------------------------------
 // Persistent sketch file (the reference rebuilds its sketch in every run and every thread).
 //   header (4096 B) : magic "ANISKTCH", version, the parameters the sketch depends on, counts, section offsets
@@ -1925,18 +2218,8 @@ int ani_sketch_save(const ani_sketch *sk, const char *path, const char *const *g
   if (fd < 0) return fail(ANI_ERR_ARG, "cannot create %s", path);
   std::string names;
   for (int32_t g = 0; g < sk->nGenomes; g++) { names += genomeNames && genomeNames[g] ? genomeNames[g] : (g < (int32_t)sk->genomeNames.size() ? sk->genomeNames[g].c_str() : ""); names.push_back('\0'); }
-  // records per genome: chunk by chunk (contigFirstMin of the chunk's genomes' first contigs)
-  std::vector<uint64_t> genomeRec((size_t)sk->nGenomes + 1, 0);
-  {
-    uint64_t base = 0;
-    for (const IndexChunk *ch : sk->chunks) {
-      std::vector<int32_t> cfm((size_t)ch->nContigs + 1);
-      if (hipMemcpy(cfm.data(), ch->contigFirstMin, cfm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { ::close(fd); return fail(ANI_ERR_DEVICE, "reading the index failed"); }
-      for (int32_t g = 0; g < ch->nGenomes; g++) genomeRec[ch->g0 + g] = base + (uint64_t)cfm[sk->genomeContigStart[ch->g0 + g] - ch->c0];
-      base += ch->n;
-    }
-    genomeRec[sk->nGenomes] = base;
-  }
+  const std::vector<uint64_t> &genomeRec = sk->genomeRecStart;      // first record of every genome (add_chunks)
+  if (genomeRec.size() != (size_t)sk->nGenomes + 1) { ::close(fd); return fail(ANI_ERR_INTERNAL, "sketch without its genome record table"); }
   SketchFileHeader h; memset(&h, 0, sizeof h);
   memcpy(h.magic, "ANISKTCH", 8); h.version = 1; h.headerBytes = (uint32_t)kFileAlign;
   h.kmerSize = sk->params.kmerSize; h.windowSize = sk->params.windowSize; h.fragLen = sk->params.fragLen; h.percentageIdentity = sk->params.percentageIdentity;
@@ -1957,6 +2240,16 @@ int ani_sketch_save(const ani_sketch *sk, const char *path, const char *const *g
   // records: joined on the device into 12-byte records, through page-locked staging, 64 M records at a time
   const size_t kPiece = (size_t)64 << 20;
   for (const IndexChunk *ch : sk->chunks) {
+    if (!ch->resident) {                     // streamed set: written from the records the sketch keeps
+      for (const RecordPiece &pc : ch->pieces)
+        for (size_t o = 0; ok && o < pc.n; o += kPiece) {
+          const size_t m = std::min<size_t>(kPiece, pc.n - o);
+          void *host = nullptr;
+          if (pinned_buffer(ctx, 0, m * 12, &host) != ANI_OK) { ok = false; break; }
+          ok = hipMemcpy(host, pc.rec + 3 * o, m * 12, hipMemcpyDeviceToHost) == hipSuccess && write_all(fd, host, m * 12);
+        }
+      continue;
+    }
     for (size_t o = 0; ok && o < ch->n; o += kPiece) {
       const size_t m = std::min<size_t>(kPiece, ch->n - o);
       uint32_t *tmp = nullptr; void *host = nullptr;
@@ -2110,7 +2403,9 @@ int ani_map_query(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t *qu
   TRY(upload_luts(sk, fs.maxS));
   if (totalQueryFragments) *totalQueryFragments = (uint64_t)fs.genomeFragments[0];
   std::vector<ani_mapping_t> maps;
-  for (IndexChunk *ch : sk->chunks) {
+  for (size_t ci = 0; ci < sk->chunks.size(); ci++) {
+    IndexChunk *ch = sk->chunks[ci];
+    TRY(ensure_chunk(sk, ci));
     int32_t nCand = 0;
     TRY(map_stage(ctx, sk, ch, fs, &nCand));
     if (!nCand) continue;
@@ -2229,6 +2524,15 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t
   TRY(check_batch(queries));
   ani_sketch *sk = const_cast<ani_sketch *>(skc);
   HIP_TRY(hipSetDevice(ctx->device));
+  if (sk->streaming) {
+    // a streamed reference set is walked chunk by chunk: the fragment sketches of ALL the queries are made first (1.6 MB per 5 Mbp
+    // genome) so that every chunk is built once
+    ani_fragset *f = nullptr;
+    TRY(ani_fragset_build(ctx, &sk->params, queries, &f));
+    const int rc = ani_map_cgi_fragset(ctx, sk, f, firstQueryId, out, m);
+    ani_fragset_free(f);
+    return rc;
+  }
   RowBuf rows;
   // sub-batches bounded by fragments (2^20), by the bin table of the largest index chunk (8 GiB) and by the dense result table
   const int L = sk->params.fragLen;

@@ -114,11 +114,14 @@ typedef struct {
   uint64_t indexChunks;       /* index chunks built (one per reference set unless it passes ANI_MAX_INDEX_MINIMIZERS) */
   uint64_t l1Probes;          /* sketch hashes looked up in an index: querySketchHashes x index chunks probed */
   uint64_t l2ChunkHalvings;   /* L2 chunks redone at half size because their code stream passed the 32-bit offset limit */
+  uint64_t indexChunkBuilds;  /* index chunks built, rebuilds of a streamed reference set included */
+  uint64_t l1BigFragments;    /* query fragments (per index chunk) whose seed hits exceeded every LDS class: batched global-memory L1 path */
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
   double msL2Kernel;          /* HIP-event time of the class-A ani::k_l2_sim launches alone (on the launch stream) */
   double msL2Ranges, msL2Codes, msL2Slow;   /* ani::k_l2_ranges, ani::k_l2_codes, ani::k_l2 */
   double msL2SimB;            /* class-B simulation launches (ani::k_l2_sim<L2Geom<319>> + its list compaction) */
   double msL1Probe, msL1Main; /* ani::k_l1_probe; ani::k_l1<0, 2048> (the small-class gather + filter + sort + candidate kernel) */
+  double msL1Big;             /* the batched global-memory L1 path (gather + device sort + candidates) */
 } ani_counters_t;
 
 /* ---- life cycle ---- */
@@ -162,6 +165,13 @@ int ani_sketch_stats(const ani_sketch *sk, uint64_t *nMinimizers, uint64_t *nUni
  * reference's own database split (src/cgi/include/computeCoreIdentity.hpp:457-487, scripts/splitDatabase.sh:12-26).
  * Returns the number of chunks and (optionally, up to `cap`) the first genome id of each. */
 int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGenome, int32_t cap);
+
+/* Reference sets larger than the device memory (BASELINE configs[4]; the reference's own answer is the database split of
+ * computeCoreIdentity.hpp:457-487 / scripts/splitDatabase.sh with every query mapped against every split): when the index
+ * (~45 bytes per minimizer) does not fit beside a working-set reserve — or when ANI_MAX_RESIDENT_CHUNKS says so — the sketch keeps
+ * the 12-byte minimizer records and at most `maxResident` chunks' index arrays; the mapping entry points then walk the set chunk by
+ * chunk (build, map every query sub-batch, drop).  Results are identical.  Reports the mode. */
+int ani_sketch_residency(const ani_sketch *sk, int32_t *streaming, int32_t *maxResident, int32_t *residentNow);
 
 /* Multi-GPU staging: rank r sketches its share of the reference genomes into device-resident
  * 12-byte records with GLOBAL seqIds (seqIdBase = contigs before this shard), the caller all-gathers the
@@ -213,6 +223,18 @@ int ani_sketch_records_self(ani_ctx *ctx, const ani_params_t *p, const ani_seq_b
 int ani_map_cgi_fragset(ani_ctx *ctx, const ani_sketch *sk, const ani_fragset *frags, int32_t firstQueryId,
                         ani_cgi_t **out, size_t *m);
 void ani_fragset_free(ani_fragset *frags);
+/* several kept sets in one call (set i's genomes get the query ids firstQueryIds[i] + 0, 1, ...): a streamed reference set builds
+ * each of its index chunks once per call, so hand over everything that is to be mapped.  Rows: set by set, (query, reference). */
+int ani_map_cgi_fragsets(ani_ctx *ctx, const ani_sketch *sk, int32_t nSets, const ani_fragset *const *frags, const int32_t *firstQueryIds,
+                         ani_cgi_t **out, size_t *m);
+int ani_fragset_info(const ani_fragset *frags, int32_t *nGenomes, int64_t *nFragments, uint64_t *nHashes);
+/* A kept set as ONE device buffer (header + tables + hash pool; plain bytes for RCCL send/recv or all-gather) and back: the
+ * multi-GPU path shards the REFERENCES, every GPU indexes its shard only, and the query fragment sketches — a third of the size
+ * of the minimizer records — travel between the GPUs.  ani_fragset_unpack returns a view: the arrays stay
+ * in devBuf, which must outlive the set. */
+int ani_fragset_pack_bytes(const ani_fragset *frags, size_t *bytes);
+int ani_fragset_pack(ani_ctx *ctx, const ani_fragset *frags, void *devBuf, size_t cap, size_t *bytes);
+int ani_fragset_unpack(ani_ctx *ctx, const void *devBuf, size_t bytes, ani_fragset **out);
 
 /* ---- reducer: replaces cgi::computeCGI (computeCoreIdentity.hpp:166-298) for one query genome ---- */
 int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *sk, const ani_mapping_t *mappings, size_t n,

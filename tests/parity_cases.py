@@ -217,6 +217,86 @@ def case_chunked(engine):
     case_empty_and_short(engine)
 
 
+def case_streamed(engine, tmpdir=None):
+    """run on an engine created with a small ANI_MAX_INDEX_MINIMIZERS and ANI_MAX_RESIDENT_CHUNKS=1 (or 2): the reference set is
+    STREAMED — the sketch keeps its minimizer records and one chunk's index arrays at a time, every mapping call walks the set chunk
+    by chunk (build, map all query sub-batches, drop) — the device-side form of running the reference once per database split
+    (computeCoreIdentity.hpp:457-487, scripts/splitDatabase.sh).  Minimizers, the exact unique count, mappings, CGI rows through every
+    entry point, several kept fragment sets in one call and the sketch file must not change."""
+    from fastani_amd.api import FragmentSet
+    genomes = [[orc.synth_genome(7, g, 45000)] for g in (0, 1, 4, 11, 16, 19, 20)] + [messy_genome(5, 50000)] + golden_cases.evolved_family(9, 40000, 3, seg=(800, 5000))
+    engine.reset_counters()
+    p, sk, osk = check_sketch(engine, genomes)
+    r = sk.residency()
+    n_chunks = len(sk.chunks())
+    assert r["streaming"] and n_chunks >= 4 and r["max_resident"] < n_chunks and r["resident_now"] <= max(2, r["max_resident"]), (r, n_chunks)
+    rows = check_queries(engine, p, sk, osk, [genomes[0], genomes[7], genomes[6], genomes[9]])
+    assert len(rows) >= 10
+    assert engine.counters()["indexChunkBuilds"] > n_chunks            # chunks were rebuilt
+    # all-vs-all through kept fragment sets: two sets in ONE call build every chunk once
+    exp = []
+    for qi, g in enumerate(genomes):
+        maps, tot = osk.map_genome(g)
+        exp.append(osk.compute_cgi(maps, tot, qi))
+    exp = np.concatenate(exp)
+    fa, fb = engine.fragment_set(p, genomes[:5]), engine.fragment_set(p, genomes[5:])
+    b0 = engine.counters()["indexChunkBuilds"]
+    got = sk.map_cgi_fragsets([fa, fb], [0, 5])
+    assert engine.counters()["indexChunkBuilds"] - b0 <= n_chunks
+    assert np.array_equal(got, exp)
+    assert np.array_equal(sk.map_cgi_fragset(fb, 5), exp[exp["qryGenomeId"] >= 5])
+    fa.close(); fb.close()
+    # the fused all-vs-all pass feeding a streamed set
+    contig_len = np.array([len(c) for g in genomes for c in g], dtype=np.int32)
+    gcs = np.cumsum([0] + [len(g) for g in genomes]).astype(np.int32)
+    ptr, n, frags = engine.sketch_records_self(p, genomes, 0)
+    sk2 = Sketch(engine, p, records=(ptr, n, contig_len, gcs))           # caller-owned records: the streamed sketch copies them
+    engine.device_free(ptr)
+    assert sk2.residency()["streaming"]
+    assert np.array_equal(sk2.map_cgi_fragset(frags, 0), exp)
+    assert np.array_equal(sk2.minimizers(), osk.minimizers())
+    frags.close()
+    if tmpdir is not None:
+        import os
+        path = os.path.join(str(tmpdir), "streamed.anisk")
+        sk.save(path, ["g%d" % i for i in range(len(genomes))])
+        sk3 = Sketch(engine, p, file=path)
+        assert np.array_equal(sk3.minimizers(), osk.minimizers()) and sk3.stats() == sk.stats()
+        assert np.array_equal(sk3.map_cgi_batch(genomes[:3], 0), exp[exp["qryGenomeId"] < 3])
+
+
+def case_fragset_wire(engine, alloc):
+    """a kept fragment set packed into one device buffer and viewed from it again (what travels between the GPUs of a
+    reference-sharded run) maps to the same rows; damaged buffers are rejected"""
+    from fastani_amd.api import AniError, FragmentSet
+    genomes = [messy_genome(5, 50000), [orc.synth_genome(5, 0, 40000)], [rng_genome(1, 10, b"ACGT")], [orc.synth_genome(5, 3, 35001)], [b""]]
+    p = engine.params()
+    sk = Sketch(engine, p, genomes)
+    rows0 = sk.map_cgi_batch(genomes, 0)
+    f = engine.fragment_set(p, genomes)
+    nb = f.packed_bytes()
+    buf, ptr = alloc(nb + 1024)
+    assert f.pack_into(ptr, nb + 1024) == nb
+    info = f.info()
+    f.close()
+    v = FragmentSet.unpack(engine, ptr, nb, keepalive=buf)
+    assert v.info() == info and info["genomes"] == len(genomes)
+    assert np.array_equal(sk.map_cgi_fragset(v, 0), rows0)
+    v.close()
+    for bad_len in (100, nb - 256):
+        try:
+            FragmentSet.unpack(engine, ptr, bad_len)
+            raise AssertionError("a truncated buffer must be rejected")
+        except AniError as e:
+            assert e.code == -1
+    # an empty set travels too
+    f0 = engine.fragment_set(p, [[b"ACGT"]])
+    n0 = f0.pack_into(ptr, nb)
+    v0 = FragmentSet.unpack(engine, ptr, n0, keepalive=buf)
+    assert len(sk.map_cgi_fragset(v0, 7)) == 0
+    v0.close(); f0.close()
+
+
 def case_uploaded(engine):
     """ani_batch_upload: genomes packed and copied to the device once, then used as references AND as queries (the all-vs-all
     command line does that); both host layouts (flat buffer, per-contig pointers); sub-ranges through ani_sketch_records"""

@@ -66,6 +66,23 @@ def test_chunked_with_small_batches(monkeypatch):
     e.close()
 
 
+def test_streamed_reference_set(monkeypatch, tmp_path):
+    """reference set streamed chunk by chunk (one resident chunk), then with two resident chunks and tiny query sub-batches"""
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=7000, ANI_MAX_RESIDENT_CHUNKS=1)
+    pc.case_streamed(e, tmp_path)
+    e.close()
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=7000, ANI_MAX_RESIDENT_CHUNKS=2, ANI_SUBBATCH_FRAGS=11, ANI_L2_CHUNK=17)
+    pc.case_streamed(e)
+    e.close()
+
+
+def test_fragset_wire_format(emu_engine):
+    def alloc(nbytes):
+        a = np.zeros(nbytes // 4 + 4, dtype=np.uint32)
+        return a, a.ctypes.data
+    pc.case_fragset_wire(emu_engine, alloc)
+
+
 def test_sketch_file(emu_engine, tmp_path):
     pc.case_sketch_file(emu_engine, tmp_path)
 

@@ -233,6 +233,53 @@ def test_repeated_runs_are_identical(monkeypatch):
     e.close()
 
 
+def test_streamed_reference_set(monkeypatch, tmp_path):
+    """reference set streamed chunk by chunk (one resident chunk), then with two resident chunks and tiny query sub-batches"""
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=7000, ANI_MAX_RESIDENT_CHUNKS=1)
+    pc.case_streamed(e, tmp_path)
+    assert pc.fuzz(e, seed=31, iterations=20) == 20
+    e.close()
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=7000, ANI_MAX_RESIDENT_CHUNKS=2, ANI_SUBBATCH_FRAGS=11, ANI_L2_CHUNK=17)
+    pc.case_streamed(e)
+    e.close()
+
+
+def test_streamed_full_size_equals_resident(gpu_engine, monkeypatch):
+    """24 x 5 Mbp: 5 chunks, one resident at a time, against the single resident index: identical rows, exact unique count"""
+    import torch
+    from fastani_amd.api import DeviceGenomes, Sketch
+    n, L = 24, 5_000_000
+    words = (L + 15) // 16
+    buf = torch.zeros(n * words + 64, dtype=torch.int32, device="cuda:0")
+    gpu_engine.synth_packed(99, 0, n, L, buf.data_ptr())
+    dg = DeviceGenomes(buf.data_ptr(), n, L)
+    p = gpu_engine.params()
+    sk = Sketch(gpu_engine, p, dg)
+    rows = sk.map_cgi_batch(dg, 0)
+    st = sk.stats()
+    sk.close()
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=2_000_000, ANI_MAX_RESIDENT_CHUNKS=1)
+    sk2 = Sketch(e, p, dg)
+    assert len(sk2.chunks()) >= 5 and sk2.residency()["streaming"]
+    assert np.array_equal(sk2.map_cgi_batch(dg, 0), rows)
+    assert sk2.stats() == st
+    ptr, nrec, frags = e.sketch_records_self(p, dg, 0)
+    e.device_free(ptr)
+    assert np.array_equal(sk2.map_cgi_fragset(frags, 0), rows)
+    frags.close()
+    e.close()
+
+
+def test_fragset_wire_format(gpu_engine):
+    import torch
+
+    def alloc(nbytes):
+        t = torch.zeros(nbytes // 4 + 4, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        return t, t.data_ptr()
+    pc.case_fragset_wire(gpu_engine, alloc)
+
+
 def test_sketch_file(gpu_engine, tmp_path):
     pc.case_sketch_file(gpu_engine, tmp_path)
 
