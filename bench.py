@@ -17,9 +17,12 @@ Workloads (config.workload):
               minimizer records are all-gathered once over RCCL/xGMI and every rank builds the full index.
   one-to-many = configs[1]: 1 query genome (cluster 0, member 1) against the 1000-genome set; a step still sketches and
       indexes the references (the reference does too); the map-only latency is reported beside it.
-  c4 = configs[3]: 10000 x 10000 (all-vs-all, 500 clusters), the reference set held as several index chunks; queries
-      sharded over the GPUs (rank r maps genomes [r*10000/N, (r+1)*10000/N)), reference records all-gathered.
-      --queries bounds the query count for a single-GPU run.
+  c4 = configs[3]: 10000 x 10000 (all-vs-all, 500 clusters).
+      N = 1 : the reference set held as several index chunks (streamed through the device when they do not fit); --queries bounds
+              the query count.
+      N > 1 : REFERENCE-sharded (fastani_amd/multi_gpu.py): rank r sketches and indexes genomes [r*10000/N, (r+1)*10000/N) only;
+              the ranks' query fragment sketches go round a ring (isend/irecv over RCCL, overlapped with the mapping) and every rank
+              maps every query against its shard.  No replicated index build, 1/N of the index memory per GPU.
 
 Prints ONE JSON line on rank 0 (see the driver contract): value = whole-job pairs/sec, plus
   roofline     — the dominant kernel (L2 sliding MinHash), algorithmic bytes (12*m_c + 4*s per candidate)
@@ -317,18 +320,36 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     dist = None
+    # ANI_BENCH_BACKEND=emu (tests only, tests/test_distributed_gloo.py): the step logic of this file on the CPU build of the
+    # product sources (tests/emu) over gloo, with tiny genomes — so that the multi-rank orchestration is exercised where there is
+    # no GPU.  Never a measurement: the line it prints says so.
+    emu = os.environ.get("ANI_BENCH_BACKEND", "") == "emu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cpu") if emu else torch.device("cuda", local)
+    if not emu:
+        torch.cuda.set_device(dev)
+
+    def dev_sync():
+        if not emu:
+            torch.cuda.synchronize()
 
     import numpy as np
     import fastani_amd
     from fastani_amd.api import DeviceGenomes, Sketch
-    e = fastani_amd.engine(local)
+    if emu:
+        import ctypes
+        from fastani_amd.api import Engine
+        e = Engine(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libfastani_emu.so")), 0)
+        args.no_cpu_baseline = args.no_e2e = args.no_verify = True
+    else:
+        e = fastani_amd.engine(local)
     p = e.params(16, 3000)
     L = args.genome_len
     words = (L + 15) // 16
@@ -372,12 +393,28 @@ def main():
 
     # multi-GPU staging buffers (allocated once): every rank's records land in its slot of `allrec`; the slot's first record
     # carries the count, so ONE all-gather moves counts and records (no count all-reduce, no compaction copy in the step)
+    ring_mode = world > 1 and cfg == "c4"        # reference-sharded: every rank indexes ITS genomes only, the query fragment sketches go round the ring
     if world > 1:
+        part_g0 = np.array([(NR * r) // world for r in range(world + 1)], dtype=np.int32)
+    if world > 1 and not ring_mode:
         slot = int((hi - lo + 1) * (2.3 * L / (p.windowSize + 1))) + 4096          # records per rank, upper bound
         allrec = torch.empty(world * (slot + 1) * 3, dtype=torch.int32, device=dev)
         mine = allrec[rank * (slot + 1) * 3:(rank + 1) * (slot + 1) * 3]
-        part_g0 = np.array([(NR * r) // world for r in range(world + 1)], dtype=np.int32)
-    timers = {"allgather_ms": 0.0, "ref_records_ms": 0.0, "index_ms": 0.0, "map_ms": 0.0}
+    if ring_mode:
+        from fastani_amd.multi_gpu import ring_map
+        nq_local = hi - lo
+        n_queries_total = NR
+        contig_len_local = np.full(hi - lo, L, dtype=np.int32)
+        gcs_local = np.arange(hi - lo + 1, dtype=np.int32)
+
+        def ring_alloc(nbytes):
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            return t, t.data_ptr()
+    # per-rank timeline of a step (host clock; the library calls return when their device work is done):
+    #   ref_records = reference sketching (the rank's share), fragsketch = fragment sketches of the rank's own queries,
+    #   allgather = the part of the record all-gather that is NOT hidden behind the fragment sketching, index = index build,
+    #   map = mapping + reduce + rows to the host, ring_wait = waiting for the next fragment set of the ring
+    timers = {"allgather_ms": 0.0, "ref_records_ms": 0.0, "fragsketch_ms": 0.0, "index_ms": 0.0, "map_ms": 0.0, "ring_pack_ms": 0.0, "ring_wait_ms": 0.0}
 
     def step():
         t_a = time.perf_counter()
@@ -392,6 +429,22 @@ def main():
         elif world == 1:
             sk = Sketch(e, p, refs)
             t_b = t_c = time.perf_counter()
+        elif ring_mode:
+            # reference-sharded all-vs-all (fastani_amd/multi_gpu.py): this rank's genomes hashed once for both roles, indexed here
+            # and nowhere else; then N ring steps, each mapping one rank's fragment set against the shard while the next one arrives
+            ptr, n, frags = e.sketch_records_self(p, my_refs, 0)
+            t_b = t_c = time.perf_counter()
+            sk = Sketch(e, p, records=(ptr, n, contig_len_local, gcs_local))
+            if n:
+                e.device_free(ptr)
+            t_d = time.perf_counter()
+            rt = {}
+            rows = ring_map(e, sk, frags, part_g0, lo, dist, rank, world, ring_alloc, dev_sync, rt)
+            frags.close()
+            sk.close()
+            timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["index_ms"] += (t_d - t_c) * 1e3
+            timers["map_ms"] += rt["map_ms"]; timers["ring_pack_ms"] += rt["pack_ms"]; timers["ring_wait_ms"] += rt["wait_ms"]
+            return rows
         else:
             ptr, n = e.sketch_records(p, my_refs, lo)         # records with global seqIds
             if n > slot:
@@ -401,11 +454,16 @@ def main():
             if n:
                 e.device_copy(mine.data_ptr() + 12, ptr, n * 12)
                 e.device_free(ptr)
-            torch.cuda.synchronize()                          # the library copies on its own stream
-            t_b = time.perf_counter()
-            dist.all_gather_into_tensor(allrec, mine)         # one collective: the reference sketch over RCCL/xGMI
-            torch.cuda.synchronize()
+            dev_sync()                          # the library copies on its own stream
+            t_r = time.perf_counter()
+            work = dist.all_gather_into_tensor(allrec, mine, async_op=True)   # one collective: the reference sketch over RCCL/xGMI ...
+            frags = e.fragment_set(p, qrys)                   # ... while this rank sketches the fragments of its own queries
+            t_f = time.perf_counter()
+            work.wait()
+            dev_sync()
             t_c = time.perf_counter()
+            timers["ref_records_ms"] += (t_r - t_a) * 1e3; timers["fragsketch_ms"] += (t_f - t_r) * 1e3
+            t_a = t_b = t_f                                    # below: allgather_ms = what is left of the gather once the fragment sketches are done
             counts = [int(x) for x in allrec[0::(slot + 1) * 3][:world].tolist()]
             ptrs = [allrec.data_ptr() + (r * (slot + 1) + 1) * 12 for r in range(world)]
             sk = Sketch(e, p, record_parts=(ptrs, counts, part_g0, contig_len, gcs))
@@ -422,10 +480,10 @@ def main():
         return rows
 
     def sync():
-        torch.cuda.synchronize()
+        dev_sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     for _ in range(args.warmup):
         step()
@@ -457,15 +515,25 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mine_info = torch.tensor([dt_local * 1e3 / args.steps, timers["allgather_ms"] / args.steps, timers["ref_records_ms"] / args.steps,
-                                  timers["index_ms"] / args.steps, timers["map_ms"] / args.steps, float(len(rows))], dtype=torch.float64, device=dev)
-        gathered = torch.empty(world * 6, dtype=torch.float64, device=dev)
+        keys = ["ref_records_ms", "fragsketch_ms", "allgather_ms", "index_ms", "map_ms", "ring_pack_ms", "ring_wait_ms"]
+        step_local = dt_local * 1e3 / args.steps
+        vals = [step_local] + [timers[k] / args.steps for k in keys]
+        vals.append(step_local - sum(vals[1:]))                       # host time of the step outside every bracket
+        vals.append(float(len(rows)))
+        mine_info = torch.tensor(vals, dtype=torch.float64, device=dev)
+        nv = len(vals)
+        gathered = torch.empty(world * nv, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(gathered, mine_info)
-        g = gathered.view(world, 6).tolist()
-        rank_info = {"ranks_seen_by_rccl": dist.get_world_size(), "step_ms": [round(x[0], 2) for x in g], "allgather_ms": [round(x[1], 2) for x in g],
-                     "ref_records_ms": [round(x[2], 2) for x in g], "index_ms": [round(x[3], 2) for x in g], "map_ms": [round(x[4], 2) for x in g],
-                     "rows": [int(x[5]) for x in g],
-                     "allgather_bytes_per_rank": int((slot + 1) * 12 * world) if world > 1 else 0}
+        g = gathered.view(world, nv).tolist()
+        rank_info = {"ranks_seen_by_rccl": dist.get_world_size(), "mode": "reference-sharded ring (fastani_amd/multi_gpu.py)" if ring_mode else "query-sharded, reference records all-gathered",
+                     "timeline_note": "per rank, ms per step: ref_records = sketching the rank's references, fragsketch = its queries' fragment sketches (runs while the records are "
+                                      "all-gathered), allgather = the part of the gather not hidden behind it, index = index build, map = mapping + reduce + rows to the host, "
+                                      "ring_pack / ring_wait = packing the fragment set / waiting for the next set of the ring, other = the rest of the step",
+                     "step_ms": [round(x[0], 2) for x in g]}
+        for i, k in enumerate(keys + ["other_ms"]):
+            rank_info[k] = [round(x[1 + i], 2) for x in g]
+        rank_info["rows"] = [int(x[-1]) for x in g]
+        rank_info["bytes_moved_per_rank"] = (int(getattr(e, "_ring_bufs", (("", 0),))[0][1]) * (world - 1)) if ring_mode else int((slot + 1) * 12 * (world - 1))
     c = e.counters()
 
     # one-to-many: the latency-shaped number — map the one query against a resident index
@@ -473,7 +541,7 @@ def main():
     if cfg == "one-to-many" and rank == 0:
         sk = Sketch(e, p, refs)
         sk.map_cgi_batch(qrys, first_query_id)
-        torch.cuda.synchronize()
+        dev_sync()
         ts = []
         for _ in range(max(3, args.steps)):
             t1 = time.perf_counter()
@@ -549,9 +617,10 @@ def main():
               "c4": "many-to-many %dx%d (configs[3] shape, all-vs-all%s)" % (NR, n_queries_total, "" if n_queries_total == NR else ", query count bounded by --queries")}[cfg]
         out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-               "higher_is_better": True, "scaling": "weak" if cfg != "c4" else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak" if cfg != "c4" else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic" if not emu else "synthetic; CPU EMULATION OF THE KERNELS (test of the orchestration, not a measurement)",
                "config": {"workload": "%s synthetic %d bp genomes (clusters of 20, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
-                                      % (wl, L, p.windowSize, "" if world == 1 else "; queries sharded %d ways, reference sketch all-gathered over RCCL" % world),
+                                      % (wl, L, p.windowSize, "" if world == 1 else ("; references sharded %d ways, query fragment sketches ring-passed over RCCL" % world if ring_mode
+                                                                                   else "; queries sharded %d ways, reference sketch all-gathered over RCCL" % world)),
                           "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM", "all_vs_all_single_hash_pass": bool(self_mode),
                           "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
                "rows_last_step": int(len(rows)), "rows_identical_across_steps": len(set(rows_crc)) == 1, "step_ms_rank0": step_ms,

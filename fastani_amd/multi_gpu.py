@@ -1,0 +1,75 @@
+"""Reference-sharded many-to-many over the GPUs of one node (one process per GPU; torch.distributed: "nccl" = RCCL over xGMI).
+
+The query-sharded form of SURVEY.md section 8e (every GPU holds the whole reference index) stops scaling where the index stops
+fitting: N GPUs hold exactly as many references as one, and every rank repeats the whole index build.  Here the REFERENCES are
+sharded: rank r sketches and indexes genomes [g0[r], g0[r+1]) only (1/N of the index memory and of the build), and what travels
+is the query side — each rank's kept fragment sketches (4 bytes per sketch hash: a third of the 12-byte minimizer records) go
+round the ring, one hop per step, while the previous set is being mapped:
+
+    step s:  rank r maps the fragment set that started at rank (r - s) mod N against its shard,
+             sends it on to rank r + 1 and receives the next one from rank r - 1  (isend / irecv, overlapped with the mapping)
+
+After N steps every rank has mapped every query against its references; a (query, reference) result does not depend on what else
+is in an index, so the union of the ranks' rows is the single-index result.  The reference itself splits its
+database the same way and maps every query against every split (computeCoreIdentity.hpp:457-487, core_genome_identity.cpp:55-121).
+xGMI is point to point: a ring hop uses one link per direction, 2 GB per 1250-genome set = ~15 ms against ~350 ms of mapping.
+"""
+import time
+
+import numpy as np
+
+from .api import FragmentSet
+
+
+def ring_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, alloc, sync, timers=None):
+    """sk: this rank's sketch over ITS reference shard (local genome ids; global id = ref_base + local id).
+    frags: this rank's kept fragment set (its query genomes); first_query_ids[r] = global id of rank r's first query genome.
+    alloc(nbytes) -> (tensor, device pointer) of a byte buffer torch.distributed can send; sync() makes received bytes visible to
+    the library's stream (torch.cuda.synchronize on a GPU).  Returns the rows of (all queries) x (this rank's references)."""
+    import torch
+    t = timers if timers is not None else {}
+    for k in ("pack_ms", "map_ms", "wait_ms"):
+        t.setdefault(k, 0.0)
+    t0 = time.perf_counter()
+    nb = frags.packed_bytes()
+    cap = nb
+    if world > 1:
+        m = torch.tensor([nb], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            m = m.cuda()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        cap = int(m.item())
+    key = ("ring_bufs", cap)
+    bufs = getattr(engine, "_ring_bufs", None)
+    if bufs is None or bufs[0] != key:
+        bufs = (key, [alloc(cap), alloc(cap)])
+        engine._ring_bufs = bufs
+    (b0, p0), (b1, p1) = bufs[1]
+    tens, ptrs = [b0, b1], [p0, p1]
+    frags.pack_into(ptrs[0], cap)
+    sync()
+    t["pack_ms"] += (time.perf_counter() - t0) * 1e3
+    out = []
+    cur = 0
+    for s in range(world):
+        src = (rank - s) % world
+        reqs = None
+        if s < world - 1:
+            ops = [dist.P2POp(dist.isend, tens[cur], (rank + 1) % world), dist.P2POp(dist.irecv, tens[1 - cur], (rank - 1) % world)]
+            reqs = dist.batch_isend_irecv(ops)
+        t1 = time.perf_counter()
+        view = FragmentSet.unpack(engine, ptrs[cur], cap, keepalive=tens[cur])
+        rows = sk.map_cgi_fragset(view, int(first_query_ids[src]))
+        view.close()
+        rows["refGenomeId"] += ref_base
+        out.append(rows)
+        t2 = time.perf_counter()
+        if reqs is not None:
+            for r in reqs:
+                r.wait()
+            sync()
+        t3 = time.perf_counter()
+        t["map_ms"] += (t2 - t1) * 1e3
+        t["wait_ms"] += (t3 - t2) * 1e3
+        cur = 1 - cur
+    return np.concatenate(out) if out else np.zeros(0, dtype=rows.dtype)

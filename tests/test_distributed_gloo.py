@@ -61,6 +61,59 @@ def _worker(rank, world, port, out_dir, n_genomes):
     dist.destroy_process_group()
 
 
+def _ring_worker(rank, world, port, out_dir, n_genomes):
+    """the reference-sharded step of bench.py --config c4 (fastani_amd/multi_gpu.py): every rank sketches and indexes ITS genomes
+    only (fused all-vs-all pass: reference records + kept fragment sketches), the packed fragment sets go round the ring and every
+    rank maps every set against its shard"""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fastani_amd.api import Engine, HostGenomes, Sketch
+    from fastani_amd.multi_gpu import ring_map
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    e = Engine(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libfastani_emu.so")), 0)
+    p = e.params()
+    genomes = _genomes(n_genomes)
+    part_g0 = [(len(genomes) * r) // world for r in range(world + 1)]
+    lo, hi = part_g0[rank], part_g0[rank + 1]                                           # uneven, possibly empty
+    mine = genomes[lo:hi]
+    contig_len = np.array([len(c) for g in mine for c in g], dtype=np.int32)
+    gcs = np.cumsum([0] + [len(g) for g in mine]).astype(np.int32)
+    ptr, n, frags = e.sketch_records_self(p, HostGenomes(mine), 0)
+    sk = Sketch(e, p, records=(ptr, n, contig_len, gcs))
+    if n:
+        e.device_free(ptr)
+
+    def alloc(nbytes):
+        t = torch.zeros(nbytes, dtype=torch.uint8)
+        return t, t.data_ptr()
+    timers = {}
+    rows = ring_map(e, sk, frags, part_g0, lo, dist, rank, world, alloc, lambda: None, timers)
+    frags.close()
+    np.save(os.path.join(out_dir, "ring%d.npy" % rank), rows)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_genomes", [(2, 5), (4, 3)])
+def test_reference_sharded_ring_matches_single_process(tmp_path, emu_engine, world, n_genomes):
+    """world 4 with 3 genomes: rank 0 has no genome at all — an empty index and an empty fragment set still travel the ring"""
+    import torch.multiprocessing as mp
+    from fastani_amd.api import Sketch
+    port = 29900 + (os.getpid() % 400) + 10 * world + n_genomes
+    mp.spawn(_ring_worker, args=(world, port, str(tmp_path), n_genomes), nprocs=world, join=True)
+    genomes = _genomes(n_genomes)
+    p = emu_engine.params()
+    single = Sketch(emu_engine, p, genomes).map_cgi_batch(genomes, 0)
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "ring%d.npy" % r)) for r in range(world)])
+    got = got[np.lexsort((got["refGenomeId"], got["qryGenomeId"]))]
+    assert np.array_equal(got, single)
+
+
 def fastani_rows_dtype():
     from fastani_amd.api import CGI_DT
     return CGI_DT
@@ -91,3 +144,29 @@ def test_sharded_sketch_allgather_matches_single_process(tmp_path, emu_engine, w
         maps, tot = osk.map_genome(g)
         exp.append(osk.compute_cgi(maps, tot, qi))
     assert np.array_equal(single, np.concatenate(exp))
+
+
+@pytest.mark.parametrize("config", ["many-to-many", "c4"])
+def test_bench_orchestration_two_ranks(config, emu_engine):
+    """bench.py's own multi-rank step — query-sharded with the reference records all-gathered (default workload), and
+    reference-sharded with the fragment sets ring-passed (--config c4) — launched the way the driver launches it, on the CPU
+    build of the product sources over gloo (ANI_BENCH_BACKEND=emu, a test-only switch): 6 genomes of one cluster, every pair related."""
+    import json
+    import subprocess
+    port = 29300 + (os.getpid() % 300) + (7 if config == "c4" else 0)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", config, "--genomes", "6", "--genome-len", "24000"],
+                       capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and "EMULATION" in out["data"] and out["rows_identical_across_steps"]
+    ranks = out["ranks"]
+    assert ranks["ranks_seen_by_rccl"] == 2 and len(ranks["step_ms"]) == 2
+    if config == "c4":
+        assert out["config"]["query_genomes"] == 6 and sum(ranks["rows"]) == 36 and "ring" in ranks["mode"]
+        assert ranks["bytes_moved_per_rank"] > 0
+    else:
+        assert out["config"]["query_genomes"] == 12 and ranks["rows"] == [36, 36]
+    for k in ("ref_records_ms", "fragsketch_ms", "allgather_ms", "index_ms", "map_ms", "ring_wait_ms", "other_ms"):
+        assert len(ranks[k]) == 2
