@@ -13,10 +13,11 @@
 // all, the paper's use) every genome is read, packed and uploaded once and stays on the device for both roles.
 // Reference sets of any size: the library cuts them into index chunks (ani_sketch_chunks).
 //
-// `--gpus N` (extension): one host thread and one context per GPU; the reference slices are sketched round-robin over the GPUs,
-// every GPU pulls the other GPUs' minimizer records peer-to-peer over xGMI (an all-gather on the fully connected mesh: each of
-// the 7 links of a GPU carries one peer's shard) and builds the full index; query slices are mapped round-robin.  `-t` keeps its
-// meaning for the readers; results do not depend on it (tests/fastani_tests.cpp:199-255), except that with `-s` the reference
+// `--gpus N` (extension): the REFERENCES are sharded — GPU d sketches and indexes a contiguous run of the reference files only — and
+// every query is mapped against every shard: the queries' fragment sketches (made once, on the GPU that read the slice) are packed
+// into one buffer per slice and pulled peer-to-peer over xGMI by the other GPUs, round by round.  No index is replicated, so N GPUs
+// hold N times the references of one; a shard that still exceeds its GPU is streamed chunk by chunk inside the library.  `-t` keeps
+// its meaning for the readers; results do not depend on it (tests/fastani_tests.cpp:199-255), except that with `-s` the reference
 // checks each of its T reference splits separately (core_genome_identity.cpp:76-79), which is reproduced by sketching the same
 // round-robin splits.
 #include <zlib.h>
@@ -430,33 +431,53 @@ int main(int argc, char **argv)
     const auto refSlices = make_slices(fp, 0, nRefFiles, kSliceBytes);
     const auto qrySlices = allVsAll ? refSlices : make_slices(fp, nRefFiles, files.size(), kSliceBytes);
 
-    // reference tables, filled slice by slice
-    std::vector<int32_t> contigLenAll, gcsAll{0};
-    std::vector<RefPart> parts(refSlices.size());
-    std::vector<ani_fragset *> kept(allVsAll ? refSlices.size() : 0, nullptr);     // all-vs-all: the slices' fragment sketches stay on their device
+    // The REFERENCES are sharded over the devices: device d takes a contiguous run of the reference slices, sketches and indexes
+    // those genomes only (no replicated index build, 1/N of the index memory per GPU, and the set may exceed one GPU's memory N
+    // times over; a shard that still does not fit is streamed chunk by chunk inside the library, ani_sketch_residency).  Every
+    // query is mapped against every shard (the reference does the same with its database splits, computeCoreIdentity.hpp:457-487,
+    // core_genome_identity.cpp:55-121): what travels between the GPUs is the queries' fragment sketches, packed into one buffer
+    // per slice (ani_fragset_pack) and pulled peer-to-peer over xGMI, a third of the size of the minimizer records.
+    struct Shard {
+      std::vector<int32_t> contigLen, gcs{0};           // the shard's own contig / genome tables (ids local to the shard)
+      std::vector<RefPart> parts;                        // one per slice of the shard (genome ranges local)
+      int32_t g0 = 0, nGenomes = 0;                      // first reference (file index) of the shard, genomes in it
+      ani_sketch *sk = nullptr;
+    };
+    std::vector<Shard> shard((size_t)nDev);
+    auto refOwner = [&](size_t k) { return (int)((k * (size_t)nDev) / std::max<size_t>(refSlices.size(), 1)); };
+    for (size_t k = 0; k < refSlices.size(); k++) {
+      Shard &sh = shard[(size_t)refOwner(k)];
+      if (sh.parts.empty()) sh.g0 = (int32_t)refSlices[k].first;
+      sh.parts.emplace_back();
+    }
+    std::vector<size_t> partOfSlice(refSlices.size(), 0);
+    { std::vector<size_t> seen((size_t)nDev, 0); for (size_t k = 0; k < refSlices.size(); k++) partOfSlice[k] = seen[(size_t)refOwner(k)]++; }
+    // fragment sketches of the query side, one entry per query slice: kept on the device that made them, packed for the others
+    struct QSet { ani_fragset *f = nullptr; void *packed = nullptr; size_t bytes = 0; int dev = 0; int32_t firstQuery = 0; };
+    std::vector<QSet> qsets(qrySlices.size());
     const auto t0 = Clock::now();
-    // Two threads per device.  The upload thread takes the device's slices in order (k = d, d + nDev, ...): waits for the readers,
-    // enters the slice into the global contig / genome tables (in slice order: contig numbering is global), packs and copies it to
-    // the device on its own context.  The compute thread sketches the uploaded slices.  So parsing (reader pool), packing + H2D and
-    // the kernels of consecutive slices overlap.  All-vs-all: the fused pass also yields the slice's fragment sketches, which are
-    // what the mapping phase needs; the packed bases are dropped right away.
+    // Two threads per device.  The upload thread takes the device's slices in order: waits for the readers, enters the slice into
+    // the shard's contig / genome tables, packs and copies it to the device on its own context.  The compute thread sketches the
+    // uploaded slices.  So parsing (reader pool), packing + H2D and the kernels of consecutive slices overlap.  All-vs-all: the fused
+    // pass also yields the slice's fragment sketches, which are what the mapping phase needs; the packed bases are dropped right away.
     struct Uploaded { ani_dev_batch *b = nullptr; std::vector<int32_t> len, gcs; int32_t seqBase = 0; bool ready = false; };
-    auto run_two_stage = [&](const std::vector<std::pair<size_t, size_t>> &slices, const char *what,
+    auto run_two_stage = [&](const std::vector<std::pair<size_t, size_t>> &slices, const char *what, const std::function<int(size_t)> &ownerOf,
                              const std::function<bool(int, size_t, SliceBatch &, Uploaded &)> &enter,          // bookkeeping before the upload (upload thread)
-                             const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute,       // device work on the uploaded slice (compute thread)
-                             const std::function<void()> &onAbort = std::function<void()>()) {                 // called by a thread that gives up (error on its device or in its input)
+                             const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute) {     // device work on the uploaded slice (compute thread)
       std::vector<Uploaded> ups(slices.size());
       std::vector<std::string> errs((size_t)nDev);
       std::mutex mu; std::condition_variable cv;
       std::vector<size_t> done((size_t)nDev, 0);          // slices the compute thread of device d has finished (bounds the upload thread's lead)
+      std::vector<std::vector<size_t>> mineOf((size_t)nDev);
+      for (size_t k = 0; k < slices.size(); k++) mineOf[(size_t)ownerOf(k)].push_back(k);
       std::vector<std::thread> th;
       for (int d = 0; d < nDev; d++) {
         th.emplace_back([&, d]() {                        // upload thread
-          size_t mine = 0;
-          for (size_t k = (size_t)d; k < slices.size(); k += (size_t)nDev, mine++) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return mine < done[d] + 2 || !errs[d].empty(); }); if (!errs[d].empty()) { lk.unlock(); if (onAbort) onAbort(); return; } }
+          for (size_t mine = 0; mine < mineOf[d].size(); mine++) {
+            const size_t k = mineOf[d][mine];
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return mine < done[d] + 2 || !errs[d].empty(); }); if (!errs[d].empty()) return; }
             const size_t a = slices[k].first, b = slices[k].second;
-            if (!fp.wait(a, b)) { { std::lock_guard<std::mutex> lk(mu); errs[d] = "input"; } cv.notify_all(); if (onAbort) onAbort(); return; }
+            if (!fp.wait(a, b)) { { std::lock_guard<std::mutex> lk(mu); errs[d] = "input"; } cv.notify_all(); return; }
             SliceBatch sb;
             for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
             Uploaded &u = ups[k];
@@ -468,22 +489,22 @@ int main(int argc, char **argv)
             u.len = std::move(sb.len); u.gcs = std::move(sb.gcs);
             { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "upload" : msg; u.ready = true; }
             cv.notify_all();
-            if (!ok) { if (onAbort) onAbort(); return; }
+            if (!ok) return;
           }
         });
         th.emplace_back([&, d]() {                        // compute thread
-          for (size_t k = (size_t)d; k < slices.size(); k += (size_t)nDev) {
+          for (size_t k : mineOf[d]) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return ups[k].ready || !errs[d].empty(); }); if (!errs[d].empty()) return; }
             std::string msg;
             const bool ok = compute(d, k, ups[k], msg);
             if (ups[k].b) { ani_batch_free(ups[k].b); ups[k].b = nullptr; }
             { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "device" : msg; done[d]++; }
             cv.notify_all();
-            if (!ok) { if (onAbort) onAbort(); return; }
+            if (!ok) return;
           }
         });
       }
-      for (auto &t : th) t.join();
+      for (auto &t : th) t.join();        // no thread waits for another device's: a failing device cannot stall the others
       for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, " << what << ": " << e << std::endl; exit(1); }
     };
     auto dev_view = [](const Uploaded &u) {
@@ -492,115 +513,96 @@ int main(int argc, char **argv)
       db.genomeContigStart = u.gcs.data(); db.contigOffset = nullptr; db.contigLen = u.len.empty() ? &zero : u.len.data(); db.data = u.b;
       return db;
     };
-    {
-      std::mutex orderMu; std::condition_variable orderCv; size_t nextSlice = 0;   // slices enter the tables in order
-      bool orderAbort = false;        // a device's threads gave up: the slices they would have entered never come, nobody may wait for them
-      run_two_stage(refSlices, "reference sketch",
-        [&](int d, size_t k, SliceBatch &sb, Uploaded &u) {
-          std::unique_lock<std::mutex> lk(orderMu);
-          orderCv.wait(lk, [&]() { return nextSlice == k || orderAbort; });
-          if (orderAbort) return false;
-          u.seqBase = (int32_t)contigLenAll.size();
-          const int32_t gBase = (int32_t)gcsAll.size() - 1;
-          contigLenAll.insert(contigLenAll.end(), sb.len.begin(), sb.len.end());
-          for (size_t g = 1; g < sb.gcs.size(); g++) gcsAll.push_back(u.seqBase + sb.gcs[g]);
-          parts[k].g0 = gBase; parts[k].g1 = gBase + (int32_t)sb.gcs.size() - 1; parts[k].dev = d;
-          nextSlice = k + 1;
-          lk.unlock(); orderCv.notify_all();
-          return true;
-        },
-        [&](int d, size_t k, Uploaded &u, std::string &msg) {
-          ani_seq_batch_t db = dev_view(u);
-          size_t n = 0;
-          const int rc = allVsAll ? ani_sketch_records_self(dev[d].ctx, &ap, &db, u.seqBase, &parts[k].rec, &n, &kept[k])
-                                  : ani_sketch_records(dev[d].ctx, &ap, &db, u.seqBase, &parts[k].rec, &n);
-          if (rc) { msg = ani_last_error(); return false; }
-          parts[k].n = n;
-          return true;
-        },
-        [&]() { { std::lock_guard<std::mutex> lk(orderMu); orderAbort = true; } orderCv.notify_all(); });
-    }
-    trace("reference slices sketched");
-    // every device gets every part (peer-to-peer pulls), then builds the full index
-    std::vector<ani_sketch *> sk((size_t)nDev, nullptr);
-    if (fromFile) {
-      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
-      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() { if (ani_sketch_load(dev[d].ctx, o.refSketch.c_str(), 0, -1, &sk[d])) errs[d] = ani_last_error(); });
-      for (auto &w : workers) w.join();
-      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, reference sketch file: " << e << std::endl; exit(1); }
-      const int32_t *cl = nullptr, *gcs = nullptr;
-      ani_sketch_tables(sk[0], &cl, &gcs);
-      for (int g = 0; g < nRef; g++) {
-        o.refs[g] = ani_sketch_genome_name(sk[0], g);
-        Genome gm; gm.lens.assign(cl + gcs[g], cl + gcs[g + 1]);
-        noteLength(o.refs[g], gm);
-      }
-    } else {
-      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
-      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
-        std::vector<const void *> recs(parts.size()); std::vector<uint64_t> ns(parts.size()); std::vector<int32_t> pgs(parts.size() + 1, 0);
-        std::vector<void *> pulled;
-        for (size_t k = 0; k < parts.size(); k++) {
-          ns[k] = parts[k].n; pgs[k] = parts[k].g0; pgs[k + 1] = parts[k].g1;
-          if (parts[k].dev == d || parts[k].n == 0) { recs[k] = parts[k].rec; continue; }
-          void *p = nullptr;
-          if (ani_device_alloc(dev[d].ctx, parts[k].n * 12, &p) || ani_device_copy_peer(dev[d].ctx, p, dev[parts[k].dev].ctx, parts[k].rec, parts[k].n * 12)) { errs[d] = ani_last_error(); return; }
-          recs[k] = p; pulled.push_back(p);
-        }
-        if (ani_sketch_from_record_parts(dev[d].ctx, &ap, (int32_t)parts.size(), recs.data(), ns.data(), pgs.data(), contigLenAll.data(), (int32_t)contigLenAll.size(),
-                                         gcsAll.data(), (int32_t)gcsAll.size() - 1, &sk[d])) { errs[d] = ani_last_error(); return; }
-        for (void *p : pulled) ani_device_free(dev[d].ctx, p);
+    run_two_stage(refSlices, "reference sketch", refOwner,
+      [&](int d, size_t k, SliceBatch &sb, Uploaded &u) {              // the device's slices arrive in order: its tables need no lock
+        Shard &sh = shard[(size_t)d];
+        u.seqBase = (int32_t)sh.contigLen.size();
+        const int32_t gBase = (int32_t)sh.gcs.size() - 1;
+        sh.contigLen.insert(sh.contigLen.end(), sb.len.begin(), sb.len.end());
+        for (size_t g = 1; g < sb.gcs.size(); g++) sh.gcs.push_back(u.seqBase + sb.gcs[g]);
+        RefPart &pt = sh.parts[partOfSlice[k]];
+        pt.g0 = gBase; pt.g1 = gBase + (int32_t)sb.gcs.size() - 1; pt.dev = d;
+        return true;
+      },
+      [&](int d, size_t k, Uploaded &u, std::string &msg) {
+        ani_seq_batch_t db = dev_view(u);
+        RefPart &pt = shard[(size_t)d].parts[partOfSlice[k]];
+        size_t n = 0;
+        const int rc = allVsAll ? ani_sketch_records_self(dev[d].ctx, &ap, &db, u.seqBase, &pt.rec, &n, &qsets[k].f)
+                                : ani_sketch_records(dev[d].ctx, &ap, &db, u.seqBase, &pt.rec, &n);
+        if (rc) { msg = ani_last_error(); return false; }
+        pt.n = n;
+        if (allVsAll) { qsets[k].dev = d; qsets[k].firstQuery = (int32_t)refSlices[k].first; }
+        return true;
       });
+    trace("reference slices sketched");
+    // every device builds the index of its shard
+    {
+      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
+      if (fromFile) {
+        for (int d = 0; d < nDev; d++) { shard[d].g0 = (int32_t)(((int64_t)nRef * d) / nDev); shard[d].nGenomes = (int32_t)(((int64_t)nRef * (d + 1)) / nDev) - shard[d].g0; }
+        for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
+          if (ani_sketch_load(dev[d].ctx, o.refSketch.c_str(), shard[d].g0, shard[d].g0 + shard[d].nGenomes, &shard[d].sk)) errs[d] = ani_last_error(); });
+      } else {
+        for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
+          Shard &sh = shard[(size_t)d];
+          sh.nGenomes = (int32_t)sh.gcs.size() - 1;
+          std::vector<const void *> recs(sh.parts.size()); std::vector<uint64_t> ns(sh.parts.size()); std::vector<int32_t> pgs(sh.parts.size() + 1, 0);
+          for (size_t k = 0; k < sh.parts.size(); k++) { recs[k] = sh.parts[k].rec; ns[k] = sh.parts[k].n; pgs[k] = sh.parts[k].g0; pgs[k + 1] = sh.parts[k].g1; }
+          if (ani_sketch_from_record_parts(dev[d].ctx, &ap, (int32_t)sh.parts.size(), recs.data(), ns.data(), pgs.data(), sh.contigLen.data(), (int32_t)sh.contigLen.size(),
+                                           sh.gcs.data(), sh.nGenomes, &sh.sk)) { errs[d] = ani_last_error(); return; }
+          for (auto &pt : sh.parts) if (pt.rec) { ani_device_free(dev[d].ctx, pt.rec); pt.rec = nullptr; }
+        });
+      }
       for (auto &w : workers) w.join();
-      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, reference index: " << e << std::endl; exit(1); }
-      for (auto &pt : parts) if (pt.rec) ani_device_free(dev[pt.dev].ctx, pt.rec);
+      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, reference " << (fromFile ? "sketch file" : "index") << ": " << e << std::endl; exit(1); }
     }
+    if (fromFile)
+      for (int d = 0; d < nDev; d++) {
+        const int32_t *cl = nullptr, *gcs = nullptr;
+        ani_sketch_tables(shard[d].sk, &cl, &gcs);
+        for (int g = 0; g < shard[d].nGenomes; g++) {
+          o.refs[shard[d].g0 + g] = ani_sketch_genome_name(shard[d].sk, g);
+          Genome gm; gm.lens.assign(cl + gcs[g], cl + gcs[g + 1]);
+          noteLength(o.refs[shard[d].g0 + g], gm);
+        }
+      }
+    bool streamed = false;
     {
       uint64_t occ = 0, uniq = 0; int32_t nChunks = 0;
-      ani_sketch_stats(sk[0], &occ, nullptr, nullptr, nullptr, nullptr);
-      ani_sketch_chunks(sk[0], &nChunks, nullptr, 0);
+      for (int d = 0; d < nDev; d++) {
+        uint64_t oc = 0; int32_t nc = 0, st = 0;
+        ani_sketch_stats(shard[d].sk, &oc, nullptr, nullptr, nullptr, nullptr);
+        ani_sketch_chunks(shard[d].sk, &nc, nullptr, 0);
+        ani_sketch_residency(shard[d].sk, &st, nullptr, nullptr);
+        occ += oc; nChunks += nc; streamed = streamed || st != 0;
+      }
       std::cerr << "INFO [thread 0], skch::Sketch::build, minimizers picked from reference = " << occ << std::endl;
-      if (nChunks <= 1) { ani_sketch_stats(sk[0], nullptr, &uniq, nullptr, nullptr, nullptr); std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl; }
-      else std::cerr << "INFO [thread 0], skch::Sketch::index, reference set held as " << nChunks << " index chunks" << std::endl;
+      if (nChunks <= 1) { ani_sketch_stats(shard[0].sk, nullptr, &uniq, nullptr, nullptr, nullptr); std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl; }
+      else std::cerr << "INFO [thread 0], skch::Sketch::index, reference set held as " << nChunks << " index chunks on " << nDev << " device(s)" << (streamed ? ", streamed" : "") << std::endl;
       std::cerr << "INFO [thread 0], skch::main, Time spent sketching the reference : " << secs_since(t0) << " sec" << std::endl;
     }
 
     if (!o.saveSketch.empty()) {
+      if (nDev > 1) { std::cerr << "ERROR, --saveSketch writes the sketch of one device: run it with --gpus 1" << std::endl; exit(1); }
       std::vector<const char *> nm; for (auto &r : o.refs) nm.push_back(r.c_str());
-      if (ani_sketch_save(sk[0], o.saveSketch.c_str(), nm.data())) die("ani_sketch_save");
+      if (ani_sketch_save(shard[0].sk, o.saveSketch.c_str(), nm.data())) die("ani_sketch_save");
       trace("sketch file written");
     }
     trace("index built");
-    // ---- queries: slices round-robin over the devices; rows are collected per slice so that the order does not depend on timing ----
-    std::vector<std::vector<ani_cgi_t>> sliceRows(qrySlices.size());
+    // ---- queries ----
+    std::vector<std::vector<ani_cgi_t>> sliceRows(qrySlices.size());        // (single device, resident index: rows per query slice)
+    std::vector<std::vector<ani_cgi_t>> devRows((size_t)nDev);
     std::mutex logMu;
     auto log_map = [&](int d, int32_t firstQ, size_t nq, double total, double post) {
       std::lock_guard<std::mutex> lk(logMu);
       std::cerr << "INFO [thread " << d << "], skch::main, Time spent mapping fragments in query #" << firstQ + 1 << "-#" << firstQ + (int32_t)nq << " : " << std::max(0.0, total - post) << " sec" << std::endl;
       std::cerr << "INFO [thread " << d << "], skch::main, Time spent post mapping : " << post << " sec" << std::endl;
     };
-    if (allVsAll) {
-      // slice k's fragment sketches are on device k % nDev already
-      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
-      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
-        for (size_t k = (size_t)d; k < qrySlices.size(); k += (size_t)nDev) {
-          const size_t a = qrySlices[k].first, b = qrySlices[k].second;
-          const auto tm = Clock::now();
-          ani_counters_t c0, c1;
-          ani_get_counters(dev[d].ctx, &c0);
-          ani_cgi_t *rows = nullptr; size_t m = 0;
-          if (ani_map_cgi_fragset(dev[d].ctx, sk[d], kept[k], (int32_t)a, &rows, &m)) { errs[d] = ani_last_error(); return; }
-          ani_fragset_free(kept[k]); kept[k] = nullptr;
-          sliceRows[k].assign(rows, rows + m);
-          ani_free(rows);
-          ani_get_counters(dev[d].ctx, &c1);
-          log_map(d, (int32_t)a, b - a, secs_since(tm), (c1.msReduce - c0.msReduce) / 1e3);
-        }
-      });
-      for (auto &w : workers) w.join();
-      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, mapping: " << e << std::endl; exit(1); }
-    } else {
-      run_two_stage(qrySlices, "mapping",
+    const bool collect = allVsAll || nDev > 1 || streamed;
+    if (!collect) {
+      // one device, index resident, queries != references: the query slices stream through (upload || sketch + map), O(slice) memory
+      run_two_stage(qrySlices, "mapping", [](size_t) { return 0; },
         [&](int, size_t, SliceBatch &, Uploaded &) { return true; },
         [&](int d, size_t k, Uploaded &u, std::string &msg) {
           const size_t a = qrySlices[k].first, b = qrySlices[k].second;
@@ -610,17 +612,80 @@ int main(int argc, char **argv)
           ani_get_counters(dev[d].ctx, &c0);
           ani_seq_batch_t db = dev_view(u);
           ani_cgi_t *rows = nullptr; size_t m = 0;
-          if (ani_map_cgi_batch(dev[d].ctx, sk[d], &db, firstQ, &rows, &m)) { msg = ani_last_error(); return false; }
+          if (ani_map_cgi_batch(dev[d].ctx, shard[d].sk, &db, firstQ, &rows, &m)) { msg = ani_last_error(); return false; }
           sliceRows[k].assign(rows, rows + m);
           ani_free(rows);
           ani_get_counters(dev[d].ctx, &c1);
           log_map(d, firstQ, b - a, secs_since(tm), (c1.msReduce - c0.msReduce) / 1e3);
           return true;
         });
+    } else {
+      // 1. the query side's fragment sketches, slice by slice, on the device that reads the slice (all-vs-all: made by the fused pass)
+      if (!allVsAll)
+        run_two_stage(qrySlices, "query sketch", [&](size_t k) { return (int)(k % (size_t)nDev); },
+          [&](int, size_t, SliceBatch &, Uploaded &) { return true; },
+          [&](int d, size_t k, Uploaded &u, std::string &msg) {
+            ani_seq_batch_t db = dev_view(u);
+            if (ani_fragset_build(dev[d].ctx, &ap, &db, &qsets[k].f)) { msg = ani_last_error(); return false; }
+            qsets[k].dev = d; qsets[k].firstQuery = (int32_t)(qrySlices[k].first - nRefFiles);
+            return true;
+          });
+      // 2. several devices: every set as one buffer the other devices can pull
+      if (nDev > 1)
+        for (auto &q : qsets) {
+          if (!q.f) continue;
+          if (ani_fragset_pack_bytes(q.f, &q.bytes) || ani_device_alloc(dev[q.dev].ctx, q.bytes, &q.packed) || ani_fragset_pack(dev[q.dev].ctx, q.f, q.packed, q.bytes, nullptr)) die("fragment set");
+          ani_fragset_free(q.f); q.f = nullptr;           // the packed form serves the home device as well
+        }
+      trace("query fragment sketches ready");
+      // 3. N rounds: in round s device d maps the sets that live on device (d - s) mod N against its shard — all of them in one call,
+      // so that a streamed shard builds each of its index chunks once per round
+      std::vector<std::thread> workers; std::vector<std::string> errs((size_t)nDev);
+      for (int d = 0; d < nDev; d++) workers.emplace_back([&, d]() {
+        for (int s = 0; s < nDev; s++) {
+          const int src = (d - s + nDev) % nDev;
+          std::vector<const ani_fragset *> sets; std::vector<ani_fragset *> views; std::vector<void *> pulled; std::vector<int32_t> firsts;
+          size_t nq = 0; int32_t firstQ = -1;
+          auto cleanup = [&]() { for (auto *v : views) ani_fragset_free(v); for (void *p : pulled) ani_device_free(dev[d].ctx, p); };
+          for (size_t k = 0; k < qsets.size(); k++) {
+            const QSet &q = qsets[k];
+            if (q.dev != src || (!q.f && !q.packed)) continue;
+            if (firstQ < 0) firstQ = q.firstQuery;
+            nq += qrySlices[k].second - qrySlices[k].first;
+            firsts.push_back(q.firstQuery);
+            if (q.f) { sets.push_back(q.f); continue; }                       // single device: the kept set itself
+            const void *buf = q.packed;
+            if (src != d) {
+              void *p = nullptr;
+              if (ani_device_alloc(dev[d].ctx, q.bytes, &p) || ani_device_copy_peer(dev[d].ctx, p, dev[src].ctx, q.packed, q.bytes)) { errs[d] = ani_last_error(); cleanup(); return; }
+              pulled.push_back(p); buf = p;
+            }
+            ani_fragset *v = nullptr;
+            if (ani_fragset_unpack(dev[d].ctx, buf, q.bytes, &v)) { errs[d] = ani_last_error(); cleanup(); return; }
+            views.push_back(v); sets.push_back(v);
+          }
+          if (sets.empty()) continue;
+          const auto tm = Clock::now();
+          ani_counters_t c0, c1;
+          ani_get_counters(dev[d].ctx, &c0);
+          ani_cgi_t *rows = nullptr; size_t m = 0;
+          if (ani_map_cgi_fragsets(dev[d].ctx, shard[d].sk, (int32_t)sets.size(), sets.data(), firsts.data(), &rows, &m)) { errs[d] = ani_last_error(); cleanup(); return; }
+          for (size_t i = 0; i < m; i++) rows[i].refGenomeId += shard[d].g0;      // shard-local -> reference file index
+          devRows[d].insert(devRows[d].end(), rows, rows + m);
+          ani_free(rows);
+          cleanup();
+          ani_get_counters(dev[d].ctx, &c1);
+          log_map(d, firstQ, nq, secs_since(tm), (c1.msReduce - c0.msReduce) / 1e3);
+        }
+      });
+      for (auto &w : workers) w.join();
+      for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, mapping: " << e << std::endl; exit(1); }
+      for (auto &q : qsets) { if (q.f) ani_fragset_free(q.f); if (q.packed) ani_device_free(dev[q.dev].ctx, q.packed); q.f = nullptr; q.packed = nullptr; }
     }
     trace("queries mapped");
     for (auto &v : sliceRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }
-    for (int d = 0; d < nDev; d++) { ani_sketch_destroy(sk[d]); std::cerr << "INFO [thread " << d << "], skch::main, ready to exit the loop" << std::endl; }
+    for (auto &v : devRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }
+    for (int d = 0; d < nDev; d++) { ani_sketch_destroy(shard[d].sk); std::cerr << "INFO [thread " << d << "], skch::main, ready to exit the loop" << std::endl; }
   } else {
     // =================================================================================================================
     // -s (per-split sanity check, winSketch.hpp:298-318) and --visualize (mappings back on the host): whole sets in memory,

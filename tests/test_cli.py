@@ -116,7 +116,10 @@ def _run_streaming_variants(binary, tmp):
         assert ra.returncode == 0
         ref[name] = (args, out)
     envs = [({}, []), ({"ANI_SLICE_BYTES": "40000"}, []), ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000"}, []),
-            ({"ANI_SLICE_BYTES": "40000"}, ["--devices", "0,0"]), ({"ANI_SLICE_BYTES": "80000", "ANI_MAX_INDEX_MINIMIZERS": "7000"}, ["--devices", "0,0,0"])]
+            ({"ANI_SLICE_BYTES": "40000"}, ["--devices", "0,0"]), ({"ANI_SLICE_BYTES": "80000", "ANI_MAX_INDEX_MINIMIZERS": "7000"}, ["--devices", "0,0,0"]),
+            # reference set streamed through the device: one index chunk resident at a time (what a set beyond the HBM gets)
+            ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, []),
+            ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "5000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, ["--devices", "0,0"])]
     for env, extra in envs:
         for name, (args, rout) in ref.items():
             out = os.path.join(tmp, "new_%s.out" % name)
