@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--queries", type=int, default=0, help="query genomes per GPU (0 = the config's)")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--seed", type=int, default=20260925)
+    ap.add_argument("--cluster-size", type=int, default=20, help="related genomes per cluster (20 = SURVEY.md section 8d; 100 / 500 = a species-dense database: "
+                                                                  "every fragment has more seed hits than the LDS classes hold and takes the batched global-memory L1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -101,7 +103,7 @@ def host_info():
     return {"cpu_model": model, "logical_cpus": logical, "physical_cores": len(phys) or logical}
 
 
-def write_fasta_set(orc, seed, ids, L, td, threads):
+def write_fasta_set(orc, seed, ids, L, td, threads, cluster_size=20):
     """FASTA copies of genomes `ids` of the synthetic set (the oracle's generator is the CPU twin of ani_synth_packed,
     byte-compared in the tests)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -109,7 +111,7 @@ def write_fasta_set(orc, seed, ids, L, td, threads):
     def one(g):
         p = os.path.join(td, "g%05d.fa" % g)
         if not os.path.exists(p):
-            seq = orc.synth_genome(seed, g, L)
+            seq = orc.synth_genome(seed, g, L, cluster_size=cluster_size)
             with open(p + ".tmp", "wb") as f:
                 f.write(b">g%d\n" % g)
                 f.write(seq.tobytes())
@@ -164,18 +166,19 @@ def oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, window, pai
     n_r = 12 if len(query_ids) >= 20 else min(n_refs, 24)
     n_q = min(len(query_ids), max(1, (pairs_wanted + n_r - 1) // n_r))
     rel = rng.choice(query_ids, size=min(len(query_ids), 4), replace=False)            # reference clusters = clusters of some queries
-    clusters = sorted(set(int(q) // 20 for q in rel))
+    cs = args.cluster_size
+    clusters = sorted(set(int(q) // cs for q in rel))
     per = max(1, n_r // max(1, len(clusters)))
     ref_ids = []
     for cl in clusters:
-        members = [cl * 20 + m for m in range(20) if cl * 20 + m < n_refs]
+        members = [cl * cs + m for m in range(cs) if cl * cs + m < n_refs]
         ref_ids += [int(x) for x in rng.choice(members, size=min(per, len(members)), replace=False)] if members else []
     while len(ref_ids) < min(n_r, n_refs):
         g = int(rng.integers(n_refs))
         if g not in ref_ids:
             ref_ids.append(g)
     ref_ids = sorted(ref_ids)[:n_r]
-    near = [q for q in query_ids if q // 20 in clusters]
+    near = [q for q in query_ids if q // cs in clusters]
     q_ids = set(int(x) for x in rng.choice(near, size=min(len(near), (n_q + 1) // 2), replace=False)) if near else set()
     for q in rng.permutation(query_ids):
         if len(q_ids) >= n_q:
@@ -183,11 +186,11 @@ def oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, window, pai
         q_ids.add(int(q))
     q_ids = sorted(q_ids)
     t0 = time.time()
-    refs = [[orc.synth_genome(args.seed, g, L)] for g in ref_ids]
+    refs = [[orc.synth_genome(args.seed, g, L, cluster_size=cs)] for g in ref_ids]
     osk = orc.Sketch(refs, 16, window)
 
     def one(q):
-        maps, tot = osk.map_genome([orc.synth_genome(args.seed, q, L)])
+        maps, tot = osk.map_genome([orc.synth_genome(args.seed, q, L, cluster_size=cs)])
         return q, osk.compute_cgi(maps, tot, q)
     with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         res = list(ex.map(one, q_ids))
@@ -230,7 +233,7 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
         want_ref = not args.no_cpu_baseline and os.path.exists(orc.REF_BIN)
         ids = list(range(n_refs if need_all else (n_cpu_refs if want_ref else 0)))
         t0 = time.time()
-        paths = write_fasta_set(orc, args.seed, ids, L, td, hi["logical_cpus"])
+        paths = write_fasta_set(orc, args.seed, ids, L, td, hi["logical_cpus"], args.cluster_size)
         out["fasta_set"] = {"files": len(paths), "bytes": int(sum(os.path.getsize(p) for p in paths)), "seconds": round(time.time() - t0, 1), "dir": "local disk (%s)" % td}
         index_of = {p: i for i, p in enumerate(paths)}
         # ---- reference binary: every reference x the first cpu_queries genomes (or the one query of one-to-many) ----
@@ -361,7 +364,7 @@ def main():
         # all-vs-all: the rank's query genomes ARE its share of the references; only that share is resident
         nq_local = min(args.queries or (hi - lo), hi - lo)
         ref_buf = torch.empty((hi - lo) * words + 64, dtype=torch.int32, device=dev)
-        e.synth_packed(args.seed, lo, hi - lo, L, ref_buf.data_ptr(), variant=0)
+        e.synth_packed(args.seed, lo, hi - lo, L, ref_buf.data_ptr(), variant=0, cluster_size=args.cluster_size)
         my_refs = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L)
         refs = my_refs if world == 1 else None
         qrys = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L, first=0, count=nq_local)
@@ -369,7 +372,7 @@ def main():
         n_queries_total = nq_local * world
     else:
         ref_buf = torch.empty(NR * words + 64, dtype=torch.int32, device=dev)
-        e.synth_packed(args.seed, 0, NR, L, ref_buf.data_ptr(), variant=0)
+        e.synth_packed(args.seed, 0, NR, L, ref_buf.data_ptr(), variant=0, cluster_size=args.cluster_size)
         refs = DeviceGenomes(ref_buf.data_ptr(), NR, L)
         my_refs = DeviceGenomes(ref_buf.data_ptr(), NR, L, first=lo, count=hi - lo)
         if cfg == "one-to-many":
@@ -382,7 +385,7 @@ def main():
                 qry_buf = ref_buf                                   # all-vs-all
             else:
                 qry_buf = torch.empty(nq_local * words + 64, dtype=torch.int32, device=dev)
-                e.synth_packed(args.seed, 0, nq_local, L, qry_buf.data_ptr(), variant=rank)
+                e.synth_packed(args.seed, 0, nq_local, L, qry_buf.data_ptr(), variant=rank, cluster_size=args.cluster_size)
             qrys = DeviceGenomes(qry_buf.data_ptr(), nq_local, L)
             first_query_id = rank * nq_local
         n_queries_total = nq_local * world
@@ -618,13 +621,13 @@ def main():
         out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak" if cfg != "c4" else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic" if not emu else "synthetic; CPU EMULATION OF THE KERNELS (test of the orchestration, not a measurement)",
-               "config": {"workload": "%s synthetic %d bp genomes (clusters of 20, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
-                                      % (wl, L, p.windowSize, "" if world == 1 else ("; references sharded %d ways, query fragment sketches ring-passed over RCCL" % world if ring_mode
+               "config": {"workload": "%s synthetic %d bp genomes (clusters of %d, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
+                                      % (wl, L, args.cluster_size, p.windowSize, "" if world == 1 else ("; references sharded %d ways, query fragment sketches ring-passed over RCCL" % world if ring_mode
                                                                                    else "; queries sharded %d ways, reference sketch all-gathered over RCCL" % world)),
                           "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM", "all_vs_all_single_hash_pass": bool(self_mode),
                           "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
                "rows_last_step": int(len(rows)), "rows_identical_across_steps": len(set(rows_crc)) == 1, "step_ms_rank0": step_ms,
-               "stage_ms_per_step_rank0": stages,
+               "stage_ms_per_step_rank0": stages, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
                "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                               "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
                                                                               "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows")},

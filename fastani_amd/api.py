@@ -101,6 +101,7 @@ def _bind(lib):
         "ani_sketch_residency": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "ani_map_cgi_batch": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
+        "ani_synth_packed_clusters": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -279,8 +280,8 @@ class Engine:
         hashes = self._take(hp, int(offs[-1]), np.dtype("<u4"))
         return [hashes[int(offs[i]):int(offs[i + 1])] for i in range(n.value)]
 
-    def synth_packed(self, seed, first_genome, n_genomes, genome_len, dev_ptr, variant=0):
-        self._chk(self.lib.ani_synth_packed(self.h, seed, variant, first_genome, n_genomes, genome_len, dev_ptr))
+    def synth_packed(self, seed, first_genome, n_genomes, genome_len, dev_ptr, variant=0, cluster_size=20):
+        self._chk(self.lib.ani_synth_packed_clusters(self.h, seed, variant, first_genome, n_genomes, genome_len, cluster_size, dev_ptr))
 
     def sketch_records(self, params, genomes, seq_id_base):
         """-> (device pointer to 12-byte records, count); free with device_free."""

@@ -42,6 +42,7 @@
 #include "kernels/synth.hpp"
 
 extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
+extern "C" int ani_sort_keys_u64_bits(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream);
 extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
                                       size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
 extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
@@ -188,6 +189,7 @@ struct ani_ctx {
   size_t l2ChunkCandidates = (size_t)1 << 21;                                      // L2 chunk size (env ANI_L2_CHUNK, tests)
   uint64_t l2CodeLimit = 0xfffffff0ull;                                             // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_L2_CODE_LIMIT, tests)
   uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
+  uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;              // seed hits / fragments per group of the batched global-memory L1 path (env ANI_L1_BIG_GROUP_HITS / _FRAGS, tests)
   int32_t maxResidentChunks = 0;                                                    // index chunks of one reference set kept on the device (env ANI_MAX_RESIDENT_CHUNKS; 0 = decide from the free memory)
   uint64_t streamChunkMinimizers = 1000000000ull;                                   // chunk size once a set is streamed (env ANI_STREAM_CHUNK_MINIMIZERS): the build's transient arrays must fit beside the records
   std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
@@ -207,7 +209,7 @@ struct ani_ctx {
   DevBuf sortTmp, unitStart, unitAux, tiles, tileInfo, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
-  DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
+  DevBuf probeFirst, probeCnt, l1LargeList, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
   DevBuf l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
@@ -237,6 +239,7 @@ struct IndexChunk {
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
   uint32_t *contigBinBase = nullptr, *genomeBinStart = nullptr, *posBase = nullptr, *posSample = nullptr;
   uint32_t totalBins = 0, totalPosBins = 0;
+  int32_t maxContigLen = 0;
 };
 
 struct ani_sketch {
@@ -808,6 +811,7 @@ int new_chunk(ani_ctx *ctx, const ani_params_t *p, size_t n, const int32_t *cont
     gBin[g] = (uint32_t)run;
     for (int32_t c = gcsAll[g0 + g] - c0; c < gcsAll[g0 + g + 1] - c0; c++) {
       cg[c] = g; binBase[c] = (uint32_t)run; run += (uint64_t)(contigLen[c] / binW) + 1;
+      sk->maxContigLen = std::max(sk->maxContigLen, contigLen[c]);
       posBase[c] = (uint32_t)runPos; runPos += ((uint64_t)contigLen[c] >> ani::kPosSampleShift) + 1;      // bins of the sampled position index
       if (run > 0xfffffff0ull || runPos > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "index chunk has more than 2^32 position bins"));
     }
@@ -1198,7 +1202,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   uint64_t ccap = (uint64_t)((double)nF * ctx->candPerFrag) + 4096;
   TRY(ctx->l1LargeList.ensure(nF * 4)); TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
   unsigned nLarge = 0, nMid = 0, nBig = 0;
-  std::vector<int32_t> bigFrags, bigS, bigH;
+  std::vector<int32_t> bigFrags, bigInfo;          // fragments beyond the LDS classes and their (sketch size, seed hits)
   unsigned long long hitsTotal = 0;
   for (int attempt = 0;; attempt++) {
     if (ccap > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
@@ -1220,6 +1224,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.largeList = ctx->l1LargeList.as<int32_t>(); a.largeCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTL);
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
+    a.overflowCount = (unsigned int *)cnt_ptr(ctx, CNT_NEG);
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
       if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
@@ -1230,29 +1235,75 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         nMid = (unsigned)nl[0]; nLarge = (unsigned)nl[1]; nBig = (unsigned)nl[2];
         if (nBig) {
-          bigFrags.resize(nBig); bigS.resize(nBig); bigH.resize(nBig);
-          HIP_TRY(hipMemcpy(bigFrags.data(), ctx->l1BigList.p, (size_t)nBig * 4, hipMemcpyDeviceToHost));
-          for (unsigned i = 0; i < nBig; i++) {
-            HIP_TRY(hipMemcpy(&bigS[i], fs.fragS + bigFrags[i], 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(&bigH[i], ctx->fragHits.as<int32_t>() + bigFrags[i], 4, hipMemcpyDeviceToHost));
-          }
+          bigFrags.resize(nBig); bigInfo.resize(2 * (size_t)nBig);
+          TRY(ctx->l1BigV.ensure((size_t)nBig * 8));
+          hipLaunchKernelGGL(k_l1_big_info, dim3(grid_for(nBig)), dim3(256), 0, ctx->stream, (const int32_t *)ctx->l1BigList.as<int32_t>(), nBig, fs.fragS,
+                             (const int32_t *)ctx->fragHits.as<int32_t>(), ctx->l1BigV.as<int32_t>());
+          HIP_TRY(hipMemcpyAsync(bigFrags.data(), ctx->l1BigList.p, (size_t)nBig * 4, hipMemcpyDeviceToHost, ctx->stream));
+          HIP_TRY(hipMemcpyAsync(bigInfo.data(), ctx->l1BigV.p, (size_t)nBig * 8, hipMemcpyDeviceToHost, ctx->stream));
+          HIP_TRY(hipStreamSynchronize(ctx->stream));
+          ctx->counters.l1BigFragments += nBig;
         }
       }
       if (nMid) hipLaunchKernelGGL((k_l1<kL1HitCapSmall, kL1HitCapMid>), dim3(nMid), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.midList);
       if (nLarge) hipLaunchKernelGGL((k_l1<kL1HitCapMid, kL1HitCapMax>), dim3(nLarge), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.largeList);
-      for (unsigned i = 0; i < nBig; i++) {          // oversized fragments: global-memory path, one at a time
-        const size_t H = (size_t)bigH[i], sz = (size_t)bigS[i];
-        if (H == 0) { int32_t z = 0; HIP_TRY(hipMemcpyAsync(ctx->fragCandCnt.as<int32_t>() + bigFrags[i], &z, 4, hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); continue; }
-        TRY(ctx->l1BigHitsA.ensure(H * 8)); TRY(ctx->l1BigHitsB.ensure(H * 8)); TRY(ctx->l1BigV.ensure(std::max(H, sz) * 4 + 16));
-        hipLaunchKernelGGL(k_l1_big_gather, dim3(1), dim3(kTPB), 0, ctx->stream, a, bigFrags[i], ctx->l1BigV.as<int>(), ctx->l1BigHitsA.as<uint64_t>());
-        size_t tb = 0;
-        int rc = ani_sort_keys_u64(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), H, nullptr, &tb, ctx->stream);
-        if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 16)); rc = ani_sort_keys_u64(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), H, ctx->sortTmp.p, &tb, ctx->stream); }
-        if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of seed hits failed (%d)", rc);
-        hipLaunchKernelGGL(k_l1_big_candidates, dim3(1), dim3(kTPB), 0, ctx->stream, a, bigFrags[i], (const uint64_t *)ctx->l1BigHitsB.as<uint64_t>(), ctx->l1BigV.as<int>());
+      if (nBig) {
+        // Fragments beyond every LDS class, batched (l1.hpp): groups of fragments whose hits fit the key buffers; one 64-bit key per
+        // hit = (fragment rank in the group, seqId, wpos), field widths from this chunk's contig count and longest contig.
+        StageTimer tb(ctx, &ctx->counters.msL1Big, 1);
+        int bitsPos = 1, bitsSeq = 1;
+        while (bitsPos < 31 && (1ll << bitsPos) <= (long long)sk->maxContigLen) bitsPos++;
+        while (bitsSeq < 31 && (1ll << bitsSeq) <= (long long)sk->nContigs) bitsSeq++;
+        const int shiftSeq = bitsPos, shiftRank = bitsPos + bitsSeq;
+        const uint64_t maxFrags = std::min<uint64_t>(1ull << std::min(20, 64 - shiftRank), ctx->l1BigGroupFrags);
+        const uint64_t budget = ctx->l1BigGroupHits;
+        for (size_t b0 = 0; b0 < nBig;) {
+          size_t b1 = b0; uint64_t hits = 0, hashes = 0, tiles = 0;
+          std::vector<uint32_t> sOff{0}, tileFirst{0}; std::vector<uint64_t> hitOff{0};
+          while (b1 < nBig && b1 - b0 < maxFrags && (b1 == b0 || hits + (uint64_t)bigInfo[2 * b1 + 1] <= budget)) {
+            const uint64_t sz = (uint64_t)std::max(bigInfo[2 * b1], 0), H = (uint64_t)std::max(bigInfo[2 * b1 + 1], 0);
+            hashes += sz; hits += H; tiles += (H + kL1BigTileHits - 1) / kL1BigTileHits;
+            sOff.push_back((uint32_t)hashes); hitOff.push_back(hits); tileFirst.push_back((uint32_t)tiles);
+            b1++;
+          }
+          const size_t n = b1 - b0;
+          if (tiles > 0x7ffffff0ull || hashes > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "group of oversized fragments with %llu seed hits", (unsigned long long)hits);
+          // group tables: [frag n][sOff n+1][tileFirst n+1] as 32-bit words, then hitOff (64-bit) — one upload
+          const size_t w32 = n + 2 * (n + 1), tblBytes = ((w32 * 4 + 7) / 8) * 8 + (n + 1) * 8;
+          TRY(ctx->l1BigTbl.ensure(tblBytes)); TRY(ctx->l1BigHash.ensure((hashes ? hashes : 1) * 4));
+          TRY(ctx->l1BigHitsA.ensure((hits ? hits : 1) * 8)); TRY(ctx->l1BigHitsB.ensure((hits ? hits : 1) * 8)); TRY(ctx->l1BigV.ensure((hits ? hits : 1) * 4 + (size_t)nBig * 8));
+          uint8_t *hostTbl = nullptr;
+          TRY(pinned_buffer(ctx, 2, tblBytes, (void **)&hostTbl));
+          uint32_t *h32 = (uint32_t *)hostTbl;
+          memcpy(h32, bigFrags.data() + b0, n * 4); memcpy(h32 + n, sOff.data(), (n + 1) * 4); memcpy(h32 + n + (n + 1), tileFirst.data(), (n + 1) * 4);
+          memcpy(hostTbl + ((w32 * 4 + 7) / 8) * 8, hitOff.data(), (n + 1) * 8);
+          HIP_TRY(hipMemcpyAsync(ctx->l1BigTbl.p, hostTbl, tblBytes, hipMemcpyHostToDevice, ctx->stream));
+          L1BigArgs g;
+          const uint32_t *d32 = ctx->l1BigTbl.as<uint32_t>();
+          g.frag = (const int32_t *)d32; g.sOff = d32 + n; g.tileFirst = d32 + n + (n + 1);
+          g.hitOff = (const uint64_t *)(ctx->l1BigTbl.as<uint8_t>() + ((w32 * 4 + 7) / 8) * 8);
+          g.hashOff = ctx->l1BigHash.as<int32_t>(); g.keys = ctx->l1BigHitsA.as<uint64_t>(); g.n = (int)n; g.shiftSeq = shiftSeq; g.shiftRank = shiftRank;
+          hipLaunchKernelGGL(k_l1_big_offsets, dim3((unsigned)n), dim3(kTPB), 0, ctx->stream, a, g);
+          if (tiles) {
+            hipLaunchKernelGGL(k_l1_big_gather, dim3((unsigned)tiles), dim3(kTPB), 0, ctx->stream, a, g);
+            int rankBits = 1; while (rankBits < 64 - shiftRank && (1ull << rankBits) < n) rankBits++;
+            size_t tbytes = 0;
+            int rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, nullptr, &tbytes, ctx->stream);
+            if (rc == 0) { TRY(ctx->sortTmp.ensure(tbytes + 16)); rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, ctx->sortTmp.p, &tbytes, ctx->stream); }
+            if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of seed hits failed (%d)", rc);
+            hipLaunchKernelGGL(k_l1_big_unpack, dim3(grid_for((size_t)hits, 256, 65535)), dim3(256), 0, ctx->stream, ctx->l1BigHitsB.as<uint64_t>(), (uint64_t)hits, shiftSeq, shiftRank);
+          }
+          g.keys = ctx->l1BigHitsB.as<uint64_t>();
+          hipLaunchKernelGGL(k_l1_big_candidates, dim3((unsigned)n), dim3(kTPB), 0, ctx->stream, a, g, ctx->l1BigV.as<int>() + 2 * (size_t)nBig);
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(hipStreamSynchronize(ctx->stream));      // the pinned table and the group buffers are reused by the next group
+          b0 = b1;
+        }
       }
+      {
       hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, ctx->fragCandCnt.as<int32_t>(), fragOrder,
-                         ctx->fragCandCntClamped.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_NEG));
+                         ctx->fragCandCntClamped.as<int32_t>());
+      }
     }
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
@@ -1262,10 +1313,9 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     ccap = (uint64_t)(1.25 * (double)host[CNT_CAND]) + 4096;       // = what candPerFrag will ask for next time
   }
   ctx->candPerFrag = std::max(ctx->candPerFrag, 1.25 * (double)host[CNT_CAND] / (double)nF);   // size the pool right next time
-  if ((uint32_t)host[CNT_NEG] != 0)
-    return fail(ANI_ERR_LIMIT, "%u query fragment(s) exceed the L1 LDS limits (sketch size > %d or seed hits > %d): "
-                               "low-complexity/repetitive input; run with the reference's -s sanity check semantics or split the reference list",
-                (uint32_t)host[CNT_NEG], kL1MaxS, kL1HitCapMax);
+  if ((uint32_t)host[CNT_NEG] != 0)            // k_l1_probe: hit counts and offsets are 32-bit per fragment
+    return fail(ANI_ERR_LIMIT, "%u query fragment(s) have 2^31 or more seed hits in one index chunk (a hash with ~10^9 occurrences: low-complexity / "
+                               "repetitive references); use the reference's -s sanity check or a smaller ANI_MAX_INDEX_MINIMIZERS", (uint32_t)host[CNT_NEG]);
   ctx->counters.seedHits += hitsTotal;
   uint64_t nCand = 0;
   {
@@ -1730,6 +1780,8 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
   if (const char *ev = getenv("ANI_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_INDEX_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->maxIndexMinimizers = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_L1_BIG_GROUP_HITS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupHits = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_L1_BIG_GROUP_FRAGS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupFrags = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev); if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
   if (const char *ev = getenv("ANI_STREAM_CHUNK_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->streamChunkMinimizers = (uint64_t)v; }
   for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
@@ -1745,7 +1797,7 @@ void ani_shutdown(ani_ctx *c)
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileInfo, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
-                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
+                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1LargeList, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->l1BigTbl, &c->l1BigHash, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->fragOrder, &c->fragOrderTmp, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
                     &c->l2Ranges[1], &c->l2CodeCount[1], &c->l2CodeOff[1], &c->l2Codes[1], &c->l2SlowFlag[1], &c->l2ClassList[1], &c->l2Order[1], &c->l2LenHist[1], &c->l2SlowList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
@@ -2564,11 +2616,16 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *skc, const ani_seq_batch_t
 
 int ani_synth_packed(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut)
 {
-  if (!ctx || !devOut || nGenomes < 0 || genomeLen <= 0 || firstGenomeId < 0) return fail(ANI_ERR_ARG, "invalid argument");
+  return ani_synth_packed_clusters(ctx, seed, variant, firstGenomeId, nGenomes, genomeLen, 20, devOut);
+}
+
+int ani_synth_packed_clusters(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, int32_t clusterSize, void *devOut)
+{
+  if (!ctx || !devOut || nGenomes < 0 || genomeLen <= 0 || firstGenomeId < 0 || clusterSize < 1) return fail(ANI_ERR_ARG, "invalid argument");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t words = (size_t)nGenomes * (((size_t)genomeLen + 15) / 16);
   if (words == 0) return ANI_OK;
-  hipLaunchKernelGGL(ani::k_synth_packed, dim3(grid_for(words, 256, 65535)), dim3(256), 0, ctx->stream, seed, variant, firstGenomeId, nGenomes, genomeLen, (uint32_t *)devOut);
+  hipLaunchKernelGGL(ani::k_synth_packed, dim3(grid_for(words, 256, 65535)), dim3(256), 0, ctx->stream, seed, variant, firstGenomeId, nGenomes, genomeLen, clusterSize, (uint32_t *)devOut);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return ANI_OK;

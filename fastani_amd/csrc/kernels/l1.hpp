@@ -17,6 +17,7 @@
 namespace ani {
 
 constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS classes accept
+constexpr int kFragHashCapL1 = 4096;    // = kFragHashCap (sketch.hpp): the most sketch hashes a fragment can have
 constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 8 KiB scratch -> 6 workgroups per CU
 constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgroups per CU
 constexpr int kL1HitCapMax = 8192;      // class L: 64 KiB + 32 KiB -> 1 workgroup per CU (rare)
@@ -34,6 +35,7 @@ struct L1Args {
   int32_t *midList; unsigned int *midCount;       // fragments with kL1HitCapSmall < H <= kL1HitCapMid
   int32_t *largeList; unsigned int *largeCount;   // fragments with kL1HitCapMid < H <= kL1HitCapMax
   int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
+  unsigned int *overflowCount;                    // fragments with >= 2^31 seed hits (fragHits = -1): the call fails
   unsigned long long *sumHits;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
@@ -111,10 +113,10 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
 constexpr int kL1ProbeFrags = 4;
 __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
 {
-  __shared__ int ws[16];
+  __shared__ unsigned long long wsum[kTPB / kWave];
   const int i0 = xcd_item(blockIdx.x, gridDim.x) * kL1ProbeFrags;
   if (i0 >= a.nFrag) return;
-  int fq[kL1ProbeFrags], s[kL1ProbeFrags]; uint32_t off[kL1ProbeFrags]; int c[kL1ProbeFrags];
+  int fq[kL1ProbeFrags], s[kL1ProbeFrags]; uint32_t off[kL1ProbeFrags]; unsigned long long c[kL1ProbeFrags];
   int smax = 0;
 #pragma unroll
   for (int q = 0; q < kL1ProbeFrags; q++) {
@@ -132,17 +134,29 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
     for (int q = 0; q < kL1ProbeFrags; q++) { fi[q] = 0; cn[q] = 0; if (i < s[q]) l1_probe(a, h[q], fi[q], cn[q]); }
 #pragma unroll
     for (int q = 0; q < kL1ProbeFrags; q++)
-      if (i < s[q]) { a.probeFirst[off[q] + i] = fi[q]; a.probeCnt[off[q] + i] = cn[q]; c[q] += (int)cn[q]; }
+      if (i < s[q]) { a.probeFirst[off[q] + i] = fi[q]; a.probeCnt[off[q] + i] = cn[q]; c[q] += cn[q]; }
   }
 #pragma unroll
   for (int q = 0; q < kL1ProbeFrags; q++) {
     const int f = fq[q];
     if (f < 0) break;                               // workgroup-uniform
-    int H; block_excl_scan(c[q], ws, &H);
+    // the fragment's seed hits: summed in 64 bits (a hash of a repetitive reference alone can have 10^9 occurrences); hit counts and
+    // offsets are 32-bit from here on, so a fragment with >= 2^31 hits is marked (-1) and the call fails with ANI_ERR_LIMIT
+    unsigned long long H64 = c[q];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) H64 += __shfl_down(H64, d);
+    block_barrier();
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x >> 6] = H64;
+    block_barrier();
     if (threadIdx.x == 0) {
+      H64 = 0;
+      for (int w = 0; w < kTPB / kWave; w++) H64 += wsum[w];
+      const bool tooMany = H64 > 0x7ffffff0ull;
+      const int H = tooMany ? -1 : (int)H64;
       a.fragHits[f] = H;
-      if (H) atomicAdd(stat_slot(a.sumHits), (unsigned long long)H);
-      if (s[q] > 0) {
+      if (H64) atomicAdd(stat_slot(a.sumHits), H64);
+      if (tooMany) atomicAdd(a.overflowCount, 1u);
+      else if (s[q] > 0) {
         // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
         if (s[q] <= kL1MaxS && H <= kL1HitCapMax) {
           if (H > kL1HitCapSmall && H <= kL1HitCapMid) a.midList[atomicAdd(a.midCount, 1u)] = f;
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   const int t = threadIdx.x;
   const int s = a.fragS[f];
   const int H = a.fragHits[f];
-  if (HLO == 0 && (s <= 0 || H == 0)) {
+  if (HLO == 0 && (s <= 0 || H <= 0)) {              // (H < 0: overflow marker of k_l1_probe, the host fails the call)
     if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; }
     return;
   }
@@ -250,30 +264,97 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   l1_emit_candidates(a, f, s, n, m, hits, V, ws, &sBase);
 }
 
-// Fragments beyond the LDS classes (low-complexity / highly repetitive references): same algorithm over global memory,
-// one workgroup per fragment, the sort done by the device radix sort between the two kernels.
-__global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, int f, int *__restrict__ offTmp, uint64_t *__restrict__ hitsOut)
+// ------------------------------------------------------------------------------------------------
+// Fragments beyond the LDS classes — thousands of near-identical references (a species-dense database sends EVERY fragment here), or
+// low-complexity references with 10^5..10^6 occurrences of one hash — take the same algorithm over global memory, BATCHED: the big
+// fragments of a sub-batch are cut into groups (a few 10^8 hits each), and a group costs five launches whatever its size:
+//   k_l1_big_offsets     per fragment: exclusive scan of its probes' run lengths (the start of every hash's hits in the fragment's list)
+//   k_l1_big_gather      one workgroup per tile of 16384 hits: hit x of fragment i -> key (i, seqId, wpos) in ONE 64-bit word
+//                        (field widths from the chunk's contig count and longest contig), read from the hash-ordered payload
+//   device radix sort    over the used key bits only: orders by fragment, then (seqId, wpos) — computeMap.hpp:320 for all fragments at once
+//   k_l1_big_unpack      keys back to (seqId << 32 | wpos)
+//   k_l1_big_candidates  one workgroup per fragment over its sorted slice (l1_emit_candidates, the code of the LDS classes)
+// ------------------------------------------------------------------------------------------------
+constexpr int kL1BigTileHits = 16384;
+struct L1BigArgs {
+  const int32_t *frag;          // [n] fragment ids of the group
+  const uint32_t *sOff;         // [n+1] prefix of the sketch sizes (into hashOff)
+  const uint64_t *hitOff;       // [n+1] prefix of the hit counts (into keys / V)
+  const uint32_t *tileFirst;    // [n+1] first tile of every fragment
+  int32_t *hashOff;             // [sum s] start of every hash's hits inside its fragment's list
+  uint64_t *keys;               // [sum H]
+  int n; int shiftSeq, shiftRank;       // key = rank << shiftRank | seqId << shiftSeq | wpos
+};
+
+__global__ void k_l1_big_info(const int32_t *__restrict__ list, uint32_t n, const int32_t *__restrict__ fragS, const int32_t *__restrict__ fragHits, int32_t *__restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int f = list[i]; out[2 * i] = fragS[f]; out[2 * i + 1] = fragHits[f]; }
+}
+
+__global__ __launch_bounds__(kTPB) void k_l1_big_offsets(L1Args a, L1BigArgs g)
 {
   __shared__ int ws[16];
+  const int i = blockIdx.x;
+  const int f = g.frag[i];
   const int s = a.fragS[f];
-  const int H = a.fragHits[f];
   const uint32_t off = a.fragOff[f];
-  for (int i = threadIdx.x; i < s; i += kTPB) offTmp[i] = (int)a.probeCnt[off + i];
+  int32_t *ho = g.hashOff + g.sOff[i];
+  for (int j = threadIdx.x; j < s; j += kTPB) ho[j] = (int)a.probeCnt[off + j];
   block_barrier_mem();
-  block_array_excl_scan(offTmp, s, ws);
-  for (int i = threadIdx.x; i < s; i += kTPB) {
-    const int o = offTmp[i], e = (i + 1 < s) ? offTmp[i + 1] : H;
-    const uint32_t fi = a.probeFirst[off + i];
-    for (int c = 0; c < e - o; c++) hitsOut[o + c] = a.sSW[fi + c];
+  block_array_excl_scan(ho, s, ws);
+}
+
+__global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, L1BigArgs g)
+{
+  __shared__ int sho[kFragHashCapL1];
+  __shared__ int sFrag;
+  // tile -> fragment: last i with tileFirst[i] <= tile
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = g.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (g.tileFirst[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    sFrag = lo;
+  }
+  block_barrier();
+  const int i = sFrag;
+  const int f = g.frag[i];
+  const int s = a.fragS[f], H = a.fragHits[f];
+  const uint32_t off = a.fragOff[f];
+  const int32_t *ho = g.hashOff + g.sOff[i];
+  for (int j = threadIdx.x; j < s; j += kTPB) sho[j] = ho[j];
+  block_barrier();
+  const int x0 = (int)(blockIdx.x - g.tileFirst[i]) * kL1BigTileHits;
+  const int x1 = x0 + kL1BigTileHits < H ? x0 + kL1BigTileHits : H;
+  uint64_t *out = g.keys + g.hitOff[i];
+  // a lane's hits are 256 apart: consecutive lanes read consecutive entries of (mostly) one hash's run
+  int j = 0;
+  for (int x = x0 + (int)threadIdx.x; x < x1; x += kTPB) {
+    // hash whose run holds hit x: last j with sho[j] <= x (runs may be empty); the previous answer is a lower bound
+    int lo = j, hi = s;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sho[mid] <= x) lo = mid; else hi = mid; }
+    j = lo;
+    const uint64_t hit = a.sSW[a.probeFirst[off + j] + (uint32_t)(x - sho[j])];
+    out[x] = ((uint64_t)(uint32_t)i << g.shiftRank) | ((hit >> 32) << g.shiftSeq) | (uint64_t)(uint32_t)hit;
   }
 }
 
-__global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, int f, const uint64_t *__restrict__ hitsSorted, int *__restrict__ V)
+__global__ void k_l1_big_unpack(uint64_t *__restrict__ keys, uint64_t n, int shiftSeq, int shiftRank)
+{
+  const uint64_t mSeq = (1ull << (shiftRank - shiftSeq)) - 1, mPos = (1ull << shiftSeq) - 1;
+  for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = keys[x];
+    keys[x] = (((k >> shiftSeq) & mSeq) << 32) | (k & mPos);
+  }
+}
+
+__global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, L1BigArgs g, int *__restrict__ V)
 {
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
+  const int i = blockIdx.x;
+  const int f = g.frag[i];
   const int s = a.fragS[f];
-  l1_emit_candidates(a, f, s, a.fragHits[f], s <= a.lutMaxS ? a.minHitsLUT[s] : 1, hitsSorted, V, ws, &sBase);
+  l1_emit_candidates(a, f, s, a.fragHits[f], s <= a.lutMaxS ? a.minHitsLUT[s] : 1, g.keys + g.hitOff[i], V + g.hitOff[i], ws, &sBase);
 }
 
 // Reorder candidates into the reference's callback order — fragment ascending, then (seqId, start) as produced — or, for a batch

@@ -138,14 +138,12 @@ __global__ void k_keep_flags(int32_t n, const uint32_t *__restrict__ idBits, int
 }
 
 // out[i] = candidates of the i-th fragment in processing order (order == nullptr: fragment i)
-__global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ order, int32_t *__restrict__ out,
-                               unsigned int *__restrict__ nNeg)
+__global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ order, int32_t *__restrict__ out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int v = in[order ? order[i] : i];
   out[i] = v > 0 ? v : 0;
-  if (v < 0) atomicAdd(nNeg, 1u);
 }
 
 // Processing order of the fragments of a multi-genome batch (see map_stage): sort key = running fragment id inside the genome

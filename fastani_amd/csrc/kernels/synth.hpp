@@ -34,7 +34,12 @@ __host__ __device__ __forceinline__ uint32_t synth_base(uint64_t keyAnc, uint64_
   return b;
 }
 
-__global__ void k_synth_packed(uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, uint32_t *__restrict__ out)
+// member m of a cluster of `clusterSize` genomes -> index into the 20 divergence rates: the first 20 members as in SURVEY.md section 8d;
+// larger clusters (a species-dense database: --cluster-size of bench.py) cycle through the 19 non-zero rates, so that no two
+// members are identical copies
+__host__ __device__ __forceinline__ int synth_rate_index(int m) { return m < 20 ? m : 1 + (m - 20) % 19; }
+
+__global__ void k_synth_packed(uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, int32_t clusterSize, uint32_t *__restrict__ out)
 {
   const int32_t wordsPerGenome = (genomeLen + 15) >> 4;
   const long long total = (long long)nGenomes * wordsPerGenome;
@@ -42,9 +47,9 @@ __global__ void k_synth_packed(uint64_t seed, uint64_t variant, int32_t firstGen
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int32_t gi = (int32_t)(i / wordsPerGenome), wi = (int32_t)(i % wordsPerGenome);
     const int32_t g = firstGenomeId + gi;
-    const uint64_t keyAnc = sm64_fin(root + 2 * (uint64_t)(g / 20));
+    const uint64_t keyAnc = sm64_fin(root + 2 * (uint64_t)(g / clusterSize));
     const uint64_t keyMut = sm64_fin(root + 2 * (uint64_t)g + 1) ^ sm64_fin(variant);   // variant 0 leaves the key unchanged
-    const uint32_t thr = (uint32_t)(((uint64_t)synth_rate_permille(g % 20) * 16777216ULL + 500ULL) / 1000ULL);
+    const uint32_t thr = (uint32_t)(((uint64_t)synth_rate_permille(synth_rate_index(g % clusterSize)) * 16777216ULL + 500ULL) / 1000ULL);
     uint32_t word = 0;
     for (int j = 0; j < 16; j++) {
       const int32_t p = wi * 16 + j;

@@ -25,6 +25,16 @@ extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size
   return (int)hipStreamSynchronize(stream);
 }
 
+// the low `endBit` bits only (the batched L1 path packs (fragment, seqId, wpos) into as few bits as the index chunk needs); no
+// host synchronisation: the caller's next launch is on the same stream
+extern "C" int ani_sort_keys_u64_bits(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
+{
+  if (n == 0) { if (!tmp) *tmpBytes = 0; return 0; }
+  if (endBit < 1) endBit = 1;
+  if (endBit > 64) endBit = 64;
+  return (int)rocprim::radix_sort_keys(tmp, *tmpBytes, keysIn, keysOut, n, 0, (unsigned)endBit, stream);
+}
+
 // (querySeqId<<32 | refSeqId, record index): orders mapping records handed to ani_compute_cgi in an arbitrary order
 extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
                                       size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream)

@@ -250,6 +250,10 @@ int ani_map_cgi_batch(ani_ctx *ctx, const ani_sketch *sk, const ani_seq_batch_t 
  * Writes nGenomes genomes of genomeLen bases, 2-bit packed, genome i at word offset i*ceil(genomeLen/16) of devOut
  * (device memory, caller-allocated).  `variant` re-draws the substitutions with the cluster ancestors kept (0 = base set). */
 int ani_synth_packed(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, void *devOut);
+/* the same population with clusters of `clusterSize` related genomes instead of 20 (a species-dense database: hundreds of strains of
+ * one species; members beyond the 20th cycle through the non-zero divergence rates) */
+int ani_synth_packed_clusters(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen,
+                              int32_t clusterSize, void *devOut);
 
 #ifdef __cplusplus
 }

@@ -596,11 +596,16 @@ static inline uint64_t sm64_fin(uint64_t z)
 static inline uint64_t sm64_stream(uint64_t key, uint64_t p) { return sm64_fin(key + (p + 1) * 0x9E3779B97F4A7C15ULL); }
 static const int32_t k_rate_permille[20] = {0, 5, 10, 20, 30, 40, 50, 60, 70, 80, 90, 100, 110, 120, 130, 140, 150, 170, 200, 250};
 
-void orc_synth_genome_v(uint64_t seed, uint64_t variant, int32_t genomeId, int32_t len, uint8_t *outAscii)
+void orc_synth_genome_v(uint64_t seed, uint64_t variant, int32_t genomeId, int32_t len, uint8_t *outAscii) { orc_synth_genome_c(seed, variant, 20, genomeId, len, outAscii); }
+
+/* clusters of clusterSize genomes: members beyond the 20th cycle through the 19 non-zero divergence rates (CPU twin of
+ * fastani_amd/csrc/kernels/synth.hpp: synth_rate_index) */
+void orc_synth_genome_c(uint64_t seed, uint64_t variant, int32_t clusterSize, int32_t genomeId, int32_t len, uint8_t *outAscii)
 {
   static const char base[4] = {'A', 'C', 'G', 'T'};
   uint64_t root = sm64_fin(seed);
-  uint64_t c = (uint64_t)(genomeId / 20), m = (uint64_t)(genomeId % 20);
+  uint64_t c = (uint64_t)(genomeId / clusterSize), m = (uint64_t)(genomeId % clusterSize);
+  if (m >= 20) m = 1 + (m - 20) % 19;
   uint64_t keyAnc = sm64_fin(root + 2 * c);
   uint64_t keyMut = sm64_fin(root + 2 * (uint64_t)genomeId + 1) ^ sm64_fin(variant);
   uint32_t thr = (uint32_t)(((uint64_t)k_rate_permille[m] * 16777216ULL + 500ULL) / 1000ULL);

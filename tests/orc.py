@@ -68,6 +68,7 @@ def lib():
         L.orc_compute_cgi.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
         L.orc_synth_genome.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]
         L.orc_synth_genome_v.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]
+        L.orc_synth_genome_c.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -124,9 +125,9 @@ def identity(shared, s, k=16):
     return np.float32(a.value), np.float32(b.value)
 
 
-def synth_genome(seed, genome_id, length, variant=0):
+def synth_genome(seed, genome_id, length, variant=0, cluster_size=20):
     out = np.zeros(length, dtype=np.uint8)
-    lib().orc_synth_genome_v(seed, variant, genome_id, length, _buf(out))
+    lib().orc_synth_genome_c(seed, variant, cluster_size, genome_id, length, _buf(out))
     return out
 
 

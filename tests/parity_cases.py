@@ -151,7 +151,22 @@ def case_l1_class_overflow(engine):
     for copies in (7, 14, 25, 40):
         genomes = [[np.concatenate([rng_genome(900 + i, 300 + 7 * i), mutate(base, 0.002 * (i % 5), 4100 + i), rng_genome(1900 + i, 500)])] for i in range(copies)]
         p, sk, osk = check_sketch(engine, genomes)
+        engine.reset_counters()
         check_queries(engine, p, sk, osk, [[base], genomes[copies // 2]])
+        assert (engine.counters()["l1BigFragments"] > 0) == (copies >= 40), copies
+
+
+def case_species_dense(engine, copies=48, n=15000):
+    """a species-dense database in miniature: `copies` strains of one 15-kb genome (0-3 % divergence, small indels) as references,
+    four of them as queries — EVERY fragment has more seed hits than the largest LDS class holds and takes the batched
+    global-memory L1 path (l1.hpp: one gather, one device sort and one candidate kernel per group of fragments)"""
+    base = rng_genome(91, n)
+    genomes = [[golden_cases.evolve(base, 600 + i, sub=0.001 * (i % 30), indel=0.0005 * (i % 3), inversions=0, duplications=0, translocations=0)] for i in range(copies)]
+    p, sk, osk = check_sketch(engine, genomes)
+    engine.reset_counters()
+    rows = check_queries(engine, p, sk, osk, [genomes[0], genomes[7], genomes[copies - 1], [base]])
+    c = engine.counters()
+    assert len(rows) == 4 * copies and c["l1BigFragments"] >= 10, (len(rows), c["l1BigFragments"])
 
 
 def case_evolved(engine, n=60000, members=7):
@@ -178,8 +193,17 @@ def case_device_synth(engine, alloc):
     n, L = 4, 33333
     words = (L + 15) // 16
     buf, ptr = alloc(n * words * 4)
-    engine.synth_packed(13, 18, n, L, ptr, variant=3)
-    host = np.asarray(buf.cpu() if hasattr(buf, "cpu") else buf).view(np.uint32)[:n * words].reshape(n, words)
+    for cs, first in ((7, 3), (50, 68), (20, 18)):                 # cluster sizes other than 20 (bench.py --cluster-size), then the default
+        engine.synth_packed(13, first, n, L, ptr, variant=3, cluster_size=cs)
+        host = np.asarray(buf.cpu() if hasattr(buf, "cpu") else buf).view(np.uint32)[:n * words].reshape(n, words)
+        for i in range(n):
+            g = orc.synth_genome(13, first + i, L, variant=3, cluster_size=cs)
+            code = np.zeros(256, dtype=np.uint32)
+            code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
+            c = np.zeros(words * 16, dtype=np.uint32)
+            c[:L] = code[g]
+            exp = (c.reshape(words, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint32)
+            assert np.array_equal(host[i], exp), (cs, i)
     for i in range(n):
         g = orc.synth_genome(13, 18 + i, L, variant=3)
         code = np.zeros(256, dtype=np.uint32)
@@ -437,7 +461,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_sparse_hits, case_l1_class_overflow, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
+             case_low_complexity_big, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):

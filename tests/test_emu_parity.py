@@ -93,6 +93,14 @@ def test_sketch_file_chunked(monkeypatch, tmp_path):
     e.close()
 
 
+def test_big_l1_groups(monkeypatch):
+    """the batched global-memory L1 path cut into many small groups (few fragments, few hits per group)"""
+    e = _emu_engine_with(monkeypatch, ANI_L1_BIG_GROUP_HITS=30000, ANI_L1_BIG_GROUP_FRAGS=3)
+    pc.case_species_dense(e, copies=52, n=9000)
+    pc.case_low_complexity_big(e)
+    e.close()
+
+
 def test_limits(emu_engine):
     pc.case_limits(emu_engine)
 
