@@ -201,6 +201,8 @@ struct ani_ctx {
   struct PendingTimer { size_t a, b; double *acc; };
   std::vector<PendingTimer> timerPending;
   ani_counters_t counters;
+  std::vector<unsigned long long> hostCounters;                 // read_counters: the raw block
+  unsigned long long poolUsed[3] = {0, 0, 0}, poolMaxStripe[3] = {0, 0, 0};
   double candPerFrag = 12.0;      // running estimate that sizes the L1 candidate pool
   // scalar device counters (array of 16 x u64)
   DevBuf dCounters;
@@ -273,22 +275,47 @@ enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4,
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
 static_assert(CNT_N == ani::kStatStripeWords, "counter block size");
+// Device counter block: kStatStripes copies of the CNT_N counters (statistics are spread over the stripes by the kernels,
+// stat_slot(), and summed here; list cursors live in stripe 0), then the striped pool cursors (common.hpp: pool_take): three pools
+// (reference minimizers, fragment-sketch hashes, L1 candidates) x kPoolStripes cursors, one per 128-byte line.
+enum { POOL_REF = 0, POOL_Q = 1, POOL_CAND = 2, POOL_N = 3 };
+constexpr size_t kCursorWords = (size_t)POOL_N * ani::kPoolStripes * ani::kPoolStripeWords;
+constexpr size_t kCounterWords = (size_t)ani::kStatStripes * CNT_N + kCursorWords;
+unsigned long long *cur_ptr(ani_ctx *c, int pool) { return c->dCounters.as<unsigned long long>() + (size_t)ani::kStatStripes * CNT_N + (size_t)pool * ani::kPoolStripes * ani::kPoolStripeWords; }
 int zero_counters(ani_ctx *c)
 {
-  HIP_TRY(hipMemsetAsync(c->dCounters.p, 0, (size_t)ani::kStatStripes * CNT_N * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(c->dCounters.p, 0, kCounterWords * 8, c->stream));
   return ANI_OK;
 }
-// cursors live in stripe 0; statistics are spread over all stripes (kernels: stat_slot()) and summed here
+int zero_cursors(ani_ctx *c, int pool)
+{
+  HIP_TRY(hipMemsetAsync(cur_ptr(c, pool), 0, (size_t)ani::kPoolStripes * ani::kPoolStripeWords * 8, c->stream));
+  return ANI_OK;
+}
+// host[]: the summed statistics (CNT_MAXS: the maximum over the stripes); c->poolUsed / c->poolMaxStripe: per pool, the entries
+// requested in total and by the fullest stripe (the launch overflowed iff that exceeds the stripe capacity it was given)
 int read_counters(ani_ctx *c, unsigned long long *host)
 {
-  unsigned long long all[ani::kStatStripes * CNT_N];
-  HIP_TRY(hipMemcpyAsync(all, c->dCounters.p, sizeof all, hipMemcpyDeviceToHost, c->stream));
+  std::vector<unsigned long long> &all = c->hostCounters;
+  all.resize(kCounterWords);
+  HIP_TRY(hipMemcpyAsync(all.data(), c->dCounters.p, kCounterWords * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (int i = 0; i < CNT_N; i++) host[i] = all[i];
   for (int s = 1; s < ani::kStatStripes; s++)
-    for (int i = 0; i < CNT_N; i++) host[i] += all[s * CNT_N + i];
+    for (int i = 0; i < CNT_N; i++) {
+      if (i == CNT_MAXS) host[i] = std::max<unsigned long long>(host[i] & 0xffffffffull, all[(size_t)s * CNT_N + i] & 0xffffffffull);
+      else host[i] += all[(size_t)s * CNT_N + i];
+    }
+  for (int p = 0; p < POOL_N; p++) {
+    c->poolUsed[p] = 0; c->poolMaxStripe[p] = 0;
+    const unsigned long long *cur = all.data() + (size_t)ani::kStatStripes * CNT_N + (size_t)p * ani::kPoolStripes * ani::kPoolStripeWords;
+    for (int r = 0; r < ani::kPoolStripes; r++) { const unsigned long long v = cur[(size_t)r * ani::kPoolStripeWords]; c->poolUsed[p] += v; c->poolMaxStripe[p] = std::max(c->poolMaxStripe[p], v); }
+  }
   return ANI_OK;
 }
+// entries per stripe for a pool meant to hold `cap` entries in all; and the capacity to retry with after an overflow
+inline uint32_t stripe_cap(uint64_t cap) { return (uint32_t)((cap + ani::kPoolStripes - 1) / ani::kPoolStripes); }
+inline uint64_t grown_cap(unsigned long long maxStripe) { return (uint64_t)(maxStripe + maxStripe / 16 + 64) * ani::kPoolStripes; }
 
 // HIP-event bracket on the launch stream; `slot` selects an event pair so that timers can nest
 // page-locked host staging buffer `slot`, at least `bytes` long (device->host copies into pageable memory crawl)
@@ -629,6 +656,26 @@ int frag_tables(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, Frag
 struct FusedOut { FragSet *fs; FragArrays *arr; uint32_t **qPool; };
 inline bool fusable(const ani_params_t *p) { return p->fragLen + p->windowSize - 1 <= kTile && p->fragLen >= p->windowSize && p->fragLen >= p->kmerSize; }
 
+// The fragment sketches of a batch as they come out of the sketch kernels lie in 64 partly filled stripes of the pool (pool_take).
+// A set that is kept is packed: sketches back to back in fragment order, exactly nHashes entries, fragOff rewritten in place.
+int compact_fragment_pool(ani_ctx *ctx, const uint32_t *pool, uint32_t *fragOff /* in: striped offsets, out: packed offsets */, const int32_t *fragS, size_t nF, uint64_t nHashes, uint32_t **out)
+{
+  *out = nullptr;
+  HIP_TRY(pool_malloc((void **)out, (nHashes ? nHashes : 1) * 4));
+  if (nF == 0) return ANI_OK;
+  TRY(ctx->scanTmpC.ensure(nF * 4)); TRY(ctx->scanTmpD.ensure(nF * 4));
+  hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, fragS, (const int32_t *)nullptr, ctx->scanTmpC.as<int32_t>());   // s = -1 marks an overflowed fragment
+  uint64_t total = 0;
+  int rc = device_scan(ctx, ctx->scanTmpC.as<int32_t>(), ctx->scanTmpD.as<uint32_t>(), (uint32_t)nF, &total);
+  if (rc == ANI_OK && total != nHashes) rc = fail(ANI_ERR_INTERNAL, "fragment sketch pool: %llu hashes counted, %llu in the sketches", (unsigned long long)nHashes, (unsigned long long)total);
+  if (rc != ANI_OK) { pool_free(*out); *out = nullptr; return rc; }
+  hipLaunchKernelGGL(k_pack_fragment_pool, dim3(grid_for(nF * 64)), dim3(256), 0, ctx->stream, pool, fragOff, (const int32_t *)ctx->scanTmpC.as<int32_t>(), (const uint32_t *)ctx->scanTmpD.as<uint32_t>(), (uint32_t)nF, *out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { pool_free(*out); *out = nullptr; HIP_TRY(e); }
+  return ANI_OK;
+}
+
 int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, int32_t seqIdBase, uint32_t **dRecords, size_t *nOut, FusedOut *fused = nullptr)
 {
   const int k = p->kmerSize, w = p->windowSize, L = p->fragLen;
@@ -687,6 +734,7 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
   uint64_t qcap = fused ? (uint64_t)nF * (uint64_t)((2.6 * L) / (w + 1) + 32) + 1024 : 0;
   unsigned long long host[CNT_N];
   for (int attempt = 0;; attempt++) {
+    cap = (uint64_t)stripe_cap(cap) * kPoolStripes; qcap = (uint64_t)stripe_cap(qcap) * kPoolStripes;      // whole stripes (common.hpp: pool_take)
     if (cap > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "reference batch yields more than 2^32 minimizers; split the reference list");
     if (qcap > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "query batch sketch exceeds 2^32 hashes");
     TRY(ctx->poolHash.ensure(cap * 4)); TRY(ctx->poolWpos.ensure(cap * 4));
@@ -700,25 +748,31 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
       if (!fused)
         hipLaunchKernelGGL(k_sketch_tiles, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff,
                            db.dContigLen, db.dContigMode, ctx->tiles.as<TileDesc>(), k, w, ctx->poolHash.as<uint32_t>(),
-                           ctx->poolWpos.as<int32_t>(), (uint32_t)cap, cnt_ptr(ctx, CNT_POOL), ctx->tileMeta.as<TileMeta>());
+                           ctx->poolWpos.as<int32_t>(), stripe_cap(cap), cur_ptr(ctx, POOL_REF), ctx->tileMeta.as<TileMeta>());
       else
         hipLaunchKernelGGL(k_sketch_fused, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigLen, db.dContigMode,
-                           ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>(), k, w, L, ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(), (uint32_t)cap,
-                           cnt_ptr(ctx, CNT_POOL), ctx->tileMeta.as<TileMeta>(), *fused->qPool, (uint32_t)qcap, cnt_ptr(ctx, CNT_QPOOL), fused->arr->fragOff, fused->arr->fragS,
+                           ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>(), k, w, L, ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(), stripe_cap(cap),
+                           cur_ptr(ctx, POOL_REF), ctx->tileMeta.as<TileMeta>(), *fused->qPool, stripe_cap(qcap), cur_ptr(ctx, POOL_Q), fused->arr->fragOff, fused->arr->fragS,
                            (int *)cnt_ptr(ctx, CNT_MAXS));
     }
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
-    if (host[CNT_POOL] <= cap && (!fused || host[CNT_QPOOL] <= qcap)) break;
+    const bool refFits = ctx->poolMaxStripe[POOL_REF] <= stripe_cap(cap), qFits = !fused || ctx->poolMaxStripe[POOL_Q] <= stripe_cap(qcap);
+    if (refFits && qFits) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "minimizer pool did not converge");
-    if (host[CNT_POOL] > cap) cap = host[CNT_POOL] + host[CNT_POOL] / 16;        // margin: the same input must not grow the pool again next time
-    if (fused && host[CNT_QPOOL] > qcap) qcap = host[CNT_QPOOL] + host[CNT_QPOOL] / 16;
+    if (!refFits) cap = grown_cap(ctx->poolMaxStripe[POOL_REF]);          // margin: the same input must not grow the pool again next time
+    if (!qFits) qcap = grown_cap(ctx->poolMaxStripe[POOL_Q]);
   }
   if (fused) {
     const int maxS = (int)(uint32_t)host[CNT_MAXS];
     if (maxS >= 0x7fffffff) return fail(ANI_ERR_LIMIT, "a query fragment produced more than %d minimizers", kFragHashCap);
-    ctx->counters.querySketchHashes += host[CNT_QPOOL];
-    fused->fs->maxS = maxS; fused->fs->nHashes = host[CNT_QPOOL]; fused->fs->poolSize = host[CNT_QPOOL]; fused->fs->qPool = *fused->qPool;
+    const uint64_t nHashes = ctx->poolUsed[POOL_Q];
+    ctx->counters.querySketchHashes += nHashes;
+    // the sketches lie in 64 partly filled stripes: a kept set is packed into fragment order (exact size; this is what travels between GPUs)
+    uint32_t *packed = nullptr;
+    TRY(compact_fragment_pool(ctx, *fused->qPool, fused->arr->fragOff, fused->arr->fragS, nF, nHashes, &packed));
+    pool_free(*fused->qPool); *fused->qPool = packed;
+    fused->fs->maxS = maxS; fused->fs->nHashes = nHashes; fused->fs->poolSize = nHashes; fused->fs->qPool = *fused->qPool;
   }
   StageTimer tm(ctx, &ctx->counters.msSketch);
   hipLaunchKernelGGL(k_sketch_tile_counts, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, ctx->tiles.as<TileDesc>(),
@@ -1132,29 +1186,30 @@ int fragment_stage(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, F
   uint64_t qcap = (uint64_t)nF * (uint64_t)((2.6 * L) / (w + 1) + 32) + 1024;
   for (int attempt = 0;; attempt++) {
     if (qcap > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "query batch sketch exceeds 2^32 hashes");
+    qcap = (uint64_t)stripe_cap(qcap) * kPoolStripes;
     TRY(ctx->qPool.ensure(qcap * 4));
     TRY(zero_counters(ctx));
     {
       StageTimer tm(ctx, &ctx->counters.msFragSketch);
       if (L - k + 1 <= kTile)
         hipLaunchKernelGGL((k_fragment_sketch<true>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigMode,
-                         ctx->frags.as<FragDesc>(), L, k, w, ctx->qPool.as<uint32_t>(), (uint32_t)qcap, cnt_ptr(ctx, CNT_QPOOL),
+                         ctx->frags.as<FragDesc>(), L, k, w, ctx->qPool.as<uint32_t>(), stripe_cap(qcap), cur_ptr(ctx, POOL_Q),
                          ctx->fragOff.as<uint32_t>(), ctx->fragS.as<int32_t>(), (int *)cnt_ptr(ctx, CNT_MAXS));
       else
         hipLaunchKernelGGL((k_fragment_sketch<false>), dim3((unsigned)nF), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigMode,
-                         ctx->frags.as<FragDesc>(), L, k, w, ctx->qPool.as<uint32_t>(), (uint32_t)qcap, cnt_ptr(ctx, CNT_QPOOL),
+                         ctx->frags.as<FragDesc>(), L, k, w, ctx->qPool.as<uint32_t>(), stripe_cap(qcap), cur_ptr(ctx, POOL_Q),
                          ctx->fragOff.as<uint32_t>(), ctx->fragS.as<int32_t>(), (int *)cnt_ptr(ctx, CNT_MAXS));
     }
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
-    if (host[CNT_QPOOL] <= qcap) break;
+    if (ctx->poolMaxStripe[POOL_Q] <= stripe_cap(qcap)) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "query sketch pool did not converge");
-    qcap = host[CNT_QPOOL] + host[CNT_QPOOL] / 16;
+    qcap = grown_cap(ctx->poolMaxStripe[POOL_Q]);
   }
   const int maxS = (int)(uint32_t)host[CNT_MAXS];
   if (maxS >= 0x7fffffff) return fail(ANI_ERR_LIMIT, "a query fragment produced more than %d minimizers", kFragHashCap);
-  ctx->counters.querySketchHashes += host[CNT_QPOOL];
-  qr->maxS = maxS; qr->nHashes = host[CNT_QPOOL]; qr->poolSize = host[CNT_QPOOL];
+  ctx->counters.querySketchHashes += ctx->poolUsed[POOL_Q];
+  qr->maxS = maxS; qr->nHashes = ctx->poolUsed[POOL_Q]; qr->poolSize = qcap;          // the pool has holes between its stripes: fragOff reaches up to qcap
   qr->qPool = ctx->qPool.as<uint32_t>();
   return ANI_OK;
 }
@@ -1206,15 +1261,16 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   unsigned long long hitsTotal = 0;
   for (int attempt = 0;; attempt++) {
     if (ccap > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
+    ccap = (uint64_t)stripe_cap(ccap) * kPoolStripes;
     TRY(ctx->candFrag.ensure(ccap * 4)); TRY(ctx->candSeq.ensure(ccap * 4)); TRY(ctx->candStart.ensure(ccap * 4)); TRY(ctx->candEnd.ensure(ccap * 4));
     if (attempt == 0) TRY(zero_counters(ctx));
-    else { HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_CAND), 0, 8, ctx->stream)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
+    else { TRY(zero_cursors(ctx, POOL_CAND)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
     L1Args a;
     a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS; a.nFrag = (int32_t)nF;
     a.table = sk->table; a.tableSlots = sk->tableSlots; a.sSW = sk->sSW; a.bucketW = w; a.nIndex = sk->n;
     a.minHitsLUT = set->dMinHits; a.lutMaxS = set->dLutMaxS; a.L = L;
     a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
-    a.candCap = (uint32_t)ccap; a.candCount = cnt_ptr(ctx, CNT_CAND);
+    a.candCap = stripe_cap(ccap); a.candCount = cur_ptr(ctx, POOL_CAND);
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
     a.filterShift = 1; while (a.filterShift < 30 && (1 << a.filterShift) < 2 * L) a.filterShift++;
@@ -1308,11 +1364,11 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
     if (attempt == 0) hitsTotal = host[CNT_HITS];
-    if (host[CNT_CAND] <= ccap) break;
+    if (ctx->poolMaxStripe[POOL_CAND] <= stripe_cap(ccap)) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "candidate pool did not converge");
-    ccap = (uint64_t)(1.25 * (double)host[CNT_CAND]) + 4096;       // = what candPerFrag will ask for next time
+    ccap = (uint64_t)(1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes) + 4096;       // = what candPerFrag will ask for next time
   }
-  ctx->candPerFrag = std::max(ctx->candPerFrag, 1.25 * (double)host[CNT_CAND] / (double)nF);   // size the pool right next time
+  ctx->candPerFrag = std::max(ctx->candPerFrag, 1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes / (double)nF);   // size the pool right next time (by the fullest stripe)
   if ((uint32_t)host[CNT_NEG] != 0)            // k_l1_probe: hit counts and offsets are 32-bit per fragment
     return fail(ANI_ERR_LIMIT, "%u query fragment(s) have 2^31 or more seed hits in one index chunk (a hash with ~10^9 occurrences: low-complexity / "
                                "repetitive references); use the reference's -s sanity check or a smaller ANI_MAX_INDEX_MINIMIZERS", (uint32_t)host[CNT_NEG]);
@@ -1602,6 +1658,24 @@ void fragset_finish(ani_fragset *f)
   f->genomeFragStart.assign(f->fs.genomeFragments.size() + 1, 0);
   for (size_t g = 0; g < f->fs.genomeFragments.size(); g++) f->genomeFragStart[g + 1] = f->genomeFragStart[g] + f->fs.genomeFragments[g];
 }
+// the fragment sketches fragment_stage left in the context's buffers -> arrays owned by the kept set (pool packed on the way)
+int keep_fragment_arrays(ani_ctx *ctx, ani_fragset *f)
+{
+  const size_t nF = (size_t)f->fs.nFrag;
+  if (!nF) return ANI_OK;
+  hipError_t e = pool_malloc((void **)&f->arr.fragOff, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragS, nF * 4);
+  if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragGenome, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragQSeq, nF * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragOff, f->fs.fragOff, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragS, f->fs.fragS, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragGenome, f->fs.fragGenome, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragQSeq, f->fs.fragQSeq, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "keeping the fragment sketches failed: %s", hipGetErrorString(e));
+  TRY(compact_fragment_pool(ctx, f->fs.qPool, f->arr.fragOff, f->arr.fragS, nF, f->fs.nHashes, &f->qPool));
+  f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq;
+  f->fs.qPool = f->qPool; f->fs.poolSize = f->fs.nHashes;
+  return ANI_OK;
+}
+
 // sketch one uploaded batch as references, optionally keeping its fragment sketches
 int records_of_batch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, int32_t seqIdBase, void **devRecords, size_t *n, ani_fragset *keep)
 {
@@ -1628,22 +1702,7 @@ int records_of_batch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
         rc = sketch_records(ctx, p, db, seqIdBase + refs->genomeContigStart[g0], &pt.rec, &pt.n);
         if (rc == ANI_OK && keep) {           // fragments that do not fit one tile: the two passes stay separate
           rc = fragment_stage(ctx, *p, db, &keep->fs);
-          const size_t nF = (size_t)keep->fs.nFrag, nH = (size_t)keep->fs.nHashes;
-          hipError_t e = hipSuccess;
-          if (rc == ANI_OK && nF) {
-            e = pool_malloc((void **)&keep->arr.fragOff, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&keep->arr.fragS, nF * 4);
-            if (e == hipSuccess) e = pool_malloc((void **)&keep->arr.fragGenome, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&keep->arr.fragQSeq, nF * 4);
-            if (e == hipSuccess) e = pool_malloc((void **)&keep->qPool, (nH ? nH : 1) * 4);
-            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragOff, keep->fs.fragOff, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragS, keep->fs.fragS, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragGenome, keep->fs.fragGenome, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(keep->arr.fragQSeq, keep->fs.fragQSeq, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess && nH) e = hipMemcpyAsync(keep->qPool, keep->fs.qPool, nH * 4, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "keeping the fragment sketches failed: %s", hipGetErrorString(e));
-            keep->fs.fragOff = keep->arr.fragOff; keep->fs.fragS = keep->arr.fragS; keep->fs.fragGenome = keep->arr.fragGenome; keep->fs.fragQSeq = keep->arr.fragQSeq;
-            keep->fs.qPool = keep->qPool;
-          }
+          if (rc == ANI_OK) rc = keep_fragment_arrays(ctx, keep);
         }
       }
     }
@@ -1785,7 +1844,7 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev); if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
   if (const char *ev = getenv("ANI_STREAM_CHUNK_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->streamChunkMinimizers = (uint64_t)v; }
   for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
-  int rc = c->dCounters.ensure((size_t)ani::kStatStripes * CNT_N * 8);
+  int rc = c->dCounters.ensure(kCounterWords * 8);
   if (rc != ANI_OK) { delete c; return rc; }
   *out = c;
   return ANI_OK;
@@ -1936,20 +1995,7 @@ int ani_fragset_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t
   DeviceBatch db;
   int rc = upload_batch(ctx, queries, 0, queries->nGenomes, &db);
   if (rc == ANI_OK) rc = fragment_stage(ctx, *p, db, &f->fs);
-  const size_t nF = (size_t)f->fs.nFrag, nH = (size_t)f->fs.nHashes;
-  if (rc == ANI_OK && nF) {
-    hipError_t e = pool_malloc((void **)&f->arr.fragOff, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragS, nF * 4);
-    if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragGenome, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragQSeq, nF * 4);
-    if (e == hipSuccess) e = pool_malloc((void **)&f->qPool, (nH ? nH : 1) * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragOff, f->fs.fragOff, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragS, f->fs.fragS, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragGenome, f->fs.fragGenome, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(f->arr.fragQSeq, f->fs.fragQSeq, nF * 4, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess && nH) e = hipMemcpyAsync(f->qPool, f->fs.qPool, nH * 4, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "keeping the fragment sketches failed: %s", hipGetErrorString(e));
-    f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq; f->fs.qPool = f->qPool;
-  }
+  if (rc == ANI_OK) rc = keep_fragment_arrays(ctx, f);
   if (rc != ANI_OK) { fragset_release(f); return rc; }
   fragset_finish(f);
   *out = f;
@@ -2430,8 +2476,8 @@ int ani_query_sketch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
   }
   std::vector<uint64_t> offs(nF + 1, 0);
   for (size_t f = 0; f < nF; f++) offs[f + 1] = offs[f] + (uint64_t)(s[f] > 0 ? s[f] : 0);
-  std::vector<uint32_t> pool((size_t)fs.nHashes), h(offs[nF]);
-  if (fs.nHashes) HIP_TRY(hipMemcpy(pool.data(), ctx->qPool.p, (size_t)fs.nHashes * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> pool((size_t)fs.poolSize), h(offs[nF]);       // the pool as the kernel left it: 64 partly filled stripes
+  if (fs.poolSize) HIP_TRY(hipMemcpy(pool.data(), ctx->qPool.p, (size_t)fs.poolSize * 4, hipMemcpyDeviceToHost));
   for (size_t f = 0; f < nF; f++)
     if (s[f] > 0) memcpy(h.data() + offs[f], pool.data() + off[f], (size_t)s[f] * 4);
   size_t dummy;

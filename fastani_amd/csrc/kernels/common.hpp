@@ -27,6 +27,23 @@ constexpr int kStatStripes = 32;
 constexpr int kStatStripeWords = 24;   // 64-bit words per stripe (= number of counters)
 __device__ __forceinline__ unsigned long long *stat_slot(unsigned long long *base) { return base + (blockIdx.x & (kStatStripes - 1)) * kStatStripeWords; }
 
+// Bump allocation out of a pool, one request per workgroup.  A returning atomicAdd on ONE address costs 12 ns on MI355X however many
+// CUs ask (tools/ubench/atomic.hip, profiles/r03_ubench_atomic.txt): with 1.67 M workgroups per launch and two such cursors per
+// workgroup, k_sketch_fused took its 41 ms whatever its instruction count or occupancy.  So a pool is cut into kPoolStripes equal
+// stripes, each with its own cursor on its own 128-byte line (64 cursors: 0.4 ns per request); workgroup b allocates from stripe
+// b mod 64, which fills them evenly.  `cursors` = kPoolStripes cursors, kPoolStripeWords apart; `stripeCap` = entries per stripe.
+// Returns the absolute offset of n entries, bit 63 set if they do not fit their stripe (the cursor keeps counting, so the host
+// learns the size a retry needs).  Consumers reach the entries through stored offsets (TileMeta::off, fragOff, fragCandOff), so
+// holes between the stripes are harmless.
+constexpr int kPoolStripes = 64, kPoolStripeWords = 16;
+constexpr unsigned long long kPoolOverflowBit = 1ull << 63;
+__device__ __forceinline__ unsigned long long pool_take(unsigned long long *cursors, uint32_t stripeCap, unsigned long long n)
+{
+  const uint32_t r = blockIdx.x & (kPoolStripes - 1);
+  const unsigned long long off = n ? atomicAdd(&cursors[r * kPoolStripeWords], n) : 0ull;
+  return ((unsigned long long)r * stripeCap + off) | (off + n > (unsigned long long)stripeCap ? kPoolOverflowBit : 0ull);
+}
+
 // ---------------------------------------------------------------------------------------------
 // MurmurHash3_x64_128 -> low 32 bits of h1
 // ---------------------------------------------------------------------------------------------
@@ -84,6 +101,35 @@ __host__ __device__ __forceinline__ uint32_t murmur32_tail(uint64_t k1, uint64_t
   h1 += h2; h2 += h1;
   h1 = fmix64(h1); h2 = fmix64(h2);
   return (uint32_t)(h1 + h2);
+}
+
+// v_perm_b32 / v_alignbyte_b32 with host stand-ins (the CPU build of the tests runs the same code)
+//   perm_b32(hi, lo, sel): result byte i = byte sel_i (0..7) of the 8 bytes {hi, lo} (lo = bytes 0..3)
+//   alignbyte(hi, lo, n):  the 32 bits of {hi, lo} that start n bytes up (n = 0..3)
+__host__ __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  const uint64_t src = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) r |= (uint32_t)((src >> (8 * ((sel >> (8 * i)) & 7u))) & 0xffu) << (8 * i);
+  return r;
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbyte(hi, lo, n);
+#else
+  return (uint32_t)(((((uint64_t)hi << 32) | lo) >> (8 * (n & 3u))) & 0xffffffffu);
+#endif
+}
+// 8 bits = four 2-bit codes -> one code per byte
+__host__ __device__ __forceinline__ uint32_t spread_codes4(uint32_t c8)
+{
+  const uint32_t t = (c8 | (c8 << 12)) & 0x000F000Fu;
+  return (t | (t << 6)) & 0x03030303u;
 }
 
 // ASCII byte of a 2-bit code (A=0 C=1 G=2 T=3) and of its complement

@@ -29,7 +29,7 @@ struct L1Args {
   const TableSlot *table; uint32_t tableSlots; const uint64_t *sSW; int bucketW; uint32_t nIndex;
   const int32_t *minHitsLUT; int32_t lutMaxS;
   int L;
-  int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
+  int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;   // striped pool (common.hpp: pool_take): capacity per stripe, cursors
   uint32_t *fragCandOff; int32_t *fragCandCnt; int32_t *fragHits;
   uint32_t *probeFirst, *probeCnt;      // per sketch hash (aligned with qPool): occurrence run in the hash-sorted index
   int32_t *midList; unsigned int *midCount;       // fragments with kL1HitCapSmall < H <= kL1HitCapMid
@@ -86,10 +86,10 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
     c = 0;
     for (int j = lo; j < hi; j++) c += l1_head(hits, V, j, m, a.L);
     int g = block_excl_scan(c, ws, &nG);
-    if (t == 0) *sBasePtr = nG ? atomicAdd(a.candCount, (unsigned long long)nG) : 0ull;
+    if (t == 0) *sBasePtr = pool_take(a.candCount, a.candCap, (unsigned long long)nG);
     block_barrier_mem();
-    const unsigned long long base = *sBasePtr;
-    if (base + (unsigned long long)nG <= (unsigned long long)a.candCap) {
+    const unsigned long long base = *sBasePtr & ~kPoolOverflowBit;
+    if (!(*sBasePtr & kPoolOverflowBit)) {
       for (int j = lo; j < hi; j++) {
         const bool head = l1_head(hits, V, j, m, a.L);
         if (head) g++;

@@ -39,10 +39,50 @@ struct TileMeta {          // produced by k_sketch_tiles
 //   PACKED: seq = const uint32_t* (16 bases per word), off in words;  else seq = const uint8_t*, off in bytes.
 // key[j] = (canonical hash << 32) | (kTile-1-local) or kSkipKey (skipped / beyond the contig end)
 // ------------------------------------------------------------------------------------------------
+// 2-bit packed input, k = 16 (the default and by far the common case).  The thread's 28 bases become two byte arrays of seven dwords
+// each — F: the ASCII letters in order, R: the letters of the reverse complement (R byte b = comp(S[i0 + 27 - b])) — with one
+// v_perm_b32 per dword (four 2-bit codes select from "ACGT" / "TGCA"); the 16-byte k-mer of a position is then four dwords cut out of
+// F at byte offset j and out of R at byte offset 12 - j with v_alignbyte_b32.  (The general form below decodes letter by letter and
+// rolls four 64-bit words byte-wise: ~55 vector instructions per position where this takes ~13.)
+__device__ __forceinline__ void hash_positions_packed16(const uint32_t *wds, int32_t len, int32_t i0, int local0, uint64_t (&key)[kPer])
+{
+  const int32_t nWords = (len + 15) >> 4;
+  const int32_t w0 = i0 >> 4;
+  const int sh = (i0 & 15) * 2;
+  const uint64_t a = w0 < nWords ? wds[w0] : 0u, b = w0 + 1 < nWords ? wds[w0 + 1] : 0u, c = w0 + 2 < nWords ? wds[w0 + 2] : 0u;
+  const uint64_t lo = a | (b << 32);
+  const uint64_t bits = sh ? ((lo >> sh) | (c << (64 - sh))) : lo;       // codes of bases i0 .. i0 + 31 (27 are used)
+  uint32_t F[7], R[7];
+#pragma unroll
+  for (int d = 0; d < 7; d++) {
+    const uint32_t c8 = (uint32_t)(bits >> (8 * d)) & 0xffu;
+    const uint32_t sp = spread_codes4(c8);
+    F[d] = perm_b32(0u, 0x54474341u, sp);                                 // "ACGT"[code]
+    R[6 - d] = perm_b32(0u, 0x41434754u, perm_b32(0u, sp, 0x00010203u));  // "TGCA"[code], the four letters in reverse order
+  }
+  const int32_t nPos = len - 16 + 1;
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    uint32_t f[4], r[4];
+    const int fq = j >> 2, fr = j & 3, rq = (12 - j) >> 2, rr = (12 - j) & 3;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      f[t] = fr ? alignbyte(F[fq + t + 1], F[fq + t], (uint32_t)fr) : F[fq + t];
+      r[t] = rr ? alignbyte(R[rq + t + 1], R[rq + t], (uint32_t)rr) : R[rq + t];
+    }
+    const uint32_t hf = murmur32_k16(((uint64_t)f[1] << 32) | f[0], ((uint64_t)f[3] << 32) | f[2]);
+    const uint32_t hb = murmur32_k16(((uint64_t)r[1] << 32) | r[0], ((uint64_t)r[3] << 32) | r[2]);
+    const bool ok = (i0 + j < nPos) && (hf != hb);                      // commonFunc.hpp:131
+    const uint32_t h = hf < hb ? hf : hb;                               // :134
+    key[j] = ok ? (((uint64_t)h << 32) | (uint32_t)(kTile - 1 - (local0 + j))) : kSkipKey;
+  }
+}
+
 template <bool PACKED>
 __device__ __forceinline__ void hash_positions(const void *seq, int64_t off, int32_t len, int32_t i0, int local0,
                                                int k, uint64_t (&key)[kPer])
 {
+  if (PACKED && k == 16) { hash_positions_packed16((const uint32_t *)seq + off, len, i0, local0, key); return; }
   // ---- fetch the 27 bases [i0, i0+27) as ASCII on demand ----
   uint64_t bits = 0;                  // PACKED: 2-bit codes of bases i0.. in bits 2j..2j+1
   const uint8_t *bytes = nullptr;
@@ -250,10 +290,10 @@ __global__ __launch_bounds__(kTPB) void k_sketch_tiles(const uint32_t *__restric
 #pragma unroll
   for (int j = 0; j < kPer; j++) cnt += em[j];
   int total; int rank = block_excl_scan(cnt, ws, &total);
-  if (threadIdx.x == 0) sBase = total ? atomicAdd(poolCount, (unsigned long long)total) : 0ull;
+  if (threadIdx.x == 0) sBase = pool_take(poolCount, poolCap, (unsigned long long)total);
   block_barrier();
-  const unsigned long long base = sBase;
-  if (base + (unsigned long long)total <= (unsigned long long)poolCap) {
+  const unsigned long long base = sBase & ~kPoolOverflowBit;
+  if (!(sBase & kPoolOverflowBit)) {
 #pragma unroll
     for (int j = 0; j < kPer; j++)
       if (em[j]) {
@@ -401,14 +441,14 @@ __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ se
   for (int i = lo; i < hi; i++) cntU += (i == 0 || hbuf[i] != hbuf[i - 1]);
   int s; int r = block_excl_scan(cntU, ws, &s);
   if (threadIdx.x == 0) {
-    *sBasePtr = s ? atomicAdd(poolCount, (unsigned long long)s) : 0ull;
+    *sBasePtr = pool_take(poolCount, poolCap, (unsigned long long)s);
     fragOff[blockIdx.x] = (uint32_t)*sBasePtr;
     fragS[blockIdx.x] = overflow ? -1 : s;
-    atomicMax(maxS, overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+    atomicMax((int *)stat_slot((unsigned long long *)maxS), overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
   }
   block_barrier();
-  const unsigned long long base = *sBasePtr;
-  if (base + (unsigned long long)s <= (unsigned long long)poolCap)
+  const unsigned long long base = *sBasePtr & ~kPoolOverflowBit;
+  if (!(*sBasePtr & kPoolOverflowBit))
     for (int i = lo; i < hi; i++)
       if (i == 0 || hbuf[i] != hbuf[i - 1]) pool[base + r++] = hbuf[i];
 }
@@ -481,16 +521,29 @@ __device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool over
   for (int i = lo; i < hi; i++) cntU += (i == 0 || hbuf[i] != hbuf[i - 1]);
   int s; int r = block_excl_scan(cntU, ws, &s);
   if (threadIdx.x == 0) {
-    *sBasePtr = s ? atomicAdd(poolCount, (unsigned long long)s) : 0ull;
+    *sBasePtr = pool_take(poolCount, poolCap, (unsigned long long)s);
     fragOff[frag] = (uint32_t)*sBasePtr;
     fragS[frag] = overflow ? -1 : s;
-    atomicMax(maxS, overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+    atomicMax((int *)stat_slot((unsigned long long *)maxS), overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
   }
   block_barrier();
-  const unsigned long long base = *sBasePtr;
-  if (base + (unsigned long long)s <= (unsigned long long)poolCap)
+  const unsigned long long base = *sBasePtr & ~kPoolOverflowBit;
+  if (!(*sBasePtr & kPoolOverflowBit))
     for (int i = lo; i < hi; i++)
       if (i == 0 || hbuf[i] != hbuf[i - 1]) pool[base + r++] = hbuf[i];
+}
+
+// one wave per fragment: its sketch from the striped pool to its place in the packed pool; fragOff is rewritten
+__global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, uint32_t *__restrict__ fragOff, const int32_t *__restrict__ s, const uint32_t *__restrict__ newOff,
+                                     uint32_t nFrag, uint32_t *__restrict__ out)
+{
+  const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (f >= nFrag) return;
+  const uint32_t src = fragOff[f], dst = newOff[f];
+  const int n = s[f];
+  for (int i = (int)lane; i < n; i += 64) out[dst + i] = pool[src + i];
+  ANI_WAVE_SYNC();                                  // every lane has read fragOff[f]
+  if (lane == 0) fragOff[f] = dst;
 }
 
 template <bool PACKED>
@@ -512,10 +565,10 @@ __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, in
 #pragma unroll
     for (int j = 0; j < kPer; j++) cnt += em[j];
     int total; int rank = block_excl_scan(cnt, ws, &total);
-    if (threadIdx.x == 0) *sBasePtr = total ? atomicAdd(poolCount, (unsigned long long)total) : 0ull;
+    if (threadIdx.x == 0) *sBasePtr = pool_take(poolCount, poolCap, (unsigned long long)total);
     block_barrier();
-    const unsigned long long base = *sBasePtr;
-    if (base + (unsigned long long)total <= (unsigned long long)poolCap) {
+    const unsigned long long base = *sBasePtr & ~kPoolOverflowBit;
+    if (!(*sBasePtr & kPoolOverflowBit)) {
 #pragma unroll
       for (int j = 0; j < kPer; j++)
         if (em[j]) {
@@ -527,20 +580,35 @@ __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, in
     if (threadIdx.x == 0) { TileMeta m; m.off = (uint32_t)base; m.cnt = total; m.firstP = firstP; m.lastP = lastP; meta[blockIdx.x] = m; }
   }
   if (fi.frag < 0) return;                          // workgroup-uniform
-  // ---- the fragment's own sketch: only k-mers that lie inside the fragment exist ----
+  // ---- the fragment's own sketch (winnowed in isolation, computeMap.hpp:260) WITHOUT a second winnowing pass.  Only k-mers inside
+  // the fragment exist for it: local positions f0 .. fEnd.  A window that ends at l in [f0 + w - 1, fEnd] covers fragment positions
+  // only, so its minimum W and its argmin P are the ones of the contig-continuous pass above; and "P differs from the previous
+  // window's" is the same decision too, except at the fragment's first window, which always emits (commonFunc.hpp:152-161: the
+  // deque starts empty).  So: the fragment's minimizers = the reference minimizers emitted in that range + its first window's.
   const int f0 = fi.fragLocal0, fEnd = f0 + fragLen - k;     // last k-mer start inside the fragment (local)
+  bool inR[kPer]; int myFirst = 0x7fffffff;
 #pragma unroll
-  for (int j = 0; j < kPer; j++) { const int l = local0 + j; if (l < f0 || l > fEnd) key[j] = kSkipKey; }
-  block_barrier();                                  // the reference pass is done with keys / ws
-  tile_winnow_keys(key, td.firstPos, 0x7fffffff, w, f0, kTile, keys, ws, W, em, firstP, lastP);
+  for (int j = 0; j < kPer; j++) {
+    const int l = local0 + j;
+    inR[j] = key[j] != kSkipKey && l >= f0 + w - 1 && l <= fEnd;
+    if (inR[j] && l < myFirst) myFirst = l;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_down(myFirst, d); myFirst = o < myFirst ? o : myFirst; }
+  block_barrier();                                  // the reference pass is done with ws / sBasePtr
+  if ((threadIdx.x & (kWave - 1)) == 0) ws[threadIdx.x >> 6] = myFirst;
+  block_barrier();
+  int firstL = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < kTPB / kWave; i++) { const int x = ws[i]; firstL = x < firstL ? x : firstL; }
   uint32_t *hbuf = (uint32_t *)keys;                // dead once the tile is winnowed (kFragHashCap * 4 <= kTile * 8)
   int cnt = 0;
 #pragma unroll
-  for (int j = 0; j < kPer; j++) cnt += em[j];
+  for (int j = 0; j < kPer; j++) { inR[j] = inR[j] && (em[j] || local0 + j == firstL); cnt += inR[j]; }
   int total; int rank = block_excl_scan(cnt, ws, &total);
 #pragma unroll
   for (int j = 0; j < kPer; j++)
-    if (em[j]) { if (rank < kFragHashCap) hbuf[rank] = (uint32_t)(W[j] >> 32); rank++; }
+    if (inR[j]) { if (rank < kFragHashCap) hbuf[rank] = (uint32_t)(W[j] >> 32); rank++; }
   const bool overflow = total > kFragHashCap;
   block_barrier();
   fragment_finish(hbuf, overflow ? kFragHashCap : total, overflow, fi.frag, qPool, qCap, qCount, fragOff, fragS, maxS, ws, sBasePtr);
