@@ -21,7 +21,10 @@
 // checks each of its T reference splits separately (core_genome_identity.cpp:76-79), which is reproduced by sketching the same
 // round-robin splits.
 #include <zlib.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
 
 #include <algorithm>
 #include <atomic>
@@ -164,13 +167,24 @@ Options parse(int argc, char **argv)
 // Block-wise: zlib hands over 1 MiB blocks, lines are located with memchr and appended with one copy.
 // ---------------------------------------------------------------------------------------------------------------
 struct BlockReader {
-  gzFile fp; std::vector<unsigned char> buf; size_t n = 0, p = 0; bool eof = false;
-  explicit BlockReader(const std::string &path) : buf(1 << 20) { fp = gzopen(path.c_str(), "r"); if (fp) gzbuffer(fp, 1 << 20); }
-  ~BlockReader() { if (fp) gzclose(fp); }
+  gzFile fp = nullptr; int fd = -1; std::vector<unsigned char> buf; size_t n = 0, p = 0; bool eof = false;
+  explicit BlockReader(const std::string &path) : buf(1 << 20)
+  {
+    // a file that does not start with the gzip magic is read with read(2) straight into the block buffer (zlib's transparent
+    // mode would copy every byte once more); anything else goes through zlib as in the reference (kseq.h over gzread)
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return;
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(fd, magic, 2, 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { fp = gzdopen(fd, "r"); if (fp) { gzbuffer(fp, 1 << 20); fd = -1; } else { ::close(fd); fd = -1; } }
+  }
+  ~BlockReader() { if (fp) gzclose(fp); if (fd >= 0) ::close(fd); }
   bool fill()
   {
-    if (eof || !fp) return false;
-    const int got = gzread(fp, buf.data(), (unsigned)buf.size());
+    if (eof || (!fp && fd < 0)) return false;
+    long got;
+    if (fp) got = gzread(fp, buf.data(), (unsigned)buf.size());
+    else do { got = (long)::read(fd, buf.data(), buf.size()); } while (got < 0 && errno == EINTR);
     if (got <= 0) { eof = true; n = p = 0; return false; }
     n = (size_t)got; p = 0;
     return true;
@@ -419,6 +433,15 @@ int main(int argc, char **argv)
   for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx) || ani_init(dev[d].id, &dev[d].up)) die("ani_init"); }
   const int nDev = (int)dev.size();
   trace("devices initialised");
+  // the index blocks of every device's shard are allocated on spare threads while the files are still being read (estimate: 2 / (w + 1)
+  // minimizers per base, FASTA bytes ~ bases)
+  std::vector<std::thread> reserveThreads;
+  if (!o.visualize && !o.sanityCheck && o.refSketch.empty() && !getenv("ANI_NO_RESERVE")) {
+    uint64_t refBytes = 0;
+    for (auto &e : o.refs) { struct stat st; if (stat(e.c_str(), &st) == 0) refBytes += (uint64_t)st.st_size * ((e.size() > 3 && e.compare(e.size() - 3, 3, ".gz") == 0) ? 4 : 1); }
+    const uint64_t est = (uint64_t)((double)refBytes * 2.0 / (ap.windowSize + 1) / (double)dev.size());
+    for (size_t d = 0; d < dev.size(); d++) reserveThreads.emplace_back([&, d, est]() { (void)ani_reserve_index(dev[d].ctx, est); });
+  }
   std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
   std::cerr << "INFO [thread 0], skch::main, Count of threads executing parallel_for : " << (o.sanityCheck ? o.threads : nDev) << std::endl;
 
@@ -535,6 +558,8 @@ int main(int argc, char **argv)
         if (allVsAll) { qsets[k].dev = d; qsets[k].firstQuery = (int32_t)refSlices[k].first; }
         return true;
       });
+    for (auto &t : reserveThreads) t.join();
+    reserveThreads.clear();
     trace("reference slices sketched");
     // every device builds the index of its shard
     {
@@ -869,8 +894,15 @@ int main(int argc, char **argv)
   }
   std::cerr << "INFO, skch::main, Time spent writing the output : " << secs_since(tOut) << " sec; total : " << secs_since(tStart) << " sec" << std::endl;
   trace("output written");
+  for (auto &t : reserveThreads) t.join();
   fpPtr.reset();
-  for (auto &d : dev) { ani_shutdown(d.up); ani_shutdown(d.ctx); }
-  trace("contexts shut down");
-  return 0;
+  if (getenv("ANI_CLEAN_EXIT")) {                     // tests / leak checkers: release everything in order
+    for (auto &d : dev) { ani_shutdown(d.up); ani_shutdown(d.ctx); }
+    trace("contexts shut down");
+    return 0;
+  }
+  // every output file is closed: returning tens of gigabytes of device memory block by block and unloading the runtime would only
+  // delay the caller (0.3 s at 1000 genomes)
+  fflush(stdout); fflush(stderr);
+  _exit(0);
 }
