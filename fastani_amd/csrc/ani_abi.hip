@@ -1472,11 +1472,12 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
           fa.nFragChunk = fB - fA + 1;
           hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)((fa.nFragChunk + 7) / 8 * 8)), dim3(kTPB), 0, ctx->stream, fa);
         }
-        // ANI_L2_OVERLAP=1 puts the simulation (VALU-bound) on the side stream so that the next chunk's ranges / codes kernels
-        // (memory- and latency-bound) can run beside it.  Measured: the L2 stage 94.7 -> 91.2 ms, all of it from the tails — a codes
-        // workgroup (25 KiB of LDS) does not fit the 16 KiB slot a retiring simulation workgroup frees, and a 128-thread variant that
-        // does (14.5 KiB) shares the CUs for real but wins nothing (95.5 ms: the two kernels compete for the same issue slots).  Off
-        // by default: the per-kernel times of the bench line and of rocprofv3 stay those of kernels that run alone.
+        // ANI_L2_OVERLAP=1 puts the simulation (VALU-bound) on the side stream so that the next chunk's ranges / codes kernels (memory-
+        // and latency-bound) can start beside it.  Measured (round 3, 1000 x 1000, profiles/r03f_bench_overlap.json.log): the L2 stage
+        // 94.8 -> 90.8 ms, the step 221.5 -> 216.8 ms — all of it from the tails: a codes workgroup (25 KiB of LDS) does not fit the
+        // 16 KiB slot a retiring simulation workgroup frees.  Off by default: with it the per-kernel times (bench line, rocprofv3) are
+        // those of kernels that share the machine (k_l2_codes reads 77 ms instead of 39.6), and the dominant-kernel accounting of the
+        // measurement contract stops meaning what it says.
         static const bool overlap = getenv("ANI_L2_OVERLAP") && !strcmp(getenv("ANI_L2_OVERLAP"), "1");
         hipStream_t simStream = ctx->stream;
         if (overlap) {
