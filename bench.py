@@ -625,7 +625,7 @@ def main():
         # + WRITE_SIZE, per launch) — only quoted when it is this default workload
         try:
             if cfg == "many-to-many" and NR == 1000 and L == 5_000_000 and world == 1:
-                for tag in ("r02", "r01p"):
+                for tag in ("r03", "r02", "r01p"):
                     fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
                     if not os.path.exists(fn):
                         continue

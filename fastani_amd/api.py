@@ -63,7 +63,6 @@ def _bind(lib):
         "ani_device_free": (None, [vp, vp]),
         "ani_device_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "ani_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
-        "ani_reserve_index": (C.c_int, [vp, C.c_uint64]),
         "ani_device_copy_peer": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
         "ani_batch_upload": (C.c_int, [vp, C.POINTER(SeqBatch), C.POINTER(vp)]),
         "ani_batch_free": (None, [vp]),

@@ -1879,25 +1879,6 @@ int ani_device_copy(ani_ctx *c, void *dst, const void *src, size_t bytes)
   return ANI_OK;
 }
 
-// Fresh device memory is slow on this stack (up to ~30 us per MB: the 18 GB index of 1000 genomes costs most of a second the first
-// time, 28 ms in a warm context): the blocks a reference index of `nMinimizers` will ask for are allocated here — typically on a
-// spare host thread while the input is still being read — and handed to the caching allocator, where build_chunk_index finds them.
-int ani_reserve_index(ani_ctx *c, uint64_t nMinimizers)
-{
-  if (!c) return fail(ANI_ERR_ARG, "null argument");
-  HIP_TRY(hipSetDevice(c->device));
-  if (nMinimizers == 0) return ANI_OK;
-  const uint64_t n = std::min<uint64_t>(nMinimizers + nMinimizers / 32 + 1024, std::min<uint64_t>(c->maxIndexMinimizers, 0x7fffffe0ull));   // a little above the estimate: the pool reuses a block up to 6 % larger than the request
-  const size_t n4 = (size_t)n * 4;
-  // build_chunk_index: seven 4-byte arrays + the flag bytes + the 8-byte payload, the sort's input copies, the probe table (2 slots of 12 bytes per distinct hash)
-  const size_t sizes[] = {n4, n4, n4, n4, n4, n4, n4, (size_t)n + 8, 2 * n4, n4, 2 * n4, (size_t)n * 2 * 12 + 64};
-  std::vector<void *> got;
-  for (size_t b : sizes) { void *p = nullptr; if (pool_malloc(&p, b) != hipSuccess) break; got.push_back(p); }
-  (void)hipGetLastError();
-  for (void *p : got) pool_free(p);
-  return ANI_OK;
-}
-
 int ani_device_alloc(ani_ctx *c, size_t bytes, void **out)
 {
   if (!c || !out) return fail(ANI_ERR_ARG, "null argument");

@@ -433,15 +433,6 @@ int main(int argc, char **argv)
   for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx) || ani_init(dev[d].id, &dev[d].up)) die("ani_init"); }
   const int nDev = (int)dev.size();
   trace("devices initialised");
-  // the index blocks of every device's shard are allocated on spare threads while the files are still being read (estimate: 2 / (w + 1)
-  // minimizers per base, FASTA bytes ~ bases)
-  std::vector<std::thread> reserveThreads;
-  if (!o.visualize && !o.sanityCheck && o.refSketch.empty() && !getenv("ANI_NO_RESERVE")) {
-    uint64_t refBytes = 0;
-    for (auto &e : o.refs) { struct stat st; if (stat(e.c_str(), &st) == 0) refBytes += (uint64_t)st.st_size * ((e.size() > 3 && e.compare(e.size() - 3, 3, ".gz") == 0) ? 4 : 1); }
-    const uint64_t est = (uint64_t)((double)refBytes * 2.0 / (ap.windowSize + 1) / (double)dev.size());
-    for (size_t d = 0; d < dev.size(); d++) reserveThreads.emplace_back([&, d, est]() { (void)ani_reserve_index(dev[d].ctx, est); });
-  }
   std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
   std::cerr << "INFO [thread 0], skch::main, Count of threads executing parallel_for : " << (o.sanityCheck ? o.threads : nDev) << std::endl;
 
@@ -558,8 +549,6 @@ int main(int argc, char **argv)
         if (allVsAll) { qsets[k].dev = d; qsets[k].firstQuery = (int32_t)refSlices[k].first; }
         return true;
       });
-    for (auto &t : reserveThreads) t.join();
-    reserveThreads.clear();
     trace("reference slices sketched");
     // every device builds the index of its shard
     {
@@ -894,7 +883,6 @@ int main(int argc, char **argv)
   }
   std::cerr << "INFO, skch::main, Time spent writing the output : " << secs_since(tOut) << " sec; total : " << secs_since(tStart) << " sec" << std::endl;
   trace("output written");
-  for (auto &t : reserveThreads) t.join();
   fpPtr.reset();
   if (getenv("ANI_CLEAN_EXIT")) {                     // tests / leak checkers: release everything in order
     for (auto &d : dev) { ani_shutdown(d.up); ani_shutdown(d.ctx); }

@@ -135,9 +135,6 @@ int ani_device_copy(ani_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* device memory of this context (released with ani_device_free) and a copy between two contexts' devices — the host side of a
  * multi-GPU run stages minimizer records with these (peer-to-peer over xGMI when the devices can access each other) */
 int ani_device_alloc(ani_ctx *ctx, size_t bytes, void **out);
-/* warm the context's caching allocator with the blocks a reference index of about nMinimizers minimizers will ask for (fresh device
- * memory is slow; call it on a spare host thread while the input is still being read — the command line does) */
-int ani_reserve_index(ani_ctx *ctx, uint64_t nMinimizers);
 int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void *src, size_t bytes);
 /* Ingest: classify + 2-bit pack host sequences on host threads into page-locked staging, copy them to the
  * device and keep them there.  The handle can be passed to every entry point that takes a sequence batch (layout
