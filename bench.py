@@ -414,6 +414,7 @@ def main():
     contig_len = np.full(NR, L, dtype=np.int32)
     gcs = np.arange(NR + 1, dtype=np.int32)
     # all-vs-all on one GPU (the query set IS the reference set): every genome is hashed once for both roles
+    self_slice = int(os.environ.get("ANI_BENCH_SELF_SLICE", "1000"))        # genomes per fused-pass slice of a large all-vs-all set (tests lower it)
     self_mode = (not args.no_self) and world == 1 and ((cfg == "many-to-many" and not args.queries) or (cfg == "c4" and nq_local == NR))
 
     # multi-GPU staging buffers (allocated once): every rank's records land in its slot of `allrec`; the slot's first record
@@ -444,7 +445,27 @@ def main():
     def step():
         t_a = time.perf_counter()
         frags = None
-        if world == 1 and self_mode:
+        if world == 1 and self_mode and NR > 2 * self_slice:
+            # the same in slices of 1000 genomes (a slice's minimizers and sketch hashes are 32-bit counts): record parts + kept
+            # fragment sets, one index over the parts, ONE mapping call over all sets (a streamed set builds each chunk once)
+            parts, sets, firsts = [], [], []
+            for s0 in range(0, NR, self_slice):
+                s1 = min(NR, s0 + self_slice)
+                ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(ref_buf.data_ptr(), NR, L, first=s0, count=s1 - s0), s0)
+                parts.append((ptr, n, s0)); sets.append(fr); firsts.append(s0)
+            sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [NR], contig_len, gcs))
+            for ptr, n, _ in parts:                  # the index is built (or, for a streamed set, the records copied): the parts can go
+                if n:
+                    e.device_free(ptr)
+            t_b = t_c = t_d = time.perf_counter()
+            rows = sk.map_cgi_fragsets(sets, firsts)
+            t_e = time.perf_counter()
+            for fr in sets:
+                fr.close()
+            sk.close()
+            timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["map_ms"] += (t_e - t_d) * 1e3
+            return rows
+        elif world == 1 and self_mode:
             # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
             ptr, n, frags = e.sketch_records_self(p, refs, 0)
             sk = Sketch(e, p, records=(ptr, n, contig_len, gcs))
