@@ -106,6 +106,61 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
   if (t == 0) a.fragCandCnt[f] = nG;
 }
 
+// The same over hits that lie in GLOBAL memory (the batched path of fragments beyond the LDS classes: 10^4..10^6 hits per
+// fragment).  l1_emit_candidates gives every thread a contiguous slice of the list, which is right for LDS and ruinous for global
+// memory (the 64 lanes of a wave touch 64 different cache lines per step: k_l1_big_candidates took 2.9 of the 5.3 seconds of the
+// cluster-size-500 benchmark step that way).  Here the list is walked in chunks of 256 consecutive entries, one per thread —
+// coalesced — with one workgroup scan per chunk; three walks: valid runs (compacted into V in order), candidate heads (counted),
+// emission.
+__device__ inline void l1_emit_candidates_stream(const L1Args &a, int f, int H, int m, const uint64_t *__restrict__ hits, int *__restrict__ V,
+                                                 int *ws, unsigned long long *sBasePtr)
+{
+  const int t = threadIdx.x;
+  if (m < 1) m = 1;                                                     // :316
+  const int nA = H - m + 1;
+  int nG = 0;
+  if (nA > 0) {
+    int nv = 0;
+    for (int base = 0; base < nA; base += kTPB) {                       // valid runs, in order
+      const int x = base + t;
+      const int c = x < nA ? (int)l1_valid(hits, x, m, a.L) : 0;
+      int tot; const int r = block_excl_scan(c, ws, &tot);
+      if (c) V[nv + r] = x;
+      nv += tot;
+    }
+    block_barrier_mem();
+    for (int base = 0; base < nv; base += kTPB) {                       // candidate heads
+      const int j = base + t;
+      const int c = j < nv ? (int)l1_head(hits, V, j, m, a.L) : 0;
+      int tot; (void)block_excl_scan(c, ws, &tot);
+      nG += tot;
+    }
+    if (t == 0) *sBasePtr = pool_take(a.candCount, a.candCap, (unsigned long long)nG);
+    block_barrier_mem();
+    const unsigned long long base0 = *sBasePtr & ~kPoolOverflowBit;
+    if (!(*sBasePtr & kPoolOverflowBit)) {
+      int gBefore = 0;                                                  // heads in the chunks before this one
+      for (int base = 0; base < nv; base += kTPB) {
+        const int j = base + t;
+        const bool in = j < nv;
+        const bool head = in && l1_head(hits, V, j, m, a.L);
+        int tot; const int g = gBefore + block_excl_scan((int)head, ws, &tot) + (head ? 1 : 0);    // group of run j, 1-based
+        if (in) {
+          const unsigned long long slot = base0 + (unsigned long long)(g - 1);
+          if (head) {
+            int32_t start = hit_wpos(hits[V[j] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
+            a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[j]]); a.candStart[slot] = start;
+          }
+          if (j == nv - 1 || l1_head(hits, V, j + 1, m, a.L)) a.candEnd[slot] = hit_wpos(hits[V[j]]);   // :336,:347
+        }
+        gBefore += tot;
+      }
+    }
+    if (t == 0) a.fragCandOff[f] = (uint32_t)base0;
+  } else if (t == 0) a.fragCandOff[f] = 0;
+  if (t == 0) a.fragCandCnt[f] = nG;
+}
+
 // Pass 1: probes only.  No LDS, one lane per query hash.  A probe is a chain of dependent loads (sketch hash -> table slot), and
 // the kernel is bound by that latency, not by bandwidth: measured, one cache line per probe instead of three bought nothing as long
 // as a lane had a single probe in flight.  So a workgroup takes kL1ProbeFrags fragments at once and every lane runs that many
@@ -273,7 +328,8 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
 //                        (field widths from the chunk's contig count and longest contig), read from the hash-ordered payload
 //   device radix sort    over the used key bits only: orders by fragment, then (seqId, wpos) — computeMap.hpp:320 for all fragments at once
 //   k_l1_big_unpack      keys back to (seqId << 32 | wpos)
-//   k_l1_big_candidates  one workgroup per fragment over its sorted slice (l1_emit_candidates, the code of the LDS classes)
+//   k_l1_big_candidates  one workgroup per fragment over its sorted slice (l1_emit_candidates_stream: the algorithm of the LDS classes,
+//                        walked in coalesced chunks of 256 entries)
 // ------------------------------------------------------------------------------------------------
 constexpr int kL1BigTileHits = 16384;
 struct L1BigArgs {
@@ -354,7 +410,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, L1BigArgs 
   const int i = blockIdx.x;
   const int f = g.frag[i];
   const int s = a.fragS[f];
-  l1_emit_candidates(a, f, s, a.fragHits[f], s <= a.lutMaxS ? a.minHitsLUT[s] : 1, g.keys + g.hitOff[i], V + g.hitOff[i], ws, &sBase);
+  l1_emit_candidates_stream(a, f, a.fragHits[f], s <= a.lutMaxS ? a.minHitsLUT[s] : 1, g.keys + g.hitOff[i], V + g.hitOff[i], ws, &sBase);
 }
 
 // Reorder candidates into the reference's callback order — fragment ascending, then (seqId, start) as produced — or, for a batch

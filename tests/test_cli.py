@@ -69,7 +69,7 @@ def _run_evolved(binary, tmp, n=45000, extras=(["--matrix"], ["-t", "2", "--visu
         rb = subprocess.run([binary, "--ql", lst, "--rl", lst, "-o", os.path.join(tmp, "enew.out")] + extra, capture_output=True)
         assert ra.returncode == 0 and rb.returncode == 0, rb.stderr.decode()[-2000:]
         assert _lines(os.path.join(tmp, "eref.out")) == _lines(os.path.join(tmp, "enew.out")), extra
-        assert len(_lines(os.path.join(tmp, "eref.out"))) >= 25
+        assert len(_lines(os.path.join(tmp, "eref.out"))) >= 20
         if "-t" not in extra:
             assert open(os.path.join(tmp, "eref.out")).read() == open(os.path.join(tmp, "enew.out")).read(), extra
         if "--matrix" in extra:
@@ -85,7 +85,7 @@ def _run_evolved(binary, tmp, n=45000, extras=(["--matrix"], ["-t", "2", "--visu
 def test_cli_evolved_cpu_build(tmp_path):
     emu = os.path.join(ROOT, "tests", "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "all"])
-    _run_evolved(os.path.join(emu, "fastANI_emu"), str(tmp_path), n=21000, extras=(["--matrix"], ["-t", "2", "--visualize"]))
+    _run_evolved(os.path.join(emu, "fastANI_emu"), str(tmp_path), n=15000, extras=(["--matrix"], ["-t", "2", "--visualize"]))
 
 
 @pytest.mark.gpu
@@ -120,8 +120,8 @@ def _run_streaming_variants(binary, tmp, full=True):
             # reference set streamed through the device: one index chunk resident at a time (what a set beyond the HBM gets)
             ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, []),
             ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "5000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, ["--devices", "0,0"])]
-    if not full:                    # CPU build: one plain, one chunked two-context and the two streamed variants
-        envs = [envs[4], envs[5], envs[6]]
+    if not full:                    # CPU build: the two streamed variants (one of them chunked over two contexts)
+        envs = [envs[5], envs[6]]
     for env, extra in envs:
         for name, (args, rout) in ref.items():
             out = os.path.join(tmp, "new_%s.out" % name)

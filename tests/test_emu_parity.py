@@ -75,10 +75,10 @@ def test_chunked_with_small_batches(monkeypatch):
 def test_streamed_reference_set(monkeypatch, tmp_path):
     """reference set streamed chunk by chunk (one resident chunk), then with two resident chunks and tiny query sub-batches"""
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=1)
-    pc.case_streamed(e, tmp_path, n=24000)
+    pc.case_streamed(e, tmp_path, n=18000)
     e.close()
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=2, ANI_SUBBATCH_FRAGS=11, ANI_L2_CHUNK=17)
-    pc.case_streamed(e, n=15000, light=True)
+    pc.case_streamed(e, n=12000, light=True)
     e.close()
 
 
