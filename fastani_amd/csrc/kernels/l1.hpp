@@ -8,8 +8,8 @@
 // Two passes.  k_l1_probe: one lane per sketch hash, the index chunk's probe table (index.hpp), no LDS.  k_l1<HLO,HCAP>: one workgroup per fragment with HLO < H <= HCAP seed hits,
 // everything in LDS: gather the hit runs as 64-bit (seqId<<32 | wpos) keys, bitonic sort, flag valid runs, compact, flag
 // group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous candidate" only needs
-// the previous valid run), scan, emit.  Three LDS classes (<= 2048 hits: 6 workgroups per CU; <= 4096; <= 8192), the larger two driven by fragment lists.  Larger
-// fragments take k_l1_big_gather -> device radix sort -> k_l1_big_candidates over global memory.
+// the previous valid run), scan, emit.  Two LDS classes (<= 2048 hits: 6 workgroups per CU; <= 4096: 3), the larger driven by a fragment list.  Fragments
+// with more hits take the batched global-memory path: k_l1_big_offsets / _gather -> device radix sort -> k_l1_big_unpack / _candidates.
 #pragma once
 #include "common.hpp"
 #include "index.hpp"
@@ -20,9 +20,11 @@ constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS cl
 constexpr int kFragHashCapL1 = 4096;    // = kFragHashCap (sketch.hpp): the most sketch hashes a fragment can have
 constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 8 KiB scratch -> 6 workgroups per CU
 constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgroups per CU
-constexpr int kL1HitCapMax = 8192;      // class L: 64 KiB + 32 KiB -> 1 workgroup per CU (rare)
+constexpr int kL1HitCapMax = kL1HitCapMid;   // beyond: the batched global-memory path.  (A class L of 8192 hits — 96 KiB of LDS, one workgroup
+                                             // per CU — existed until round 3: 0.43 us per fragment where the batched path takes 0.33, measured at
+                                             // 493 k such fragments per step of the cluster-size-100 benchmark.)
 constexpr int kL1FilterMinHits = 300;   // below this the sort is cheaper than the noise filter
-template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 14 : HCAP == 4096 ? 15 : 16; }   // log2(8 * HCAP) occupancy counters per tiling
+template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 14 : 15; }   // log2(8 * HCAP) occupancy counters per tiling
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
@@ -33,13 +35,13 @@ struct L1Args {
   uint32_t *fragCandOff; int32_t *fragCandCnt; int32_t *fragHits;
   uint32_t *probeFirst, *probeCnt;      // per sketch hash (aligned with qPool): occurrence run in the hash-sorted index
   int32_t *midList; unsigned int *midCount;       // fragments with kL1HitCapSmall < H <= kL1HitCapMid
-  int32_t *largeList; unsigned int *largeCount;   // fragments with kL1HitCapMid < H <= kL1HitCapMax
   int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
   unsigned int *overflowCount;                    // fragments with >= 2^31 seed hits (fragHits = -1): the call fails
   unsigned long long *sumHits;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
   int filterMinHits;                    // kL1FilterMinHits (ANI_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
+  int ldsHitCap;                        // fragments with more seed hits take the batched global-memory path (<= kL1HitCapMax; ANI_L1_LDS_MAX)
 };
 
 // occurrences of hash h in the hash-ordered payload array: [first, first+cnt)
@@ -213,9 +215,8 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
       if (tooMany) atomicAdd(a.overflowCount, 1u);
       else if (s[q] > 0) {
         // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
-        if (s[q] <= kL1MaxS && H <= kL1HitCapMax) {
-          if (H > kL1HitCapSmall && H <= kL1HitCapMid) a.midList[atomicAdd(a.midCount, 1u)] = f;
-          else if (H > kL1HitCapMid) a.largeList[atomicAdd(a.largeCount, 1u)] = f;
+        if (s[q] <= kL1MaxS && H <= a.ldsHitCap) {
+          if (H > kL1HitCapSmall) a.midList[atomicAdd(a.midCount, 1u)] = f;
         } else a.bigList[atomicAdd(a.bigCount, 1u)] = f;         // beyond every LDS class: global-memory path
       }
     }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
     if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; }
     return;
   }
-  if (HLO == 0 && (s > kL1MaxS || H > kL1HitCapMax)) return;       // beyond every LDS class: k_l1_big_* below
+  if (HLO == 0 && (s > kL1MaxS || H > a.ldsHitCap)) return;        // beyond the LDS classes: k_l1_big_* below
   if (H <= HLO || H > HCAP || s <= 0 || s > kL1MaxS) return;     // another class handles it
   const uint32_t off = a.fragOff[f];
   const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather

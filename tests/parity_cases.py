@@ -145,15 +145,14 @@ def case_sparse_hits(engine):
 
 def case_l1_class_overflow(engine):
     """N near-identical copies of one 6-kb region: N x ~240 seed hits per query fragment, nearly all of them with neighbours, so the
-    noise filter keeps them and the fragment overflows the LDS of its hit-count class — 7 copies: class S -> M, 14: M -> L,
-    25: L -> the global-memory path, 40: global path directly"""
+    noise filter keeps them — 7 copies: class S, 14: class M (<= 4096 hits), 25 and 40: the batched global-memory path"""
     base = rng_genome(77, 6000)
     for copies in (7, 14, 25, 40):
         genomes = [[np.concatenate([rng_genome(900 + i, 300 + 7 * i), mutate(base, 0.002 * (i % 5), 4100 + i), rng_genome(1900 + i, 500)])] for i in range(copies)]
         p, sk, osk = check_sketch(engine, genomes)
         engine.reset_counters()
         check_queries(engine, p, sk, osk, [[base], genomes[copies // 2]])
-        assert (engine.counters()["l1BigFragments"] > 0) == (copies >= 40), copies
+        assert (engine.counters()["l1BigFragments"] > 0) == (copies >= 25), copies
 
 
 def case_species_dense(engine, copies=48, n=15000):

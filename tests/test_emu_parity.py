@@ -105,6 +105,13 @@ def test_big_l1_groups(monkeypatch):
     pc.case_species_dense(e, copies=52, n=9000)
     pc.case_low_complexity_big(e)
     e.close()
+    # ANI_L1_LDS_MAX=0: EVERY fragment takes the batched path (the LDS classes are an optimisation of it, not a different algorithm)
+    e = _emu_engine_with(monkeypatch, ANI_L1_LDS_MAX=0, ANI_L1_BIG_GROUP_HITS=200000)
+    e.reset_counters()
+    pc.case_synthetic_cluster(e, 24000)
+    pc.case_tandem_repeats(e)
+    assert e.counters()["l1BigFragments"] > 0
+    e.close()
 
 
 def test_limits(emu_engine):

@@ -296,6 +296,17 @@ def test_big_l1_groups(monkeypatch):
     pc.case_species_dense(e, copies=52, n=9000)
     pc.case_low_complexity_big(e)
     e.close()
+    # ANI_L1_LDS_MAX=0: EVERY fragment takes the batched path (the LDS classes are an optimisation of it, not a different algorithm)
+    e = _engine_with(monkeypatch, ANI_L1_LDS_MAX=0, ANI_L1_BIG_GROUP_HITS=200000)
+    e.reset_counters()
+    pc.case_synthetic_cluster(e)
+    pc.case_messy(e)
+    pc.case_tandem_repeats(e)
+    pc.case_evolved(e)
+    pc.case_sparse_hits(e)
+    assert pc.fuzz(e, seed=53, iterations=30) == 30
+    assert e.counters()["l1BigFragments"] > 0
+    e.close()
 
 
 def test_limits(gpu_engine):
