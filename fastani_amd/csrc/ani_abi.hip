@@ -189,6 +189,8 @@ struct ani_ctx {
   size_t l2ChunkCandidates = (size_t)1 << 21;                                      // L2 chunk size (env ANI_L2_CHUNK, tests)
   uint64_t l2CodeLimit = 0xfffffff0ull;                                             // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_L2_CODE_LIMIT, tests)
   uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
+  int l1FilterMin = ani::kL1FilterMinHits, l1LdsMax = ani::kL1HitCapMax;           // env ANI_L1_FILTER_MIN / ANI_L1_LDS_MAX, read by ani_init (tests: per engine, not per process)
+  bool l2Overlap = false;                                                           // env ANI_L2_OVERLAP=1 (see the L2 loop)
   uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;              // seed hits / fragments per group of the batched global-memory L1 path (env ANI_L1_BIG_GROUP_HITS / _FRAGS, tests)
   int32_t maxResidentChunks = 0;                                                    // index chunks of one reference set kept on the device (env ANI_MAX_RESIDENT_CHUNKS; 0 = decide from the free memory)
   uint64_t streamChunkMinimizers = 1000000000ull;                                   // chunk size once a set is streamed (env ANI_STREAM_CHUNK_MINIMIZERS): the build's transient arrays must fit beside the records
@@ -1275,8 +1277,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
     a.filterShift = 1; while (a.filterShift < 30 && (1 << a.filterShift) < 2 * L) a.filterShift++;
     a.fragOrder = fragOrder;
-    { static const int fm = getenv("ANI_L1_FILTER_MIN") ? atoi(getenv("ANI_L1_FILTER_MIN")) : kL1FilterMinHits; a.filterMinHits = fm; }
-    { static const int lm = getenv("ANI_L1_LDS_MAX") ? std::max(0, std::min(atoi(getenv("ANI_L1_LDS_MAX")), (int)kL1HitCapMax)) : (int)kL1HitCapMax; a.ldsHitCap = lm; }
+    a.filterMinHits = ctx->l1FilterMin; a.ldsHitCap = ctx->l1LdsMax;
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
@@ -1477,7 +1478,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         // 16 KiB slot a retiring simulation workgroup frees.  Off by default: with it the per-kernel times (bench line, rocprofv3) are
         // those of kernels that share the machine (k_l2_codes reads 77 ms instead of 39.6), and the dominant-kernel accounting of the
         // measurement contract stops meaning what it says.
-        static const bool overlap = getenv("ANI_L2_OVERLAP") && !strcmp(getenv("ANI_L2_OVERLAP"), "1");
+        const bool overlap = ctx->l2Overlap;
         hipStream_t simStream = ctx->stream;
         if (overlap) {
           HIP_TRY(hipEventRecord(ctx->evSimA[p], ctx->stream));            // codes of this chunk are written
@@ -1839,6 +1840,9 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
   if (const char *ev = getenv("ANI_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_INDEX_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->maxIndexMinimizers = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_L1_FILTER_MIN")) c->l1FilterMin = atoi(ev);
+  if (const char *ev = getenv("ANI_L1_LDS_MAX")) c->l1LdsMax = std::max(0, std::min(atoi(ev), (int)ani::kL1HitCapMax));
+  if (const char *ev = getenv("ANI_L2_OVERLAP")) c->l2Overlap = !strcmp(ev, "1");
   if (const char *ev = getenv("ANI_L1_BIG_GROUP_HITS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupHits = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L1_BIG_GROUP_FRAGS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupFrags = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev); if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
