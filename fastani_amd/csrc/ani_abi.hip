@@ -1794,16 +1794,21 @@ int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_frags
       TRY(collect_rows(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, &part[i], ch));
     }
   }
-  // a sub-batch's rows are (chunk, query, reference)-ordered and a chunk's references all precede the next chunk's: a stable sort by
-  // query restores (query, reference) order
+  // a sub-batch's rows are (chunk, query, reference)-ordered and a chunk's references all precede the next chunk's: a stable
+  // distribution by query — one counting pass, one scatter; the 7.8e7 rows of a 10 000 x 10 000 run are not comparison-sorted —
+  // restores (query, reference) order
   for (size_t i = 0; i < sub.size(); i++) {
     RowBuf &pb = part[i];
     if (!pb.n) continue;
-    std::stable_sort(pb.p, pb.p + pb.n, [](const ani_cgi_t &a, const ani_cgi_t &b) { return a.qryGenomeId < b.qryGenomeId; });
     ani_cgi_t *out = rows->grow(pb.n);
     if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", pb.n);
-    memcpy(out, pb.p, pb.n * sizeof(ani_cgi_t));
+    const int32_t q0 = sub[i].firstQueryId, nq = sub[i].g1 - sub[i].g0;
+    std::vector<size_t> start((size_t)nq + 1, 0);
+    for (size_t r = 0; r < pb.n; r++) start[(size_t)(pb.p[r].qryGenomeId - q0) + 1]++;
+    for (int32_t q = 0; q < nq; q++) start[(size_t)q + 1] += start[(size_t)q];
+    for (size_t r = 0; r < pb.n; r++) out[start[(size_t)(pb.p[r].qryGenomeId - q0)]++] = pb.p[r];
     rows->n += pb.n;
+    free(pb.p); pb.p = nullptr; pb.n = pb.cap = 0;                  // host memory of a big run: give each part back as soon as it is merged
   }
   return ANI_OK;
 }
