@@ -675,7 +675,7 @@ def main():
                           "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM", "all_vs_all_single_hash_pass": bool(self_mode),
                           "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
                "rows_last_step": int(len(rows)), "rows_identical_across_steps": len(set(rows_crc)) == 1, "step_ms_rank0": step_ms,
-               "stage_ms_per_step_rank0": stages, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
+               "stage_ms_per_step_rank0": stages, "host_timeline_ms_per_step_rank0": {k: round(v / args.steps, 2) for k, v in timers.items() if v}, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
                "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                               "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
                                                                               "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows")},
