@@ -349,9 +349,14 @@ def main():
     # product sources (tests/emu) over gloo, with tiny genomes — so that the multi-rank orchestration is exercised where there is
     # no GPU.  Never a measurement: the line it prints says so.
     emu = os.environ.get("ANI_BENCH_BACKEND", "") == "emu"
-    if world > 1:
+    # ANI_BENCH_FORCE_DIST=1 (hardware check on a 1-GPU box): take the multi-rank code path — process group over RCCL, the record
+    # all-gather or the fragment-set ring, the timing all-reduce — with a world of one rank
+    multi = world > 1 or bool(os.environ.get("ANI_BENCH_FORCE_DIST"))
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if emu:
             dist.init_process_group("gloo")
         else:
@@ -388,7 +393,7 @@ def main():
         ref_buf = torch.empty((hi - lo) * words + 64, dtype=torch.int32, device=dev)
         e.synth_packed(args.seed, lo, hi - lo, L, ref_buf.data_ptr(), variant=0, cluster_size=args.cluster_size)
         my_refs = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L)
-        refs = my_refs if world == 1 else None
+        refs = my_refs if not multi else None
         qrys = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L, first=0, count=nq_local)
         first_query_id = lo
         n_queries_total = nq_local * world
@@ -403,7 +408,7 @@ def main():
             first_query_id = 1
         else:
             nq_local = args.queries or NR
-            if rank == 0 and world == 1:
+            if rank == 0 and not multi:
                 qry_buf = ref_buf                                   # all-vs-all
             else:
                 qry_buf = torch.empty(nq_local * words + 64, dtype=torch.int32, device=dev)
@@ -415,14 +420,14 @@ def main():
     gcs = np.arange(NR + 1, dtype=np.int32)
     # all-vs-all on one GPU (the query set IS the reference set): every genome is hashed once for both roles
     self_slice = int(os.environ.get("ANI_BENCH_SELF_SLICE", "1000"))        # genomes per fused-pass slice of a large all-vs-all set (tests lower it)
-    self_mode = (not args.no_self) and world == 1 and ((cfg == "many-to-many" and not args.queries) or (cfg == "c4" and nq_local == NR))
+    self_mode = (not args.no_self) and not multi and ((cfg == "many-to-many" and not args.queries) or (cfg == "c4" and nq_local == NR))
 
     # multi-GPU staging buffers (allocated once): every rank's records land in its slot of `allrec`; the slot's first record
     # carries the count, so ONE all-gather moves counts and records (no count all-reduce, no compaction copy in the step)
-    ring_mode = world > 1 and cfg == "c4"        # reference-sharded: every rank indexes ITS genomes only, the query fragment sketches go round the ring
-    if world > 1:
+    ring_mode = multi and cfg == "c4"        # reference-sharded: every rank indexes ITS genomes only, the query fragment sketches go round the ring
+    if multi:
         part_g0 = np.array([(NR * r) // world for r in range(world + 1)], dtype=np.int32)
-    if world > 1 and not ring_mode:
+    if multi and not ring_mode:
         slot = int((hi - lo + 1) * (2.3 * L / (p.windowSize + 1))) + 4096          # records per rank, upper bound
         allrec = torch.empty(world * (slot + 1) * 3, dtype=torch.int32, device=dev)
         mine = allrec[rank * (slot + 1) * 3:(rank + 1) * (slot + 1) * 3]
@@ -445,7 +450,7 @@ def main():
     def step():
         t_a = time.perf_counter()
         frags = None
-        if world == 1 and self_mode and NR > 2 * self_slice:
+        if self_mode and NR > 2 * self_slice:
             # the same in slices of 1000 genomes (a slice's minimizers and sketch hashes are 32-bit counts): record parts + kept
             # fragment sets, one index over the parts, ONE mapping call over all sets (a streamed set builds each chunk once)
             parts, sets, firsts = [], [], []
@@ -465,14 +470,14 @@ def main():
             sk.close()
             timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["map_ms"] += (t_e - t_d) * 1e3
             return rows
-        elif world == 1 and self_mode:
+        elif self_mode:
             # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
             ptr, n, frags = e.sketch_records_self(p, refs, 0)
             sk = Sketch(e, p, records=(ptr, n, contig_len, gcs))
             if n:
                 e.device_free(ptr)
             t_b = t_c = time.perf_counter()
-        elif world == 1:
+        elif not multi:
             sk = Sketch(e, p, refs)
             t_b = t_c = time.perf_counter()
         elif ring_mode:
