@@ -302,6 +302,138 @@ __device__ inline void block_bitonic_sort(K *a, int n2)
   block_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bitonic sort in REGISTERS.
+//
+// block_bitonic_sort above moves every key through LDS once per two stages: at 1024 64-bit keys that is 30 passes, and the L1
+// kernel spent its time in the LDS pipe (SQ counters, profiles/r03c_pmc_sq_summary.txt: 1.07e9 LDS instructions and 3.9e9
+// bank-conflict cycles per step against 4.9e9 vector instructions).  Here a thread keeps KPT consecutive keys of the sequence in
+// registers (element e = t * KPT + r).  A stage whose stride stays inside a thread is compare-exchanges between registers; a stride
+// of KPT * m, m < 64, pairs a lane with lane ^ m of the same wave: the partner's key comes over the DPP / permlane data paths
+// (lane_xor below; no LDS bandwidth, no bank conflicts, no barrier); only strides that pair two WAVES go through LDS (3 of the 55
+// stages at 1024 keys in four waves).
+// ---------------------------------------------------------------------------------------------
+// value of lane ^ M for M = 1, 2, 4, 8, 16, 32.  (Checked lane by lane on an MI355X: tools/ubench/lanexor.hip.)
+template <int M> __device__ __forceinline__ uint32_t lane_xor(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);         // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) {
+    int r = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);                               // row_shl:4 into lanes 0-3, 8-11 of a row
+    return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xf, 0xA, false);                      // row_shr:4 into lanes 4-7, 12-15
+  }
+  else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xf, 0xf, true);   // row_ror:8
+  else if constexpr (M == 16) {                                                                           // v_permlane16_swap (gfx950): odd rows of one <-> even rows of the other
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return (threadIdx.x & 16) ? r[0] : r[1];
+  } else {                                                                                                // v_permlane32_swap: upper half of one <-> lower half of the other
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (threadIdx.x & 32) ? r[0] : r[1];
+  }
+#else
+  return __shfl_xor(x, M);
+#endif
+}
+template <int M> __device__ __forceinline__ uint64_t lane_xor(uint64_t x)
+{
+  return ((uint64_t)lane_xor<M>((uint32_t)(x >> 32)) << 32) | lane_xor<M>((uint32_t)x);
+}
+
+// this element keeps the smaller (keepMin) or the larger of its own key and its partner's
+template <class K> __device__ __forceinline__ K sort_pick(K own, K partner, bool keepMin) { return ((partner < own) == keepMin) ? partner : own; }
+
+// one stage with thread stride m (1..32): every key against the same register of lane ^ m
+template <class K, int KPT, int M> __device__ __forceinline__ void sort_lane_stage(K (&k)[KPT], bool keepMin)
+{
+#pragma unroll
+  for (int r = 0; r < KPT; r++) k[r] = sort_pick(k[r], lane_xor<M>(k[r]), keepMin);
+}
+// strides KPT/2 .. 1 of a merge whose direction `up` is the same for all keys of the thread
+template <class K, int KPT> __device__ __forceinline__ void sort_thread_merge(K (&k)[KPT], bool up)
+{
+#pragma unroll
+  for (int st = KPT >> 1; st >= 1; st >>= 1)
+#pragma unroll
+    for (int r = 0; r < KPT; r++)
+      if ((r & st) == 0) bitonic_ce(k[r], k[r + st], up);
+}
+
+// Sorts the n2 = 64 * WAVES * KPT keys a[0 .. n2) ascending; waves >= WAVES return at once (WAVES = 1: no workgroup barrier inside, the
+// caller's barriers frame it).  WAVES is 1 or kTPB / kWave.
+template <class K, int KPT, int WAVES>
+__device__ __forceinline__ void block_sort_regs(K *a)
+{
+  constexpr int NT = kWave * WAVES;                      // threads that hold keys
+  const int t = threadIdx.x;
+  if (WAVES == 1 && t >= kWave) return;
+  K k[KPT];
+  // the input is unordered, so any assignment of keys to (thread, register) will do: the conflict-free one
+#pragma unroll
+  for (int r = 0; r < KPT; r++) k[r] = a[r * NT + t];
+  if (WAVES > 1) block_barrier();                        // every key is in a register: `a` is free for the cross-wave stages
+  // sizes 2 .. KPT: inside the thread; the direction of an element is bit `size` of e = t * KPT + r
+#pragma unroll
+  for (int size = 2; size <= KPT; size <<= 1)
+#pragma unroll
+    for (int st = size >> 1; st >= 1; st >>= 1)
+#pragma unroll
+      for (int r = 0; r < KPT; r++)
+        if ((r & st) == 0) bitonic_ce(k[r], k[r + st], size < KPT ? (r & size) == 0 : (t & 1) == 0);
+  // sizes 2 KPT .. n2: thread strides m = size / (2 KPT) .. 1, then the thread's own merge
+  for (int ts = 2; ts <= NT; ts <<= 1) {                 // ts = size / KPT
+    const bool up = (t & ts) == 0;
+    for (int m = ts >> 1; m >= 1; m >>= 1) {
+      const bool keepMin = ((t & m) == 0) == up;
+      if (WAVES > 1 && m >= kWave) {                     // partner in another wave: through LDS
+#pragma unroll
+        for (int r = 0; r < KPT; r++) a[r * NT + t] = k[r];
+        block_barrier();
+#pragma unroll
+        for (int r = 0; r < KPT; r++) k[r] = sort_pick(k[r], a[r * NT + (t ^ m)], keepMin);
+        block_barrier();
+      } else {
+        switch (m) {                                     // wave-uniform
+          case 32: sort_lane_stage<K, KPT, 32>(k, keepMin); break;
+          case 16: sort_lane_stage<K, KPT, 16>(k, keepMin); break;
+          case 8: sort_lane_stage<K, KPT, 8>(k, keepMin); break;
+          case 4: sort_lane_stage<K, KPT, 4>(k, keepMin); break;
+          case 2: sort_lane_stage<K, KPT, 2>(k, keepMin); break;
+          default: sort_lane_stage<K, KPT, 1>(k, keepMin); break;
+        }
+      }
+    }
+    sort_thread_merge<K, KPT>(k, up);
+  }
+#pragma unroll
+  for (int r = 0; r < KPT; r++) a[t * KPT + r] = k[r];
+}
+
+// Sorts a[0 .. n) ascending, n <= 4096 (the caller's array has room for next_pow2(max(n, 64)) keys; the tail is padded with ~0).
+// Frames itself with workgroup barriers: the keys are complete before, the sorted sequence is visible after.
+__host__ __device__ __forceinline__ int next_pow2_dev(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+template <class K>
+__device__ __forceinline__ void block_sort(K *a, int n)      // (inlined: an out-of-line copy would see `a` as a generic pointer and use flat instead of ds instructions)
+{
+  int n2 = next_pow2_dev(n); n2 = n2 < kWave ? kWave : n2;
+  for (int i = n + (int)threadIdx.x; i < n2; i += kTPB) a[i] = (K)~(K)0;
+#ifdef ANI_SORT_LDS                                          // build switch for A/B measurements: the LDS network above
+  block_bitonic_sort<K>(a, n2);
+  return;
+#endif
+  block_barrier();
+  switch (n2) {                                           // workgroup-uniform
+    case 64: block_sort_regs<K, 1, 1>(a); break;
+    case 128: block_sort_regs<K, 2, 1>(a); break;
+    case 256: block_sort_regs<K, 4, 1>(a); break;
+    case 512: block_sort_regs<K, 2, kTPB / kWave>(a); break;
+    case 1024: block_sort_regs<K, 4, kTPB / kWave>(a); break;
+    case 2048: block_sort_regs<K, 8, kTPB / kWave>(a); break;
+    default: block_sort_regs<K, 16, kTPB / kWave>(a); break;
+  }
+  block_barrier();
+}
+
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A grid padded to a multiple of 8 is turned inside out:
 // XCD x works through the x-th eighth of the items in order, so items that are neighbours in the list (and share data) meet in
 // one L2 at about the same time.  The caller drops indices >= its item count.

@@ -432,9 +432,7 @@ __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ se
   }
   // ---- sort + unique (computeMap.hpp:268-274) ----
   const int n = produced;
-  const int n2 = next_pow2(n > 1 ? n : 1);
-  for (int i = n + threadIdx.x; i < n2; i += kTPB) hbuf[i] = 0xffffffffu;
-  block_bitonic_sort<uint32_t>(hbuf, n2);
+  block_sort<uint32_t>(hbuf, n);
   const int per = (n + kTPB - 1) / kTPB;
   const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
   int cntU = 0;
@@ -512,9 +510,7 @@ __device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool over
                                                 unsigned long long *__restrict__ poolCount, uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS,
                                                 int *__restrict__ maxS, int *ws, unsigned long long *sBasePtr)
 {
-  const int n2 = next_pow2(n > 1 ? n : 1);
-  for (int i = n + threadIdx.x; i < n2; i += kTPB) hbuf[i] = 0xffffffffu;
-  block_bitonic_sort<uint32_t>(hbuf, n2);
+  block_sort<uint32_t>(hbuf, n);
   const int per = (n + kTPB - 1) / kTPB;
   const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
   int cntU = 0;
