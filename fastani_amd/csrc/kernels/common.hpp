@@ -337,6 +337,9 @@ template <int M> __device__ __forceinline__ uint32_t lane_xor(uint32_t x)
 }
 template <int M> __device__ __forceinline__ uint64_t lane_xor(uint64_t x)
 {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return __shfl_xor(x, M);
+#endif
   return ((uint64_t)lane_xor<M>((uint32_t)(x >> 32)) << 32) | lane_xor<M>((uint32_t)x);
 }
 

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <ucontext.h>
+#include <cstdlib>
 #include <vector>
 #include <stdexcept>
 
@@ -12,31 +13,87 @@ dim3 g_blockDim, g_gridDim;
 
 namespace {
 enum State { READY = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+/* Context switch.  swapcontext() saves and restores the signal mask with a system call on every switch; a kernel of this library
+ * switches at every barrier and wave collective of every lane (the register bitonic sort alone: hundreds of lane exchanges per
+ * workgroup), and the CPU test suite spent most of its time there.  On x86-64 the switch is done by hand: callee-saved registers
+ * and the stack pointer, nothing else (no signal mask, no floating-point control words: the kernels touch neither). */
+#if defined(__x86_64__)
+#define EMU_FAST_SWITCH 1
+extern "C" void hipemu_switch(void **saveSp, void *loadSp);
+asm(".text\n"
+    ".globl hipemu_switch\n"
+    ".type hipemu_switch,@function\n"
+    "hipemu_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size hipemu_switch, .-hipemu_switch\n");
+#endif
 struct Fiber {
+#ifdef EMU_FAST_SWITCH
+  void *sp = nullptr;
+#else
   ucontext_t ctx;
+#endif
   char *stack = nullptr;
   State st = DONE;
   emu_uint3 tid;
 };
 const size_t kStack = 256 * 1024;
 std::vector<Fiber> g_fibers;
+#ifdef EMU_FAST_SWITCH
+void *g_schedSp = nullptr;
+#else
 ucontext_t g_sched;
+#endif
 int g_cur = -1;
 const std::function<void()> *g_body = nullptr;
 /* per-wave exchange */
 struct WaveBuf { uint64_t v[64]; uint64_t mask; };
 std::vector<WaveBuf> g_waves;
 
+inline void to_scheduler(int me) {
+#ifdef EMU_FAST_SWITCH
+  hipemu_switch(&g_fibers[me].sp, g_schedSp);
+#else
+  swapcontext(&g_fibers[me].ctx, &g_sched);
+#endif
+}
 void fiber_entry() {
   (*g_body)();
   g_fibers[g_cur].st = DONE;
-  swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+  to_scheduler(g_cur);
+  abort();                       /* a finished fiber is never resumed */
 }
 void yield(State s) {
   int me = g_cur;
   g_fibers[me].st = s;
-  swapcontext(&g_fibers[me].ctx, &g_sched);
+  to_scheduler(me);
   g_threadIdx = g_fibers[me].tid; /* restored by scheduler too; belt and braces */
+}
+/* makes fiber t start at fiber_entry on its own stack the next time it is switched to */
+void fiber_reset(Fiber &f) {
+#ifdef EMU_FAST_SWITCH
+  uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+  void **sp = (void **)top;
+  *--sp = nullptr;                      /* the return address fiber_entry would see: it never returns (and rsp = 8 mod 16 on entry) */
+  *--sp = (void *)&fiber_entry;         /* popped by the `ret` of hipemu_switch */
+  for (int i = 0; i < 6; i++) *--sp = nullptr;   /* rbp rbx r12 r13 r14 r15 */
+  f.sp = (void *)sp;
+#else
+  getcontext(&f.ctx);
+  f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = &g_sched;
+  makecontext(&f.ctx, fiber_entry, 0);
+#endif
+}
+inline void run_fiber(Fiber &f) {
+#ifdef EMU_FAST_SWITCH
+  hipemu_switch(&g_schedSp, f.sp);
+#else
+  swapcontext(&g_sched, &f.ctx);
+#endif
 }
 }  // namespace
 
@@ -76,11 +133,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     g_blockIdx = {bx, by, bz};
     for (size_t t = 0; t < nthreads; t++) {
       Fiber &f = g_fibers[t];
-      getcontext(&f.ctx);
-      f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = &g_sched;
       f.tid = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / ((size_t)block.x * block.y))};
       f.st = READY;
-      makecontext(&f.ctx, fiber_entry, 0);
+      fiber_reset(f);
     }
     for (;;) {
       bool any = false;
@@ -88,7 +143,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
         if (g_fibers[t].st != READY) continue;
         any = true;
         g_cur = (int)t; g_threadIdx = g_fibers[t].tid;
-        swapcontext(&g_sched, &g_fibers[t].ctx);
+        run_fiber(g_fibers[t]);
       }
       /* everyone is now waiting or done: release waves first, then the block barrier */
       size_t done = 0, wb = 0, ww = 0;
