@@ -85,7 +85,7 @@ def _run_evolved(binary, tmp, n=45000, extras=(["--matrix"], ["-t", "2", "--visu
 def test_cli_evolved_cpu_build(tmp_path):
     emu = os.path.join(ROOT, "tests", "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "all"])
-    _run_evolved(os.path.join(emu, "fastANI_emu"), str(tmp_path), n=15000, extras=(["--matrix"], ["-t", "2", "--visualize"]))
+    _run_evolved(os.path.join(emu, "fastANI_emu"), str(tmp_path), n=30000)
 
 
 @pytest.mark.gpu
@@ -152,7 +152,7 @@ def _run_streaming_variants(binary, tmp, full=True):
 def test_cli_streaming_variants_cpu_build(tmp_path):
     emu = os.path.join(ROOT, "tests", "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "all"])
-    _run_streaming_variants(os.path.join(emu, "fastANI_emu"), str(tmp_path), full=False)
+    _run_streaming_variants(os.path.join(emu, "fastANI_emu"), str(tmp_path))
 
 
 @pytest.mark.gpu

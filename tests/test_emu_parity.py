@@ -9,15 +9,9 @@ import parity_cases as pc
 
 @pytest.mark.parametrize("case", pc.ALL_CASES, ids=lambda c: c.__name__)
 def test_case(emu_engine, case):
-    # (the CPU stand-in runs every lane as a fiber: sizes are cut here, the GPU suite runs the cases at their full size)
+    # (the CPU stand-in runs every lane as a fiber: the largest case is cut here, the GPU suite runs it at its full size)
     if case is pc.case_synthetic_cluster:
         case(emu_engine, 45000)
-    elif case is pc.case_self:
-        case(emu_engine, combos=((16, 3000), (12, 3000), (16, 3050)))
-    elif case is pc.case_window_sizes:
-        case(emu_engine, windows=(2, 12, 25, 48, 49, 97))
-    elif case is pc.case_evolved:
-        case(emu_engine, n=36000, members=5)
     else:
         case(emu_engine)
 
@@ -30,7 +24,7 @@ def test_device_synth(emu_engine):
 
 
 def test_fuzz(emu_engine):
-    assert pc.fuzz(emu_engine, seed=7, iterations=6) == 6
+    assert pc.fuzz(emu_engine, seed=7, iterations=12) == 12
 
 
 def test_small_batches_and_chunks(monkeypatch):
@@ -59,16 +53,17 @@ def _emu_engine_with(monkeypatch, **env):
 
 def test_chunked_reference_set(monkeypatch):
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=8000)
-    pc.case_chunked(e, extra=False)
-    assert pc.fuzz(e, seed=23, iterations=2) == 2
+    pc.case_chunked(e)
+    assert pc.fuzz(e, seed=23, iterations=3) == 3
     e.close()
 
 
 def test_chunked_with_small_batches(monkeypatch):
     """index chunks x query sub-batches x L2 chunks, all tiny"""
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_L2_CHUNK=11)
-    pc.case_synthetic_cluster(e, 24000)
-    pc.case_self(e, combos=((16, 3000),))
+    pc.case_synthetic_cluster(e, 30000)
+    pc.case_sparse_hits(e)
+    pc.case_self(e, combos=((16, 3000), (16, 3050)))
     e.close()
 
 
