@@ -951,7 +951,7 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
     {
       const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
       if (n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask)        // otherwise the L2 fast path is off (map_stage) and the links are never read
-        hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
+        hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + kWinBlock - 1) / kWinBlock)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
                            (const int32_t *)sk->contigFirstMin, (const uint8_t *)sk->mDelta, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
     }
     // probe table: the distinct hashes in an order-preserving open-addressing table, load 0.5 (index.hpp)

@@ -134,6 +134,43 @@ def case_low_complexity_big(engine):
     assert c["l2SlowCandidates"] > 0          # candidate ranges longer than 16384 entries went through the general kernel
 
 
+def case_gap_counter_overflow(engine):
+    """a fragment whose sketch is a single hash (a period-23 tandem repeat) against windows of ordinary sequence: more than 127
+    distinct reference hashes fall into one gap of the query sketch, the 7-bit gap counters of k_l2_sim overflow — while the first
+    super-window is still filling (k_l2_sim's fill phase) and later — and those candidates must come back from the general
+    kernel, their lane neighbours (ordinary fragments of the same query, in the same wave) unharmed"""
+    ref = rng_genome(5, 30000)
+    rep = np.tile(rng_genome(9, 23), 400)[:9000]
+    related = mutate(ref[14000:23000], 0.05, 3)
+    genomes = [[np.concatenate([ref[:12000], rep[:300], ref[12000:]])],
+               [np.concatenate([rng_genome(6, 7000), rep[:150], rng_genome(7, 9000), rep[:300], rng_genome(8, 5000)])],
+               [orc.synth_genome(2, 0, 9000)]]
+    p, sk, osk = check_sketch(engine, genomes)
+    engine.reset_counters()
+    check_queries(engine, p, sk, osk, [[np.concatenate([rep[:3000], related])], [rep[:6000]], [np.concatenate([related[:3000], rep[:3000], related[3000:6000]])]])
+    c = engine.counters()
+    assert c["l2SlowOverflow"] > 0 and c["l2FastCandidates"] > 0, c
+    # the same with single occurrences of the repeat's hash in the references (40 bases of the repeat here and there: no same-hash
+    # neighbours, so the overflow happens in the fill phase; an experimental fill phase that let an overflowing byte carry into the
+    # next lane's field gave wrong rows on this input).
+    r = np.random.default_rng(105)
+    ref = rng_genome(10, 60000)
+    rep = np.tile(rng_genome(14, 23), 400)[:9000]
+    parts, pos = [], 0
+    for i in range(12):
+        step = int(r.integers(2500, 4500))
+        parts += [ref[pos:pos + step], rep[:40]]
+        pos += step
+    g0 = np.concatenate(parts + [ref[pos:]])
+    related = mutate(ref[2000:32000], 0.06, 8)
+    genomes = [[g0], [mutate(g0[:40000], 0.03, 77)], [orc.synth_genome(2, 0, 9000)]]
+    p, sk, osk = check_sketch(engine, genomes)
+    engine.reset_counters()
+    check_queries(engine, p, sk, osk, [[np.concatenate([related[:6000], rep[:3000], related[6000:15000], rep[:3000], related[15000:30000]])]])
+    c = engine.counters()
+    assert c["l2SlowOverflow"] > 0 and c["l2FastCandidates"] > 0, c
+
+
 def case_sparse_hits(engine):
     """few, scattered seed hits per reference (10-20 % divergence, 60 references): most hits are isolated and the L1 noise
     filter drops them before the sort; the candidates must not change"""
@@ -463,7 +500,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
+             case_low_complexity_big, case_gap_counter_overflow, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):
