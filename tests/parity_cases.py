@@ -171,6 +171,34 @@ def case_gap_counter_overflow(engine):
     assert c["l2SlowOverflow"] > 0 and c["l2FastCandidates"] > 0, c
 
 
+def case_l1_mid_two_walk(engine):
+    """a fragment with 2048 < seed hits <= 4096 most of which are noise: one k-mer of the fragment (chosen with a tiny hash, so that
+    it is the minimizer of every window that holds it) sits on 2300 short contigs of one reference genome — isolated hits on 2300
+    different contigs, all dropped by the noise filter; ani::k_l1_mid reads the hit runs twice and stages only the survivors (the
+    hits on the two relatives).  case_tandem_repeats / case_low_complexity cover the fragments it hands on to k_l1<2048,4096>."""
+    r = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    while True:
+        x = acgt[r.integers(0, 4, 16)]
+        if orc.hash_kmer(x) < (1 << 32) // 20000:
+            break
+    base = rng_genome(31, 9000)
+    base[1500:1516] = x                                                   # in the first fragment
+    contigs = []
+    for i in range(2300):
+        c = acgt[r.integers(0, 4, 60)]
+        c[22:38] = x
+        contigs.append(c)
+    genomes = [[mutate(base, 0.04, 1)], contigs, [mutate(base, 0.08, 2)], [orc.synth_genome(2, 0, 9000)]]
+    for g in (genomes[0], genomes[2]):
+        g[0][1500:1516] = x
+    p, sk, osk = check_sketch(engine, genomes)
+    engine.reset_counters()
+    rows = check_queries(engine, p, sk, osk, [[base]])
+    c = engine.counters()
+    assert len(rows) >= 2 and c["l1MidFragments"] >= 1 and c["l1MidStaged"] < c["l1MidFragments"], (len(rows), c["l1MidFragments"], c["l1MidStaged"])
+
+
 def case_sparse_hits(engine):
     """few, scattered seed hits per reference (10-20 % divergence, 60 references): most hits are isolated and the L1 noise
     filter drops them before the sort; the candidates must not change"""
@@ -500,7 +528,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_gap_counter_overflow, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
+             case_low_complexity_big, case_gap_counter_overflow, case_l1_mid_two_walk, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):
