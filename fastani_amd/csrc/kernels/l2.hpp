@@ -615,7 +615,8 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
   // them; from then on the general loop below takes over, mid-window if need be.
   // What it buys is bounded by the LDS round trip of the byte read-modify-write chain (eight dependent ones per block, 2.5 waves
   // per SIMD to hide them): k_l2_sim 47.7 -> 43.7 ms per step.  Measured and dropped: the updates as LDS atomics on the shared
-  // dwords, returning (43.9 ms) or fire-and-forget with a sum check against carries between the lanes' bytes (46.7 ms).
+  // dwords, returning (43.9 ms) or fire-and-forget with a sum check against carries between the lanes' bytes (46.7 ms); four events
+  // at a time with their fields read together and same-field events added up in registers (44.5 ms).
   int blk = 0;
   {
     constexpr uint32_t kFillPair = (kL2InsBit | kL2NoEvalBit) * 0x10001u, kDupPair = kL2DupBit * 0x10001u;
