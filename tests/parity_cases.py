@@ -576,6 +576,26 @@ def fuzz(engine, seed, seconds=None, iterations=None):
             return golden_cases.evolve(base, int(rng.integers(1e9)), sub=rate, indel=float(rng.choice([0.0, 0.001, 0.005, 0.02])), inversions=int(rng.integers(0, 3)),
                                        duplications=int(rng.integers(0, 3)), translocations=int(rng.integers(0, 3)), seg=(max(50, L // 4), 3 * L))
 
+        if rng.random() < 0.12 and len(base) >= L:  # one minimizer of the first fragment on hundreds or thousands of short contigs: isolated seed hits (L1 classes M / big, noise filter)
+            w = orc.recommended_window(k, L)
+            mins = orc.winnow(orc.upper(base[:L]), k, w)
+            x = None
+            if len(mins):
+                best = mins[int(np.argmin(mins["hash"]))]              # wpos is the window's start (winSketch.hpp:120-155): the k-mer lies in [wpos, wpos + w)
+                ub = orc.upper(base[:L])
+                for pos in range(int(best["wpos"]), min(int(best["wpos"]) + w, L - k + 1)):
+                    if orc.hash_kmer(ub[pos:pos + k]) == int(best["hash"]):
+                        x = ub[pos:pos + k]
+                        break
+            if x is not None:
+                acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+                many = []
+                for _ in range(int(rng.choice([300, 1200, 2300, 3000]))):
+                    c = acgt[rng.integers(0, 4, int(rng.integers(3 * k + w, 6 * k + w)))]
+                    o = int(rng.integers(0, len(c) - k + 1))
+                    c[o:o + k] = x
+                    many.append(c)
+                genomes.append(many)
         for _ in range(int(rng.integers(1, 5))):
             if rng.random() < 0.6:
                 g = relative(float(rng.choice([0, 0.01, 0.05, 0.1, 0.2])))
@@ -583,6 +603,11 @@ def fuzz(engine, seed, seconds=None, iterations=None):
                 g = rand_genome(int(rng.integers(10, 10 * L)))
             genomes.append(contigs(g))
         qs = [genomes[int(rng.integers(len(genomes)))] for _ in range(2)] + [contigs(relative(0.03))]
+        if rng.random() < 0.15:                      # a query whose fragments alternate between a short-period repeat (sketches of one or two hashes) and ordinary sequence
+            unit = rng_genome(int(rng.integers(1e9)), int(rng.integers(5, 40)))
+            rep = np.tile(unit, L // len(unit) + 1)[:L]
+            rel = relative(0.04)
+            qs.append([np.concatenate([rep, rel[:2 * L], rep, rel[2 * L:4 * L]])])
         p, sk, osk = check_sketch(engine, genomes, k=k, frag_len=L)
         check_queries(engine, p, sk, osk, qs, k=k, frag_len=L)
     return it
