@@ -1281,13 +1281,15 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   TRY(ctx->fragCandOff.ensure(nF * 4)); TRY(ctx->fragCandCnt.ensure(nF * 4)); TRY(ctx->fragCandCntClamped.ensure(nF * 4));
   TRY(ctx->fragHits.ensure(nF * 4)); TRY(ctx->fragOrdOff.ensure((nF + 1) * 4));
   TRY(ctx->probeFirst.ensure((fs.poolSize + 1) * 4)); TRY(ctx->probeCnt.ensure((fs.poolSize + 1) * 4));      // indexed like the sketch pool
-  uint64_t ccap = (uint64_t)((double)nF * ctx->candPerFrag) + 4096;
+  // First guess of the candidate pool from the context's running estimate, never beyond what 32-bit candidate ids allow (the limit
+  // is an error only when the batch really needs more: the retry below).
+  const uint64_t kCandLimit = 0x7fffff00ull;      // whole stripes below 2^31
+  uint64_t ccap = std::min<uint64_t>((uint64_t)((double)nF * ctx->candPerFrag) + 4096, kCandLimit);
   TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
   unsigned nMid = 0, nBig = 0;
   std::vector<int32_t> bigFrags, bigInfo;          // fragments beyond the LDS classes and their (sketch size, seed hits)
   unsigned long long hitsTotal = 0;
   for (int attempt = 0;; attempt++) {
-    if (ccap > 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
     ccap = (uint64_t)stripe_cap(ccap) * kPoolStripes;
     TRY(ctx->candFrag.ensure(ccap * 4)); TRY(ctx->candSeq.ensure(ccap * 4)); TRY(ctx->candStart.ensure(ccap * 4)); TRY(ctx->candEnd.ensure(ccap * 4));
     if (attempt == 0) TRY(zero_counters(ctx));
@@ -1398,9 +1400,17 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     if (attempt == 0) { hitsTotal = host[CNT_HITS]; ctx->counters.l1MidFragments += nMid; if (nMid) ctx->counters.l1MidStaged += (uint32_t)host[CNT_LISTL]; }
     if (ctx->poolMaxStripe[POOL_CAND] <= stripe_cap(ccap)) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "candidate pool did not converge");
-    ccap = (uint64_t)(1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes) + 4096;       // = what candPerFrag will ask for next time
+    if (ccap >= kCandLimit) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
+    ccap = std::min<uint64_t>((uint64_t)(1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes) + 4096, kCandLimit);
   }
-  ctx->candPerFrag = std::max(ctx->candPerFrag, 1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes / (double)nF);   // size the pool right next time (by the fullest stripe)
+  // Size the pool right next time (by the fullest stripe).  Only a batch that fills the stripes evenly says anything about the next
+  // one: a handful of fragments sit in a handful of stripes, and "fullest stripe x 64 / fragments" of a one-fragment batch with
+  // 1000 candidates would ask for 80 000 candidates per fragment of the next, million-fragment batch (a bogus 2^31 limit error
+  // after 34 GB of pool; seen in the parity suite under ANI_POOL_POISON).  The estimate follows the batches down as well as up.
+  if (nF >= 64 * kPoolStripes) {
+    const double seen = 1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes / (double)nF;
+    ctx->candPerFrag = std::max(12.0, seen >= ctx->candPerFrag ? seen : 0.5 * (ctx->candPerFrag + seen));
+  }
   if ((uint32_t)host[CNT_NEG] != 0)            // k_l1_probe: hit counts and offsets are 32-bit per fragment
     return fail(ANI_ERR_LIMIT, "%u query fragment(s) have 2^31 or more seed hits in one index chunk (a hash with ~10^9 occurrences: low-complexity / "
                                "repetitive references); use the reference's -s sanity check or a smaller ANI_MAX_INDEX_MINIMIZERS", (uint32_t)host[CNT_NEG]);

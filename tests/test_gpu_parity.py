@@ -206,6 +206,27 @@ def test_chunked_full_size_equals_unchunked(gpu_engine, monkeypatch):
     e.close()
 
 
+def test_tiny_batches_do_not_inflate_the_candidate_pool(monkeypatch):
+    """a context that mapped single fragments with thousands of candidates (low-complexity input) and then gets a large batch: the
+    running estimate of candidates per fragment once took "fullest pool stripe x 64 / fragments" of the one-fragment batches at face
+    value and failed the 40 000-fragment batch with a bogus 2^31-candidates error"""
+    import torch
+    from fastani_amd.api import DeviceGenomes, Sketch
+    e = _engine_with(monkeypatch)
+    pc.case_low_complexity_big(e)
+    pc.case_low_complexity(e)
+    n, L = 24, 5_000_000
+    words = (L + 15) // 16
+    buf = torch.zeros(n * words + 64, dtype=torch.int32, device="cuda:0")
+    e.synth_packed(99, 0, n, L, buf.data_ptr())
+    dg = DeviceGenomes(buf.data_ptr(), n, L)
+    sk = Sketch(e, e.params(), dg)
+    rows = sk.map_cgi_batch(dg, 0)
+    assert len(rows) >= n
+    sk.close()
+    e.close()
+
+
 def test_repeated_runs_are_identical(monkeypatch):
     """24 x 5 Mbp mapped 25 times with the L1 noise filter forced on for every fragment (its compaction hands the sort a different
     permutation every time): rows, candidate and window counters must not move.  Regression test for a barrier without its LDS
