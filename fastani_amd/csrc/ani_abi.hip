@@ -238,7 +238,7 @@ struct ani_ctx {
   DevBuf sortTmp, unitStart, unitAux, tiles, tileInfo, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
-  DevBuf probeFirst, probeCnt, l1MidList, l1MidList2, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
+  DevBuf probeFirst, probeCnt, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
   DevBuf l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
@@ -1312,7 +1312,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
       if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
-      { StageTimer tk(ctx, &ctx->counters.msL1Main, 1); hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3(pad8(nF)), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr, (const unsigned int *)nullptr); }
+      { StageTimer tk(ctx, &ctx->counters.msL1Main, 1); hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3(pad8(nF)), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr); }
       if (attempt == 0) {
         unsigned long long nl[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(nl, cnt_ptr(ctx, CNT_LISTM), 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -1329,14 +1329,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
           ctx->counters.l1BigFragments += nBig;
         }
       }
-      if (nMid) {
-        // class M: two walks in the LDS budget of class S (l1.hpp: k_l1_mid); what keeps more than 2048 hits goes on to the 48 KiB kernel
-        TRY(ctx->l1MidList2.ensure((size_t)nMid * 4));
-        unsigned int *mid2Count = (unsigned int *)cnt_ptr(ctx, CNT_LISTL);
-        HIP_TRY(hipMemsetAsync(mid2Count, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(k_l1_mid, dim3(nMid), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.midList, ctx->l1MidList2.as<int32_t>(), mid2Count);
-        hipLaunchKernelGGL((k_l1<kL1HitCapSmall, kL1HitCapMid>), dim3(nMid), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)ctx->l1MidList2.as<int32_t>(), (const unsigned int *)mid2Count);
-      }
+      if (nMid) hipLaunchKernelGGL((k_l1<kL1HitCapSmall, kL1HitCapMid>), dim3(nMid), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)a.midList);
       if (nBig) {
         // Fragments beyond every LDS class, batched (l1.hpp): groups of fragments whose hits fit the key buffers; one 64-bit key per
         // hit = (fragment rank in the group, seqId, wpos), field widths from this chunk's contig count and longest contig.
@@ -1397,7 +1390,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     }
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
-    if (attempt == 0) { hitsTotal = host[CNT_HITS]; ctx->counters.l1MidFragments += nMid; if (nMid) ctx->counters.l1MidStaged += (uint32_t)host[CNT_LISTL]; }
+    if (attempt == 0) { hitsTotal = host[CNT_HITS]; ctx->counters.l1MidFragments += nMid; }
     if (ctx->poolMaxStripe[POOL_CAND] <= stripe_cap(ccap)) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "candidate pool did not converge");
     if (ccap >= kCandLimit) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
@@ -1907,7 +1900,7 @@ void ani_shutdown(ani_ctx *c)
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileInfo, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
-                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1MidList, &c->l1MidList2, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->l1BigTbl, &c->l1BigHash, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
+                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->l1BigTbl, &c->l1BigHash, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->fragOrder, &c->fragOrderTmp, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
                     &c->l2Ranges[1], &c->l2CodeCount[1], &c->l2CodeOff[1], &c->l2Codes[1], &c->l2SlowFlag[1], &c->l2ClassList[1], &c->l2Order[1], &c->l2LenHist[1], &c->l2SlowList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};

@@ -237,8 +237,11 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
 }
 
 // Pass 2: gather + sort + candidate regions for the fragments whose hit count is in (HLO, HCAP]; everything in LDS.
+// (Measured and removed in round 3: class M "in two walks" — the hit runs read twice, first only to feed the filter's counters,
+// then to stage the survivors in the 24 KiB of class S instead of 48 KiB.  1000 references: class M 4.8 -> 4.3 ms per launch; 10 000
+// references, where class M is mostly noise and the gather is all there is: L1 stage 83 -> 87 ms per 300 queries.  One read wins.)
 template <int HLO, int HCAP>
-__global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict__ list, const unsigned int *__restrict__ listCount)
+__global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict__ list)
 {
   __shared__ uint64_t hits[HCAP];
   __shared__ int V[HCAP];
@@ -246,10 +249,8 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   __shared__ unsigned long long sBase;
   __shared__ int sKeep;
   int f;
-  if (list) {
-    if (listCount && blockIdx.x >= *listCount) return;        // the list was filled on the device (k_l1_mid): the grid is its upper bound
-    f = list[blockIdx.x];
-  } else {
+  if (list) f = list[blockIdx.x];
+  else {
     const int i = xcd_item(blockIdx.x, gridDim.x);
     if (i >= a.nFrag) return;
     f = a.fragOrder ? a.fragOrder[i] : i;
@@ -331,72 +332,6 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   }
   block_sort<uint64_t>(hits, n);                    // :320 (starts with a barrier: the gather is complete)
 
-  l1_emit_candidates(a, f, s, n, m, hits, V, ws, &sBase);
-}
-
-// Class M in two walks.  A fragment with 2048 < H <= 4096 seed hits has about as many hits worth sorting as any other (the hits on
-// its relatives); what it has more of is chance hits, which the noise filter drops.  k_l1<2048,4096> stages all H hits in LDS
-// first — 48 KiB, three workgroups per CU, five times the cost per fragment of class S.  Here the hit runs are read twice instead:
-// walk 1 only feeds the filter's occupancy counters, walk 2 reads the runs again (from L2 by then) and stages the survivors — in the
-// LDS budget of class S, six workgroups per CU.  A fragment that keeps more than 2048 hits (or has minimumHits < 2: no filter) is
-// handed on to k_l1<2048,4096> through list2.
-__global__ __launch_bounds__(kTPB) void k_l1_mid(L1Args a, const int32_t *__restrict__ list, int32_t *__restrict__ list2, unsigned int *__restrict__ list2Count)
-{
-  constexpr int HCAP = kL1HitCapSmall;
-  __shared__ uint64_t hits[HCAP];
-  __shared__ int V[HCAP];
-  __shared__ int ws[16];
-  __shared__ unsigned long long sBase;
-  __shared__ int sKeep;
-  const int f = list[blockIdx.x];
-  const int t = threadIdx.x;
-  const int s = a.fragS[f];
-  const int H = a.fragHits[f];
-  const uint32_t off = a.fragOff[f];
-  const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;
-  if (m < 2 || H <= a.filterMinHits) {              // no filter for this fragment (workgroup-uniform; filterMinHits: the test knob of k_l1)
-    if (t == 0) list2[atomicAdd(list2Count, 1u)] = f;
-    return;
-  }
-  constexpr int kPerS = kL1MaxS / kTPB;
-  uint32_t pFirst[kPerS], pCnt[kPerS];
-#pragma unroll
-  for (int j = 0; j < kPerS; j++) {
-    const int i = t + j * kTPB;
-    pCnt[j] = i < s ? a.probeCnt[off + i] : 0u; pFirst[j] = i < s ? a.probeFirst[off + i] : 0u;
-  }
-  constexpr int NBW = HCAP / 4;                      // V holds {seenA, twiceA, seenB, twiceB}, as in k_l1
-  uint32_t *bits = (uint32_t *)V;
-  for (int i = t; i < HCAP; i += kTPB) bits[i] = 0u;
-  if (t == 0) sKeep = 0;
-  block_barrier();
-  auto tiles = [&](uint64_t hv, uint32_t &ia, uint32_t &ib) { l1_filter_tiles<kL1FilterBits<HCAP>()>(hv, a.filterShift, ia, ib); };
-#pragma unroll
-  for (int j = 0; j < kPerS; j++)
-    for (uint32_t c = 0; c < pCnt[j]; c++) {
-      uint32_t ia, ib; tiles(a.sSW[pFirst[j] + c], ia, ib);
-      const uint32_t ba = 1u << (ia & 31), bb = 1u << (ib & 31);
-      if (atomicOr(&bits[ia >> 5], ba) & ba) atomicOr(&bits[NBW + (ia >> 5)], ba);
-      if (atomicOr(&bits[2 * NBW + (ib >> 5)], bb) & bb) atomicOr(&bits[3 * NBW + (ib >> 5)], bb);
-    }
-  block_barrier();
-#pragma unroll
-  for (int j = 0; j < kPerS; j++)
-    for (uint32_t c = 0; c < pCnt[j]; c++) {
-      const uint64_t hv = a.sSW[pFirst[j] + c];
-      uint32_t ia, ib; tiles(hv, ia, ib);
-      if (((bits[NBW + (ia >> 5)] >> (ia & 31)) | (bits[3 * NBW + (ib >> 5)] >> (ib & 31))) & 1u) {
-        const int pos = atomicAdd(&sKeep, 1);
-        if (pos < HCAP) hits[pos] = hv;
-      }
-    }
-  block_barrier();
-  const int n = sKeep;
-  if (n > HCAP) {                                   // workgroup-uniform
-    if (t == 0) list2[atomicAdd(list2Count, 1u)] = f;
-    return;
-  }
-  block_sort<uint64_t>(hits, n);
   l1_emit_candidates(a, f, s, n, m, hits, V, ws, &sBase);
 }
 

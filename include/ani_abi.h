@@ -116,8 +116,7 @@ typedef struct {
   uint64_t l2ChunkHalvings;   /* L2 chunks redone at half size because their code stream passed the 32-bit offset limit */
   uint64_t indexChunkBuilds;  /* index chunks built, rebuilds of a streamed reference set included */
   uint64_t l1BigFragments;    /* query fragments (per index chunk) whose seed hits exceeded every LDS class: batched global-memory L1 path */
-  uint64_t l1MidFragments;    /* query fragments (per index chunk) with 2048 < seed hits <= 4096: class M, read twice (ani::k_l1_mid) */
-  uint64_t l1MidStaged;       /* ... of which kept more than 2048 hits after the noise filter (or cannot be filtered): ani::k_l1<2048, 4096> */
+  uint64_t l1MidFragments;    /* query fragments (per index chunk) with 2048 < seed hits <= 4096: LDS class M (ani::k_l1<2048, 4096>) */
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
   double msL2Kernel;          /* HIP-event time of the class-A ani::k_l2_sim launches alone (on the launch stream) */
   double msL2Ranges, msL2Codes, msL2Slow;   /* ani::k_l2_ranges, ani::k_l2_codes, ani::k_l2 */

@@ -171,11 +171,11 @@ def case_gap_counter_overflow(engine):
     assert c["l2SlowOverflow"] > 0 and c["l2FastCandidates"] > 0, c
 
 
-def case_l1_mid_two_walk(engine):
+def case_l1_mid_noise(engine):
     """a fragment with 2048 < seed hits <= 4096 most of which are noise: one k-mer of the fragment (chosen with a tiny hash, so that
     it is the minimizer of every window that holds it) sits on 2300 short contigs of one reference genome — isolated hits on 2300
-    different contigs, all dropped by the noise filter; ani::k_l1_mid reads the hit runs twice and stages only the survivors (the
-    hits on the two relatives).  case_tandem_repeats / case_low_complexity cover the fragments it hands on to k_l1<2048,4096>."""
+    consecutive contigs, which the noise filter of LDS class M must drop (its tile hash once mapped tile 0 of consecutive contigs
+    onto half of its counters and kept 97 % of such hits), leaving the hits on the two relatives"""
     r = np.random.default_rng(77)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     while True:
@@ -196,7 +196,7 @@ def case_l1_mid_two_walk(engine):
     engine.reset_counters()
     rows = check_queries(engine, p, sk, osk, [[base]])
     c = engine.counters()
-    assert len(rows) >= 2 and c["l1MidFragments"] >= 1 and c["l1MidStaged"] < c["l1MidFragments"], (len(rows), c["l1MidFragments"], c["l1MidStaged"])
+    assert len(rows) >= 2 and c["l1MidFragments"] >= 1, (len(rows), c["l1MidFragments"])
 
 
 def case_sparse_hits(engine):
@@ -528,7 +528,7 @@ def case_limits(engine):
 
 
 ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
-             case_low_complexity_big, case_gap_counter_overflow, case_l1_mid_two_walk, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
+             case_low_complexity_big, case_gap_counter_overflow, case_l1_mid_noise, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
 def fuzz(engine, seed, seconds=None, iterations=None):
