@@ -1284,7 +1284,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // First guess of the candidate pool from the context's running estimate, never beyond what 32-bit candidate ids allow (the limit
   // is an error only when the batch really needs more: the retry below).
   const uint64_t kCandLimit = 0x7fffff00ull;      // whole stripes below 2^31
-  uint64_t ccap = std::min<uint64_t>((uint64_t)((double)nF * ctx->candPerFrag) + 4096, kCandLimit);
+  uint64_t ccap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)nF * ctx->candPerFrag) + 4096, 4096 * kPoolStripes), kCandLimit);   // at least 4096 per stripe (4 MB): a few heavy fragments fit without a retry
   TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
   unsigned nMid = 0, nBig = 0;
   std::vector<int32_t> bigFrags, bigInfo;          // fragments beyond the LDS classes and their (sketch size, seed hits)
@@ -1400,7 +1400,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // one: a handful of fragments sit in a handful of stripes, and "fullest stripe x 64 / fragments" of a one-fragment batch with
   // 1000 candidates would ask for 80 000 candidates per fragment of the next, million-fragment batch (a bogus 2^31 limit error
   // after 34 GB of pool; seen in the parity suite under ANI_POOL_POISON).  The estimate follows the batches down as well as up.
-  if (nF >= 64 * kPoolStripes) {
+  if (nF >= 16 * kPoolStripes) {                 // (a one-to-many query of 1666 fragments counts: without its update every call ran the L1 kernels twice)
     const double seen = 1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes / (double)nF;
     ctx->candPerFrag = std::max(12.0, seen >= ctx->candPerFrag ? seen : 0.5 * (ctx->candPerFrag + seen));
   }
