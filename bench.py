@@ -303,6 +303,12 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
             tr = [ln.replace("[fastANI trace]", "").strip() for ln in err_lines if ln.startswith("[fastANI trace]")]
             if tr:
                 e2e["phases"] = tr
+            pool = [ln for ln in err_lines if ln.startswith("[ani pool] hipMalloc")]          # only with ANI_POOL_TRACE=1 in the environment
+            if pool:
+                mb = [float(ln.split()[3]) for ln in pool]
+                ms = [float(ln.split()[5]) for ln in pool]
+                e2e["fresh_device_memory"] = {"hipMalloc_calls": len(pool), "GB": round(sum(mb) / 1024.0, 2), "seconds_inside_hipMalloc": round(sum(ms) / 1e3, 3),
+                                              "largest": sorted(((round(a / 1024.0, 2), round(b, 1)) for a, b in zip(mb, ms)), reverse=True)[:12]}
             if r.returncode == 0 and not args.no_verify:
                 printed = read_ref_out(e2e_out, index_of)
                 want = {k: v for k, v in rows_by_pair.items() if trusted(v[1], L)}
