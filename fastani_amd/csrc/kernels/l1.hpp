@@ -239,7 +239,11 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
 // Pass 2: gather + sort + candidate regions for the fragments whose hit count is in (HLO, HCAP]; everything in LDS.
 // (Measured and removed in round 3: class M "in two walks" — the hit runs read twice, first only to feed the filter's counters,
 // then to stage the survivors in the 24 KiB of class S instead of 48 KiB.  1000 references: class M 4.8 -> 4.3 ms per launch; 10 000
-// references, where class M is mostly noise and the gather is all there is: L1 stage 83 -> 87 ms per 300 queries.  One read wins.)
+// references, where class M is mostly noise and the gather is all there is: L1 stage 83 -> 87 ms per 300 queries.  One read wins.
+// Also measured and removed: 32-bit sort keys (rank of the contig among the fragment's distinct contigs << posBits | wpos: 3 instead of
+// 7 instructions per key and lane-exchange stage).  The ranks need a hash set of the contig ids in LDS, the distinct ids sorted, a
+// look-up per hit — five more barrier-separated phases and 20 more registers (5 instead of 6 workgroups per CU): k_l1<0,2048> went
+// from 30.7 to 41.2 ms per step, bit-exact.)
 template <int HLO, int HCAP>
 __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict__ list)
 {
