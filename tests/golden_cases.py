@@ -47,7 +47,58 @@ def cases():
     c["tandem"] = ([[ref], [qry]], [[qry], [ref]], 16, 3000)
     fam = evolved_family(3, 60000, 6, seg=(800, 6000))
     c["evolved"] = (fam, [fam[0], fam[2], fam[4], fam[5]], 16, 3000)
+    c["onehash"] = one_hash_sketch_case()
+    c["manycontigs"] = many_short_contigs_case()
     return c
+
+
+def _mutate(g, rate, seed):
+    r = np.random.default_rng(seed)
+    g = g.copy()
+    m = r.random(len(g)) < rate
+    g[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, int(m.sum()))]
+    return g
+
+
+def one_hash_sketch_case():
+    """query fragments whose sketch is a single hash (a period-23 tandem repeat) beside ordinary ones, against references of ordinary
+    sequence that hold 40 bases of the repeat here and there: more than 127 distinct reference hashes fall into one gap of such a
+    query sketch (round 3: the gap counters of the GPU's L2 simulation overflow on it, in the fill of the first super-window)"""
+    r = np.random.default_rng(105)
+    ref = _rng(10, 60000)
+    rep = np.tile(_rng(14, 23), 400)[:9000]
+    parts, pos = [], 0
+    for i in range(12):
+        step = int(r.integers(2500, 4500))
+        parts += [ref[pos:pos + step], rep[:40]]
+        pos += step
+    g0 = np.concatenate(parts + [ref[pos:]])
+    related = _mutate(ref[2000:32000], 0.06, 8)
+    refs = [[g0], [_mutate(g0[:40000], 0.03, 77)], [orc.synth_genome(2, 0, 9000)]]
+    qrys = [[np.concatenate([related[:6000], rep[:3000], related[6000:15000], rep[:3000], related[15000:30000]])], [rep[:6000]]]
+    return (refs, qrys, 16, 3000)
+
+
+def many_short_contigs_case():
+    """one k-mer of the query's first fragment (chosen with a tiny hash: the minimizer of every window that holds it) on 2300 contigs of
+    60 bases of one reference genome, two relatives beside it: thousands of isolated seed hits on consecutive contig ids"""
+    r = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    while True:
+        x = acgt[r.integers(0, 4, 16)]
+        if orc.hash_kmer(x) < (1 << 32) // 20000:
+            break
+    base = _rng(31, 9000)
+    base[1500:1516] = x
+    contigs = []
+    for i in range(2300):
+        c = acgt[r.integers(0, 4, 60)]
+        c[22:38] = x
+        contigs.append(c)
+    refs = [[_mutate(base, 0.04, 1)], contigs, [_mutate(base, 0.08, 2)], [orc.synth_genome(2, 0, 9000)]]
+    for g in (refs[0], refs[2]):
+        g[0][1500:1516] = x
+    return (refs, [[base]], 16, 3000)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -74,6 +74,32 @@ def check_queries(engine, p, sk, osk, queries, k=16, frag_len=3000):
     return rows
 
 
+def case_goldens(engine):
+    """the HIP path against the committed golden fixtures themselves — outputs of the untouched reference (tests/golden/*.npz, written
+    by tests/golden/make_golden.py from oracle/_ref/ref_dump), no oracle in between: minimizers, fragment sketches, the 44-byte mapping
+    records and the CGI rows of every golden case, bit for bit"""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, (refs, qrys, k, L) in sorted(golden_cases.cases().items()):
+        g = np.load(os.path.join(gold, "case_%s.npz" % name))
+        p = engine.params(k, L)
+        assert p.windowSize == int(g["w"]), name
+        sk = Sketch(engine, p, refs)
+        assert np.array_equal(sk.minimizers(), g["minimizers"].view(orc.MINIMIZER_DT).reshape(-1)), name
+        rows = []
+        for qi, q in enumerate(qrys):
+            fr = engine.query_sketch(p, [q])
+            assert [len(x) for x in fr] == list(g["fragS%d" % qi]), (name, qi)
+            assert np.array_equal(np.concatenate(fr) if len(fr) else np.zeros(0, np.uint32), g["fragH%d" % qi]), (name, qi)
+            maps, tot = sk.map_query(q)
+            assert np.array_equal(maps, g["maps%d" % qi].view(orc.MAPPING_DT).reshape(-1)), (name, qi)
+            rows.append(sk.compute_cgi(maps, tot, qi))
+        want = g["cgi"].view(orc.CGI_DT).reshape(-1)
+        assert np.array_equal(np.concatenate(rows) if rows else want[:0], want), name
+        assert np.array_equal(sk.map_cgi_batch(qrys, 0), want), name
+        sk.close()
+
+
 def case_synthetic_cluster(engine, n=120000):
     genomes = [[orc.synth_genome(7, g, n)] for g in (0, 1, 4, 11, 16, 19, 20)]
     p, sk, osk = check_sketch(engine, genomes)
@@ -527,7 +553,7 @@ def case_limits(engine):
         assert e.code == -4
 
 
-ALL_CASES = [case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
+ALL_CASES = [case_goldens, case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
              case_low_complexity_big, case_gap_counter_overflow, case_l1_mid_noise, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
