@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — ANI pairs/sec, many-to-many NxN ~5 Mbp genomes (BASELINE.json metric) on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W [--config many-to-many|one-to-many|c4]
+    python bench.py --gpus 1 --steps K --warmup W [--config many-to-many|one-to-many|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one pass of the whole hot path over the workload with the packed genomes already resident in HBM:
@@ -11,12 +11,19 @@ reference sketch + index build (skch::Sketch), mapping of every query genome (sk
 Workloads (config.workload):
   many-to-many (default) = BASELINE.json configs[2], 1000x1000 synthetic ~5 Mbp genomes, k=16 fragLen=3000.
       N = 1 : 1000 reference genomes x 1000 query genomes (the same set: all-vs-all).
-      N > 1 : weak scaling over the query stream — the 1000-genome reference database is fixed, every GPU maps its own
-              1000 query genomes (rank r maps variant r of the clustered set: same ancestors and divergences, fresh
-              substitutions), so the job is 1000 x (1000*N) pairs.  Each rank sketches 1/N of the references; the 12-byte
-              minimizer records are all-gathered once over RCCL/xGMI and every rank builds the full index.
+      N > 1 : STRONG scaling (default, --scaling strong): the SAME 1000 x 1000 job on N GPUs, reference-sharded — rank r hashes
+              genomes [r*1000/N, (r+1)*1000/N) once for both roles, indexes that shard only, and the ranks' packed fragment
+              sketches go round a ring (isend/irecv over RCCL, overlapped with the mapping): nothing is replicated.  value =
+              10^6 pairs / step.  The WEAK-scaling figure is measured beside it (weak_scaling_leg; --scaling weak makes it the
+              timed region): the 1000-genome reference database is fixed, every GPU maps its own 1000 query genomes (rank r
+              maps variant r of the clustered set), each rank sketches 1/N of the references, the 12-byte minimizer records
+              are all-gathered once over RCCL/xGMI and every rank builds the full index.
+      --simulate-world W (one GPU): the compute of ONE rank of the W-GPU strong job, without communication — the measured
+              per-rank time behind the predicted W-GPU figure.
   one-to-many = configs[1]: 1 query genome (cluster 0, member 1) against the 1000-genome set; a step still sketches and
       indexes the references (the reference does too); the map-only latency is reported beside it.
+  c5 = configs[4] in miniature: a reference set that does not stay resident (default 30 000 x 5 Mbp, generated and sketched slice by
+      slice; only the 12-byte minimizer records stay, the index is streamed chunk by chunk) x --queries genomes (default 300).
   c4 = configs[3]: 10000 x 10000 (all-vs-all, 500 clusters).
       N = 1 : the reference set held as several index chunks (streamed through the device when they do not fit); --queries bounds
               the query count.
@@ -61,8 +68,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="many-to-many", choices=["many-to-many", "one-to-many", "c4"])
-    ap.add_argument("--genomes", type=int, default=0, help="reference genomes (0 = the config's: 1000, c4: 10000)")
+    ap.add_argument("--config", default="many-to-many", choices=["many-to-many", "one-to-many", "c4", "c5"])
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="N > 1, many-to-many: strong (default) = the fixed 1000 x 1000 job, references sharded, fragment sketches ring-passed; "
+                         "weak = fixed database, 1000 queries per GPU, records all-gathered (also measured beside the strong figure, weak_scaling_leg)")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, many-to-many: skip the weak-scaling measurement beside the strong one")
+    ap.add_argument("--simulate-world", type=int, default=0, help="ONE GPU computes what one rank of a W-GPU strong-scaling (ring) job computes, without the communication: "
+                                                                  "the measured per-rank time behind the predicted W-GPU figure (DESIGN.md section 5)")
+    ap.add_argument("--simulate-rank", type=int, default=0)
+    ap.add_argument("--dump-rows", default="", help="write the rows of the last timed step to <path>[.rank<r>].npy (tests)")
+    ap.add_argument("--slice-genomes", type=int, default=1000, help="c5: genomes generated and sketched per slice")
+    ap.add_argument("--genomes", type=int, default=0, help="reference genomes (0 = the config's: 1000, c4: 10000, c5: 30000)")
     ap.add_argument("--queries", type=int, default=0, help="query genomes per GPU (0 = the config's)")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
     ap.add_argument("--seed", type=int, default=20260925)
@@ -107,15 +123,24 @@ def write_fasta_set(orc, seed, ids, L, td, threads, cluster_size=20):
     """FASTA copies of genomes `ids` of the synthetic set (the oracle's generator is the CPU twin of ani_synth_packed,
     byte-compared in the tests)."""
     from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
 
     def one(g):
         p = os.path.join(td, "g%05d.fa" % g)
         if not os.path.exists(p):
             seq = orc.synth_genome(seed, g, L, cluster_size=cluster_size)
+            # 80-column FASTA, header >g<i> (SURVEY.md section 8d): 62 500 lines per 5 Mbp genome, the layout the reference's kseq
+            # reader and the command line's block reader are both timed on
+            b = seq.tobytes()
+            n80 = len(b) // 80
+            body = np.empty((n80, 81), dtype=np.uint8)
+            body[:, :80] = np.frombuffer(b, dtype=np.uint8, count=n80 * 80).reshape(n80, 80)
+            body[:, 80] = 10
             with open(p + ".tmp", "wb") as f:
                 f.write(b">g%d\n" % g)
-                f.write(seq.tobytes())
-                f.write(b"\n")
+                f.write(body.tobytes())
+                if len(b) > n80 * 80:
+                    f.write(b[n80 * 80:] + b"\n")
             os.replace(p + ".tmp", p)
         return p
     with ThreadPoolExecutor(max(1, min(threads, 32))) as ex:
@@ -154,7 +179,7 @@ def compare_with_reference(rows_by_pair, ref_rows, queries, nrefs, L):
     return {"rows_compared": len(ref_rows), "ok": bool(ok), "mismatching_rows": bad + len(set(got) ^ set(ref_rows)), "max_abs_ani_diff": round(max_d, 6)}
 
 
-def oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, window, pairs_wanted):
+def oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, window, pairs_wanted, ref_base=0):
     """>= pairs_wanted (query, reference) pairs of the timed result against the C oracle, pair by pair (SURVEY.md App. A.7:
     a pair's result does not depend on what else is in the index, so a small oracle index over the sampled references is
     comparable with the 1000-genome GPU index).  Bit-exact: countSeq, totalQueryFragments and the float identity.
@@ -165,16 +190,18 @@ def oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, window, pai
     query_ids = sorted(int(q) for q in query_ids)
     n_r = 12 if len(query_ids) >= 20 else min(n_refs, 24)
     n_q = min(len(query_ids), max(1, (pairs_wanted + n_r - 1) // n_r))
-    rel = rng.choice(query_ids, size=min(len(query_ids), 4), replace=False)            # reference clusters = clusters of some queries
+    # the references of the rows are genomes [ref_base, ref_base + n_refs) (a rank's shard, or the whole set)
+    in_shard = [q for q in query_ids if ref_base <= q < ref_base + n_refs] or query_ids
+    rel = rng.choice(in_shard, size=min(len(in_shard), 4), replace=False)              # reference clusters = clusters of some queries
     cs = args.cluster_size
     clusters = sorted(set(int(q) // cs for q in rel))
     per = max(1, n_r // max(1, len(clusters)))
     ref_ids = []
     for cl in clusters:
-        members = [cl * cs + m for m in range(cs) if cl * cs + m < n_refs]
+        members = [cl * cs + m for m in range(cs) if ref_base <= cl * cs + m < ref_base + n_refs]
         ref_ids += [int(x) for x in rng.choice(members, size=min(per, len(members)), replace=False)] if members else []
     while len(ref_ids) < min(n_r, n_refs):
-        g = int(rng.integers(n_refs))
+        g = ref_base + int(rng.integers(n_refs))
         if g not in ref_ids:
             ref_ids.append(g)
     ref_ids = sorted(ref_ids)[:n_r]
@@ -342,368 +369,616 @@ def int_ops_block(c, steps, fused=False):
     return out
 
 
-def main():
-    args = parse()
+class Run:
+    """Everything a step needs: the process group (RCCL), the engine, the synthetic genomes in HBM, the staging buffers."""
+    pass
+
+
+def setup_runtime(args):
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    dist = None
+    R = Run()
+    R.args, R.torch = args, torch
+    R.world = int(os.environ.get("WORLD_SIZE", "1"))
+    R.rank = int(os.environ.get("RANK", "0"))
+    R.local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and R.world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, R.world))
+    R.dist = None
     # ANI_BENCH_BACKEND=emu (tests only, tests/test_distributed_gloo.py): the step logic of this file on the CPU build of the
     # product sources (tests/emu) over gloo, with tiny genomes — so that the multi-rank orchestration is exercised where there is
     # no GPU.  Never a measurement: the line it prints says so.
-    emu = os.environ.get("ANI_BENCH_BACKEND", "") == "emu"
-    # ANI_BENCH_FORCE_DIST=1 (hardware check on a 1-GPU box): take the multi-rank code path — process group over RCCL, the record
-    # all-gather or the fragment-set ring, the timing all-reduce — with a world of one rank
-    multi = world > 1 or bool(os.environ.get("ANI_BENCH_FORCE_DIST"))
-    if multi:
+    R.emu = os.environ.get("ANI_BENCH_BACKEND", "") == "emu"
+    # ANI_BENCH_FORCE_DIST=1 (hardware check on a 1-GPU box, tests/test_rccl_gpu.py): take the multi-rank code path — process group
+    # over RCCL, the record all-gather or the fragment-set ring, the timing all-reduce — with a world of one rank
+    R.multi = R.world > 1 or bool(os.environ.get("ANI_BENCH_FORCE_DIST"))
+    if args.simulate_world > 1 and R.multi:
+        raise SystemExit("--simulate-world is a single-process measurement")
+    if R.multi:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if emu:
-            dist.init_process_group("gloo")
+        # a bounded collective timeout: a rank that dies inside a step must turn the others' wait into an error, not a hang
+        tmo = datetime.timedelta(seconds=int(os.environ.get("ANI_BENCH_COLLECTIVE_TIMEOUT_S", "600")))
+        if R.emu:
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cpu") if emu else torch.device("cuda", local)
-    if not emu:
-        torch.cuda.set_device(dev)
-
-    def dev_sync():
-        if not emu:
-            torch.cuda.synchronize()
-
-    import numpy as np
+            torch.cuda.set_device(R.local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", R.local), timeout=tmo)
+        R.dist = dist
+    R.dev = torch.device("cpu") if R.emu else torch.device("cuda", R.local)
+    if not R.emu:
+        torch.cuda.set_device(R.dev)
     import fastani_amd
-    from fastani_amd.api import DeviceGenomes, Sketch
-    if emu:
+    if R.emu:
         import ctypes
         from fastani_amd.api import Engine
-        e = Engine(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libfastani_emu.so")), 0)
+        R.e = Engine(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libfastani_emu.so")), 0)
         args.no_cpu_baseline = args.no_e2e = args.no_verify = True
     else:
-        e = fastani_amd.engine(local)
-    p = e.params(16, 3000)
-    L = args.genome_len
+        R.e = fastani_amd.engine(R.local)
+    R.p = R.e.params(16, 3000)
+    return R
+
+
+def dev_sync(R):
+    if not R.emu:
+        R.torch.cuda.synchronize()
+
+
+def resolve_mode(R):
+    """which step runs in the timed region:
+         single    one GPU: sketch + index + map (all-vs-all: every genome hashed once for both roles)
+         ring      N GPUs, STRONG scaling: the references are sharded, the query fragment sketches go round a ring (fastani_amd/multi_gpu.py)
+         gather    N GPUs, WEAK scaling over the query stream: every rank maps its own queries against the full index built from all-gathered records
+         simulate  one GPU doing the compute of ONE rank of a W-rank ring job (no communication): the measured per-rank time behind the predicted N-GPU figure"""
+    a = R.args
+    if a.simulate_world > 1:
+        return "simulate"
+    if not R.multi:
+        return "single"
+    if a.config in ("c4", "c5"):
+        return "ring"
+    if a.config == "many-to-many" and a.scaling in ("auto", "strong"):
+        return "ring"
+    return "gather"
+
+
+def make_inputs(R):
+    """synthetic input, generated straight into HBM (untimed)"""
+    import numpy as np
+    from fastani_amd.api import DeviceGenomes
+    a, e, torch = R.args, R.e, R.torch
+    L = a.genome_len
     words = (L + 15) // 16
-    cfg = args.config
-    NR = args.genomes or (10000 if cfg == "c4" else 1000)                # reference genomes
-    # ---- synthetic input, generated straight into HBM (untimed) ----
-    lo, hi = (NR * rank) // world, (NR * (rank + 1)) // world            # this rank's share of the references
-    if cfg == "c4":
+    cfg = a.config
+    R.L, R.words = L, words
+    R.NR = NR = a.genomes or {"c4": 10000, "c5": 30000}.get(cfg, 1000)
+    R.mode = resolve_mode(R)
+    W = R.world if R.mode != "simulate" else a.simulate_world
+    r = R.rank if R.mode != "simulate" else a.simulate_rank
+    R.W, R.r = W, r
+    R.part_g0 = np.array([(NR * x) // W for x in range(W + 1)], dtype=np.int32)
+    lo, hi = int(R.part_g0[r]), int(R.part_g0[r + 1])          # this rank's share of the references
+    R.lo, R.hi = lo, hi
+    R.contig_len = np.full(NR, L, dtype=np.int32)
+    R.gcs = np.arange(NR + 1, dtype=np.int32)
+    R.contig_len_local = np.full(hi - lo, L, dtype=np.int32)
+    R.gcs_local = np.arange(hi - lo + 1, dtype=np.int32)
+    R.qry_buf = None
+    if cfg == "c5":
+        # a reference set whose genomes do not stay resident: generated and sketched slice by slice through ONE slice buffer
+        # (the minimizer records are what stays); the queries are the first --queries genomes of the set
+        if R.mode != "single":
+            raise SystemExit("--config c5 is a single-GPU run (on N GPUs configs[4] is the reference-sharded ring of --config c4 with more genomes)")
+        R.nq_local = min(a.queries or 300, NR)
+        R.slice_n = min(a.slice_genomes, NR)
+        R.ref_buf = torch.empty(R.slice_n * words + 64, dtype=torch.int32, device=R.dev)
+        R.qry_buf = torch.empty(R.nq_local * words + 64, dtype=torch.int32, device=R.dev)
+        e.synth_packed(a.seed, 0, R.nq_local, L, R.qry_buf.data_ptr(), variant=0, cluster_size=a.cluster_size)
+        R.qrys = DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, L)
+        R.refs = R.my_refs = None
+        R.first_query_id = 0
+        R.n_queries_total = R.nq_local
+    elif cfg == "c4" and R.mode in ("single", "ring"):
         # all-vs-all: the rank's query genomes ARE its share of the references; only that share is resident
-        nq_local = min(args.queries or (hi - lo), hi - lo)
-        ref_buf = torch.empty((hi - lo) * words + 64, dtype=torch.int32, device=dev)
-        e.synth_packed(args.seed, lo, hi - lo, L, ref_buf.data_ptr(), variant=0, cluster_size=args.cluster_size)
-        my_refs = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L)
-        refs = my_refs if not multi else None
-        qrys = DeviceGenomes(ref_buf.data_ptr(), hi - lo, L, first=0, count=nq_local)
-        first_query_id = lo
-        n_queries_total = nq_local * world
+        R.nq_local = min(a.queries or (hi - lo), hi - lo)
+        R.ref_buf = torch.empty((hi - lo) * words + 64, dtype=torch.int32, device=R.dev)
+        e.synth_packed(a.seed, lo, hi - lo, L, R.ref_buf.data_ptr(), variant=0, cluster_size=a.cluster_size)
+        R.my_refs = DeviceGenomes(R.ref_buf.data_ptr(), hi - lo, L)
+        R.refs = R.my_refs if R.mode == "single" else None
+        R.qrys = DeviceGenomes(R.ref_buf.data_ptr(), hi - lo, L, first=0, count=R.nq_local)
+        R.first_query_id = lo
+        R.n_queries_total = R.nq_local * W
     else:
-        ref_buf = torch.empty(NR * words + 64, dtype=torch.int32, device=dev)
-        e.synth_packed(args.seed, 0, NR, L, ref_buf.data_ptr(), variant=0, cluster_size=args.cluster_size)
-        refs = DeviceGenomes(ref_buf.data_ptr(), NR, L)
-        my_refs = DeviceGenomes(ref_buf.data_ptr(), NR, L, first=lo, count=hi - lo)
+        R.ref_buf = torch.empty(NR * words + 64, dtype=torch.int32, device=R.dev)
+        e.synth_packed(a.seed, 0, NR, L, R.ref_buf.data_ptr(), variant=0, cluster_size=a.cluster_size)
+        R.refs = DeviceGenomes(R.ref_buf.data_ptr(), NR, L)
+        R.my_refs = DeviceGenomes(R.ref_buf.data_ptr(), NR, L, first=lo, count=hi - lo)
         if cfg == "one-to-many":
-            nq_local = 1
-            qrys = DeviceGenomes(ref_buf.data_ptr(), NR, L, first=1, count=1)     # cluster 0, member 1
-            first_query_id = 1
+            R.nq_local = 1
+            R.qrys = DeviceGenomes(R.ref_buf.data_ptr(), NR, L, first=1, count=1)     # cluster 0, member 1
+            R.first_query_id = 1
+            R.n_queries_total = R.nq_local * W
+        elif R.mode in ("ring", "simulate"):
+            # strong scaling of the all-vs-all set: the rank's queries are its share of the references
+            R.nq_local = hi - lo
+            R.qrys = R.my_refs
+            R.first_query_id = lo
+            R.n_queries_total = NR
+        elif R.mode == "gather":
+            R.nq_local = a.queries or NR
+            alloc_variant_queries(R)
+            R.first_query_id = R.rank * R.nq_local
+            R.n_queries_total = R.nq_local * W
         else:
-            nq_local = args.queries or NR
-            if rank == 0 and not multi:
-                qry_buf = ref_buf                                   # all-vs-all
-            else:
-                qry_buf = torch.empty(nq_local * words + 64, dtype=torch.int32, device=dev)
-                e.synth_packed(args.seed, 0, nq_local, L, qry_buf.data_ptr(), variant=rank, cluster_size=args.cluster_size)
-            qrys = DeviceGenomes(qry_buf.data_ptr(), nq_local, L)
-            first_query_id = rank * nq_local
-        n_queries_total = nq_local * world
-    contig_len = np.full(NR, L, dtype=np.int32)
-    gcs = np.arange(NR + 1, dtype=np.int32)
+            R.nq_local = a.queries or NR
+            R.qry_buf = R.ref_buf                                 # all-vs-all
+            R.qrys = DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, L)
+            R.first_query_id = 0
+            R.n_queries_total = R.nq_local
+    if R.mode in ("ring", "simulate"):
+        R.nq_local = hi - lo
+        R.n_queries_total = NR
     # all-vs-all on one GPU (the query set IS the reference set): every genome is hashed once for both roles
-    self_slice = int(os.environ.get("ANI_BENCH_SELF_SLICE", "1000"))        # genomes per fused-pass slice of a large all-vs-all set (tests lower it)
-    self_mode = (not args.no_self) and not multi and ((cfg == "many-to-many" and not args.queries) or (cfg == "c4" and nq_local == NR))
-
-    # multi-GPU staging buffers (allocated once): every rank's records land in its slot of `allrec`; the slot's first record
-    # carries the count, so ONE all-gather moves counts and records (no count all-reduce, no compaction copy in the step)
-    ring_mode = multi and cfg == "c4"        # reference-sharded: every rank indexes ITS genomes only, the query fragment sketches go round the ring
-    if multi:
-        part_g0 = np.array([(NR * r) // world for r in range(world + 1)], dtype=np.int32)
-    if multi and not ring_mode:
-        slot = int((hi - lo + 1) * (2.3 * L / (p.windowSize + 1))) + 4096          # records per rank, upper bound
-        allrec = torch.empty(world * (slot + 1) * 3, dtype=torch.int32, device=dev)
-        mine = allrec[rank * (slot + 1) * 3:(rank + 1) * (slot + 1) * 3]
-    if ring_mode:
-        from fastani_amd.multi_gpu import ring_map
-        nq_local = hi - lo
-        n_queries_total = NR
-        contig_len_local = np.full(hi - lo, L, dtype=np.int32)
-        gcs_local = np.arange(hi - lo + 1, dtype=np.int32)
-
-        def ring_alloc(nbytes):
-            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            return t, t.data_ptr()
+    R.self_slice = int(os.environ.get("ANI_BENCH_SELF_SLICE", "1000"))        # genomes per fused-pass slice of a large all-vs-all set (tests lower it)
+    R.self_mode = (not a.no_self) and R.mode == "single" and ((cfg == "many-to-many" and not a.queries) or (cfg == "c4" and R.nq_local == NR))
     # per-rank timeline of a step (host clock; the library calls return when their device work is done):
     #   ref_records = reference sketching (the rank's share), fragsketch = fragment sketches of the rank's own queries,
     #   allgather = the part of the record all-gather that is NOT hidden behind the fragment sketching, index = index build,
     #   map = mapping + reduce + rows to the host, ring_wait = waiting for the next fragment set of the ring
-    timers = {"allgather_ms": 0.0, "ref_records_ms": 0.0, "fragsketch_ms": 0.0, "index_ms": 0.0, "map_ms": 0.0, "ring_pack_ms": 0.0, "ring_wait_ms": 0.0}
+    R.timers = {k: 0.0 for k in TIMER_KEYS}
+    R.slot = 0
+    R.allrec = None
 
-    def step():
-        t_a = time.perf_counter()
-        frags = None
-        if self_mode and NR > 2 * self_slice:
-            # the same in slices of 1000 genomes (a slice's minimizers and sketch hashes are 32-bit counts): record parts + kept
-            # fragment sets, one index over the parts, ONE mapping call over all sets (a streamed set builds each chunk once)
-            parts, sets, firsts = [], [], []
-            for s0 in range(0, NR, self_slice):
-                s1 = min(NR, s0 + self_slice)
-                ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(ref_buf.data_ptr(), NR, L, first=s0, count=s1 - s0), s0)
-                parts.append((ptr, n, s0)); sets.append(fr); firsts.append(s0)
-            sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [NR], contig_len, gcs))
-            for ptr, n, _ in parts:                  # the index is built (or, for a streamed set, the records copied): the parts can go
-                if n:
-                    e.device_free(ptr)
-            t_b = t_c = t_d = time.perf_counter()
-            rows = sk.map_cgi_fragsets(sets, firsts)
-            t_e = time.perf_counter()
-            for fr in sets:
-                fr.close()
-            sk.close()
-            timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["map_ms"] += (t_e - t_d) * 1e3
-            return rows
-        elif self_mode:
-            # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
-            ptr, n, frags = e.sketch_records_self(p, refs, 0)
-            sk = Sketch(e, p, records=(ptr, n, contig_len, gcs))
-            if n:
-                e.device_free(ptr)
-            t_b = t_c = time.perf_counter()
-        elif not multi:
-            sk = Sketch(e, p, refs)
-            t_b = t_c = time.perf_counter()
-        elif ring_mode:
-            # reference-sharded all-vs-all (fastani_amd/multi_gpu.py): this rank's genomes hashed once for both roles, indexed here
-            # and nowhere else; then N ring steps, each mapping one rank's fragment set against the shard while the next one arrives
-            ptr, n, frags = e.sketch_records_self(p, my_refs, 0)
-            t_b = t_c = time.perf_counter()
-            sk = Sketch(e, p, records=(ptr, n, contig_len_local, gcs_local))
-            if n:
-                e.device_free(ptr)
-            t_d = time.perf_counter()
-            rt = {}
-            rows = ring_map(e, sk, frags, part_g0, lo, dist, rank, world, ring_alloc, dev_sync, rt)
-            frags.close()
-            sk.close()
-            timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["index_ms"] += (t_d - t_c) * 1e3
-            timers["map_ms"] += rt["map_ms"]; timers["ring_pack_ms"] += rt["pack_ms"]; timers["ring_wait_ms"] += rt["wait_ms"]
-            return rows
-        else:
-            ptr, n = e.sketch_records(p, my_refs, lo)         # records with global seqIds
-            if n > slot:
-                raise SystemExit("record slot too small: %d > %d" % (n, slot))
-            hdr = torch.tensor([n, 0, 0], dtype=torch.int32)
-            mine[:3].copy_(hdr)
-            if n:
-                e.device_copy(mine.data_ptr() + 12, ptr, n * 12)
-                e.device_free(ptr)
-            dev_sync()                          # the library copies on its own stream
-            t_r = time.perf_counter()
-            work = dist.all_gather_into_tensor(allrec, mine, async_op=True)   # one collective: the reference sketch over RCCL/xGMI ...
-            frags = e.fragment_set(p, qrys)                   # ... while this rank sketches the fragments of its own queries
-            t_f = time.perf_counter()
-            work.wait()
-            dev_sync()
-            t_c = time.perf_counter()
-            timers["ref_records_ms"] += (t_r - t_a) * 1e3; timers["fragsketch_ms"] += (t_f - t_r) * 1e3
-            t_a = t_b = t_f                                    # below: allgather_ms = what is left of the gather once the fragment sketches are done
-            counts = [int(x) for x in allrec[0::(slot + 1) * 3][:world].tolist()]
-            ptrs = [allrec.data_ptr() + (r * (slot + 1) + 1) * 12 for r in range(world)]
-            sk = Sketch(e, p, record_parts=(ptrs, counts, part_g0, contig_len, gcs))
+
+TIMER_KEYS = ["ref_records_ms", "fragsketch_ms", "allgather_ms", "index_ms", "map_ms", "ring_pack_ms", "ring_wait_ms"]
+
+
+def alloc_variant_queries(R):
+    """weak scaling: rank r maps variant r of the clustered set (same ancestors and divergences, fresh substitutions)"""
+    from fastani_amd.api import DeviceGenomes
+    a = R.args
+    R.qry_buf = R.torch.empty(R.nq_local * R.words + 64, dtype=R.torch.int32, device=R.dev)
+    R.e.synth_packed(a.seed, 0, R.nq_local, R.L, R.qry_buf.data_ptr(), variant=R.rank, cluster_size=a.cluster_size)
+    R.qrys = DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, R.L)
+
+
+def ring_alloc_fn(R):
+    def ring_alloc(nbytes):
+        t = R.torch.empty(nbytes, dtype=R.torch.uint8, device=R.dev)
+        return t, t.data_ptr()
+    return ring_alloc
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the steps
+# ---------------------------------------------------------------------------------------------------------------------------
+def step_single(R):
+    """one GPU: reference sketch + index (skch::Sketch), every query mapped (skch::Map) and reduced (cgi::computeCGI)"""
+    from fastani_amd.api import DeviceGenomes, Sketch
+    e, p, T = R.e, R.p, R.timers
+    t_a = time.perf_counter()
+    frags = None
+    if R.args.config == "c5" or (R.self_mode and R.NR > 2 * R.self_slice):
+        # a large set in slices of 1000 genomes (a slice's minimizers and sketch hashes are 32-bit counts): record parts (+ kept
+        # fragment sets when the genomes are queries too), ONE index over the parts — handed over to the library, so a streamed set
+        # keeps them without a copy — and ONE mapping call (a streamed set builds each chunk once)
+        parts, sets, firsts = [], [], []
+        c5 = R.args.config == "c5"
+        step_n = R.slice_n if c5 else R.self_slice
+        for s0 in range(0, R.NR, step_n):
+            s1 = min(R.NR, s0 + step_n)
+            if c5:
+                e.synth_packed(R.args.seed, s0, s1 - s0, R.L, R.ref_buf.data_ptr(), variant=0, cluster_size=R.args.cluster_size)
+                ptr, n = e.sketch_records(p, DeviceGenomes(R.ref_buf.data_ptr(), s1 - s0, R.L), s0)
+            else:
+                ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(R.ref_buf.data_ptr(), R.NR, R.L, first=s0, count=s1 - s0), s0)
+                sets.append(fr); firsts.append(s0)
+            parts.append((ptr, n, s0))
+        t_b = time.perf_counter()
+        sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [R.NR], R.contig_len, R.gcs), adopt=True)
         t_d = time.perf_counter()
-        if frags is not None:
-            rows = sk.map_cgi_fragset(frags, first_query_id)
-            frags.close()
-        else:
-            rows = sk.map_cgi_batch(qrys, first_query_id)
+        rows = sk.map_cgi_batch(R.qrys, R.first_query_id) if c5 else sk.map_cgi_fragsets(sets, firsts)
         t_e = time.perf_counter()
+        R.last_residency = sk.residency()
+        for fr in sets:
+            fr.close()
         sk.close()
-        timers["ref_records_ms"] += (t_b - t_a) * 1e3; timers["allgather_ms"] += (t_c - t_b) * 1e3
-        timers["index_ms"] += (t_d - t_c) * 1e3; timers["map_ms"] += (t_e - t_d) * 1e3
+        T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
         return rows
+    if R.self_mode:
+        # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
+        ptr, n, frags = e.sketch_records_self(p, R.refs, 0)
+        t_b = time.perf_counter()
+        sk = Sketch(e, p, records=(ptr, n, R.contig_len, R.gcs))
+        if n:
+            e.device_free(ptr)
+    else:
+        t_b = t_a
+        sk = Sketch(e, p, R.refs)
+    t_d = time.perf_counter()
+    if frags is not None:
+        rows = sk.map_cgi_fragset(frags, R.first_query_id)
+        frags.close()
+    else:
+        rows = sk.map_cgi_batch(R.qrys, R.first_query_id)
+    t_e = time.perf_counter()
+    sk.close()
+    T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
+    return rows
 
-    def sync():
-        dev_sync()
-        if dist is not None:
-            dist.barrier()
-        dev_sync()
 
-    for _ in range(args.warmup):
-        step()
-    e.reset_counters()
-    for k in timers:
-        timers[k] = 0.0
-    sync()
+def step_ring(R):
+    """reference-sharded all-vs-all (fastani_amd/multi_gpu.py): this rank's genomes hashed once for both roles, indexed here and
+    nowhere else; then N ring steps, each mapping one rank's fragment set against the shard while the next one arrives.
+    STRONG scaling: the job (NR x NR pairs) is fixed, every stage of it shards."""
+    from fastani_amd.api import Sketch
+    from fastani_amd.multi_gpu import ring_map
+    e, p, T = R.e, R.p, R.timers
+    t_a = time.perf_counter()
+    ptr, n, frags = e.sketch_records_self(p, R.my_refs, 0)
+    t_b = time.perf_counter()
+    sk = Sketch(e, p, records=(ptr, n, R.contig_len_local, R.gcs_local))
+    if n:
+        e.device_free(ptr)
+    t_d = time.perf_counter()
+    rt = {}
+    rows = ring_map(e, sk, frags, R.part_g0, R.lo, R.dist, R.rank, R.world, ring_alloc_fn(R), lambda: dev_sync(R), rt)
+    frags.close()
+    sk.close()
+    T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3
+    T["map_ms"] += rt["map_ms"]; T["ring_pack_ms"] += rt["pack_ms"]; T["ring_wait_ms"] += rt["wait_ms"]
+    return rows
+
+
+def step_gather(R):
+    """query-sharded (WEAK scaling over the query stream): rank r sketches its share of the references, ONE all-gather moves every
+    rank's 12-byte records (the slot's first record carries the count) while the rank sketches the fragments of its own queries,
+    then every rank builds the full index and maps its queries."""
+    from fastani_amd.api import Sketch
+    e, p, T, torch, dist = R.e, R.p, R.timers, R.torch, R.dist
+    t_a = time.perf_counter()
+    ptr, n = e.sketch_records(p, R.my_refs, R.lo)         # records with global seqIds
+    # the gather slot is sized from the ranks' REAL counts (one tiny all-reduce), never from a density guess: no rank can find its
+    # records too many for the slot and leave the others waiting in the collective
+    m = torch.tensor([n], dtype=torch.int64, device=R.dev)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    need = int(m.item())
+    if R.allrec is None or need > R.slot:
+        R.slot = need + need // 16 + 1024                  # every rank sees the same maximum, so every rank makes the same decision
+        R.allrec = torch.empty(R.world * (R.slot + 1) * 3, dtype=torch.int32, device=R.dev)
+    slot, allrec = R.slot, R.allrec
+    mine = allrec[R.rank * (slot + 1) * 3:(R.rank + 1) * (slot + 1) * 3]
+    mine[:3].copy_(torch.tensor([n, 0, 0], dtype=torch.int32))
+    if n:
+        e.device_copy(mine.data_ptr() + 12, ptr, n * 12)
+        e.device_free(ptr)
+    dev_sync(R)                          # the library copies on its own stream
+    t_r = time.perf_counter()
+    work = dist.all_gather_into_tensor(allrec, mine, async_op=True)   # one collective: the reference sketch over RCCL/xGMI ...
+    frags = e.fragment_set(p, R.qrys)                 # ... while this rank sketches the fragments of its own queries
+    t_f = time.perf_counter()
+    work.wait()
+    dev_sync(R)
+    t_c = time.perf_counter()
+    counts = [int(x) for x in allrec[0::(slot + 1) * 3][:R.world].tolist()]
+    ptrs = [allrec.data_ptr() + (r * (slot + 1) + 1) * 12 for r in range(R.world)]
+    sk = Sketch(e, p, record_parts=(ptrs, counts, R.part_g0, R.contig_len, R.gcs))
+    t_d = time.perf_counter()
+    rows = sk.map_cgi_fragset(frags, R.first_query_id)
+    frags.close()
+    t_e = time.perf_counter()
+    sk.close()
+    T["ref_records_ms"] += (t_r - t_a) * 1e3; T["fragsketch_ms"] += (t_f - t_r) * 1e3; T["allgather_ms"] += (t_c - t_f) * 1e3
+    T["index_ms"] += (t_d - t_c) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
+    return rows
+
+
+def prepare_simulation(R):
+    """--simulate-world W: the fragment sets the other W - 1 ranks would send, made here (untimed) and packed the way the ring moves them"""
+    from fastani_amd.api import DeviceGenomes
+    e, p = R.e, R.p
+    R.sim_bufs = []
+    for x in range(R.W):
+        g0, g1 = int(R.part_g0[x]), int(R.part_g0[x + 1])
+        ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(R.ref_buf.data_ptr(), R.NR, R.L, first=g0, count=g1 - g0), 0)
+        if n:
+            e.device_free(ptr)
+        nb = fr.packed_bytes()
+        t = R.torch.empty(nb, dtype=R.torch.uint8, device=R.dev)
+        fr.pack_into(t.data_ptr(), nb)
+        fr.close()
+        R.sim_bufs.append((t, nb))
+    dev_sync(R)
+
+
+def step_simulate(R):
+    """the compute of rank r of a W-rank ring job, alone on this GPU: its shard sketched and indexed, its own set packed, then W
+    mapping calls — its own set and the W - 1 sets the ring would deliver (they are already here: no communication is timed)"""
+    from fastani_amd.api import FragmentSet, Sketch
+    e, p, T = R.e, R.p, R.timers
+    t_a = time.perf_counter()
+    ptr, n, frags = e.sketch_records_self(p, R.my_refs, 0)
+    t_b = time.perf_counter()
+    sk = Sketch(e, p, records=(ptr, n, R.contig_len_local, R.gcs_local))
+    if n:
+        e.device_free(ptr)
+    t_d = time.perf_counter()
+    own_t, own_nb = R.sim_bufs[R.r]
+    frags.pack_into(own_t.data_ptr(), own_nb)
+    frags.close()
+    dev_sync(R)
+    t_p = time.perf_counter()
+    out = []
+    for s in range(R.W):
+        src = (R.r - s) % R.W
+        t, nb = R.sim_bufs[src]
+        view = FragmentSet.unpack(e, t.data_ptr(), nb, keepalive=t)
+        rows = sk.map_cgi_fragset(view, int(R.part_g0[src]))
+        view.close()
+        rows["refGenomeId"] += R.lo
+        out.append(rows)
+    t_e = time.perf_counter()
+    sk.close()
+    T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["ring_pack_ms"] += (t_p - t_d) * 1e3; T["map_ms"] += (t_e - t_p) * 1e3
+    import numpy as np
+    return np.concatenate(out)
+
+
+STEPS = {"single": step_single, "ring": step_ring, "gather": step_gather, "simulate": step_simulate}
+
+
+def sync(R):
+    dev_sync(R)
+    if R.dist is not None:
+        R.dist.barrier()
+    dev_sync(R)
+
+
+def timed_loop(R, step, steps, warmup):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronisation; the job's time is the MAX over ranks"""
+    import zlib
+    import numpy as np
+    for _ in range(warmup):
+        step(R)
+    R.e.reset_counters()
+    for k in R.timers:
+        R.timers[k] = 0.0
+    sync(R)
     t0 = time.perf_counter()
     rows = None
-    step_ms = []
-    rows_all = []
+    step_ms, crc = [], []
     trace = bool(os.environ.get("ANI_POOL_TRACE"))
-    for i in range(args.steps):
+    rows_all = []
+    for i in range(steps):
         if trace:
             print("[bench] timed step %d" % i, file=sys.stderr, flush=True)
         ts = time.perf_counter()
-        rows = step()                                        # returns with the rows on the host: the step's device work is done
+        rows = step(R)                                        # returns with the rows on the host: the step's device work is done
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
         rows_all.append(rows)
-    sync()
+    sync(R)
     dt_local = time.perf_counter() - t0
     # outside the timed region: every step must have produced the same rows (run-to-run determinism, DESIGN.md section 4)
-    import zlib
-    rows_crc = [zlib.crc32(np.ascontiguousarray(r).tobytes()) & 0xffffffff for r in rows_all]
+    crc = [zlib.crc32(np.ascontiguousarray(r).tobytes()) & 0xffffffff for r in rows_all]
     del rows_all
     dt = dt_local
-    rank_info = None
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if R.dist is not None:
+        t = R.torch.tensor([dt], dtype=R.torch.float64, device=R.dev)
+        R.dist.all_reduce(t, op=R.dist.ReduceOp.MAX)
         dt = float(t.item())
-        keys = ["ref_records_ms", "fragsketch_ms", "allgather_ms", "index_ms", "map_ms", "ring_pack_ms", "ring_wait_ms"]
-        step_local = dt_local * 1e3 / args.steps
-        vals = [step_local] + [timers[k] / args.steps for k in keys]
-        vals.append(step_local - sum(vals[1:]))                       # host time of the step outside every bracket
-        vals.append(float(len(rows)))
-        mine_info = torch.tensor(vals, dtype=torch.float64, device=dev)
-        nv = len(vals)
-        gathered = torch.empty(world * nv, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, mine_info)
-        g = gathered.view(world, nv).tolist()
-        rank_info = {"ranks_seen_by_rccl": dist.get_world_size(), "mode": "reference-sharded ring (fastani_amd/multi_gpu.py)" if ring_mode else "query-sharded, reference records all-gathered",
-                     "timeline_note": "per rank, ms per step: ref_records = sketching the rank's references, fragsketch = its queries' fragment sketches (runs while the records are "
-                                      "all-gathered), allgather = the part of the gather not hidden behind it, index = index build, map = mapping + reduce + rows to the host, "
-                                      "ring_pack / ring_wait = packing the fragment set / waiting for the next set of the ring, other = the rest of the step",
-                     "step_ms": [round(x[0], 2) for x in g]}
-        for i, k in enumerate(keys + ["other_ms"]):
-            rank_info[k] = [round(x[1 + i], 2) for x in g]
-        rank_info["rows"] = [int(x[-1]) for x in g]
-        rank_info["bytes_moved_per_rank"] = (int(getattr(e, "_ring_bufs", (("", 0),))[0][1]) * (world - 1)) if ring_mode else int((slot + 1) * 12 * (world - 1))
+    return {"rows": rows, "dt": dt, "dt_local": dt_local, "step_ms": step_ms, "rows_crc": crc}
+
+
+def gather_rank_info(R, res, steps, mode):
+    """per-rank timeline of the timed region, gathered on every rank (rank 0 prints it)"""
+    torch, dist = R.torch, R.dist
+    step_local = res["dt_local"] * 1e3 / steps
+    vals = [step_local] + [R.timers[k] / steps for k in TIMER_KEYS]
+    vals.append(step_local - sum(vals[1:]))                       # host time of the step outside every bracket
+    vals.append(float(len(res["rows"])))
+    mine_info = torch.tensor(vals, dtype=torch.float64, device=R.dev)
+    nv = len(vals)
+    gathered = torch.empty(R.world * nv, dtype=torch.float64, device=R.dev)
+    dist.all_gather_into_tensor(gathered, mine_info)
+    g = gathered.view(R.world, nv).tolist()
+    info = {"ranks_seen_by_rccl": dist.get_world_size(), "mode": "reference-sharded ring (fastani_amd/multi_gpu.py)" if mode == "ring" else "query-sharded, reference records all-gathered",
+            "timeline_note": "per rank, ms per step: ref_records = sketching the rank's references, fragsketch = its queries' fragment sketches (runs while the records are "
+                             "all-gathered), allgather = the part of the gather not hidden behind it, index = index build, map = mapping + reduce + rows to the host, "
+                             "ring_pack / ring_wait = packing the fragment set / waiting for the next set of the ring, other = the rest of the step",
+            "step_ms": [round(x[0], 2) for x in g]}
+    for i, k in enumerate(TIMER_KEYS + ["other_ms"]):
+        info[k] = [round(x[1 + i], 2) for x in g]
+    info["rows"] = [int(x[-1]) for x in g]
+    info["bytes_moved_per_rank"] = (int(getattr(R.e, "_ring_bufs", (("", 0),))[0][1]) * (R.world - 1)) if mode == "ring" else int((R.slot + 1) * 12 * (R.world - 1))
+    return info
+
+
+def main():
+    args = parse()
+    R = setup_runtime(args)
+    import numpy as np
+    e, p, cfg = R.e, R.p, args.config
+    make_inputs(R)
+    mode, NR, L, world, rank = R.mode, R.NR, R.L, R.world, R.rank
+    if mode == "simulate":
+        prepare_simulation(R)
+    res = timed_loop(R, STEPS[mode], args.steps, args.warmup)
+    rows, dt = res["rows"], res["dt"]
+    rank_info = gather_rank_info(R, res, args.steps, mode) if R.dist is not None else None
     c = e.counters()
+    host_timeline = {k: round(v / args.steps, 2) for k, v in R.timers.items() if v}
+    if args.dump_rows:
+        np.save(args.dump_rows + (".rank%d" % rank if R.multi else "") + ".npy", rows)
+
+    # N > 1, headline set: the timed region above is the STRONG-scaling job (fixed 1000 x 1000); the weak-scaling figure of the same
+    # kernels (fixed database, 1000 queries per GPU) is measured beside it, outside the contract's timed region
+    weak_leg = None
+    if mode == "ring" and cfg == "many-to-many" and not args.no_weak_leg:
+        R.nq_local = args.queries or NR
+        alloc_variant_queries(R)
+        R.first_query_id = rank * R.nq_local
+        wres = timed_loop(R, step_gather, max(1, min(args.steps, 3)), 1)
+        winfo = gather_rank_info(R, wres, max(1, min(args.steps, 3)), "gather")
+        wsteps = max(1, min(args.steps, 3))
+        weak_leg = {"scaling": "weak", "value": round(NR * R.nq_local * world * wsteps / wres["dt"], 1), "unit": "pairs/s", "steps": wsteps, "ms_per_step": round(wres["dt"] / wsteps * 1e3, 2),
+                    "workload": "many-to-many %dx%d: fixed %d-genome database, %d query genomes per GPU (rank r maps variant r of the clustered set); queries sharded, reference records all-gathered"
+                                % (NR, R.nq_local * world, NR, R.nq_local), "ranks": winfo}
 
     # one-to-many: the latency-shaped number — map the one query against a resident index
     map_only = None
     if cfg == "one-to-many" and rank == 0:
-        sk = Sketch(e, p, refs)
-        sk.map_cgi_batch(qrys, first_query_id)
-        dev_sync()
+        from fastani_amd.api import Sketch
+        sk = Sketch(e, p, R.refs)
+        sk.map_cgi_batch(R.qrys, R.first_query_id)
+        dev_sync(R)
         ts = []
         for _ in range(max(3, args.steps)):
             t1 = time.perf_counter()
-            sk.map_cgi_batch(qrys, first_query_id)
+            sk.map_cgi_batch(R.qrys, R.first_query_id)
             ts.append((time.perf_counter() - t1) * 1e3)
         sk.close()
         map_only = {"ms": round(min(ts), 3), "ms_all": [round(x, 3) for x in ts], "what": "ani_map_cgi_batch of the one query genome (1666 fragments) against the resident 1000-genome index, rows on the host"}
 
     if rank == 0:
-        pairs = NR * n_queries_total
-        value = pairs * args.steps / dt
-        # roofline of the dominant kernel: algorithmic bytes / HIP-event time of its launches, timed region only
-        l2_bytes = 12.0 * c["l2WindowEntries"] + 4.0 * c["l2QueryHashes"]
-        cand = {
-            "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes - (12.0 * c["l2WindowEntriesB"] + 4.0 * c["l2QueryHashesB"]),
-                              "class-A launches (k_l2_sim<L2Geom<255>>): 12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per class-A candidate"),
-            "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate (the SAME bytes as k_l2_sim: the two kernels share one set of algorithmic bytes, see roofline.stage)"),
-            "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
-            "ani::k_l1_probe": (c["msL1Probe"], 4.0 * c["l1Probes"], "4 B x fragment sketch hashes probed (per index chunk)"),
-            "ani::k_l1<0,2048>": (c["msL1Main"], 8.0 * c["seedHits"], "8 B x seed hits (all LDS classes; the small class handles nearly all fragments)"),
-            ("ani::k_sketch_fused" if self_mode else "ani::k_sketch_tiles"):
-                (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"] + (4.0 * c["querySketchHashes"] if self_mode else 0.0),
-                 "G/4 packed bases + 12 B x minimizers" + (" + 4 B x fragment sketch hashes (fused all-vs-all pass)" if self_mode else "")),
-            "ani::k_fragment_sketch": (c["msFragSketch"], c["queryBases"] / 4.0 + 4.0 * c["querySketchHashes"], "G/4 packed bases + 4 B x sketch hashes"),
-        }
-        # whole-job figure of SURVEY.md §8d: B_total = N_r (G/4 + 36 M) + N_q (G/4 + 8 F s) + 8 H + sum(12 m_c + 4 s) + 112 #mappings
-        # (#mappings bounded below by the candidates: the fused path does not count the survivors of the identity filter separately)
-        b_total = (c["refBases"] / 4.0 + 36.0 * c["refMinimizers"] + c["queryBases"] / 4.0 + 8.0 * c["querySketchHashes"]
-                   + 8.0 * c["seedHits"] + l2_bytes)
-        job = {"algorithmic_bytes_per_step": round(b_total / args.steps, 1), "bytes_per_pair": round(b_total / args.steps / max(1, NR * nq_local), 1),
-               "achieved_GBs": round(b_total * world / dt / 1e9, 2), "frac_of_hbm_peak": round(b_total / dt / 1e9 / HBM_PEAK_GBS, 5)}
-        dom = max(cand, key=lambda k: cand[k][0])
-        ms, nbytes, what = cand[dom]
-        achieved = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "kernel_achieved": round(achieved, 2), "kernel_frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "algorithmic_bytes": what, "kernel_ms_per_step": round(ms / args.steps, 3),
-                "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in cand.items()},
-                "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()},
-                "whole_job": job}
-        # the L2 stage as a whole (ranges + length order + codes + simulation + leftovers) on the one set of L2 bytes
-        if c["msL2"] > 0:
-            st = l2_bytes / (c["msL2"] / 1e3) / 1e9
-            roof["stage"] = {"stage": "L2 (k_l2_ranges + k_l2_len_* + k_l2_codes + k_l2_sim<A,B> + k_l2)", "ms_per_step": round(c["msL2"] / args.steps, 3),
-                             "algorithmic_bytes_per_step": round(l2_bytes / args.steps, 1), "achieved": round(st, 2), "unit": "GB/s", "frac": round(st / HBM_PEAK_GBS, 5)}
-            if dom in ("ani::k_l2_sim", "ani::k_l2_codes"):
-                # the kernels of the L2 stage share ONE set of algorithmic bytes: quoting them per kernel counts the bytes twice, so the
-                # headline fraction is the stage's (kernel_frac keeps the dominant kernel's own figure)
-                roof["achieved"], roof["frac"] = roof["stage"]["achieved"], roof["stage"]["frac"]
-                roof["frac_note"] = "achieved / frac = the L2 stage as a whole (its kernels share one set of algorithmic bytes); kernel_achieved / kernel_frac = the dominant kernel alone; whole_job = the step"
-        roof["int_ops"] = int_ops_block(c, args.steps, self_mode)
-        roof["bound_note"] = ("'hbm' by the algorithmic-byte accounting of SURVEY.md section 8d (12 B per reference minimizer in a candidate range); what "
-                              "limits k_l2_sim is vector instruction issue: its VALU wave-instructions x 4 cycles are 86 % of the kernel's SIMD cycles at 2.5 "
-                              "waves per SIMD (LDS-bound occupancy), profiles/r02X_pmc_sq_summary.txt; its HBM traffic is roofline.traffic, a third of the algorithmic bytes")
-        # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
-        # + WRITE_SIZE, per launch) — only quoted when it is this default workload
-        try:
-            if cfg == "many-to-many" and NR == 1000 and L == 5_000_000 and world == 1:
-                for tag in ("r03", "r02", "r01p"):
-                    fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
-                    if not os.path.exists(fn):
-                        continue
-                    tj = json.load(open(fn))
-                    key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
-                    hit = [k for k in tj["kernels"] if k.startswith(key)]
-                    if hit:
-                        roof["traffic"] = tj["kernels"][hit[0]]["hbm_bytes_per_launch_corrected"]
-                        roof["traffic_source"] = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag
-                        break
-        except Exception:
-            pass
-        if dom == "ani::k_l2_sim":
-            launches = max(1, c["l2Launches"])
-            roof.update({"launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
-                         "algorithmic_bytes_per_launch": round(nbytes / launches, 1)})
-        stages = {k: round(c[k] / args.steps, 3) for k in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce")}
-        wl = {"many-to-many": "many-to-many %dx%d" % (NR, n_queries_total), "one-to-many": "one-to-many 1x%d (query = cluster 0 member 1)" % NR,
-              "c4": "many-to-many %dx%d (configs[3] shape, all-vs-all%s)" % (NR, n_queries_total, "" if n_queries_total == NR else ", query count bounded by --queries")}[cfg]
-        out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-               "higher_is_better": True, "scaling": "weak" if cfg != "c4" else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic" if not emu else "synthetic; CPU EMULATION OF THE KERNELS (test of the orchestration, not a measurement)",
-               "config": {"workload": "%s synthetic %d bp genomes (clusters of %d, 0-25%% divergence), k=16 fragLen=3000 w=%d%s"
-                                      % (wl, L, args.cluster_size, p.windowSize, "" if world == 1 else ("; references sharded %d ways, query fragment sketches ring-passed over RCCL" % world if ring_mode
-                                                                                   else "; queries sharded %d ways, reference sketch all-gathered over RCCL" % world)),
-                          "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM", "all_vs_all_single_hash_pass": bool(self_mode),
-                          "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
-               "rows_last_step": int(len(rows)), "rows_identical_across_steps": len(set(rows_crc)) == 1, "step_ms_rank0": step_ms,
-               "stage_ms_per_step_rank0": stages, "host_timeline_ms_per_step_rank0": {k: round(v / args.steps, 2) for k, v in timers.items() if v}, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
-               "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
-                                                                              "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
-                                                                              "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows")},
-               "roofline": roof}
-        if rank_info:
-            out["ranks"] = rank_info
-        if map_only:
-            out["map_only"] = map_only
-        if world == 1 and not (args.no_cpu_baseline and args.no_e2e and args.no_verify):
-            legs = cpu_legs(args, e, p, rows, NR, list(range(first_query_id, first_query_id + nq_local)), L)
-            out.update(legs)
-        if "cpu_baseline" not in out:
-            out["cpu_baseline"] = None
+        out = report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only)
         print(json.dumps(out), flush=True)
     e.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if R.dist is not None:
+        R.dist.destroy_process_group()
+
+
+def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
+    """the ONE JSON line of the driver contract (rank 0)"""
+    e, p, cfg, mode, NR, L, world = R.e, R.p, args.config, R.mode, R.NR, R.L, R.world
+    rows, dt = res["rows"], res["dt"]
+    self_mode = R.self_mode
+    n_queries_total, nq_local = R.n_queries_total, R.nq_local
+    sim = mode == "simulate"
+    pairs = NR * n_queries_total if not sim else NR * NR
+    value = pairs * args.steps / dt
+    fused = self_mode or mode in ("ring", "simulate")
+    # roofline of the dominant kernel: algorithmic bytes (SURVEY.md §8d) / HIP-event time of its launches, timed region only
+    l2_bytes = 12.0 * c["l2WindowEntries"] + 4.0 * c["l2QueryHashes"]
+    cand = {
+        "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes - (12.0 * c["l2WindowEntriesB"] + 4.0 * c["l2QueryHashesB"]),
+                          "class-A launches (k_l2_sim<L2Geom<255>>): 12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per class-A candidate"),
+        "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate (the SAME bytes as k_l2_sim: the two kernels share one set of algorithmic bytes, see roofline.stage)"),
+        "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
+        "ani::k_l1_probe": (c["msL1Probe"], 4.0 * c["l1Probes"], "4 B x fragment sketch hashes probed (per index chunk)"),
+        "ani::k_l1<0,2048>": (c["msL1Main"], 8.0 * c["seedHits"], "8 B x seed hits (all LDS classes; the small class handles nearly all fragments)"),
+        ("ani::k_sketch_fused" if fused else "ani::k_sketch_tiles"):
+            (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"] + (4.0 * c["querySketchHashes"] if fused else 0.0),
+             "G/4 packed bases + 12 B x minimizers" + (" + 4 B x fragment sketch hashes (fused all-vs-all pass)" if fused else "")),
+        "ani::k_fragment_sketch": (c["msFragSketch"], c["queryBases"] / 4.0 + 4.0 * c["querySketchHashes"], "G/4 packed bases + 4 B x sketch hashes"),
+    }
+    # whole-job figure of SURVEY.md §8d: B_total = N_r (G/4 + 36 M) + N_q (G/4 + 8 F s) + 8 H + sum(12 m_c + 4 s) + 112 #mappings
+    # (#mappings bounded below by the candidates: the fused path does not count the survivors of the identity filter separately)
+    b_total = (c["refBases"] / 4.0 + 36.0 * c["refMinimizers"] + c["queryBases"] / 4.0 + 8.0 * c["querySketchHashes"]
+               + 8.0 * c["seedHits"] + l2_bytes)
+    job = {"algorithmic_bytes_per_step": round(b_total / args.steps, 1), "bytes_per_pair": round(b_total / args.steps / max(1, NR * nq_local), 1),
+           "achieved_GBs": round(b_total * world / dt / 1e9, 2), "frac_of_hbm_peak": round(b_total / dt / 1e9 / HBM_PEAK_GBS, 5),
+           "note": "rank 0's counters; achieved_GBs scales them by the number of ranks"}
+    dom = max(cand, key=lambda k: cand[k][0])
+    ms, nbytes, what = cand[dom]
+    achieved = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "kernel_achieved": round(achieved, 2), "kernel_frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes": what, "kernel_ms_per_step": round(ms / args.steps, 3),
+            "all_kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in cand.items()},
+            "all_kernels_achieved_GBs": {k: (round(v[1] / (v[0] / 1e3) / 1e9, 2) if v[0] > 0 else None) for k, v in cand.items()},
+            "whole_job": job}
+    # the L2 stage as a whole (ranges + length order + codes + simulation + leftovers) on the one set of L2 bytes
+    if c["msL2"] > 0:
+        st = l2_bytes / (c["msL2"] / 1e3) / 1e9
+        roof["stage"] = {"stage": "L2 (k_l2_ranges + k_l2_len_* + k_l2_codes + k_l2_sim<A,B> + k_l2)", "ms_per_step": round(c["msL2"] / args.steps, 3),
+                         "algorithmic_bytes_per_step": round(l2_bytes / args.steps, 1), "achieved": round(st, 2), "unit": "GB/s", "frac": round(st / HBM_PEAK_GBS, 5)}
+        if dom in ("ani::k_l2_sim", "ani::k_l2_codes"):
+            # the kernels of the L2 stage share ONE set of algorithmic bytes: quoting them per kernel counts the bytes twice, so the
+            # headline fraction is the stage's (kernel_frac keeps the dominant kernel's own figure)
+            roof["achieved"], roof["frac"] = roof["stage"]["achieved"], roof["stage"]["frac"]
+            roof["frac_note"] = "achieved / frac = the L2 stage as a whole (its kernels share one set of algorithmic bytes); kernel_achieved / kernel_frac = the dominant kernel alone; whole_job = the step"
+    roof["int_ops"] = int_ops_block(c, args.steps, fused)
+    roof["bound_note"] = ("'hbm' by the algorithmic-byte accounting of SURVEY.md section 8d (12 B per reference minimizer in a candidate range); what "
+                          "limits k_l2_sim is vector instruction issue: its VALU wave-instructions x 4 cycles are 86 % of the kernel's SIMD cycles at 2.5 "
+                          "waves per SIMD (LDS-bound occupancy), profiles/r02X_pmc_sq_summary.txt; its HBM traffic is roofline.traffic, a third of the algorithmic bytes")
+    # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
+    # + WRITE_SIZE, per launch) — only quoted when it is this default workload
+    try:
+        if cfg == "many-to-many" and NR == 1000 and L == 5_000_000 and world == 1 and mode == "single":
+            for tag in ("r04", "r03", "r02", "r01p"):
+                fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+                if not os.path.exists(fn):
+                    continue
+                tj = json.load(open(fn))
+                key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
+                hit = [k for k in tj["kernels"] if k.startswith(key)]
+                if hit:
+                    roof["traffic"] = tj["kernels"][hit[0]]["hbm_bytes_per_launch_corrected"]
+                    roof["traffic_source"] = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag
+                    break
+    except Exception:
+        pass
+    if dom == "ani::k_l2_sim":
+        launches = max(1, c["l2Launches"])
+        roof.update({"launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
+                     "algorithmic_bytes_per_launch": round(nbytes / launches, 1)})
+    stages = {k: round(c[k] / args.steps, 3) for k in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce")}
+    wl = {"many-to-many": "many-to-many %dx%d" % (NR, n_queries_total), "one-to-many": "one-to-many 1x%d (query = cluster 0 member 1)" % NR,
+          "c4": "many-to-many %dx%d (configs[3] shape, all-vs-all%s)" % (NR, n_queries_total, "" if n_queries_total == NR else ", query count bounded by --queries"),
+          "c5": "many-to-many %dx%d (configs[4] shape: a reference set beyond the device memory's index capacity, streamed; the set is generated and sketched slice by slice, "
+                "only its minimizer records stay resident)" % (NR, n_queries_total)}[cfg]
+    how = ""
+    if sim:
+        how = "; SIMULATED rank %d of a %d-rank reference-sharded ring job on one GPU (its compute only, no communication)" % (R.r, R.W)
+    elif world > 1 or R.multi:
+        how = ("; STRONG scaling: references sharded %d ways, query fragment sketches ring-passed over RCCL" % world if mode == "ring"
+               else "; WEAK scaling: queries sharded %d ways (%d per GPU), reference sketch all-gathered over RCCL" % (world, nq_local))
+    out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+           "higher_is_better": True, "scaling": "weak" if mode == "gather" else "strong", "vs_baseline": None, "dtype": "u32",
+           "data": "synthetic" if not R.emu else "synthetic; CPU EMULATION OF THE KERNELS (test of the orchestration, not a measurement)",
+           "config": {"workload": "%s synthetic %d bp genomes (clusters of %d, 0-25%% divergence), k=16 fragLen=3000 w=%d%s" % (wl, L, args.cluster_size, p.windowSize, how),
+                      "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM" if cfg != "c5" else "2-bit packed, generated in HBM slice by slice inside the step",
+                      "all_vs_all_single_hash_pass": bool(fused), "mode": mode,
+                      "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
+           "rows_last_step": int(len(rows)), "rows_identical_across_steps": len(set(res["rows_crc"])) == 1, "step_ms_rank0": res["step_ms"],
+           "stage_ms_per_step_rank0": stages, "host_timeline_ms_per_step_rank0": host_timeline, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
+           "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
+                                                                          "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
+                                                                          "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments")},
+           "roofline": roof}
+    if sim:
+        out["simulated"] = {"world": R.W, "rank": R.r, "what": "value = %d x %d pairs / the time ONE rank of a %d-GPU strong-scaling job computes (sketch + index of its %d genomes, %d mapping calls); "
+                                                              "the ring's transfers (one packed fragment set per hop, %d bytes) overlap the mapping and are not in it"
+                                                              % (NR, NR, R.W, R.hi - R.lo, R.W, R.sim_bufs[R.r][1]),
+                            "n_gpus_simulated": R.W}
+    if getattr(R, "last_residency", None):
+        out["config"]["residency"] = R.last_residency
+    if rank_info:
+        out["ranks"] = rank_info
+    if weak_leg:
+        out["weak_scaling_leg"] = weak_leg
+    if map_only:
+        out["map_only"] = map_only
+    if world == 1 and mode == "single" and not R.multi and not (args.no_cpu_baseline and args.no_e2e and args.no_verify):
+        legs = cpu_legs(args, e, p, rows, NR, list(range(R.first_query_id, R.first_query_id + nq_local)), L)
+        out.update(legs)
+    elif (mode == "simulate" or R.multi) and world == 1 and not args.no_verify and not R.emu:
+        # the rows of a one-rank ring / gather / simulated-rank run against the oracle, pair by pair
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        rows_by_pair = {(int(q), int(r)): (float(a), int(cn), int(t)) for q, r, a, cn, t in
+                        zip(rows["qryGenomeId"], rows["refGenomeId"], rows["identity"], rows["countSeq"], rows["totalQueryFragments"])}
+        qids = list(range(NR)) if mode != "gather" else list(range(R.first_query_id, R.first_query_id + nq_local))
+        out["parity_timed_rows"] = {"vs_oracle": oracle_spot_check(orc, args, rows_by_pair, R.hi - R.lo if mode != "gather" else NR, qids, L, p.windowSize, min(args.oracle_pairs, 120),
+                                                                  ref_base=R.lo if mode != "gather" else 0)}
+        out["parity_timed_rows"]["ok"] = out["parity_timed_rows"]["vs_oracle"]["ok"]
+    if "cpu_baseline" not in out:
+        out["cpu_baseline"] = None
+    return out
 
 
 if __name__ == "__main__":

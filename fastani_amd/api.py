@@ -81,6 +81,7 @@ def _bind(lib):
         "ani_sketch_records": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_sketch_from_records": (C.c_int, [vp, C.POINTER(Params), vp, C.c_size_t, vp, C.c_int32, vp, C.c_int32, C.POINTER(vp)]),
         "ani_sketch_from_record_parts": (C.c_int, [vp, C.POINTER(Params), C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.POINTER(vp)]),
+        "ani_sketch_adopt_record_parts": (C.c_int, [vp, C.POINTER(Params), C.c_int32, vp, vp, vp, vp, C.c_int32, vp, C.c_int32, C.POINTER(vp)]),
         "ani_map_query": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
         "ani_query_sketch": (C.c_int, [vp, C.POINTER(Params), C.POINTER(SeqBatch), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_compute_cgi": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
@@ -357,10 +358,11 @@ class FragmentSet:
 
 
 class Sketch:
-    def __init__(self, engine, params, genomes=None, records=None, record_parts=None, file=None, genome_range=(0, -1)):
+    def __init__(self, engine, params, genomes=None, records=None, record_parts=None, file=None, genome_range=(0, -1), adopt=False):
         """Either `genomes` (≙ Sketch::Sketch over the reference files), or for the multi-GPU staging path
         records=(dev_ptr, n, contig_len[int32], genome_contig_start[int32]) or
-        record_parts=(dev_ptrs, counts, part_genome_start[nParts+1], contig_len, genome_contig_start)."""
+        record_parts=(dev_ptrs, counts, part_genome_start[nParts+1], contig_len, genome_contig_start); adopt=True hands the
+        record buffers of record_parts over to the library (ani_sketch_adopt_record_parts: no copy for a streamed set)."""
         self.e = engine
         self.params = params
         h = C.c_void_p()
@@ -373,8 +375,9 @@ class Sketch:
             pgs = np.ascontiguousarray(pgs, dtype=np.int32)
             clen = np.ascontiguousarray(clen, dtype=np.int32)
             gcs = np.ascontiguousarray(gcs, dtype=np.int32)
-            engine._chk(engine.lib.ani_sketch_from_record_parts(engine.h, C.byref(params), len(ptrs), ptrs.ctypes.data, counts.ctypes.data,
-                                                                pgs.ctypes.data, clen.ctypes.data, len(clen), gcs.ctypes.data, len(gcs) - 1, C.byref(h)))
+            fn = engine.lib.ani_sketch_adopt_record_parts if adopt else engine.lib.ani_sketch_from_record_parts
+            engine._chk(fn(engine.h, C.byref(params), len(ptrs), ptrs.ctypes.data, counts.ctypes.data,
+                        pgs.ctypes.data, clen.ctypes.data, len(clen), gcs.ctypes.data, len(gcs) - 1, C.byref(h)))
         elif records is not None:
             ptr, n, clen, gcs = records
             clen = np.ascontiguousarray(clen, dtype=np.int32)

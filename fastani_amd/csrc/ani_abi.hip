@@ -216,6 +216,8 @@ struct ani_ctx {
   uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
   int l1FilterMin = ani::kL1FilterMinHits, l1LdsMax = ani::kL1HitCapMax;           // env ANI_L1_FILTER_MIN / ANI_L1_LDS_MAX, read by ani_init (tests: per engine, not per process)
   bool l2Overlap = false;                                                           // env ANI_L2_OVERLAP=1 (see the L2 loop)
+  uint64_t l1HitLimit = 0x7ffffff0ull;                                              // seed hits per fragment and index chunk (32-bit hit offsets; env ANI_L1_HIT_LIMIT, tests)
+  uint64_t candPoolMin = 4096;                                                      // floor of the L1 candidate pool, per stripe (env ANI_CAND_POOL_MIN, tests: forces the retry path)
   uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;              // seed hits / fragments per group of the batched global-memory L1 path (env ANI_L1_BIG_GROUP_HITS / _FRAGS, tests)
   int32_t maxResidentChunks = 0;                                                    // index chunks of one reference set kept on the device (env ANI_MAX_RESIDENT_CHUNKS; 0 = decide from the free memory)
   uint64_t streamChunkMinimizers = 1000000000ull;                                   // chunk size once a set is streamed (env ANI_STREAM_CHUNK_MINIMIZERS): the build's transient arrays must fit beside the records
@@ -230,7 +232,8 @@ struct ani_ctx {
   ani_counters_t counters;
   std::vector<unsigned long long> hostCounters;                 // read_counters: the raw block
   unsigned long long poolUsed[3] = {0, 0, 0}, poolMaxStripe[3] = {0, 0, 0};
-  double candPerFrag = 12.0;      // running estimate that sizes the L1 candidate pool
+  double candPerFrag = 12.0;      // running estimate that sizes the L1 candidate pool (learnt from batches that fill the pool stripes evenly)
+  uint64_t smallBatchCandCap = 0; // ... and what the last batch too small for that estimate needed (a few hundred fragments against a species-dense index, call after call)
   // scalar device counters (array of 16 x u64)
   DevBuf dCounters;
   // workspaces reused across calls
@@ -1287,16 +1290,19 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // First guess of the candidate pool from the context's running estimate, never beyond what 32-bit candidate ids allow (the limit
   // is an error only when the batch really needs more: the retry below).
   const uint64_t kCandLimit = 0x7fffff00ull;      // whole stripes below 2^31
-  uint64_t ccap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)nF * ctx->candPerFrag) + 4096, 4096 * kPoolStripes), kCandLimit);   // at least 4096 per stripe (4 MB): a few heavy fragments fit without a retry
+  uint64_t ccap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)nF * ctx->candPerFrag) + ctx->candPoolMin, ctx->candPoolMin * kPoolStripes), kCandLimit);   // at least 4096 per stripe (4 MB): a few heavy fragments fit without a retry
+  const bool smallBatch = nF < 16 * (size_t)kPoolStripes;
+  if (smallBatch) ccap = std::min<uint64_t>(std::max<uint64_t>(ccap, ctx->smallBatchCandCap), kCandLimit);
   TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
   unsigned nMid = 0, nBig = 0;
   std::vector<int32_t> bigFrags, bigInfo;          // fragments beyond the LDS classes and their (sketch size, seed hits)
   unsigned long long hitsTotal = 0;
+  uint32_t probeOverflow = 0;                       // fragments k_l1_probe marked with >= 2^31 seed hits: latched after attempt 0 (the probe runs once)
   for (int attempt = 0;; attempt++) {
     ccap = (uint64_t)stripe_cap(ccap) * kPoolStripes;
     TRY(ctx->candFrag.ensure(ccap * 4)); TRY(ctx->candSeq.ensure(ccap * 4)); TRY(ctx->candStart.ensure(ccap * 4)); TRY(ctx->candEnd.ensure(ccap * 4));
     if (attempt == 0) TRY(zero_counters(ctx));
-    else { TRY(zero_cursors(ctx, POOL_CAND)); HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_NEG), 0, 8, ctx->stream)); }
+    else TRY(zero_cursors(ctx, POOL_CAND));            // only the candidate pool is redone: k_l1_probe's results (CNT_HITS, CNT_NEG = its overflow marker, the class lists) stay
     L1Args a;
     a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS; a.nFrag = (int32_t)nF;
     a.table = sk->table; a.tableSlots = sk->tableSlots; a.sSW = sk->sSW; a.bucketW = w; a.nIndex = sk->n;
@@ -1311,7 +1317,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
-    a.overflowCount = (unsigned int *)cnt_ptr(ctx, CNT_NEG);
+    a.overflowCount = (unsigned int *)cnt_ptr(ctx, CNT_NEG); a.hitLimit = ctx->l1HitLimit;
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
       if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
@@ -1393,23 +1399,23 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     }
     HIP_TRY(hipGetLastError());
     TRY(read_counters(ctx, host));
-    if (attempt == 0) { hitsTotal = host[CNT_HITS]; ctx->counters.l1MidFragments += nMid; }
+    if (attempt == 0) { hitsTotal = host[CNT_HITS]; probeOverflow = (uint32_t)host[CNT_NEG]; ctx->counters.l1MidFragments += nMid; }
     if (ctx->poolMaxStripe[POOL_CAND] <= stripe_cap(ccap)) break;
     if (attempt > 2) return fail(ANI_ERR_INTERNAL, "candidate pool did not converge");
     if (ccap >= kCandLimit) return fail(ANI_ERR_LIMIT, "more than 2^31 L1 candidates in one query batch");
-    ccap = std::min<uint64_t>((uint64_t)(1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes) + 4096, kCandLimit);
+    ccap = std::min<uint64_t>((uint64_t)(1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes) + ctx->candPoolMin, kCandLimit);
   }
   // Size the pool right next time (by the fullest stripe).  Only a batch that fills the stripes evenly says anything about the next
   // one: a handful of fragments sit in a handful of stripes, and "fullest stripe x 64 / fragments" of a one-fragment batch with
   // 1000 candidates would ask for 80 000 candidates per fragment of the next, million-fragment batch (a bogus 2^31 limit error
   // after 34 GB of pool; seen in the parity suite under ANI_POOL_POISON).  The estimate follows the batches down as well as up.
-  if (nF >= 16 * kPoolStripes) {                 // (a one-to-many query of 1666 fragments counts: without its update every call ran the L1 kernels twice)
+  if (!smallBatch) {                             // (a one-to-many query of 1666 fragments counts: without its update every call ran the L1 kernels twice)
     const double seen = 1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes / (double)nF;
     ctx->candPerFrag = std::max(12.0, seen >= ctx->candPerFrag ? seen : 0.5 * (ctx->candPerFrag + seen));
-  }
-  if ((uint32_t)host[CNT_NEG] != 0)            // k_l1_probe: hit counts and offsets are 32-bit per fragment
+  } else ctx->smallBatchCandCap = std::min<uint64_t>(grown_cap(ctx->poolMaxStripe[POOL_CAND]), (uint64_t)1 << 26);   // the next small batch starts from what this one needed (bounded: 1 GB of pool)
+  if (probeOverflow != 0)                      // k_l1_probe: hit counts and offsets are 32-bit per fragment
     return fail(ANI_ERR_LIMIT, "%u query fragment(s) have 2^31 or more seed hits in one index chunk (a hash with ~10^9 occurrences: low-complexity / "
-                               "repetitive references); use the reference's -s sanity check or a smaller ANI_MAX_INDEX_MINIMIZERS", (uint32_t)host[CNT_NEG]);
+                               "repetitive references); use the reference's -s sanity check or a smaller ANI_MAX_INDEX_MINIMIZERS", probeOverflow);
   ctx->counters.seedHits += hitsTotal;
   uint64_t nCand = 0;
   {
@@ -1886,6 +1892,8 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_L1_FILTER_MIN")) c->l1FilterMin = atoi(ev);
   if (const char *ev = getenv("ANI_L1_LDS_MAX")) c->l1LdsMax = std::max(0, std::min(atoi(ev), (int)ani::kL1HitCapMax));
   if (const char *ev = getenv("ANI_L2_OVERLAP")) c->l2Overlap = !strcmp(ev, "1");
+  if (const char *ev = getenv("ANI_L1_HIT_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l1HitLimit = std::min<uint64_t>((uint64_t)v, 0x7ffffff0ull); }
+  if (const char *ev = getenv("ANI_CAND_POOL_MIN")) { const long long v = atoll(ev); if (v >= 1) c->candPoolMin = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L1_BIG_GROUP_HITS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupHits = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L1_BIG_GROUP_FRAGS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupFrags = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev); if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
@@ -2200,9 +2208,34 @@ int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *dev
   return ANI_OK;
 }
 
+namespace {
+int sketch_from_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords, const uint64_t *n,
+                      const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                      const int32_t *genomeContigStart, int32_t nGenomes, bool adopt, ani_sketch **out, bool *consumed);
+}
 int ani_sketch_from_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords, const uint64_t *n,
                                  const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
                                  const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  bool consumed = false;
+  return sketch_from_parts(ctx, p, nParts, devRecords, n, partGenomeStart, contigLen, nContigs, genomeContigStart, nGenomes, false, out, &consumed);
+}
+int ani_sketch_adopt_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, void *const *devRecords, const uint64_t *n,
+                                  const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                                  const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  bool consumed = false;
+  const int rc = sketch_from_parts(ctx, p, nParts, devRecords, n, partGenomeStart, contigLen, nContigs, genomeContigStart, nGenomes, true, out, &consumed);
+  if (!consumed && ctx && devRecords && nParts > 0) {        // rejected before anything was taken over: the buffers are the library's all the same
+    (void)hipSetDevice(ctx->device);
+    for (int32_t i = 0; i < nParts; i++) if (devRecords[i]) pool_free(devRecords[i]);
+  }
+  return rc;
+}
+namespace {
+int sketch_from_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords, const uint64_t *n,
+                      const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                      const int32_t *genomeContigStart, int32_t nGenomes, bool adopt, ani_sketch **out, bool *consumed)
 {
   if (!ctx || !out || nParts < 0 || (nParts && (!devRecords || !n || !partGenomeStart)) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
     return fail(ANI_ERR_ARG, "invalid argument");
@@ -2216,12 +2249,18 @@ int ani_sketch_from_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nP
     if (partGenomeStart[i + 1] < partGenomeStart[i] || (n[i] && !devRecords[i])) return fail(ANI_ERR_ARG, "record part %d is malformed", i);
     parts[i].rec = (uint32_t *)devRecords[i]; parts[i].n = (size_t)n[i]; parts[i].g0 = partGenomeStart[i]; parts[i].g1 = partGenomeStart[i + 1]; parts[i].owned = false;
   }
+  // adopted buffers: a streamed set keeps them as they are (no copy of the records: a set near the device's capacity has no room
+  // for one), a resident set releases each as soon as the chunks that need it are built; whatever add_chunks did not take goes back here
+  for (auto &q : parts) q.owned = adopt;
+  *consumed = true;
   ani_sketch *sk = new_sketch(ctx, p, contigLen, nContigs, genomeContigStart, nGenomes);
   const int rc = add_chunks(ctx, sk, parts);
+  if (adopt) for (auto &q : parts) if (q.rec) { pool_free(q.rec); q.rec = nullptr; }
   if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
   *out = sk;
   return ANI_OK;
 }
+}  // namespace
 
 int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, ani_sketch **out)
 {

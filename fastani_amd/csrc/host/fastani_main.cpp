@@ -190,11 +190,16 @@ struct BlockReader {
     return true;
   }
   int getc() { if (p >= n && !fill()) return -1; return buf[p++]; }
-  // appends the rest of the current line to `dst` (without the '\n'); returns false if the input ended before a '\n'
+  // appends the rest of the current line to `dst` (without the '\n'); returns false if the input ended before a '\n'.
+  // gotAny = the call saw input at all (ks_getuntil2 strips a trailing '\r' only then: `if (!gotany && ks_eof(ks)) return -1`
+  // comes before the strip, kseq.h:138-141)
+  bool gotAny = false;
   template <class V> bool rest_of_line(V *dst, size_t *count, int *lastByte = nullptr)
   {
+    gotAny = false;
     for (;;) {
       if (p >= n && !fill()) return false;
+      gotAny = true;
       const unsigned char *s = buf.data() + p;
       const unsigned char *nl = (const unsigned char *)memchr(s, '\n', n - p);
       const size_t len = nl ? (size_t)(nl - s) : n - p;
@@ -242,7 +247,7 @@ bool readFile(const std::string &path, FileData &fd)
       if (c == '\n') continue;
       fd.data.push_back((uint8_t)c);
       rd.rest_of_line(&fd.data, nullptr);
-      if (fd.data.size() - start > 1 && fd.data.back() == '\r') fd.data.pop_back();    // KS_SEP_LINE: a trailing '\r' goes once the sequence so far has more than one byte (kseq.h:141)
+      if (rd.gotAny && fd.data.size() - start > 1 && fd.data.back() == '\r') fd.data.pop_back();    // KS_SEP_LINE: a trailing '\r' goes once the sequence so far has more than one byte (kseq.h:141) — unless this byte was the very last of the input (:138)
     }
     const size_t len = fd.data.size() - start;
     bool ok = true;
@@ -255,7 +260,7 @@ bool readFile(const std::string &path, FileData &fd)
         size_t line = 0; int lastB = -1;
         const bool more = rd.rest_of_line((std::vector<uint8_t> *)nullptr, &line, &lastB);
         q += line;
-        if (line && lastB == '\r' && q > 1) q--;
+        if (rd.gotAny && line && lastB == '\r' && q > 1) q--;
         if (!more) break;
       }
       last = 0;

@@ -37,6 +37,7 @@ struct L1Args {
   int32_t *midList; unsigned int *midCount;       // fragments with kL1HitCapSmall < H <= kL1HitCapMid
   int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
   unsigned int *overflowCount;                    // fragments with >= 2^31 seed hits (fragHits = -1): the call fails
+  unsigned long long hitLimit;                    // ... 2^31 - 16 (lowered by tests: ANI_L1_HIT_LIMIT)
   unsigned long long *sumHits;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
     if (threadIdx.x == 0) {
       H64 = 0;
       for (int w = 0; w < kTPB / kWave; w++) H64 += wsum[w];
-      const bool tooMany = H64 > 0x7ffffff0ull;
+      const bool tooMany = H64 > a.hitLimit;
       const int H = tooMany ? -1 : (int)H64;
       a.fragHits[f] = H;
       if (H64) atomicAdd(stat_slot(a.sumHits), H64);

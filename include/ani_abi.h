@@ -190,6 +190,16 @@ int ani_sketch_from_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nP
                                  const int32_t *contigLen, int32_t nContigs,
                                  const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out);
 
+/* The same, but the library TAKES the record buffers OVER (they must be device memory of this context that came from
+ * ani_sketch_records / ani_sketch_records_self / ani_device_alloc; the caller must not free or touch them afterwards, whatever the
+ * return code).  A set that is streamed (see ani_sketch_residency) keeps them as its records — no copy, which a set near the
+ * device's capacity has no room for —, a resident set releases each buffer as soon as the index chunks that need it are built.
+ * (The reference's counterpart of a set this large is the database split of computeCoreIdentity.hpp:457-487.) */
+int ani_sketch_adopt_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, void *const *devRecords,
+                                  const uint64_t *n, const int32_t *partGenomeStart,
+                                  const int32_t *contigLen, int32_t nContigs,
+                                  const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out);
+
 /* ---- persistent sketch file: the position-ordered minimizer records + contig / genome tables + genome names,
  * sections 4096-byte aligned (mmap-able); the reference has nothing like it (every run and every thread re-sketches).  Saving
  * costs one pass over the index; loading is an mmap, one host-to-device copy of the records and the device-side index build.

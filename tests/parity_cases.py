@@ -553,6 +553,28 @@ def case_limits(engine):
         assert e.code == -4
 
 
+def case_cand_pool_retry(engine_plain, engine_limited):
+    """the L1 candidate pool starts too small (ANI_CAND_POOL_MIN=1: one candidate per stripe) and the L1 kernels are repeated with the
+    size the first attempt asked for — same rows as the oracle; and when the batch ALSO holds a fragment beyond the seed-hit limit
+    (ANI_L1_HIT_LIMIT lowered: k_l1_probe marks it, and k_l1_probe runs on the first attempt only) the call must still fail with
+    ANI_ERR_LIMIT after the retry instead of silently dropping the fragment's mappings (the retry used to erase the marker)"""
+    from fastani_amd.api import AniError
+    base = rng_genome(191, 9000)
+    genomes = [[mutate(base, 0.003 * (i % 7), 7100 + i)] for i in range(12)] + [[rng_genome(2900 + i, 7000)] for i in range(3)]
+    p, sk, osk = check_sketch(engine_plain, genomes)
+    engine_plain.reset_counters()
+    check_queries(engine_plain, p, sk, osk, [genomes[0], genomes[5], genomes[13]])
+    sk2 = Sketch(engine_limited, p, genomes)
+    try:
+        sk2.map_cgi_batch([genomes[0], genomes[13]], 0)
+        raise AssertionError("a fragment beyond the seed-hit limit must fail the call, also when the candidate pool is retried")
+    except AniError as e:
+        assert e.code == -4 and "seed hits" in str(e), str(e)
+    rows = sk2.map_cgi_batch([genomes[13]], 0)           # the unrelated genome alone stays below the limit: the engine still works
+    assert len(rows) == 1 and rows["refGenomeId"][0] == 13
+    sk2.close()
+
+
 ALL_CASES = [case_goldens, case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
              case_low_complexity_big, case_gap_counter_overflow, case_l1_mid_noise, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 

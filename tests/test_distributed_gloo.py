@@ -146,27 +146,54 @@ def test_sharded_sketch_allgather_matches_single_process(tmp_path, emu_engine, w
     assert np.array_equal(single, np.concatenate(exp))
 
 
-@pytest.mark.parametrize("config", ["many-to-many", "c4"])
-def test_bench_orchestration_two_ranks(config, emu_engine):
-    """bench.py's own multi-rank step — query-sharded with the reference records all-gathered (default workload), and
-    reference-sharded with the fragment sets ring-passed (--config c4) — launched the way the driver launches it, on the CPU
-    build of the product sources over gloo (ANI_BENCH_BACKEND=emu, a test-only switch): 6 genomes of one cluster, every pair related."""
+@pytest.mark.parametrize("config,scaling", [("many-to-many", "auto"), ("many-to-many", "weak"), ("c4", "auto")])
+def test_bench_orchestration_two_ranks(config, scaling, emu_engine, tmp_path):
+    """bench.py's own multi-rank steps launched the way the driver launches it, on the CPU build of the product sources over gloo
+    (ANI_BENCH_BACKEND=emu, a test-only switch): 6 genomes of one cluster, every pair related.
+      many-to-many (default at N > 1) = STRONG scaling: the fixed 6 x 6 job, reference-sharded, fragment sets ring-passed; the
+          weak-scaling leg (query-sharded, reference records all-gathered) is measured beside it
+      many-to-many --scaling weak     = the weak leg as the timed region
+      c4                              = the reference-sharded ring again (configs[3] shape)
+    The rows every rank dumps must add up to the single-process rows."""
     import json
     import subprocess
-    port = 29300 + (os.getpid() % 300) + (7 if config == "c4" else 0)
+    from fastani_amd.api import DeviceGenomes, Sketch
+    port = 29300 + (os.getpid() % 300) + (7 if config == "c4" else 0) + (13 if scaling == "weak" else 0)
+    dump = os.path.join(str(tmp_path), "rows")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", config, "--genomes", "6", "--genome-len", "24000"],
-                       capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=900)
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", config, "--scaling", scaling, "--genomes", "6", "--genome-len", "24000",
+                        "--dump-rows", dump],
+                       capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=1200)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and "EMULATION" in out["data"] and out["rows_identical_across_steps"]
     ranks = out["ranks"]
     assert ranks["ranks_seen_by_rccl"] == 2 and len(ranks["step_ms"]) == 2
-    if config == "c4":
+    strong = not (config == "many-to-many" and scaling == "weak")
+    assert out["scaling"] == ("strong" if strong else "weak")
+    if strong:
         assert out["config"]["query_genomes"] == 6 and sum(ranks["rows"]) == 36 and "ring" in ranks["mode"]
         assert ranks["bytes_moved_per_rank"] > 0
+        if config == "many-to-many":
+            wl = out["weak_scaling_leg"]
+            assert wl["scaling"] == "weak" and wl["ranks"]["rows"] == [36, 36] and wl["value"] > 0
     else:
-        assert out["config"]["query_genomes"] == 12 and ranks["rows"] == [36, 36]
+        assert out["config"]["query_genomes"] == 12 and ranks["rows"] == [36, 36] and "weak_scaling_leg" not in out
     for k in ("ref_records_ms", "fragsketch_ms", "allgather_ms", "index_ms", "map_ms", "ring_wait_ms", "other_ms"):
         assert len(ranks[k]) == 2
+    # the union of the ranks' rows = the single-process rows of the same synthetic set (device generator on the emulator)
+    got = np.concatenate([np.load("%s.rank%d.npy" % (dump, x)) for x in range(2)])
+    got = got[np.lexsort((got["refGenomeId"], got["qryGenomeId"]))]
+    L, n = 24000, 6
+    words = (L + 15) // 16
+    buf = np.zeros(n * words + 64, dtype=np.uint32)
+    emu_engine.synth_packed(20260925, 0, n, L, buf.ctypes.data)
+    dg = DeviceGenomes(buf.ctypes.data, n, L)
+    p = emu_engine.params()
+    single = Sketch(emu_engine, p, dg).map_cgi_batch(dg, 0)
+    if strong:
+        assert np.array_equal(got, single)
+    else:
+        # rank 0 maps variant 0 (= the references themselves), rank 1 variant 1 with query ids 6..11
+        assert np.array_equal(got[got["qryGenomeId"] < 6], single) and len(got) == 72

@@ -340,3 +340,12 @@ def test_l2_code_overflow_halves_the_chunk(monkeypatch):
     pc.case_synthetic_cluster(e, 60000)
     assert e.counters()["l2ChunkHalvings"] > 0
     e.close()
+
+
+@pytest.mark.gpu
+def test_candidate_pool_retry_keeps_the_overflow_marker(monkeypatch):
+    """a batch that both overflows the L1 candidate pool and holds a fragment beyond the seed-hit limit"""
+    e1 = _engine_with(monkeypatch, ANI_CAND_POOL_MIN=1)
+    e2 = _engine_with(monkeypatch, ANI_CAND_POOL_MIN=1, ANI_L1_HIT_LIMIT=600)
+    pc.case_cand_pool_retry(e1, e2)
+    e1.close(); e2.close()
