@@ -41,12 +41,14 @@
 #include "kernels/sketch.hpp"
 #include "kernels/synth.hpp"
 
-extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
+// kernels/radix.hpp through sort_device.hip (hand-written LSD radix sort; two-phase calls: tmp == nullptr returns the workspace size)
 extern "C" int ani_sort_keys_u64_bits(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream);
 extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
-                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
-extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
-                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream);
+                                      size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream);
+extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN, int nPieces, uint32_t seqBase, size_t n,
+                              uint32_t *mHash, int32_t *mSeq, int32_t *mWpos, uint32_t *tmpK, uint64_t *tmpV, uint32_t *sHash, uint64_t *sSW,
+                              void *tmp, size_t *tmpBytes, hipStream_t stream, hipEvent_t soaReady, hipStream_t sideStream);
+extern "C" int ani_sort_check(void *tmp, hipStream_t stream);
 
 namespace {
 
@@ -215,6 +217,8 @@ struct ani_ctx {
   uint64_t l2CodeLimit = 0xfffffff0ull;                                             // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_L2_CODE_LIMIT, tests)
   uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
   int l1FilterMin = ani::kL1FilterMinHits, l1LdsMax = ani::kL1HitCapMax;           // env ANI_L1_FILTER_MIN / ANI_L1_LDS_MAX, read by ani_init (tests: per engine, not per process)
+  uint64_t dupPairCap = 0;                                                           // first guess of the same-hash link list (env ANI_DUP_PAIR_CAP, tests: forces the rerun)
+  bool l1Tiny = true;                                                               // env ANI_L1_TINY=0: fragments with <= 64 seed hits take the workgroup path like the others
   bool l2Overlap = false;                                                           // env ANI_L2_OVERLAP=1 (see the L2 loop)
   uint64_t l1HitLimit = 0x7ffffff0ull;                                              // seed hits per fragment and index chunk (32-bit hit offsets; env ANI_L1_HIT_LIMIT, tests)
   uint64_t candPoolMin = 4096;                                                      // floor of the L1 candidate pool, per stripe (env ANI_CAND_POOL_MIN, tests: forces the retry path)
@@ -264,8 +268,9 @@ struct IndexChunk {
   uint64_t lastUse = 0;
   std::vector<RecordPiece> pieces;
   // device arrays
-  uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr, *prevSame = nullptr, *nextSame = nullptr;
-  uint32_t *sHash = nullptr, *mWin = nullptr; uint8_t *mDelta = nullptr;
+  uint32_t *mHash = nullptr; int32_t *mSeq = nullptr, *mWpos = nullptr;
+  uint32_t *sHash = nullptr, *mWin = nullptr;
+  uint32_t *dupBits = nullptr; uint64_t *dupList = nullptr; uint32_t nDup = 0;   // same-hash links of near duplicates (index.hpp: DupLinks)
   uint64_t *sSW = nullptr;
   ani::TableSlot *table = nullptr; uint32_t tableSlots = 0;     // order-preserving probe table over the distinct hashes (index.hpp)
   int32_t *contigFirstMin = nullptr, *contigGenome = nullptr;
@@ -826,10 +831,10 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
 // the index arrays of a chunk (not its reducer tables): dropped when the chunk is evicted in streaming mode
 void free_chunk_index(IndexChunk *ch)
 {
-  void **ptrs[] = {(void **)&ch->mWin, (void **)&ch->sSW, (void **)&ch->mDelta, (void **)&ch->mHash, (void **)&ch->mSeq, (void **)&ch->mWpos, (void **)&ch->prevSame,
-                   (void **)&ch->nextSame, (void **)&ch->sHash, (void **)&ch->table, (void **)&ch->contigFirstMin, (void **)&ch->posSample};
+  void **ptrs[] = {(void **)&ch->mWin, (void **)&ch->sSW, (void **)&ch->dupBits, (void **)&ch->dupList, (void **)&ch->mHash, (void **)&ch->mSeq, (void **)&ch->mWpos,
+                   (void **)&ch->sHash, (void **)&ch->table, (void **)&ch->contigFirstMin, (void **)&ch->posSample};
   for (void **q : ptrs) if (*q) { pool_free(*q); *q = nullptr; }
-  ch->resident = false;
+  ch->resident = false; ch->nDup = 0;
 }
 void free_chunk(IndexChunk *ch)
 {
@@ -922,46 +927,85 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
 #define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
 #define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const size_t n4 = (n ? n : 1) * 4;
+  const size_t bitWords = (n + 31) / 32 + 1;
   SK_HIP(pool_malloc((void **)&sk->mHash, n4)); SK_HIP(pool_malloc((void **)&sk->mSeq, n4)); SK_HIP(pool_malloc((void **)&sk->mWpos, n4));
-  SK_HIP(pool_malloc((void **)&sk->prevSame, n4)); SK_HIP(pool_malloc((void **)&sk->nextSame, n4));
-  SK_HIP(pool_malloc((void **)&sk->sHash, n4)); SK_HIP(pool_malloc((void **)&sk->mDelta, n + 8)); SK_HIP(pool_malloc((void **)&sk->sSW, 2 * n4));
-  SK_HIP(pool_malloc((void **)&sk->mWin, n4));
+  SK_HIP(pool_malloc((void **)&sk->sHash, n4)); SK_HIP(pool_malloc((void **)&sk->sSW, 2 * n4));
+  SK_HIP(pool_malloc((void **)&sk->mWin, n4)); SK_HIP(pool_malloc((void **)&sk->dupBits, bitWords * 4));
+  SK_HIP(pool_malloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
+  SK_HIP(pool_malloc((void **)&sk->posSample, ((size_t)sk->totalPosBins + 1) * 4));
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
+    const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
+    const bool winLinks = n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask;        // otherwise the L2 fast path is off (map_stage) and the window links are never read
     uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
     SK_HIP(pool_malloc((void **)&tmpK, n4));
     { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
+    SK_HIP(hipMemsetAsync(sk->dupBits, 0, bitWords * 4, ctx->stream));
+    // Main stream: the index sort (radix.hpp) — its histogram read of the records writes the position-ordered SoA arrays, its passes
+    // are bound by memory bandwidth.  Side stream, as soon as the SoA arrays exist (evSimA[0]): everything that needs positions only —
+    // contig slices, the window links of the L2 event stream (binary searches over LDS-staged positions: latency- and LDS-bound),
+    // the sampled position index — runs underneath the sort's passes instead of after them.
+    struct SideJoin { ani_ctx *c; ~SideJoin() { (void)hipStreamSynchronize(c->stream2); } } sideJoin{ctx};   // also on the error paths below
+    bool sorting = false;
     if (n) {
-      size_t o = 0;                                 // the pieces (slices of record parts, in order) go straight into the chunk's arrays: no concatenated copy
-      for (const RecordPiece &pc : sk->pieces) {
-        if (!pc.n) continue;
-        hipLaunchKernelGGL(k_index_split, dim3(grid_for(pc.n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, pc.rec, (uint32_t)pc.n, (uint32_t)c0, sk->mHash + o, sk->mSeq + o, sk->mWpos + o,
-                           sk->mDelta + o, sk->prevSame + o, sk->nextSame + o, tmpK + o, tmpV + o);
-        o += pc.n;
-      }
+      std::vector<const void *> recs; std::vector<size_t> cnts;
+      for (const RecordPiece &pc : sk->pieces) if (pc.n) { recs.push_back(pc.rec); cnts.push_back(pc.n); }
       size_t tb = 0;
-      int rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, nullptr, &tb, ctx->stream);
-      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 16); if (rc == ANI_OK) rc = ani_sort_pairs_u32_u64(tmpK, sk->sHash, tmpV, sk->sSW, n, ctx->sortTmp.p, &tb, ctx->stream); }
-      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(ANI_ERR_DEVICE, "radix sort failed (%d)", rc)); }
+      int rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, nullptr, &tb, ctx->stream, nullptr, nullptr);
+      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, ctx->evSimA[0], ctx->stream2); }
+      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
+      sorting = true;                               // the passes are in flight; stream2 waits for the SoA arrays
+    }
+    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    if (winLinks)
+      hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + kWinBlock - 1) / kWinBlock)), dim3(256), 0, ctx->stream2, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
+                         (const int32_t *)sk->contigFirstMin, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
+    if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
+                                    sk->totalPosBins, (uint32_t)n, sk->posSample);
+    if (sorting) {
+      const int rc = ani_sort_check(ctx->sortTmp.p, ctx->stream);
+      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
     }
     pool_free(tmpK); pool_free(tmpV);
-    SK_TRY(zero_counters(ctx));
-    SK_HIP(pool_malloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
-    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
-    if (n) hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
-                              (int32_t)(p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1)), sk->prevSame, sk->nextSame, sk->mDelta, cnt_ptr(ctx, CNT_UNIQ));
-    // window links of the L2 event stream (after the links kernel: both write flag bits of mDelta)
-    {
-      const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
-      if (n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask)        // otherwise the L2 fast path is off (map_stage) and the links are never read
-        hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + kWinBlock - 1) / kWinBlock)), dim3(256), 0, ctx->stream, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
-                           (const int32_t *)sk->contigFirstMin, (const uint8_t *)sk->mDelta, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipEventRecord(ctx->evSimA[1], ctx->stream2));
+    SK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evSimA[1], 0));            // the links kernel needs the contig slices and ORs into the window links
+    // same-hash links of near duplicates (index.hpp: DupLinks) and the number of distinct hashes
+    unsigned long long host[CNT_N];
+    host[CNT_UNIQ] = 0;
+    if (n) {
+      uint32_t pairCap = (uint32_t)std::min<uint64_t>(n, ctx->dupPairCap ? ctx->dupPairCap : n / 64 + 4096);     // first guess; a repetitive reference reruns with the exact count
+      for (int attempt = 0;; attempt++) {
+        uint64_t *pairs = nullptr;
+        SK_HIP(pool_malloc((void **)&pairs, (size_t)pairCap * 16));
+        { const int rz = zero_counters(ctx); if (rz != ANI_OK) { pool_free(pairs); return bail(rz); } }
+        hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
+                           cmw, pairs, pairCap, (unsigned int *)cnt_ptr(ctx, CNT_NEG), sk->dupBits, winLinks ? sk->mWin : (uint32_t *)nullptr, cnt_ptr(ctx, CNT_UNIQ));
+        { const int rr = read_counters(ctx, host); if (rr != ANI_OK) { pool_free(pairs); return bail(rr); } }
+        const uint64_t nPairs = (uint32_t)host[CNT_NEG];
+        if (nPairs > pairCap) {                                  // a repetitive reference: again with room for every pair (bits and flags are idempotent)
+          pool_free(pairs);
+          if (attempt > 0) return bail(fail(ANI_ERR_INTERNAL, "same-hash links did not converge"));
+          pairCap = (uint32_t)nPairs;
+          continue;
+        }
+        sk->nDup = (uint32_t)(2 * nPairs);
+        if (nPairs) {
+          // the half-records sorted by (entry, kind): bisection finds an entry's links (keys are unique: every key bit is significant up to the entry's)
+          int keyBits = 33; while (keyBits < 64 && (1ull << (keyBits - 32)) <= (uint64_t)n) keyBits++;
+          SK_HIP(pool_malloc((void **)&sk->dupList, (size_t)sk->nDup * 8));
+          size_t tb = 0;
+          int rc = ani_sort_keys_u64_bits(pairs, sk->dupList, sk->nDup, keyBits, nullptr, &tb, ctx->stream);
+          if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_keys_u64_bits(pairs, sk->dupList, sk->nDup, keyBits, ctx->sortTmp.p, &tb, ctx->stream); }
+          if (rc != 0) { pool_free(pairs); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(ANI_ERR_DEVICE, "radix sort of the same-hash links failed (%d)", rc)); }
+        }
+        pool_free(pairs);
+        break;
+      }
     }
     // probe table: the distinct hashes in an order-preserving open-addressing table, load 0.5 (index.hpp)
     {
-      unsigned long long host[CNT_N];
-      SK_TRY(read_counters(ctx, host));                       // k_index_links counted the distinct hashes
-      sk->nUnique = host[CNT_UNIQ];
+      sk->nUnique = host[CNT_UNIQ];                           // k_index_links counted the distinct hashes
       const uint32_t nSlots = (uint32_t)std::min<uint64_t>(0x7ffffff0ull, std::max<uint64_t>(1024, (uint64_t)sk->nUnique * 2));
       const uint32_t nb = (uint32_t)((n + kTableBlock - 1) / kTableBlock);
       std::vector<int32_t> cnt(nb ? nb : 1), best(nb ? nb : 1);
@@ -996,10 +1040,6 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
       SK_HIP(hipStreamSynchronize(ctx->stream));                             // cnt / best / sentinel are host memory
       sk->tableSlots = nSlots;
     }
-    SK_HIP(hipGetLastError());
-    SK_HIP(pool_malloc((void **)&sk->posSample, ((size_t)sk->totalPosBins + 1) * 4));
-    if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
-                                    sk->totalPosBins, (uint32_t)n, sk->posSample);
     SK_HIP(hipGetLastError());
   }
   SK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1277,8 +1317,10 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       uint64_t *keyIn = ctx->fragOrderTmp.as<uint64_t>(), *keyOut = keyIn + nF; uint32_t *idxIn = (uint32_t *)(keyOut + nF);
       hipLaunchKernelGGL(k_frag_order_keys, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, fs.fragQSeq, (int32_t)nF, keyIn, idxIn);
       size_t tb = 0;
-      int rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, nullptr, &tb, ctx->stream);
-      if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 16)); rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, ctx->sortTmp.p, &tb, ctx->stream); }
+      int keyBits = 1;                              // keys are running fragment ids inside a genome: 11 bits for 5 Mbp genomes, two 8-bit passes
+      { int32_t mx = 0; for (int32_t v : fs.genomeFragments) mx = std::max(mx, v); while (keyBits < 32 && (1ll << keyBits) <= (long long)mx) keyBits++; }
+      int rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, keyBits, nullptr, &tb, ctx->stream);
+      if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 256)); rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, keyBits, ctx->sortTmp.p, &tb, ctx->stream); }
       if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of the fragment order failed (%d)", rc);
       fragOrder = ctx->fragOrder.as<int32_t>();
     } }
@@ -1313,7 +1355,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.sumHits = cnt_ptr(ctx, CNT_HITS);
     a.filterShift = 1; while (a.filterShift < 30 && (1 << a.filterShift) < 2 * L) a.filterShift++;
     a.fragOrder = fragOrder;
-    a.filterMinHits = ctx->l1FilterMin; a.ldsHitCap = ctx->l1LdsMax;
+    a.filterMinHits = ctx->l1FilterMin; a.ldsHitCap = ctx->l1LdsMax; a.tinyPath = ctx->l1Tiny ? 1 : 0;
     a.probeFirst = ctx->probeFirst.as<uint32_t>(); a.probeCnt = ctx->probeCnt.as<uint32_t>();
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
@@ -1381,7 +1423,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
             int rankBits = 1; while (rankBits < 64 - shiftRank && (1ull << rankBits) < n) rankBits++;
             size_t tbytes = 0;
             int rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, nullptr, &tbytes, ctx->stream);
-            if (rc == 0) { TRY(ctx->sortTmp.ensure(tbytes + 16)); rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, ctx->sortTmp.p, &tbytes, ctx->stream); }
+            if (rc == 0) { TRY(ctx->sortTmp.ensure(tbytes + 256)); rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, ctx->sortTmp.p, &tbytes, ctx->stream); }
             if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of seed hits failed (%d)", rc);
             hipLaunchKernelGGL(k_l1_big_unpack, dim3(grid_for((size_t)hits, 256, 65535)), dim3(256), 0, ctx->stream, ctx->l1BigHitsB.as<uint64_t>(), (uint64_t)hits, shiftSeq, shiftRank);
           }
@@ -1442,7 +1484,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     L2Args a;
     a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS;
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.prevSame = sk->prevSame; a.nextSame = sk->nextSame; a.mWin = sk->mWin; a.posBase = sk->posBase; a.posSample = sk->posSample;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.dup = DupLinks{sk->dupList, sk->nDup, sk->dupBits}; a.mWin = sk->mWin; a.posBase = sk->posBase; a.posSample = sk->posSample;
     a.contigFirstMin = sk->contigFirstMin;
     { int lg = 0; while ((2 << lg) <= w) lg++; a.rankShift = 21 - std::max(0, lg - 1); }   // w = 24: 2048 buckets over [0, 2^29)
     a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
@@ -1891,6 +1933,8 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_MAX_INDEX_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->maxIndexMinimizers = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L1_FILTER_MIN")) c->l1FilterMin = atoi(ev);
   if (const char *ev = getenv("ANI_L1_LDS_MAX")) c->l1LdsMax = std::max(0, std::min(atoi(ev), (int)ani::kL1HitCapMax));
+  if (const char *ev = getenv("ANI_DUP_PAIR_CAP")) { const long long v = atoll(ev); if (v >= 1) c->dupPairCap = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_L1_TINY")) c->l1Tiny = strcmp(ev, "0") != 0;
   if (const char *ev = getenv("ANI_L2_OVERLAP")) c->l2Overlap = !strcmp(ev, "1");
   if (const char *ev = getenv("ANI_L1_HIT_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l1HitLimit = std::min<uint64_t>((uint64_t)v, 0x7ffffff0ull); }
   if (const char *ev = getenv("ANI_CAND_POOL_MIN")) { const long long v = atoll(ev); if (v >= 1) c->candPoolMin = (uint64_t)v; }
@@ -2656,8 +2700,8 @@ int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *skc, const ani_mapping_t *ma
     HIP_TRY(hipMemcpyAsync(ctx->l1BigHitsA.p, keys.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->keepFlags.p, ord.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
     size_t tb = 0;
-    int rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, nullptr, &tb, ctx->stream);
-    if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 16)); rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, ctx->sortTmp.p, &tb, ctx->stream); }
+    int rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, 64, nullptr, &tb, ctx->stream);
+    if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 256)); rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, 64, ctx->sortTmp.p, &tb, ctx->stream); }
     if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of mappings failed (%d)", rc);
     HIP_TRY(hipMemcpyAsync(ord.data(), ctx->keepOff.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -2,31 +2,50 @@
 //
 // Replaces skch::Sketch::index (src/map/include/winSketch.hpp:181-193: unordered_map<hash, vector<{seqId,wpos}>>)
 // and skch::Sketch::searchIndex (:259-270) by flat device arrays:
-//   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n], mDelta[n] (flag byte), mWin[n] (window links of the L2 event stream) + contigFirstMin[nContigs+1]
+//   position order (≙ minimizerIndex :93)      mHash[n], mSeq[n], mWpos[n], mWin[n] (window links of the L2 event stream) + contigFirstMin[nContigs+1]
 //   hash order    (≙ minimizerPosLookupIndex)  sHash[n] (sorted), sSW[n] = seqId<<32|wpos carried through the stable sort, so
 //                                              every hash's occurrence list is one contiguous run in (seqId,wpos) order (:186-190)
 //   probe table   table[2 x distinct]          order-preserving open-addressing table {hash, first, count} over the distinct hashes (below)
-//   same-hash links (for the L2 set semantics) prevSame[n], nextSame[n]: neighbouring NEAR occurrence of the same hash in
-//                                              position order (one that can share a super-window), -1 otherwise
+//   same-hash links (for the L2 set semantics) DupLinks: for the few entries that have one, the neighbouring NEAR occurrence of the same hash in
+//                                              position order (one that can share a super-window) — a sorted list + one bit per entry
 #pragma once
 #include "common.hpp"
 
 namespace ani {
 
-// records: 12-byte (hash, seqId, wpos) triples in position order -> SoA + sort input (key = hash, value = seqId<<32 | wpos)
-__global__ void k_index_split(const uint32_t *__restrict__ records, uint32_t n, uint32_t seqBase /* first contig of this index chunk */,
-                              uint32_t *__restrict__ mHash, int32_t *__restrict__ mSeq, int32_t *__restrict__ mWpos,
-                              uint8_t *__restrict__ mDelta, int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame,
-                              uint32_t *__restrict__ keyOut, uint64_t *__restrict__ valOut)
+constexpr uint32_t kWinMask = 0x3fffu, kWinMoreBit = 1u << 30, kWinDupBit = 1u << 31;
+constexpr int kWinShiftA = 14;
+
+// (records -> position-ordered SoA arrays: written by the histogram read of the index sort, radix.hpp: k_radix_histogram)
+
+// Same-hash links.  The sliding map of the reference is a SET (slidingMap.hpp:150-154, :178): an entry whose hash already sits in the
+// super-window changes nothing when it enters, and one whose hash stays behind changes nothing when it leaves.  What L2 needs for
+// that is, per entry, the neighbouring occurrence of the same hash in position order IF it is near enough to share a super-window —
+// which almost no entry has (two of ~240 32-bit hashes colliding inside 3 kb, or a tandem repeat).  Round 3 kept two dense int32
+// arrays (8 of the index's 45 bytes per minimizer); now: one bit per entry ("has a link") and a sorted list of 64-bit half-records
+//     entry << 32 | kind << 31 | other entry          kind 0 = `other` is the previous near occurrence, 1 = the next one
+// searched by bisection — only behind the bit (general kernel) or the event's nearDup flag (k_l2_sim).
+struct DupLinks { const uint64_t *list; uint32_t n; const uint32_t *bits; };
+__host__ __device__ __forceinline__ uint32_t dup_lower_bound(const DupLinks &d, uint32_t j)
 {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint32_t h = records[3 * (size_t)i], sq = records[3 * (size_t)i + 1] - seqBase, wp = records[3 * (size_t)i + 2];   // chunk-local seqId
-    mHash[i] = h; mSeq[i] = (int32_t)sq; mWpos[i] = (int32_t)wp;
-    // one flag byte per entry: bit 5 = nearDup (k_index_links; k_index_window_links copies it into mWin)
-    mDelta[i] = 0;
-    prevSame[i] = -1; nextSame[i] = -1;                          // links/flags are only written for near duplicates (rare)
-    keyOut[i] = h; valOut[i] = ((uint64_t)sq << 32) | wp;
-  }
+  uint32_t lo = 0, hi = d.n;
+  const uint64_t key = (uint64_t)j << 32;
+  while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (d.list[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__host__ __device__ __forceinline__ bool dup_flag(const DupLinks &d, uint32_t j) { return d.n != 0 && ((d.bits[j >> 5] >> (j & 31u)) & 1u); }
+// previous / next near occurrence of entry j's hash, -1 if none (call behind dup_flag or the nearDup flag of the window links)
+__host__ __device__ __forceinline__ int32_t dup_prev(const DupLinks &d, uint32_t j)
+{
+  const uint32_t x = dup_lower_bound(d, j);
+  if (x < d.n) { const uint64_t v = d.list[x]; if ((uint32_t)(v >> 32) == j && !((v >> 31) & 1ull)) return (int32_t)(v & 0x7fffffffull); }
+  return -1;
+}
+__host__ __device__ __forceinline__ int32_t dup_next(const DupLinks &d, uint32_t j)
+{
+  uint32_t x = dup_lower_bound(d, j);
+  for (int k = 0; k < 2 && x < d.n; k++, x++) { const uint64_t v = d.list[x]; if ((uint32_t)(v >> 32) != j) break; if ((v >> 31) & 1ull) return (int32_t)(v & 0x7fffffffull); }
+  return -1;
 }
 
 __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
@@ -38,16 +57,17 @@ __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *
 }
 
 // After the stable sort by hash (sHash[r], sSW[r] = seqId<<32|wpos; equal hashes stay in position order): unique-hash count
-// and, for NEAR duplicates only, the same-hash links and the nearDup flag (bit 5 of mDelta).
+// and, for NEAR duplicates only, the same-hash links: two half-records per pair appended to `pairs` (unordered; the host sorts them),
+// the "has a link" bit of both entries, and the nearDup flag in their window links (bit 31 of mWin, if the chunk has window links).
 //   nearDup: two same-hash entries j' < j of one contig can share a super-window.  All entries of a window except its first
 //   lie within cmw = countMinimizerWindows positions; the first entry (MIIteratorL2 keeps the minimizer that is active at the
 //   window start) may trail by less than the gap to its successor: possible iff wpos[j] - wpos[j'] <= cmw + (wpos[j'+1] - wpos[j']).
-// Entries without the flag behave as plain set members in L2; prevSame/nextSame of non-near pairs stay -1, which is equivalent
-// for every consumer (they are only ever compared against the bounds of one window).
+// Entries without a link behave as plain set members in L2 (links of non-near pairs would only ever be compared against the bounds of
+// one window).  `nPairs` counts every pair; a pair beyond `pairCap` is not stored (the host reruns the kernel with room for all).
 __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t *__restrict__ sSW, uint32_t n,
                               const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin, int32_t cmw,
-                              int32_t *__restrict__ prevSame, int32_t *__restrict__ nextSame, uint8_t *__restrict__ mDelta,
-                              unsigned long long *__restrict__ nUnique)
+                              uint64_t *__restrict__ pairs, uint32_t pairCap, unsigned int *__restrict__ nPairs,
+                              uint32_t *__restrict__ dupBits, uint32_t *__restrict__ mWin, unsigned long long *__restrict__ nUnique)
 {
   unsigned long long uniq = 0;
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
@@ -67,8 +87,13 @@ __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t
     hi = cHi;
     while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wb) lo = mid + 1; else hi = mid; }
     const int32_t ib = lo;
-    nextSame[ia] = ib; prevSame[ib] = ia;
-    atomicOr((uint32_t *)mDelta + (ia >> 2), 0x20u << (8 * (ia & 3))); atomicOr((uint32_t *)mDelta + (ib >> 2), 0x20u << (8 * (ib & 3)));
+    const unsigned int slot = atomicAdd(nPairs, 1u);
+    if (slot < pairCap) {
+      pairs[2 * (size_t)slot] = ((uint64_t)(uint32_t)ia << 32) | (1ull << 31) | (uint32_t)ib;         // ia: its next near occurrence is ib
+      pairs[2 * (size_t)slot + 1] = ((uint64_t)(uint32_t)ib << 32) | (uint32_t)ia;                    // ib: its previous one is ia
+    }
+    atomicOr(&dupBits[ia >> 5], 1u << (ia & 31)); atomicOr(&dupBits[ib >> 5], 1u << (ib & 31));
+    if (mWin) { atomicOr(&mWin[ia], kWinDupBit); atomicOr(&mWin[ib], kWinDupBit); }
   }
   // one atomic per workgroup (the grid is small: a grid-stride loop covers the index)
   __shared__ unsigned long long part[8];
@@ -217,16 +242,14 @@ __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t 
 //   bits 14..27  A[j] = (first e with I_e >= D_j) - j            inserts that precede the delete of j: entries below j + A[j]
 //   bits  0..13  B[e] = e - (first x with wpos[x] > wpos[e] - cmw + 1)   deletes that precede the insert of e: entries up to e - B[e] - 2
 //   bit 30       the insert at the same position follows the delete of j (I_e == D_j): no evaluation in between
-//   bit 31       nearDup (copied from mDelta bit 5, set by k_index_links)
+//   bit 31       nearDup (OR-ed in afterwards by k_index_links, which needs the hash-sorted index; this kernel runs beside the sort)
 // Both offsets count entries inside one super-window (<= cmw + 1 < 2^14, checked by the host).  One thread per entry, two binary
 // searches over at most cmw entries; the lanes of a wave search neighbouring ranges with the same step pattern, so the loads
 // coalesce.
-constexpr uint32_t kWinMask = 0x3fffu, kWinMoreBit = 1u << 30, kWinDupBit = 1u << 31;
-constexpr int kWinShiftA = 14;
 constexpr int kWinHalo = 768;             // positions staged in LDS on either side of a workgroup's entries (~3 typical spans)
 constexpr int kWinBlock = 1024;           // entries per workgroup (four per thread: the halo is read once per 1024 entries, 2.5 x the data instead of 7 x)
 __global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
-                                                            const int32_t *__restrict__ contigFirstMin, const uint8_t *__restrict__ mDelta, uint32_t n,
+                                                            const int32_t *__restrict__ contigFirstMin, uint32_t n,
                                                             int32_t cmw1, int32_t expect /* entries per cmw positions */, uint32_t *__restrict__ mWin)
 {
   // The searches of neighbouring entries touch the same few hundred positions on either side: staged once (coalesced), searched
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__res
       a = (uint32_t)(lo - (int32_t)j);
       more = (lo < cHi && wpos_at(lo) == tgt) ? kWinMoreBit : 0u;
     }
-    mWin[j] = (a > kWinMask ? kWinMask : a) << kWinShiftA | (b > kWinMask ? kWinMask : b) | more | ((mDelta[j] & 0x20u) ? kWinDupBit : 0u);
+    mWin[j] = (a > kWinMask ? kWinMask : a) << kWinShiftA | (b > kWinMask ? kWinMask : b) | more;
   }
 }
 

@@ -43,6 +43,7 @@ struct L1Args {
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
   int filterMinHits;                    // kL1FilterMinHits (ANI_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
   int ldsHitCap;                        // fragments with more seed hits take the batched global-memory path (<= kL1HitCapMax; ANI_L1_LDS_MAX)
+  int tinyPath;                         // fragments with <= 64 seed hits are finished by one wave (l1_tiny; ANI_L1_TINY=0 switches it off: A/B and tests)
 };
 
 // Counter indices of a hit's two tiles for the noise filter (k_l1): tiles of width 2^shift, the second tiling offset by half a tile.
@@ -237,6 +238,60 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
   }
 }
 
+// A fragment with at most 64 seed hits, by ONE wave of its workgroup (the other three have left): no workgroup barrier, no scan over
+// LDS, one key per lane.  This is what a fragment looks like against an index that holds no relative of its genome — every visit of a
+// fragment to a foreign reference shard of a multi-GPU run, to a foreign index chunk of a large database: ~240 probes, a few chance
+// hits (minimizer hashes crowd the low end of the 32-bit range), rarely a candidate.  The workgroup path spends ~14 barriers on it.
+//   gather: lane l takes the sketch hashes l, l + 64, ...; the order of the hits does not matter (they are sorted next), so a wave
+//           scan of the lanes' hit counts places them;  sort: 64 keys in registers over the lane-exchange network (common.hpp);
+//   runs / heads / emission: computeMap.hpp:313-354 with one run per lane, ballots instead of scans.
+constexpr int kL1HitCapTiny = kWave;
+__device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, uint64_t *hits, int *V)
+{
+  const int lane = threadIdx.x;                      // wave 0 only
+  const uint32_t off = a.fragOff[f];
+  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;
+  if (m < 1) m = 1;                                  // :316
+  int mine = 0;
+  for (int i = lane; i < s; i += kWave) mine += (int)a.probeCnt[off + i];
+  int o = wave_incl_scan(mine) - mine;
+  for (int i = lane; i < s; i += kWave) {
+    const int c = (int)a.probeCnt[off + i];
+    if (c) { const uint32_t fi = a.probeFirst[off + i]; for (int x = 0; x < c; x++) hits[o + x] = a.sSW[fi + x]; o += c; }
+  }
+  if (lane >= H) hits[lane] = ~0ull;                 // pad: sorts behind every real hit (seqId < 2^31)
+  ANI_WAVE_SYNC();
+  block_sort_regs<uint64_t, 1, 1>(hits);             // :320
+  ANI_WAVE_SYNC();
+  const int nA = H - m + 1;
+  int nG = 0;
+  if (nA > 0) {
+    const bool valid = lane < nA && l1_valid(hits, lane, m, a.L);
+    const unsigned long long vm = __ballot(valid);
+    const int nv = __popcll(vm);
+    if (valid) V[__popcll(vm & ((1ull << lane) - 1ull))] = lane;
+    ANI_WAVE_SYNC();
+    const bool head = lane < nv && l1_head(hits, V, lane, m, a.L);
+    const unsigned long long hm = __ballot(head);
+    nG = __popcll(hm);
+    unsigned long long take = 0;
+    if (lane == 0) take = pool_take(a.candCount, a.candCap, (unsigned long long)nG);
+    take = __shfl(take, 0);
+    const unsigned long long base = take & ~kPoolOverflowBit;
+    if (!(take & kPoolOverflowBit) && lane < nv) {
+      const int g = __popcll(hm & ((2ull << lane) - 1ull));                       // group of run `lane`, 1-based
+      const unsigned long long slot = base + (unsigned long long)(g - 1);
+      if (head) {
+        int32_t start = hit_wpos(hits[V[lane] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
+        a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[lane]]); a.candStart[slot] = start;
+      }
+      if (lane == nv - 1 || ((hm >> (lane + 1)) & 1ull)) a.candEnd[slot] = hit_wpos(hits[V[lane]]);   // :336,:347
+    }
+    if (lane == 0) a.fragCandOff[f] = (uint32_t)base;
+  } else if (lane == 0) a.fragCandOff[f] = 0;
+  if (lane == 0) a.fragCandCnt[f] = nG;
+}
+
 // Pass 2: gather + sort + candidate regions for the fragments whose hit count is in (HLO, HCAP]; everything in LDS.
 // (Measured and removed in round 3: class M "in two walks" — the hit runs read twice, first only to feed the filter's counters,
 // then to stage the survivors in the 24 KiB of class S instead of 48 KiB.  1000 references: class M 4.8 -> 4.3 ms per launch; 10 000
@@ -269,6 +324,10 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   }
   if (HLO == 0 && (s > kL1MaxS || H > a.ldsHitCap)) return;        // beyond the LDS classes: k_l1_big_* below
   if (H <= HLO || H > HCAP || s <= 0 || s > kL1MaxS) return;     // another class handles it
+  if (HLO == 0 && H <= kL1HitCapTiny && a.tinyPath) {              // a handful of hits: one wave, no workgroup barrier (l1_tiny)
+    if (t < kWave) l1_tiny(a, f, s, H, hits, V);
+    return;
+  }
   const uint32_t off = a.fragOff[f];
   const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather
   int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)

@@ -12,9 +12,10 @@
 //   shared = sum_{i<=iStar} b[i].
 // One window event changes G by exactly one at the affected ranks, so iStar moves by at most one step per event
 // and every update is O(1).  Hashes that occur several times inside one window behave as a set in the reference
-// (slidingMap.hpp:150-154: REV status; :178: NOOP when a later occurrence re-tagged wposR); with prevSame/nextSame
-// links over the position-ordered index this is: an insertion of entry j is effective iff prevSame[j] < beg, a
-// deletion of entry j is effective iff nextSame[j] is not inside the inserted range [.., endIns).
+// (slidingMap.hpp:150-154: REV status; :178: NOOP when a later occurrence re-tagged wposR); with the same-hash
+// links over the position-ordered index (index.hpp: DupLinks) this is: an insertion of entry j is effective iff its
+// previous near occurrence is < beg, a deletion of entry j is effective iff its next near occurrence is not inside
+// the inserted range [.., endIns).
 //
 // Parallelisation: one lane per candidate (tens of millions of candidates per many-to-many run give the
 // parallelism); state words live in a lane-interleaved scratch array so that lane l touches
@@ -121,7 +122,7 @@ struct L2Sim {
 // One candidate, sequentially.  [cLo, cHi) = slice of the position-ordered index that belongs to the candidate's contig.
 __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
                                                  const uint32_t *mHash, const int32_t *mWpos,
-                                                 const int32_t *prevSame, const int32_t *nextSame,
+                                                 const DupLinks &dup,
                                                  int32_t cLo, int32_t cHi, int32_t rangeStart, int32_t rangeEnd,
                                                  int L, int w, int k, L2State st)
 {
@@ -133,16 +134,16 @@ __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
   r.entries = last - beg;
   L2Sim sim; sim.init(s, st);
   for (int32_t j = beg; j < end; j++)                                            // :448 first super-window
-    if (prevSame[j] < beg) sim.insert(q_rank(q, s, mHash[j]));
+    if (!dup_flag(dup, (uint32_t)j) || dup_prev(dup, (uint32_t)j) < beg) sim.insert(q_rank(q, s, mHash[j]));
   int32_t pb = beg, pe = end;
   int32_t pos = mWpos[beg];
   while (end < last) {                                                           // :455
     if (pb != beg) {                                                             // :461 delete_ref(prev_beg)
-      const int32_t nx = nextSame[pb];
+      const int32_t nx = dup_flag(dup, (uint32_t)pb) ? dup_next(dup, (uint32_t)pb) : -1;
       if (!(nx >= 0 && nx < pe)) sim.erase(q_rank(q, s, mHash[pb]));
     }
     if (pe != end) {                                                             // :465 insert_ref(prev_end)
-      if (prevSame[pe] < beg) sim.insert(q_rank(q, s, mHash[pe]));
+      if (!dup_flag(dup, (uint32_t)pe) || dup_prev(dup, (uint32_t)pe) < beg) sim.insert(q_rank(q, s, mHash[pe]));
     }
     const int32_t wb = mWpos[beg];
     if (sim.shared > r.best) { r.best = sim.shared; r.firstPos = wb; r.lastPos = wb; }   // :468-476
@@ -182,7 +183,7 @@ __host__ __device__ inline L2Result l2_candidate(const uint32_t *q, int s,
 //                  the same position follows)
 //   k_l2_sim     one lane per candidate: applies its events in order, one per loop pass, 8 events per 16-byte load, no position
 //                arithmetic and no second cursor.  State in LDS: one byte per sketch rank (7-bit gap counter + presence bit),
-//                byte-interleaved over the wave.  Entries flagged nearDup consult prevSame/nextSame (exact set semantics,
+//                byte-interleaved over the wave.  Entries flagged nearDup consult the same-hash links (exact set semantics,
 //                slidingMap.hpp:150-154,:178).  A gap counter that would pass 127 sends the candidate to k_l2.
 // ------------------------------------------------------------------------------------------------
 struct L2Args {
@@ -192,7 +193,7 @@ struct L2Args {
   // fragment sketches
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS;
   // reference index, position order
-  const uint32_t *mHash; const int32_t *mWpos; const int32_t *prevSame; const int32_t *nextSame;
+  const uint32_t *mHash; const int32_t *mWpos; DupLinks dup;       // same-hash links of near duplicates (index.hpp)
   const uint32_t *mWin;            // window links + flags per entry (index.hpp: k_index_window_links)
   const int32_t *contigFirstMin;   // [nContigs+1]
   const uint32_t *posBase, *posSample;   // sampled position index (index.hpp: k_index_pos_sample)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__restrict
     const int32_t f = a.candFrag[c];
     const int32_t seq = a.candSeq[c];
     L2State state; state.w = a.scratch + lane; state.stride = a.laneStride;
-    L2Result r = l2_candidate(a.qPool + a.fragOff[f], a.fragS[f], a.mHash, a.mWpos, a.prevSame, a.nextSame,
+    L2Result r = l2_candidate(a.qPool + a.fragOff[f], a.fragS[f], a.mHash, a.mWpos, a.dup,
                               a.contigFirstMin[seq], a.contigFirstMin[seq + 1], a.candStart[c], a.candEnd[c],
                               a.L, a.w, a.k, state);
     a.outBest[c] = r.best; a.outFirst[c] = r.firstPos; a.outLast[c] = r.lastPos;
@@ -590,8 +591,8 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
         if (__any(on && (code & kL2DupBit) != 0)) {
           if (on && (code & kL2DupBit)) {
             const int insCount = ev - delCount;                       // entries [delCount, insCount) are in the window
-            if (INS) eff = a.g.prevSame[r.beg0 + insCount] < r.beg0 + delCount;            // new iff no same-hash entry in [beg, end)
-            else { const int32_t nx = a.g.nextSame[r.beg0 + delCount]; eff = !(nx >= 0 && nx < r.beg0 + insCount); }   // stays iff a later same-hash entry is in the window
+            if (INS) eff = dup_prev(a.g.dup, (uint32_t)(r.beg0 + insCount)) < r.beg0 + delCount;            // new iff no same-hash entry in [beg, end)
+            else { const int32_t nx = dup_next(a.g.dup, (uint32_t)(r.beg0 + delCount)); eff = !(nx >= 0 && nx < r.beg0 + insCount); }   // stays iff a later same-hash entry is in the window
           }
         }
       }
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
           int d = (int)((code >> kL2DeltaShift) & 7u);                   // an insert's change is +1 or +2
           // the window starts at the candidate's first entry and nothing has left it: entry number 8 blk + e is new unless a
           // same-hash entry lies in [beg0, it) (slidingMap.hpp:150-154)
-          if (anyDup && (code & kL2DupBit) && a.g.prevSame[r.beg0 + 8 * blk + e] >= r.beg0) d = 0;
+          if (anyDup && (code & kL2DupBit) && dup_prev(a.g.dup, (uint32_t)(r.beg0 + 8 * blk + e)) >= r.beg0) d = 0;
           uint8_t *pOwn = F + l2_field_off((int)((code >> 1) & 0x1ffu));
           const int nw = (int)*pOwn + d;
           R.ovfAcc |= (uint32_t)nw;

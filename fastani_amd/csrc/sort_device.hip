@@ -1,46 +1,165 @@
-// sort_device.hip — the one library call on the path: a stable LSD radix sort of (hash, seqId<<32|wpos) pairs that
-// orders the reference minimizers by hash (≙ filling minimizerPosLookupIndex, src/map/include/winSketch.hpp:181-193), and of
-// the 64-bit seed hits of an oversized fragment.  rocPRIM's device radix sort is used as plumbing;
-// everything else on the path is hand-written.  Temporary storage is supplied by the caller (two-phase API: tmp == nullptr
-// returns the required size) so that it comes out of the caching allocator.
-#include <cstring>
+// sort_device.hip — host side of the hand-written radix sort (kernels/radix.hpp): the hash-ordered half of the reference index
+// (≙ filling minimizerPosLookupIndex, src/map/include/winSketch.hpp:181-193), the seed hits of the batched L1 path
+// (src/map/include/computeMap.hpp:320) and the small orderings of the host orchestration.  No library sort is linked.
+//
+// Every entry point has the two-phase shape the caching allocator wants: tmp == nullptr returns the workspace size in *tmpBytes.
+// Workspace = [digit histograms / offsets: 8 x 256 x u64][tile counters: 64 x u32][error flag][look-back status: tiles x 256 x u64]
+// [ping-pong buffer for sorts of more than one pass].  The calls return when the sort is done (they check the error flag).
+#include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
-extern "C" int ani_sort_pairs_u32_u64(const uint32_t *keysIn, uint32_t *keysOut, const uint64_t *valsIn, uint64_t *valsOut,
-                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream)
+#include "kernels/radix.hpp"
+
+namespace {
+using namespace ani;
+
+constexpr size_t kHistBytes = (size_t)kRadixMaxPasses * kRadixDigits * 8;
+constexpr int kMaxLaunches = 1024;                          // tile counters: one per (pass, input buffer)
+constexpr size_t kCtrBytes = (size_t)kMaxLaunches * 4 + 64;  // + the error flag (at the end) and padding
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+inline uint64_t tiles_of(uint64_t n) { return (n + kRadixTile - 1) / kRadixTile; }
+
+struct Workspace {
+  unsigned long long *hist; unsigned int *counters, *err; unsigned long long *status; unsigned char *pong;
+  size_t statusBytes;
+};
+// `tiles`: look-back tiles of one pass (partial tiles at buffer ends included); `pongBytes`: ping-pong storage
+size_t workspace_bytes(uint64_t tiles, size_t pongBytes) { return align256(kHistBytes) + align256(kCtrBytes) + align256(tiles * kRadixDigits * 8) + align256(pongBytes) + 256; }
+Workspace carve(void *tmp, uint64_t tiles)
 {
-  if (n == 0) { if (!tmp) *tmpBytes = 0; return 0; }
-  hipError_t e = rocprim::radix_sort_pairs(tmp, *tmpBytes, keysIn, keysOut, valsIn, valsOut, n, 0, 32, stream);
-  if (e != hipSuccess || !tmp) return (int)e;
-  return (int)hipStreamSynchronize(stream);
+  Workspace w;
+  unsigned char *p = (unsigned char *)(((uintptr_t)tmp + 255) / 256 * 256);
+  w.hist = (unsigned long long *)p; p += align256(kHistBytes);
+  w.counters = (unsigned int *)p; w.err = w.counters + kMaxLaunches; p += align256(kCtrBytes);
+  w.status = (unsigned long long *)p; w.statusBytes = tiles * kRadixDigits * 8; p += align256(w.statusBytes);
+  w.pong = p;
+  return w;
+}
+int finish(const Workspace &w, hipStream_t stream)
+{
+  unsigned int err = 0;
+  hipError_t e = hipMemcpyAsync(&err, w.err, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return err ? 9001 : 0;                                    // a look-back gave up (kRadixSpinLimit): the output is incomplete
 }
 
-extern "C" int ani_sort_keys_u64(const uint64_t *keysIn, uint64_t *keysOut, size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream)
+// generic: keys (and values) in arrays, bits [0, endBit) significant
+template <class KeyT, class ValT>
+int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *valsOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
 {
-  if (n == 0) { if (!tmp) *tmpBytes = 0; return 0; }
-  hipError_t e = rocprim::radix_sort_keys(tmp, *tmpBytes, keysIn, keysOut, n, 0, 64, stream);
-  if (e != hipSuccess || !tmp) return (int)e;
-  return (int)hipStreamSynchronize(stream);
+  constexpr bool kHasVal = !std::is_same<ValT, RadixNoVal>::value;
+  if (endBit < 1) endBit = 1;
+  if (endBit > (int)sizeof(KeyT) * 8) endBit = (int)sizeof(KeyT) * 8;
+  const int P = (endBit + kRadixBits - 1) / kRadixBits;
+  const uint64_t tiles = tiles_of(n);
+  const size_t keyBytes = align256(n * sizeof(KeyT)), valBytes = kHasVal ? align256(n * sizeof(ValT)) : 0;
+  const size_t need = workspace_bytes(tiles, P > 1 ? keyBytes + valBytes : 0);
+  if (!tmp) { *tmpBytes = need; return 0; }
+  if (n == 0) return 0;
+  if (n > 0xfffffff0ull) return 9002;
+  if (*tmpBytes < need) return 9003;
+  Workspace w = carve(tmp, tiles);
+  KeyT *pongK = (KeyT *)w.pong; ValT *pongV = (ValT *)(w.pong + keyBytes);
+  hipError_t e = hipMemsetAsync(w.hist, 0, align256(kHistBytes) + align256(kCtrBytes), stream);
+  if (e != hipSuccess) return (int)e;
+  const unsigned hg = (unsigned)std::min<uint64_t>((n + kTPB * 8 - 1) / (kTPB * 8), 4096);
+  ArraySrc<KeyT, ValT> in{keysIn, valsIn};
+  hipLaunchKernelGGL((k_radix_histogram<KeyT, ArraySrc<KeyT, ValT>>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, in, (uint64_t)n, endBit, P, w.hist, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+  hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kTPB), 0, stream, w.hist, P);
+  for (int p = 0; p < P; p++) {
+    const bool toOut = ((P - 1 - p) & 1) == 0;
+    ArraySrc<KeyT, ValT> src = p == 0 ? in : (toOut ? ArraySrc<KeyT, ValT>{pongK, pongV} : ArraySrc<KeyT, ValT>{keysOut, valsOut});
+    KeyT *dk = toOut ? keysOut : pongK; ValT *dv = toOut ? valsOut : pongV;
+    e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_radix_pass<KeyT, ValT, ArraySrc<KeyT, ValT>>), dim3((unsigned)tiles), dim3(kRadixTPB), 0, stream, src, dk, dv, (uint64_t)n, p * kRadixBits, endBit,
+                       (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + p, 0u, w.err);
+  }
+  return finish(w, stream);
+}
+}  // namespace
+
+// (64-bit key, 32-bit payload), the low endBit bits of the key significant: the processing order of the fragments (key = running
+// fragment id inside its genome) and foreign mapping lists handed to ani_compute_cgi (key = querySeqId << 32 | refSeqId)
+extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                                      size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
+{
+  return sort_arrays<uint64_t, uint32_t>(keysIn, keysOut, valsIn, valsOut, n, endBit, tmp, tmpBytes, stream);
 }
 
-// the low `endBit` bits only (the batched L1 path packs (fragment, seqId, wpos) into as few bits as the index chunk needs); no
-// host synchronisation: the caller's next launch is on the same stream
+// 64-bit keys, the low endBit bits significant (the batched L1 path packs (fragment, seqId, wpos) into as few bits as the index
+// chunk needs)
 extern "C" int ani_sort_keys_u64_bits(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
 {
-  if (n == 0) { if (!tmp) *tmpBytes = 0; return 0; }
-  if (endBit < 1) endBit = 1;
-  if (endBit > 64) endBit = 64;
-  return (int)rocprim::radix_sort_keys(tmp, *tmpBytes, keysIn, keysOut, n, 0, (unsigned)endBit, stream);
+  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, endBit, tmp, tmpBytes, stream);
 }
 
-// (querySeqId<<32 | refSeqId, record index): orders mapping records handed to ani_compute_cgi in an arbitrary order
-extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
-                                      size_t n, void *tmp, size_t *tmpBytes, hipStream_t stream)
+// The index sort (Sketch::index, winSketch.hpp:181-193).  Input: the chunk's minimizer records as `nPieces` device buffers of
+// 12-byte records in position order (seqIds global: seqBase = first contig of the chunk).  Output: the position-ordered SoA arrays
+// mHash / mSeq / mWpos (written by the histogram read) and the hash-ordered sHash / sSW (stable: every hash's occurrences stay in
+// (seqId, wpos) order).  tmpK / tmpV: n-element ping-pong arrays.  soaReady / sideStream (optional): the event is recorded once the SoA
+// arrays are written and sideStream is made to wait for it; the call then returns with the passes still running — the caller queues its
+// side work and calls ani_sort_check.  Four 8-bit passes: SoA -> tmp -> (sHash, sSW) -> tmp -> (sHash, sSW).
+extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN, int nPieces, uint32_t seqBase, size_t n,
+                              uint32_t *mHash, int32_t *mSeq, int32_t *mWpos, uint32_t *tmpK, uint64_t *tmpV, uint32_t *sHash, uint64_t *sSW,
+                              void *tmp, size_t *tmpBytes, hipStream_t stream, hipEvent_t soaReady, hipStream_t sideStream)
 {
-  if (n == 0) { if (!tmp) *tmpBytes = 0; return 0; }
-  hipError_t e = rocprim::radix_sort_pairs(tmp, *tmpBytes, keysIn, keysOut, valsIn, valsOut, n, 0, 64, stream);
-  if (e != hipSuccess || !tmp) return (int)e;
-  return (int)hipStreamSynchronize(stream);
+  constexpr int P = 4;
+  const uint64_t tiles = tiles_of(n);
+  const size_t need = workspace_bytes(tiles, 0);
+  if (!tmp) { *tmpBytes = need; return 0; }
+  if (n == 0) return 0;
+  if (n > 0x7ffffff0ull) return 9002;
+  if (*tmpBytes < need) return 9003;
+  if (nPieces + P > kMaxLaunches) return 9004;
+  Workspace w = carve(tmp, tiles);
+  hipError_t e = hipMemsetAsync(w.hist, 0, align256(kHistBytes) + align256(kCtrBytes), stream);
+  if (e != hipSuccess) return (int)e;
+  size_t o = 0;
+  for (int i = 0; i < nPieces; i++) {
+    if (!pieceN[i]) continue;
+    const unsigned hg = (unsigned)std::min<uint64_t>((pieceN[i] + kTPB * 8 - 1) / (kTPB * 8), 4096);
+    RecordSrc src{(const uint32_t *)pieceRec[i], seqBase};
+    hipLaunchKernelGGL((k_radix_histogram<uint32_t, RecordSrc>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, src, (uint64_t)pieceN[i], 32, P, w.hist, mHash + o, mSeq + o, mWpos + o);
+    o += pieceN[i];
+  }
+  // the SoA arrays are complete: work that only needs positions may start on the caller's side stream, underneath the passes
+  if (soaReady && sideStream) {
+    e = hipEventRecord(soaReady, stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sideStream, soaReady, 0);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kTPB), 0, stream, w.hist, P);
+  // pass 0 reads the SoA arrays the histogram pass has just written (three coalesced streams; the 12-byte records would be three
+  // strided ones), so the record buffers are read exactly once
+  e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
+  if (e != hipSuccess) return (int)e;
+  int launch = 0;
+  {
+    SoaSrc src{mHash, mSeq, mWpos};
+    hipLaunchKernelGGL((k_radix_pass<uint32_t, uint64_t, SoaSrc>), dim3((unsigned)tiles_of(n)), dim3(kRadixTPB), 0, stream, src, tmpK, tmpV, (uint64_t)n, 0, 32,
+                       (const unsigned long long *)w.hist, w.status, w.counters + launch, 0u, w.err);
+    launch++;
+  }
+  for (int p = 1; p < P; p++) {
+    const bool toOut = (p & 1) == 1;                         // tmp -> S -> tmp -> S
+    ArraySrc<uint32_t, uint64_t> src = toOut ? ArraySrc<uint32_t, uint64_t>{tmpK, tmpV} : ArraySrc<uint32_t, uint64_t>{sHash, sSW};
+    e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_radix_pass<uint32_t, uint64_t, ArraySrc<uint32_t, uint64_t>>), dim3((unsigned)tiles_of(n)), dim3(kRadixTPB), 0, stream, src, toOut ? sHash : tmpK, toOut ? sSW : tmpV,
+                       (uint64_t)n, p * kRadixBits, 32, (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + launch, 0u, w.err);
+    launch++;
+  }
+  return (soaReady && sideStream) ? 0 : finish(w, stream);     // with a side stream the caller queues its side work first, then ani_sort_check
+}
+
+// completes an ani_sort_index call that was given a side stream: waits for the sort and checks its error flag
+extern "C" int ani_sort_check(void *tmp, hipStream_t stream)
+{
+  return finish(carve(tmp, 0), stream);
 }

@@ -349,3 +349,26 @@ def test_candidate_pool_retry_keeps_the_overflow_marker(monkeypatch):
     e2 = _engine_with(monkeypatch, ANI_CAND_POOL_MIN=1, ANI_L1_HIT_LIMIT=600)
     pc.case_cand_pool_retry(e1, e2)
     e1.close(); e2.close()
+
+
+@pytest.mark.gpu
+def test_l1_tiny_path_off(monkeypatch):
+    """fragments with <= 64 seed hits are finished by one wave (l1.hpp: l1_tiny) — nearly every fragment of the small cases; with
+    ANI_L1_TINY=0 they take the workgroup path like the others: same candidates, same rows"""
+    e = _engine_with(monkeypatch, ANI_L1_TINY=0)
+    pc.case_synthetic_cluster(e, 30000)
+    pc.case_sparse_hits(e)
+    pc.case_tandem_repeats(e)
+    pc.case_l1_class_overflow(e)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_same_hash_links_rerun(monkeypatch):
+    """the list of same-hash links (index.hpp: DupLinks) is sized from a guess; a repetitive reference (tandem repeats, one k-mer on
+    thousands of contigs) holds more near-duplicate pairs than that and the links kernel runs again with room for all"""
+    e = _engine_with(monkeypatch, ANI_DUP_PAIR_CAP=3)
+    pc.case_tandem_repeats(e)
+    pc.case_low_complexity(e)
+    pc.case_gap_counter_overflow(e)
+    e.close()
