@@ -869,6 +869,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
         "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
         "ani::k_l1_probe": (c["msL1Probe"], 4.0 * c["l1Probes"], "4 B x fragment sketch hashes probed (per index chunk)"),
         "ani::k_l1<0,2048>": (c["msL1Main"], 8.0 * c["seedHits"], "8 B x seed hits (all LDS classes; the small class handles nearly all fragments)"),
+        "ani::k_l1_tiny": (c["msL1Tiny"], 4.0 * c["l1TinyFragments"] * 240.0, "4 B x ~240 probe results per fragment with <= 64 seed hits (one wave each)"),
         ("ani::k_sketch_fused" if fused else "ani::k_sketch_tiles"):
             (c["msSketch"], c["refBases"] / 4.0 + 12.0 * c["refMinimizers"] + (4.0 * c["querySketchHashes"] if fused else 0.0),
              "G/4 packed bases + 12 B x minimizers" + (" + 4 B x fragment sketch hashes (fused all-vs-all pass)" if fused else "")),
@@ -948,7 +949,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
            "stage_ms_per_step_rank0": stages, "host_timeline_ms_per_step_rank0": host_timeline, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
            "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                           "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
-                                                                          "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments")},
+                                                                          "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments", "l1TinyFragments")},
            "roofline": roof}
     if sim:
         out["simulated"] = {"world": R.W, "rank": R.r, "what": "value = %d x %d pairs / the time ONE rank of a %d-GPU strong-scaling job computes (sketch + index of its %d genomes, %d mapping calls); "

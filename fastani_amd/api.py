@@ -46,8 +46,8 @@ class SeqBatch(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
                                           "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
-                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "indexChunks", "l1Probes", "l2ChunkHalvings", "indexChunkBuilds", "l1BigFragments", "l1MidFragments")] + \
-               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main", "msL1Big")]
+                                          "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "indexChunks", "l1Probes", "l2ChunkHalvings", "indexChunkBuilds", "l1BigFragments", "l1MidFragments", "l1TinyFragments")] + \
+               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main", "msL1Big", "msL1Tiny")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

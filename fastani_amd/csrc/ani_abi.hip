@@ -236,7 +236,9 @@ struct ani_ctx {
   ani_counters_t counters;
   std::vector<unsigned long long> hostCounters;                 // read_counters: the raw block
   unsigned long long poolUsed[3] = {0, 0, 0}, poolMaxStripe[3] = {0, 0, 0};
-  double candPerFrag = 12.0;      // running estimate that sizes the L1 candidate pool (learnt from batches that fill the pool stripes evenly)
+  double candPerFrag = 12.0;      // estimate that sizes the L1 candidate pool: the LARGEST need of the last 32 batches that fill the pool stripes evenly
+  double candSeen[32] = {0}; int candSeenAt = 0;   // (a ring of fragment sets alternates between sets with ~16 candidates per fragment — the rank's own genomes — and sets
+                                                    //  with < 1: an estimate that follows the batches down runs the L1 kernels twice for every dense one)
   uint64_t smallBatchCandCap = 0; // ... and what the last batch too small for that estimate needed (a few hundred fragments against a species-dense index, call after call)
   // scalar device counters (array of 16 x u64)
   DevBuf dCounters;
@@ -245,7 +247,7 @@ struct ani_ctx {
   DevBuf sortTmp, unitStart, unitAux, tiles, tileInfo, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
-  DevBuf probeFirst, probeCnt, l1MidList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
+  DevBuf probeFirst, probeCnt, l1MidList, l1SmallList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
   DevBuf l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
@@ -305,7 +307,7 @@ struct ani_sketch {
 namespace {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_ENTRIES_B = 19, CNT_SUMQ_B = 20, CNT_STEPS_B = 21, CNT_N = 24 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_ENTRIES_B = 19, CNT_SUMQ_B = 20, CNT_STEPS_B = 21, CNT_TINY = 22, CNT_SMALL = 23, CNT_N = 24 };
 
 unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }
 
@@ -1028,6 +1030,8 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
       const uint64_t alloc = std::max<uint64_t>(nSlots, (uint64_t)(lastP + 1)) + 2;        // the clusters at the end may run past nSlots
       if (alloc > 0x7ffffff0ull) return bail(fail(ANI_ERR_LIMIT, "probe table of %llu slots", (unsigned long long)alloc));
       SK_HIP(pool_malloc((void **)&sk->table, alloc * sizeof(TableSlot)));
+      // (measured, round 4: writing the empty slots from k_table_scatter instead — every entry with the gap in front of it — made that
+      //  kernel 1.3 ms slower per 4 x 10^8 minimizers and saved 0.5 ms of fill: the device fills 9.6 GB in 0.65 ms)
       SK_HIP(hipMemsetAsync(sk->table, 0xff, alloc * sizeof(TableSlot), ctx->stream));
       if (n) {
         SK_HIP(hipMemcpyAsync(ctx->scanTmpA.p, cnt.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1336,7 +1340,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   const bool smallBatch = nF < 16 * (size_t)kPoolStripes;
   if (smallBatch) ccap = std::min<uint64_t>(std::max<uint64_t>(ccap, ctx->smallBatchCandCap), kCandLimit);
   TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
-  unsigned nMid = 0, nBig = 0;
+  unsigned nMid = 0, nBig = 0; unsigned long long nTiny = 0, nSmall = 0;
   std::vector<int32_t> bigFrags, bigInfo;          // fragments beyond the LDS classes and their (sketch size, seed hits)
   unsigned long long hitsTotal = 0;
   uint32_t probeOverflow = 0;                       // fragments k_l1_probe marked with >= 2^31 seed hits: latched after attempt 0 (the probe runs once)
@@ -1352,7 +1356,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
     a.candCap = stripe_cap(ccap); a.candCount = cur_ptr(ctx, POOL_CAND);
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
-    a.sumHits = cnt_ptr(ctx, CNT_HITS);
+    a.sumHits = cnt_ptr(ctx, CNT_HITS); a.tinyCount = cnt_ptr(ctx, CNT_TINY); a.smallCount = cnt_ptr(ctx, CNT_SMALL);
     a.filterShift = 1; while (a.filterShift < 30 && (1 << a.filterShift) < 2 * L) a.filterShift++;
     a.fragOrder = fragOrder;
     a.filterMinHits = ctx->l1FilterMin; a.ldsHitCap = ctx->l1LdsMax; a.tinyPath = ctx->l1Tiny ? 1 : 0;
@@ -1362,13 +1366,27 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.overflowCount = (unsigned int *)cnt_ptr(ctx, CNT_NEG); a.hitLimit = ctx->l1HitLimit;
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
-      if (attempt == 0) { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
-      { StageTimer tk(ctx, &ctx->counters.msL1Main, 1); hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3(pad8(nF)), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr); }
       if (attempt == 0) {
-        unsigned long long nl[3] = {0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(nl, cnt_ptr(ctx, CNT_LISTM), 24, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        nMid = (unsigned)nl[0]; nBig = (unsigned)nl[2];
+        { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
+        // the probe routed the fragments to their classes: how many of each decides what is launched
+        unsigned long long cls[CNT_N];
+        TRY(read_counters(ctx, cls));
+        nMid = (unsigned)cls[CNT_LISTM]; nBig = (unsigned)cls[CNT_LISTBIG]; nTiny = cls[CNT_TINY]; nSmall = cls[CNT_SMALL];
+        ctx->counters.l1TinyFragments += nTiny;
+      }
+      if (nTiny && ctx->l1Tiny) { StageTimer tk(ctx, &ctx->counters.msL1Tiny, 1); hipLaunchKernelGGL(k_l1_tiny, dim3(pad8((nF + kL1TinyFrags - 1) / kL1TinyFrags)), dim3(kTPB), 0, ctx->stream, a); }
+      {
+        StageTimer tk(ctx, &ctx->counters.msL1Main, 1);
+        if (2 * nSmall >= nF || getenv("ANI_L1_DENSE"))                  // the usual case: (nearly) every fragment is of class S, one workgroup per fragment
+          hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3(pad8(nF)), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr);
+        else {                                                            // a fragment set against a foreign shard / chunk: class S is the exception, listed
+          TRY(ctx->l1SmallList.ensure((nSmall + 1) * 4));
+          HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_LISTL), 0, 8, ctx->stream));
+          hipLaunchKernelGGL(k_l1_list, dim3(grid_for(nF, kTPB)), dim3(kTPB), 0, ctx->stream, a, ctx->l1SmallList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_LISTL));
+          if (nSmall) hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nSmall), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)ctx->l1SmallList.as<int32_t>());
+        }
+      }
+      if (attempt == 0) {
         if (nBig) {
           bigFrags.resize(nBig); bigInfo.resize(2 * (size_t)nBig);
           TRY(ctx->l1BigV.ensure((size_t)nBig * 8));
@@ -1453,7 +1471,10 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // after 34 GB of pool; seen in the parity suite under ANI_POOL_POISON).  The estimate follows the batches down as well as up.
   if (!smallBatch) {                             // (a one-to-many query of 1666 fragments counts: without its update every call ran the L1 kernels twice)
     const double seen = 1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes / (double)nF;
-    ctx->candPerFrag = std::max(12.0, seen >= ctx->candPerFrag ? seen : 0.5 * (ctx->candPerFrag + seen));
+    ctx->candSeen[ctx->candSeenAt++ & 31] = seen;
+    double mx = 12.0;
+    for (double v : ctx->candSeen) mx = std::max(mx, v);
+    ctx->candPerFrag = mx;
   } else ctx->smallBatchCandCap = std::min<uint64_t>(grown_cap(ctx->poolMaxStripe[POOL_CAND]), (uint64_t)1 << 26);   // the next small batch starts from what this one needed (bounded: 1 GB of pool)
   if (probeOverflow != 0)                      // k_l1_probe: hit counts and offsets are 32-bit per fragment
     return fail(ANI_ERR_LIMIT, "%u query fragment(s) have 2^31 or more seed hits in one index chunk (a hash with ~10^9 occurrences: low-complexity / "
@@ -1955,7 +1976,7 @@ void ani_shutdown(ani_ctx *c)
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileInfo, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
-                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1MidList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->l1BigTbl, &c->l1BigHash, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
+                    &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1MidList, &c->l1SmallList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->l1BigTbl, &c->l1BigHash, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->fragOrder, &c->fragOrderTmp, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
                     &c->l2Ranges[1], &c->l2CodeCount[1], &c->l2CodeOff[1], &c->l2Codes[1], &c->l2SlowFlag[1], &c->l2ClassList[1], &c->l2Order[1], &c->l2LenHist[1], &c->l2SlowList, &c->l2Best,
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};

@@ -412,6 +412,36 @@ __device__ __forceinline__ void block_sort_regs(K *a)
   for (int r = 0; r < KPT; r++) a[t * KPT + r] = k[r];
 }
 
+// 64 x KPT keys held by ONE wave (any wave of a workgroup), lane l owning the elements l * KPT .. l * KPT + KPT - 1 of the sequence,
+// sorted ascending: the register network of block_sort_regs for a single wave, addressed by lane.  No LDS, no barrier.
+template <class K, int KPT> __device__ __forceinline__ void wave_sort_regs(K (&k)[KPT])
+{
+  const int lane = threadIdx.x & (kWave - 1);
+  // sizes 2 .. KPT: inside the lane; the direction of an element is bit `size` of e = lane * KPT + r
+#pragma unroll
+  for (int size = 2; size <= KPT; size <<= 1)
+#pragma unroll
+    for (int st = size >> 1; st >= 1; st >>= 1)
+#pragma unroll
+      for (int r = 0; r < KPT; r++)
+        if ((r & st) == 0) bitonic_ce(k[r], k[r + st], size < KPT ? (r & size) == 0 : (lane & 1) == 0);
+  for (int ts = 2; ts <= kWave; ts <<= 1) {              // ts = size / KPT
+    const bool up = (lane & ts) == 0;                    // (ts = 64: every lane)
+    for (int m = ts >> 1; m >= 1; m >>= 1) {
+      const bool keepMin = ((lane & m) == 0) == up;
+      switch (m) {                                       // wave-uniform
+        case 32: sort_lane_stage<K, KPT, 32>(k, keepMin); break;
+        case 16: sort_lane_stage<K, KPT, 16>(k, keepMin); break;
+        case 8: sort_lane_stage<K, KPT, 8>(k, keepMin); break;
+        case 4: sort_lane_stage<K, KPT, 4>(k, keepMin); break;
+        case 2: sort_lane_stage<K, KPT, 2>(k, keepMin); break;
+        default: sort_lane_stage<K, KPT, 1>(k, keepMin); break;
+      }
+    }
+    sort_thread_merge<K, KPT>(k, up);
+  }
+}
+
 // Sorts a[0 .. n) ascending, n <= 4096 (the caller's array has room for next_pow2(max(n, 64)) keys; the tail is padded with ~0).
 // Frames itself with workgroup barriers: the keys are complete before, the sorted sequence is visible after.
 __host__ __device__ __forceinline__ int next_pow2_dev(int n) { int p = 1; while (p < n) p <<= 1; return p; }

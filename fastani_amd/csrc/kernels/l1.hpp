@@ -38,7 +38,7 @@ struct L1Args {
   int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
   unsigned int *overflowCount;                    // fragments with >= 2^31 seed hits (fragHits = -1): the call fails
   unsigned long long hitLimit;                    // ... 2^31 - 16 (lowered by tests: ANI_L1_HIT_LIMIT)
-  unsigned long long *sumHits;
+  unsigned long long *sumHits, *tinyCount, *smallCount;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
   int filterMinHits;                    // kL1FilterMinHits (ANI_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
@@ -232,23 +232,42 @@ __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
         // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
         if (s[q] <= kL1MaxS && H <= a.ldsHitCap) {
           if (H > kL1HitCapSmall) a.midList[atomicAdd(a.midCount, 1u)] = f;
+          else if (H > 0 && H <= 4 * kWave && a.tinyPath) atomicAdd(stat_slot(a.tinyCount), 1ull);      // (striped statistics counters: the host launches k_l1_tiny if there are any,
+          else if (H > 0) atomicAdd(stat_slot(a.smallCount), 1ull);                                 //  and k_l1<0, 2048> over a list instead of over every fragment if there are few)
         } else a.bigList[atomicAdd(a.bigCount, 1u)] = f;         // beyond every LDS class: global-memory path
       }
     }
   }
 }
 
-// A fragment with at most 64 seed hits, by ONE wave of its workgroup (the other three have left): no workgroup barrier, no scan over
-// LDS, one key per lane.  This is what a fragment looks like against an index that holds no relative of its genome — every visit of a
-// fragment to a foreign reference shard of a multi-GPU run, to a foreign index chunk of a large database: ~240 probes, a few chance
-// hits (minimizer hashes crowd the low end of the 32-bit range), rarely a candidate.  The workgroup path spends ~14 barriers on it.
+// Fragments with at most 256 seed hits: ONE WAVE per fragment, four fragments per workgroup, 3 KiB of LDS each — no workgroup
+// barrier, no scan over LDS, one key per lane.  This is what a fragment looks like against an index that holds no relative of its
+// genome — every visit of a fragment to a foreign reference shard of a multi-GPU run, to a foreign index chunk of a large database:
+// ~240 probes, a few chance hits (minimizer hashes crowd the low end of the 32-bit range), rarely a candidate.  Such a fragment is a
+// chain of five dependent round trips to memory and nothing else, so what counts is how many of them a CU has in flight: 32 here,
+// 6 in the workgroup kernel (24 KiB of LDS per fragment), which took 17.5 ms for the 1.67 M fragment visits of one rank of an 8-GPU
+// job, 1.46 M of them of this kind (profiles/r04g_bench_sim8.json.log).
 //   gather: lane l takes the sketch hashes l, l + 64, ...; the order of the hits does not matter (they are sorted next), so a wave
-//           scan of the lanes' hit counts places them;  sort: 64 keys in registers over the lane-exchange network (common.hpp);
-//   runs / heads / emission: computeMap.hpp:313-354 with one run per lane, ballots instead of scans.
-constexpr int kL1HitCapTiny = kWave;
+//           scan of the lanes' hit counts places them;  sort: 1, 2 or 4 keys per lane in registers over the lane-exchange network
+//           (common.hpp: wave_sort_regs);  runs / heads / emission: computeMap.hpp:313-354 in rounds of 64 runs, ballots instead of scans.
+constexpr int kL1HitCapTiny = 4 * kWave;           // 256 hits: four keys per lane
+constexpr int kL1TinyFrags = kTPB / kWave;
+// sort the H <= 64 * KPT hits in hits[] (LDS of this wave; padded with ~0 up to 64 * KPT) through registers
+template <int KPT> __device__ __forceinline__ void l1_tiny_sort(uint64_t *hits, int H)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+  uint64_t k[KPT];
+#pragma unroll
+  for (int r = 0; r < KPT; r++) { const int x = r * kWave + lane; k[r] = x < H ? hits[x] : ~0ull; }     // any assignment of the unordered keys will do: the conflict-free one
+  ANI_WAVE_SYNC();
+  wave_sort_regs<uint64_t, KPT>(k);                  // :320
+#pragma unroll
+  for (int r = 0; r < KPT; r++) hits[lane * KPT + r] = k[r];
+  ANI_WAVE_SYNC();
+}
 __device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, uint64_t *hits, int *V)
 {
-  const int lane = threadIdx.x;                      // wave 0 only
+  const int lane = threadIdx.x & (kWave - 1);
   const uint32_t off = a.fragOff[f];
   int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;
   if (m < 1) m = 1;                                  // :316
@@ -259,37 +278,95 @@ __device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, ui
     const int c = (int)a.probeCnt[off + i];
     if (c) { const uint32_t fi = a.probeFirst[off + i]; for (int x = 0; x < c; x++) hits[o + x] = a.sSW[fi + x]; o += c; }
   }
-  if (lane >= H) hits[lane] = ~0ull;                 // pad: sorts behind every real hit (seqId < 2^31)
   ANI_WAVE_SYNC();
-  block_sort_regs<uint64_t, 1, 1>(hits);             // :320
-  ANI_WAVE_SYNC();
+  if (H <= kWave) l1_tiny_sort<1>(hits, H);          // wave-uniform
+  else if (H <= 2 * kWave) l1_tiny_sort<2>(hits, H);
+  else l1_tiny_sort<4>(hits, H);
+  // runs of m hits on one contig within < L (computeMap.hpp:326-336), positions x = r * 64 + lane, compacted in order
   const int nA = H - m + 1;
   int nG = 0;
   if (nA > 0) {
-    const bool valid = lane < nA && l1_valid(hits, lane, m, a.L);
-    const unsigned long long vm = __ballot(valid);
-    const int nv = __popcll(vm);
-    if (valid) V[__popcll(vm & ((1ull << lane) - 1ull))] = lane;
+    int nv = 0;
+    for (int r = 0; r * kWave < nA; r++) {
+      const int x = r * kWave + lane;
+      const bool valid = x < nA && l1_valid(hits, x, m, a.L);
+      const unsigned long long vm = __ballot(valid);
+      if (valid) V[nv + __popcll(vm & ((1ull << lane) - 1ull))] = x;
+      nv += __popcll(vm);
+    }
     ANI_WAVE_SYNC();
-    const bool head = lane < nv && l1_head(hits, V, lane, m, a.L);
-    const unsigned long long hm = __ballot(head);
-    nG = __popcll(hm);
+    // candidate heads (:342-350): counted, then emitted with the group number of every run
+    for (int r = 0; r * kWave < nv; r++) {
+      const int j = r * kWave + lane;
+      nG += __popcll(__ballot(j < nv && l1_head(hits, V, j, m, a.L)));
+    }
     unsigned long long take = 0;
     if (lane == 0) take = pool_take(a.candCount, a.candCap, (unsigned long long)nG);
     take = __shfl(take, 0);
     const unsigned long long base = take & ~kPoolOverflowBit;
-    if (!(take & kPoolOverflowBit) && lane < nv) {
-      const int g = __popcll(hm & ((2ull << lane) - 1ull));                       // group of run `lane`, 1-based
-      const unsigned long long slot = base + (unsigned long long)(g - 1);
-      if (head) {
-        int32_t start = hit_wpos(hits[V[lane] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
-        a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[lane]]); a.candStart[slot] = start;
+    if (!(take & kPoolOverflowBit)) {
+      int gBefore = 0;                                                            // heads in the rounds before this one
+      for (int r = 0; r * kWave < nv; r++) {
+        const int j = r * kWave + lane;
+        const bool in = j < nv;
+        const bool head = in && l1_head(hits, V, j, m, a.L);
+        const unsigned long long hm = __ballot(head);
+        if (in) {
+          const int g = gBefore + __popcll(hm & ((2ull << lane) - 1ull));         // group of run j, 1-based
+          const unsigned long long slot = base + (unsigned long long)(g - 1);
+          if (head) {
+            int32_t start = hit_wpos(hits[V[j] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
+            a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[j]]); a.candStart[slot] = start;
+          }
+          if (j == nv - 1 || l1_head(hits, V, j + 1, m, a.L)) a.candEnd[slot] = hit_wpos(hits[V[j]]);   // :336,:347
+        }
+        gBefore += __popcll(hm);
       }
-      if (lane == nv - 1 || ((hm >> (lane + 1)) & 1ull)) a.candEnd[slot] = hit_wpos(hits[V[lane]]);   // :336,:347
     }
     if (lane == 0) a.fragCandOff[f] = (uint32_t)base;
   } else if (lane == 0) a.fragCandOff[f] = 0;
   if (lane == 0) a.fragCandCnt[f] = nG;
+}
+__global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
+{
+  __shared__ uint64_t hits[kL1TinyFrags][kL1HitCapTiny];
+  __shared__ int V[kL1TinyFrags][kL1HitCapTiny];
+  const int wv = threadIdx.x >> 6;
+  const int i = xcd_item(blockIdx.x, gridDim.x) * kL1TinyFrags + wv;
+  if (i >= a.nFrag) return;
+  const int f = a.fragOrder ? a.fragOrder[i] : i;
+  const int s = a.fragS[f], H = a.fragHits[f];
+  if (s <= 0 || s > kL1MaxS || H <= 0 || H > kL1HitCapTiny) return;        // the workgroup classes / the batched path / nothing to do (k_l1<0, 2048> or k_l1_list writes the zero counts)
+  l1_tiny(a, f, s, H, hits[wv], V[wv]);
+}
+
+// The fragments of class S (256 < H <= 2048) as a list, for batches in which they are the exception: a fragment set that meets a
+// foreign reference shard or index chunk has no seed hit at all for most of its fragments, and a workgroup that finds nothing to do
+// still costs its dispatch — ~9 ns each with 24 KiB of LDS to reserve, 13 of the 17 ms k_l1<0, 2048> took for the 1.67 M fragment
+// visits of one rank of an 8-GPU job (profiles/r04h_bench_sim8.json.log).  One thread per fragment: fragments without hits get their
+// zero counts here, class-S fragments are appended in order (one atomic per workgroup).
+__global__ __launch_bounds__(kTPB) void k_l1_list(L1Args a, int32_t *__restrict__ list, unsigned int *__restrict__ cursor)
+{
+  __shared__ unsigned int wcount[kTPB / kWave], sBase;
+  const int i = blockIdx.x * kTPB + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  int f = -1; bool small = false;
+  if (i < a.nFrag) {
+    f = a.fragOrder ? a.fragOrder[i] : i;
+    const int s = a.fragS[f], H = a.fragHits[f];
+    if (s <= 0 || H <= 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; }        // (H < 0: overflow marker of k_l1_probe, the host fails the call)
+    else small = s <= kL1MaxS && H <= a.ldsHitCap && H <= kL1HitCapSmall && !(H <= kL1HitCapTiny && a.tinyPath);
+  }
+  const unsigned long long m = __ballot(small);
+  if (lane == 0) wcount[wv] = (unsigned int)__popcll(m);
+  block_barrier();
+  if (threadIdx.x == 0) {
+    unsigned int tot = 0;
+    for (int w = 0; w < kTPB / kWave; w++) { const unsigned int c = wcount[w]; wcount[w] = tot; tot += c; }
+    sBase = tot ? atomicAdd(cursor, tot) : 0u;
+  }
+  block_barrier();
+  if (small) list[sBase + wcount[wv] + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = f;
 }
 
 // Pass 2: gather + sort + candidate regions for the fragments whose hit count is in (HLO, HCAP]; everything in LDS.
@@ -324,10 +401,7 @@ __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict
   }
   if (HLO == 0 && (s > kL1MaxS || H > a.ldsHitCap)) return;        // beyond the LDS classes: k_l1_big_* below
   if (H <= HLO || H > HCAP || s <= 0 || s > kL1MaxS) return;     // another class handles it
-  if (HLO == 0 && H <= kL1HitCapTiny && a.tinyPath) {              // a handful of hits: one wave, no workgroup barrier (l1_tiny)
-    if (t < kWave) l1_tiny(a, f, s, H, hits, V);
-    return;
-  }
+  if (HLO == 0 && H <= kL1HitCapTiny && a.tinyPath) return;        // a handful of hits: k_l1_tiny has them (one wave per fragment)
   const uint32_t off = a.fragOff[f];
   const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather
   int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)

@@ -75,6 +75,18 @@ struct RecordSrc {
   __device__ __forceinline__ uint64_t val(uint64_t i) const { return ((uint64_t)(rec[3 * i + 1] - seqBase) << 32) | rec[3 * i + 2]; }
 };
 
+// number of set bits of the 64-bit mask (lo, hi) in the lanes below this one
+__device__ __forceinline__ uint32_t radix_mbcnt(uint32_t lo, uint32_t hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+#else
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned long long m = (((unsigned long long)hi << 32) | lo) & ((1ull << lane) - 1ull);
+  return (uint32_t)__popcll(m);
+#endif
+}
+
 // ---- agent-scope loads / stores of the look-back status words (cross-XCD visibility: these go past the per-XCD L2).  RELAXED: a
 // status word carries everything the reader needs (flag and count in one 64-bit value), nothing else is published through it — and
 // acquire / release at agent scope would invalidate / write back the XCD's caches on every poll (measured: 605 ms instead of ~12 for
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restr
   constexpr int kWaves = kRadixTPB / kWave;
   __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
   __shared__ unsigned int wc[kWaves * kRadixDigits];                // per-wave digit counters, then each wave's base inside the tile
-  __shared__ unsigned long long gbase[kRadixDigits];                // global position of local position 0 of each digit's run, minus that local position
+  __shared__ uint32_t gbase[kRadixDigits];                          // global position of local position 0 of each digit's run, minus that local position (mod 2^32: n < 2^32)
   __shared__ int ws[32];
   __shared__ unsigned int sTile, sErr;
   const int t = threadIdx.x, lane = t & (kWave - 1), wv = t >> 6;
@@ -179,28 +191,34 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restr
   unsigned int *myWc = wc + wv * kRadixDigits;
   KeyT key[kRadixKPT]; uint32_t rank[kRadixKPT];
   // ---- 1. digits and ranks inside the tile ----
+  // (32-bit element numbers relative to the tile: the 64-bit part of an address is the tile's, once)
+  const uint32_t nHere = (uint32_t)(n - base < (uint64_t)kRadixTile ? n - base : (uint64_t)kRadixTile);     // keys of this tile
+  const uint32_t digitMask = (1u << (endBit - shift < kRadixBits ? endBit - shift : kRadixBits)) - 1u;
+  const uint32_t e0 = (uint32_t)(wv * kRadixKPT) * kWave + lane;     // this thread's element j is e0 + j * 64
+#pragma unroll
+  for (int j = 0; j < kRadixKPT; j++) key[j] = e0 + j * kWave < nHere ? src.key(base + e0 + j * kWave) : (KeyT)0;
 #pragma unroll
   for (int j = 0; j < kRadixKPT; j++) {
-    const uint64_t i = base + (uint64_t)(wv * kRadixKPT + j) * kWave + lane;
-    key[j] = i < n ? src.key(i) : (KeyT)0;
-  }
-#pragma unroll
-  for (int j = 0; j < kRadixKPT; j++) {
-    const uint64_t i = base + (uint64_t)(wv * kRadixKPT + j) * kWave + lane;
-    const bool valid = i < n;
-    const uint32_t d = radix_digit(key[j], shift, endBit);
-    unsigned long long peers = __ballot(valid);
+    const bool valid = e0 + j * kWave < nHere;
+    const uint32_t d = (uint32_t)(key[j] >> shift) & digitMask;
+    // match-any: the lanes of the wave that hold the same digit.  Per digit bit one vote; a lane's copy of the vote is XOR-ed with
+    // its own bit (all ones / zero), and what is left set in the OR over the eight bits are the lanes that differ somewhere.
+    // (The vector ALU is half of this kernel's time — 142 wave instructions per key in the first form, SQ counters
+    // profiles/r04n_pmcradix_SQ_WAVES_summary.txt — so the votes are spelled in 32-bit halves.)
+    const unsigned long long vmask = __ballot(valid);
+    uint32_t dl = 0, dh = 0;
 #pragma unroll
     for (int b = 0; b < kRadixBits; b++) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long m = __ballot(valid && bit);
-      peers &= bit ? m : ~m;
+      const uint32_t B = 0u - ((d >> b) & 1u);
+      const unsigned long long m = __ballot(B != 0u);
+      dl |= (uint32_t)m ^ B; dh |= (uint32_t)(m >> 32) ^ B;
     }
-    const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), cnt = (uint32_t)__popcll(peers);
+    const uint32_t pl = ~dl & (uint32_t)vmask, ph = ~dh & (uint32_t)(vmask >> 32);
+    const uint32_t below = radix_mbcnt(pl, ph), cnt = (uint32_t)__popc(pl) + (uint32_t)__popc(ph);
     // the group's lowest lane moves the wave's counter on (one returning LDS add per group) and hands the old value to the others
     uint32_t pre = 0;
     if (valid && below == 0) pre = atomicAdd(&myWc[d], cnt);
-    const int leader = valid ? __ffsll((unsigned long long)peers) - 1 : lane;
+    const int leader = pl ? __ffs(pl) - 1 : (ph ? __ffs(ph) + 31 : lane);
     pre = (uint32_t)__shfl((int)pre, leader);
     rank[j] = pre + below;
   }
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restr
 #endif
       radix_status_store(st, kRadixFlagPrefix | (excl + total));
     }
-    gbase[t] = digitBase[t] + excl - (unsigned long long)localOff;
+    gbase[t] = (uint32_t)(digitBase[t] + excl) - (uint32_t)localOff;
     // local position of a key = keys of smaller digits (localOff) + same-digit keys of earlier waves (the wave's base) + its rank inside
     // the wave: the wave bases take the digit's local offset in place
 #pragma unroll
@@ -263,18 +281,14 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restr
   uint32_t lpos[kRadixKPT];
 #pragma unroll
   for (int j = 0; j < kRadixKPT; j++) {
-    const uint64_t i = base + (uint64_t)(wv * kRadixKPT + j) * kWave + lane;
-    const uint32_t d = radix_digit(key[j], shift, endBit);
+    const uint32_t d = (uint32_t)(key[j] >> shift) & digitMask;
     lpos[j] = myWc[d] + rank[j];
-    if (i < n) sk[lpos[j]] = key[j];
+    if (e0 + j * kWave < nHere) sk[lpos[j]] = key[j];
   }
   [[maybe_unused]] ValT val[kHasVal ? kRadixKPT : 1];
   if constexpr (kHasVal) {                                           // the values' round trip to memory runs under the keys' way out
 #pragma unroll
-    for (int j = 0; j < kRadixKPT; j++) {
-      const uint64_t i = base + (uint64_t)(wv * kRadixKPT + j) * kWave + lane;
-      if (i < n) val[j] = src.val(i);
-    }
+    for (int j = 0; j < kRadixKPT; j++) if (e0 + j * kWave < nHere) val[j] = src.val(base + e0 + j * kWave);
   }
   block_barrier();
   uint32_t opos[kRadixKPT];                                          // n < 2^32 (checked by the host)
@@ -283,8 +297,8 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restr
     const int x = t + j * kRadixTPB;
     if (x < tileCount) {
       const KeyT k = sk[x];
-      const uint32_t d = radix_digit(k, shift, endBit);
-      opos[j] = (uint32_t)(gbase[d] + (unsigned long long)x);
+      const uint32_t d = (uint32_t)(k >> shift) & digitMask;
+      opos[j] = gbase[d] + (uint32_t)x;
       keysOut[opos[j]] = k;
     }
   }
@@ -292,10 +306,7 @@ __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restr
     ValT *sv = (ValT *)stage;
     block_barrier();                                                 // every key has left the stage
 #pragma unroll
-    for (int j = 0; j < kRadixKPT; j++) {
-      const uint64_t i = base + (uint64_t)(wv * kRadixKPT + j) * kWave + lane;
-      if (i < n) sv[lpos[j]] = val[j];
-    }
+    for (int j = 0; j < kRadixKPT; j++) if (e0 + j * kWave < nHere) sv[lpos[j]] = val[j];
     block_barrier();
 #pragma unroll
     for (int j = 0; j < kRadixKPT; j++) {

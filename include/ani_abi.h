@@ -117,12 +117,14 @@ typedef struct {
   uint64_t indexChunkBuilds;  /* index chunks built, rebuilds of a streamed reference set included */
   uint64_t l1BigFragments;    /* query fragments (per index chunk) whose seed hits exceeded every LDS class: batched global-memory L1 path */
   uint64_t l1MidFragments;    /* query fragments (per index chunk) with 2048 < seed hits <= 4096: LDS class M (ani::k_l1<2048, 4096>) */
+  uint64_t l1TinyFragments;   /* query fragments (per index chunk) with 1..64 seed hits: one wave each (ani::k_l1_tiny) */
   double msSketch, msIndex, msFragSketch, msL1, msL2, msReduce;   /* HIP-event time per stage, accumulated */
   double msL2Kernel;          /* HIP-event time of the class-A ani::k_l2_sim launches alone (on the launch stream) */
   double msL2Ranges, msL2Codes, msL2Slow;   /* ani::k_l2_ranges, ani::k_l2_codes, ani::k_l2 */
   double msL2SimB;            /* class-B simulation launches (ani::k_l2_sim<L2Geom<319>> + its list compaction) */
   double msL1Probe, msL1Main; /* ani::k_l1_probe; ani::k_l1<0, 2048> (the small-class gather + filter + sort + candidate kernel) */
   double msL1Big;             /* the batched global-memory L1 path (gather + device sort + candidates) */
+  double msL1Tiny;            /* ani::k_l1_tiny */
 } ani_counters_t;
 
 /* ---- life cycle ---- */

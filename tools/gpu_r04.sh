@@ -21,6 +21,15 @@ if has profradix; then
   if [ -n "$f" ]; then cp "$f" "$OUT/radix_kernel_stats.csv"; cut -c1-240 "$f" | head -24; fi
   rm -rf "$OUT/profradix"
 fi
+if has pmcradix; then
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+    name=$(echo $set | cut -d' ' -f1)
+    (cd /tmp && timeout 200 rocprofv3 --pmc $set --kernel-trace -d "$OUT/pmcr_$name" -o pmc --output-format csv -- "$REPO/tools/ubench/radix" 400000000 > "$OUT/pmcr_$name.log" 2>&1)
+    f=$(find "$OUT/pmcr_$name" -name "*counter_collection*.csv" | head -1)
+    [ -n "$f" ] && python "$REPO/tools/pmc_summary.py" "$f" > "$OUT/pmcradix_${name}_summary.txt" 2>&1 && grep -E "radix|onesweep|Kernel|kernel" "$OUT/pmcradix_${name}_summary.txt" | cut -c1-250 | head -12
+    rm -rf "$OUT/pmcr_$name"
+  done
+fi
 if has l1tests; then
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -5 | tee "$OUT/l1tests.log"
 fi
@@ -44,6 +53,12 @@ if has prof; then
   f=$(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv" && head -32 "$f" | cut -c1-200
   find "$OUT/prof" -name "*kernel_trace*" -size +5M -delete 2>/dev/null
+fi
+if has profsim8; then
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/profsim" -o sim --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 --simulate-world 8 --no-verify > "$OUT/profsim.log" 2>&1)
+  f=$(find "$OUT/profsim" -name "*kernel_stats*.csv" 2>/dev/null | head -1)
+  if [ -n "$f" ]; then cp "$f" "$OUT/sim8_kernel_stats.csv"; cut -c1-200 "$f" | head -24; fi
+  rm -rf "$OUT/profsim"
 fi
 if has sim8; then
   for w in 8; do
