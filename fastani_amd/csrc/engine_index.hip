@@ -1,0 +1,776 @@
+// engine_index.hip — the reference set: index chunks (≙ Sketch::index, src/map/include/winSketch.hpp:181-193) built from minimizer
+// records, chunk streaming for sets beyond the device memory (the reference's database split, computeCoreIdentity.hpp:457-487),
+// export / statistics (Sketch::sanityCheck inputs, winSketch.hpp:298-318) and the sketch file.
+#include "host/engine.hpp"
+#include "kernels/index.hpp"
+
+namespace anih {
+using namespace ani;
+
+// the index arrays of a chunk (not its reducer tables): dropped when the chunk is evicted in streaming mode
+void free_chunk_index(IndexChunk *ch)
+{
+  void **ptrs[] = {(void **)&ch->mWin, (void **)&ch->sSW, (void **)&ch->dupBits, (void **)&ch->dupList, (void **)&ch->mHash, (void **)&ch->mSeq, (void **)&ch->mWpos,
+                   (void **)&ch->sHash, (void **)&ch->table, (void **)&ch->contigFirstMin, (void **)&ch->posSample};
+  for (void **q : ptrs) if (*q) { pool_free(*q); *q = nullptr; }
+  ch->resident = false; ch->nDup = 0;
+}
+void free_chunk(IndexChunk *ch)
+{
+  if (!ch) return;
+  free_chunk_index(ch);
+  void *ptrs[] = {ch->contigGenome, ch->contigBinBase, ch->genomeBinStart, ch->posBase};
+  for (void *q : ptrs) if (q) pool_free(q);
+  delete ch;
+}
+void free_sketch_device(ani_sketch *sk)
+{
+  for (IndexChunk *ch : sk->chunks) free_chunk(ch);
+  sk->chunks.clear();
+  for (void *q : sk->kept) if (q) pool_free(q);
+  sk->kept.clear();
+  void *ptrs[] = {sk->dMinHits, sk->dMinShared, sk->dIdLUT};
+  for (void *q : ptrs) if (q) pool_free(q);
+  sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr;
+}
+
+int upload_luts(ani_sketch *sk, int maxS)
+{
+  if (maxS <= sk->dLutMaxS) return ANI_OK;
+  int target = std::max(maxS, 512);
+  if (target > sk->params.fragLen) target = std::max(maxS, std::min(target, sk->params.fragLen));
+  // the LUTs depend on (k, cutoff) only and cost milliseconds of host arithmetic: one growing copy per context
+  ani_ctx *ctx = sk->ctx;
+  sk->luts = nullptr;
+  for (auto &l : ctx->lutCache) if (l->k == sk->params.kmerSize && l->identityCutoff == sk->params.percentageIdentity) sk->luts = l.get();
+  if (!sk->luts) { ctx->lutCache.emplace_back(new ani::stat::Luts()); sk->luts = ctx->lutCache.back().get(); }
+  sk->luts->extend(sk->params.kmerSize, sk->params.percentageIdentity, target);
+  if (sk->dMinHits) { pool_free(sk->dMinHits); pool_free(sk->dMinShared); pool_free(sk->dIdLUT); sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr; }
+  const size_t n1 = (size_t)target + 1, n2 = ani::stat::Luts::off(target + 1);
+  HIP_TRY(pool_malloc((void **)&sk->dMinHits, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dMinShared, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dIdLUT, n2 * 4 + 4));
+  HIP_TRY(hipMemcpy(sk->dMinHits, sk->luts->minHits.data(), n1 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(sk->dMinShared, sk->luts->minShared.data(), n1 * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(sk->dIdLUT, sk->luts->idBits.data(), n2 * 4, hipMemcpyHostToDevice));
+  sk->dLutMaxS = target;
+  return ANI_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// One index chunk (≙ Sketch::index, winSketch.hpp:181-193) over the genomes [g0, g0 + nGenomes) = contigs [c0, c0 + nContigs) of
+// a reference set.  new_chunk fills the small tables that depend on the contig lengths only (reducer bins, sampled-position
+// bins); build_chunk_index builds the index arrays from the chunk's records (`pieces`: position order, set-global seqIds) and can
+// be repeated after free_chunk_index.
+// -----------------------------------------------------------------------------------------------------
+int new_chunk(ani_ctx *ctx, const ani_params_t *p, size_t n, const int32_t *contigLenAll, const int32_t *gcsAll, int32_t g0, int32_t nGenomes, IndexChunk **out)
+{
+  if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "index chunk of %zu minimizers exceeds 2^31", n);
+  IndexChunk *sk = new IndexChunk();
+  const int32_t c0 = gcsAll[g0], nContigs = gcsAll[g0 + nGenomes] - c0;
+  const int32_t *contigLen = contigLenAll + c0;
+  sk->n = (uint32_t)n; sk->c0 = c0; sk->nContigs = nContigs; sk->g0 = g0; sk->nGenomes = nGenomes;
+  auto bail = [&](int rc) { free_chunk(sk); return rc; };
+#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194); all chunk-local
+  std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);
+  std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1), posBase((size_t)nContigs + 1);
+  const int32_t binW = p->fragLen - 20;
+  uint64_t run = 0, runPos = 0;
+  for (int32_t g = 0; g < nGenomes; g++) {
+    gBin[g] = (uint32_t)run;
+    for (int32_t c = gcsAll[g0 + g] - c0; c < gcsAll[g0 + g + 1] - c0; c++) {
+      cg[c] = g; binBase[c] = (uint32_t)run; run += (uint64_t)(contigLen[c] / binW) + 1;
+      sk->maxContigLen = std::max(sk->maxContigLen, contigLen[c]);
+      posBase[c] = (uint32_t)runPos; runPos += ((uint64_t)contigLen[c] >> ani::kPosSampleShift) + 1;      // bins of the sampled position index
+      if (run > 0xfffffff0ull || runPos > 0xfffffff0ull) return bail(fail(ANI_ERR_LIMIT, "index chunk has more than 2^32 position bins"));
+    }
+  }
+  gBin[nGenomes] = (uint32_t)run; binBase[nContigs] = (uint32_t)run; posBase[nContigs] = (uint32_t)runPos;
+  sk->totalBins = (uint32_t)run; sk->totalPosBins = (uint32_t)runPos;
+  SK_HIP(pool_malloc((void **)&sk->contigGenome, ((size_t)nContigs + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->contigBinBase, ((size_t)nContigs + 1) * 4));
+  SK_HIP(pool_malloc((void **)&sk->genomeBinStart, ((size_t)nGenomes + 1) * 4)); SK_HIP(pool_malloc((void **)&sk->posBase, ((size_t)nContigs + 1) * 4));
+  SK_HIP(hipMemcpyAsync(sk->contigGenome, cg.data(), cg.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->contigBinBase, binBase.data(), binBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->genomeBinStart, gBin.data(), gBin.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipMemcpyAsync(sk->posBase, posBase.data(), posBase.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SK_HIP(hipStreamSynchronize(ctx->stream));      // the host tables above die at scope exit
+#undef SK_HIP
+  *out = sk;
+  return ANI_OK;
+}
+
+int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
+{
+  const size_t n = sk->n;
+  const int32_t c0 = sk->c0, nContigs = sk->nContigs;
+  auto bail = [&](int rc) { free_chunk_index(sk); return rc; };
+#define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
+#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+  const size_t n4 = (n ? n : 1) * 4;
+  const size_t bitWords = (n + 31) / 32 + 1;
+  SK_HIP(pool_malloc((void **)&sk->mHash, n4)); SK_HIP(pool_malloc((void **)&sk->mSeq, n4)); SK_HIP(pool_malloc((void **)&sk->mWpos, n4));
+  SK_HIP(pool_malloc((void **)&sk->sHash, n4)); SK_HIP(pool_malloc((void **)&sk->sSW, 2 * n4));
+  SK_HIP(pool_malloc((void **)&sk->mWin, n4)); SK_HIP(pool_malloc((void **)&sk->dupBits, bitWords * 4));
+  SK_HIP(pool_malloc((void **)&sk->contigFirstMin, ((size_t)nContigs + 1) * 4));
+  SK_HIP(pool_malloc((void **)&sk->posSample, ((size_t)sk->totalPosBins + 1) * 4));
+  {
+    StageTimer tm(ctx, &ctx->counters.msIndex);
+    const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
+    const bool winLinks = n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask;        // otherwise the L2 fast path is off (map_stage) and the window links are never read
+    uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
+    SK_HIP(pool_malloc((void **)&tmpK, n4));
+    { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
+    SK_HIP(hipMemsetAsync(sk->dupBits, 0, bitWords * 4, ctx->stream));
+    // Main stream: the index sort (radix.hpp) — its histogram read of the records writes the position-ordered SoA arrays, its passes
+    // are bound by memory bandwidth.  Side stream, as soon as the SoA arrays exist (evSimA[0]): everything that needs positions only —
+    // contig slices, the window links of the L2 event stream (binary searches over LDS-staged positions: latency- and LDS-bound),
+    // the sampled position index — runs underneath the sort's passes instead of after them.
+    struct SideJoin { ani_ctx *c; ~SideJoin() { (void)hipStreamSynchronize(c->stream2); } } sideJoin{ctx};   // also on the error paths below
+    bool sorting = false;
+    if (n) {
+      std::vector<const void *> recs; std::vector<size_t> cnts;
+      for (const RecordPiece &pc : sk->pieces) if (pc.n) { recs.push_back(pc.rec); cnts.push_back(pc.n); }
+      size_t tb = 0;
+      int rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, nullptr, &tb, ctx->stream, nullptr, nullptr);
+      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, ctx->evSimA[0], ctx->stream2); }
+      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
+      sorting = true;                               // the passes are in flight; stream2 waits for the SoA arrays
+    }
+    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    if (winLinks)
+      hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + kWinBlock - 1) / kWinBlock)), dim3(256), 0, ctx->stream2, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
+                         (const int32_t *)sk->contigFirstMin, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
+    if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
+                                    sk->totalPosBins, (uint32_t)n, sk->posSample);
+    if (sorting) {
+      const int rc = ani_sort_check(ctx->sortTmp.p, ctx->stream);
+      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
+    }
+    pool_free(tmpK); pool_free(tmpV);
+    SK_HIP(hipGetLastError());
+    SK_HIP(hipEventRecord(ctx->evSimA[1], ctx->stream2));
+    SK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evSimA[1], 0));            // the links kernel needs the contig slices and ORs into the window links
+    // same-hash links of near duplicates (index.hpp: DupLinks) and the number of distinct hashes
+    unsigned long long host[CNT_N];
+    host[CNT_UNIQ] = 0;
+    if (n) {
+      uint32_t pairCap = (uint32_t)std::min<uint64_t>(n, ctx->dupPairCap ? ctx->dupPairCap : n / 64 + 4096);     // first guess; a repetitive reference reruns with the exact count
+      for (int attempt = 0;; attempt++) {
+        uint64_t *pairs = nullptr;
+        SK_HIP(pool_malloc((void **)&pairs, (size_t)pairCap * 16));
+        { const int rz = zero_counters(ctx); if (rz != ANI_OK) { pool_free(pairs); return bail(rz); } }
+        hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
+                           cmw, pairs, pairCap, (unsigned int *)cnt_ptr(ctx, CNT_NEG), sk->dupBits, winLinks ? sk->mWin : (uint32_t *)nullptr, cnt_ptr(ctx, CNT_UNIQ));
+        { const int rr = read_counters(ctx, host); if (rr != ANI_OK) { pool_free(pairs); return bail(rr); } }
+        const uint64_t nPairs = (uint32_t)host[CNT_NEG];
+        if (nPairs > pairCap) {                                  // a repetitive reference: again with room for every pair (bits and flags are idempotent)
+          pool_free(pairs);
+          if (attempt > 0) return bail(fail(ANI_ERR_INTERNAL, "same-hash links did not converge"));
+          pairCap = (uint32_t)nPairs;
+          continue;
+        }
+        sk->nDup = (uint32_t)(2 * nPairs);
+        if (nPairs) {
+          // the half-records sorted by (entry, kind): bisection finds an entry's links (keys are unique: every key bit is significant up to the entry's)
+          int keyBits = 33; while (keyBits < 64 && (1ull << (keyBits - 32)) <= (uint64_t)n) keyBits++;
+          SK_HIP(pool_malloc((void **)&sk->dupList, (size_t)sk->nDup * 8));
+          size_t tb = 0;
+          int rc = ani_sort_keys_u64_bits(pairs, sk->dupList, sk->nDup, keyBits, nullptr, &tb, ctx->stream);
+          if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_keys_u64_bits(pairs, sk->dupList, sk->nDup, keyBits, ctx->sortTmp.p, &tb, ctx->stream); }
+          if (rc != 0) { pool_free(pairs); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(ANI_ERR_DEVICE, "radix sort of the same-hash links failed (%d)", rc)); }
+        }
+        pool_free(pairs);
+        break;
+      }
+    }
+    // probe table: the distinct hashes in an order-preserving open-addressing table, load 0.5 (index.hpp)
+    {
+      sk->nUnique = host[CNT_UNIQ];                           // k_index_links counted the distinct hashes
+      const uint32_t nSlots = (uint32_t)std::min<uint64_t>(0x7ffffff0ull, std::max<uint64_t>(1024, (uint64_t)sk->nUnique * 2));
+      const uint32_t nb = (uint32_t)((n + kTableBlock - 1) / kTableBlock);
+      std::vector<int32_t> cnt(nb ? nb : 1), best(nb ? nb : 1);
+      int64_t lastP = -1;
+      if (n) {
+        SK_TRY(ctx->scanTmpA.ensure((size_t)nb * 4)); SK_TRY(ctx->scanTmpB.ensure((size_t)nb * 4));
+        hipLaunchKernelGGL(k_table_block_totals, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize, nSlots,
+                           ctx->scanTmpA.as<int32_t>(), ctx->scanTmpB.as<int32_t>());
+        SK_HIP(hipMemcpyAsync(cnt.data(), ctx->scanTmpA.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIP(hipMemcpyAsync(best.data(), ctx->scanTmpB.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIP(hipStreamSynchronize(ctx->stream));
+        int64_t before = 0, run = INT32_MIN;                              // distinct hashes before the block; max(slot - global index) over them
+        for (uint32_t b = 0; b < nb; b++) {
+          const int32_t c = cnt[b], bb = best[b];
+          cnt[b] = (int32_t)before; best[b] = (int32_t)std::max<int64_t>(run, INT32_MIN);
+          if (c > 0) { run = std::max<int64_t>(run, (int64_t)bb - before); lastP = before + c - 1 + run; }
+          before += c;
+        }
+      }
+      const uint64_t alloc = std::max<uint64_t>(nSlots, (uint64_t)(lastP + 1)) + 2;        // the clusters at the end may run past nSlots
+      if (alloc > 0x7ffffff0ull) return bail(fail(ANI_ERR_LIMIT, "probe table of %llu slots", (unsigned long long)alloc));
+      SK_HIP(pool_malloc((void **)&sk->table, alloc * sizeof(TableSlot)));
+      // (measured, round 4: writing the empty slots from k_table_scatter instead — every entry with the gap in front of it — made that
+      //  kernel 1.3 ms slower per 4 x 10^8 minimizers and saved 0.5 ms of fill: the device fills 9.6 GB in 0.65 ms)
+      SK_HIP(hipMemsetAsync(sk->table, 0xff, alloc * sizeof(TableSlot), ctx->stream));
+      if (n) {
+        SK_HIP(hipMemcpyAsync(ctx->scanTmpA.p, cnt.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        SK_HIP(hipMemcpyAsync(ctx->scanTmpB.p, best.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_table_scatter, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize, nSlots,
+                           (const int32_t *)ctx->scanTmpA.as<int32_t>(), (const int32_t *)ctx->scanTmpB.as<int32_t>(), sk->table);
+      }
+      const TableSlot sentinel{0xffffffffu, (uint32_t)n | 0x80000000u, 0u};
+      SK_HIP(hipMemcpyAsync(sk->table + (alloc - 2), &sentinel, sizeof sentinel, hipMemcpyHostToDevice, ctx->stream));
+      SK_HIP(hipStreamSynchronize(ctx->stream));                             // cnt / best / sentinel are host memory
+      sk->tableSlots = nSlots;
+    }
+    SK_HIP(hipGetLastError());
+  }
+  SK_HIP(hipStreamSynchronize(ctx->stream));
+  if (!sk->everBuilt) ctx->counters.refMinimizers += n;
+  ctx->counters.indexChunkBuilds++;
+  sk->resident = true; sk->everBuilt = true;
+#undef SK_TRY
+#undef SK_HIP
+  return ANI_OK;
+}
+
+// A reference set = its contig/genome tables + the LUTs; index chunks are attached by add_chunks.
+ani_sketch *new_sketch(ani_ctx *ctx, const ani_params_t *p, const int32_t *contigLen, int32_t nContigs, const int32_t *genomeContigStart, int32_t nGenomes)
+{
+  ani_sketch *sk = new ani_sketch();
+  sk->ctx = ctx; sk->device = ctx->device; sk->params = *p; sk->nContigs = nContigs; sk->nGenomes = nGenomes;
+  sk->contigLen.assign(contigLen, contigLen + nContigs);
+  sk->genomeContigStart.assign(genomeContigStart, genomeContigStart + nGenomes + 1);
+  for (int32_t c = 0; c < nContigs; c++) sk->totalLen += (uint64_t)contigLen[c];
+  return sk;
+}
+
+// Streaming mode: make chunk i's index arrays resident, evicting the least recently used ones beyond the set's limit (`pin`, if
+// >= 0, is never evicted and raises the limit to two: exact_unique compares pairs of chunks).
+int ensure_chunk(ani_sketch *sk, size_t i, int pin)
+{
+  IndexChunk *ch = sk->chunks[i];
+  ch->lastUse = ++sk->useClock;
+  if (ch->resident) return ANI_OK;
+  auto evict_one = [&]() -> bool {
+    IndexChunk *victim = nullptr;
+    for (size_t x = 0; x < sk->chunks.size(); x++) {
+      IndexChunk *c = sk->chunks[x];
+      if (!c->resident || x == i || (int)x == pin) continue;
+      if (!victim || c->lastUse < victim->lastUse) victim = c;
+    }
+    if (!victim) return false;
+    (void)hipStreamSynchronize(sk->ctx->stream); (void)hipStreamSynchronize(sk->ctx->stream2);   // nothing in flight reads the arrays that go back to the pool
+    free_chunk_index(victim);
+    return true;
+  };
+  const int limit = std::max<int>(sk->maxResident > 0 ? sk->maxResident : (int)sk->chunks.size(), pin >= 0 ? 2 : 1);
+  for (;;) {
+    int res = 0;
+    for (IndexChunk *c : sk->chunks) res += c->resident;
+    if (res < limit || !evict_one()) break;
+  }
+  int rc = build_chunk_index(sk->ctx, &sk->params, ch);
+  while (rc == ANI_ERR_NOMEM && evict_one()) rc = build_chunk_index(sk->ctx, &sk->params, ch);     // estimate too optimistic: make room, try again
+  return rc;
+}
+
+// Cut the record parts into index chunks at genome borders (each chunk <= ctx->maxIndexMinimizers records, balanced) and build
+// them.  Owned parts are released as soon as the chunks that need them exist — unless the set is streamed: then the sketch takes
+// the records over (unowned parts are copied) and builds index arrays on demand.
+int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
+{
+  const int32_t *gcs = sk->genomeContigStart.data();
+  // records per genome: first record of every contig inside its part (binary search on the device), then differences
+  std::vector<uint64_t> genomeRecs((size_t)sk->nGenomes, 0), genomeOffInPart((size_t)sk->nGenomes, 0);
+  std::vector<int32_t> genomePart((size_t)sk->nGenomes, -1);
+  uint64_t total = 0;
+  for (size_t pi = 0; pi < parts.size(); pi++) {
+    const RecordPart &pt = parts[pi];
+    if (pt.g1 <= pt.g0) continue;
+    const int32_t c0 = gcs[pt.g0], nc = gcs[pt.g1] - c0;
+    std::vector<uint64_t> first((size_t)nc + 1, 0);
+    if (pt.n) {
+      TRY(ctx->unitAux.ensure(((size_t)nc + 1) * 8));
+      hipLaunchKernelGGL(k_records_contig_first, dim3(grid_for((size_t)nc + 1, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)pt.rec, (uint64_t)pt.n, c0, nc,
+                         ctx->unitAux.as<uint64_t>());
+      HIP_TRY(hipMemcpyAsync(first.data(), ctx->unitAux.p, ((size_t)nc + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (first[nc] != pt.n || first[0] != 0) return fail(ANI_ERR_ARG, "minimizer records carry seqIds outside their genome range [%d, %d)", c0, c0 + nc);
+    }
+    for (int32_t g = pt.g0; g < pt.g1; g++) {
+      genomePart[g] = (int32_t)pi; genomeOffInPart[g] = first[gcs[g] - c0]; genomeRecs[g] = first[gcs[g + 1] - c0] - first[gcs[g] - c0];
+    }
+    total += pt.n;
+  }
+  for (int32_t g = 0; g < sk->nGenomes; g++) if (genomePart[g] < 0) return fail(ANI_ERR_INTERNAL, "genome %d is in no record part", g);
+  sk->genomeRecStart.assign((size_t)sk->nGenomes + 1, 0);
+  for (int32_t g = 0; g < sk->nGenomes; g++) sk->genomeRecStart[g + 1] = sk->genomeRecStart[g] + genomeRecs[g];
+  // Resident or streamed?  The index takes ~36 bytes per minimizer and its build another ~13 of transient
+  // arrays; a set that does not fit beside a working-set reserve keeps its 12-byte records instead and at most `maxResident`
+  // chunks' arrays (ANI_MAX_RESIDENT_CHUNKS forces a limit: the tests stream tiny sets that way).
+  uint64_t maxN = std::min<uint64_t>(ctx->maxIndexMinimizers, 0x7fffffe0ull);
+  int32_t resident = ctx->maxResidentChunks;
+  if (resident == 0) {
+    size_t freeB = 0, totB = 0;
+    if (hipMemGetInfo(&freeB, &totB) == hipSuccess) {
+      uint64_t cached = 0;
+      for (int cls = 0; cls < 2; cls++) { DevicePool &pl = cur_pool(cls); std::lock_guard<std::mutex> g(pl.mu); cached += pl.cachedBytes; }
+      const uint64_t avail = (uint64_t)freeB + cached, reserve = std::min<uint64_t>((uint64_t)32 << 30, (uint64_t)totB / 8);
+      const uint64_t largest = std::min<uint64_t>(total, maxN);
+      // (Streamed chunks of a fixed 10^9 minimizers.  Measured: chunks as large as the free memory allows — 4 instead of 5 for
+      // 10 000 x 5 Mbp — save a probe pass, but more fragments then have > 2048 seed hits per chunk and move to LDS class M:
+      // the 10 000 x 10 000 step stayed at 6.1 s.)
+      if (36 * total + 14 * largest + reserve > avail) { resident = 1; maxN = std::min<uint64_t>(maxN, ctx->streamChunkMinimizers); }
+    }
+  }
+  // balanced chunk sizes: ceil(total / max) chunks of about total / that
+  const uint64_t nCh = std::max<uint64_t>(1, (total + maxN - 1) / maxN);
+  const uint64_t target = std::min<uint64_t>(maxN, (total + nCh - 1) / nCh + (total / nCh) / 50 + 1);
+  // the plan: genome ranges and the record slices they are built from
+  int32_t g0 = 0;
+  while (g0 < sk->nGenomes || (sk->nGenomes == 0 && sk->chunks.empty())) {
+    int32_t g1 = g0; uint64_t n = 0;
+    while (g1 < sk->nGenomes && (g1 == g0 || n + genomeRecs[g1] <= target)) { n += genomeRecs[g1]; g1++; }
+    if (n >= 0x7ffffff0ull) return fail(ANI_ERR_LIMIT, "reference genome %d alone yields %llu minimizers (>= 2^31)", g0, (unsigned long long)n);
+    IndexChunk *ch = nullptr;
+    TRY(new_chunk(ctx, &sk->params, (size_t)n, sk->contigLen.data(), gcs, g0, g1 - g0, &ch));
+    for (int32_t g = g0; g < g1;) {                 // runs of genomes inside one part
+      const int32_t pi = genomePart[g]; int32_t h = g; uint64_t m = 0;
+      while (h < g1 && genomePart[h] == pi) { m += genomeRecs[h]; h++; }
+      if (m) ch->pieces.push_back(RecordPiece{parts[pi].rec + 3 * genomeOffInPart[g], (size_t)m});
+      g = h;
+    }
+    sk->chunks.push_back(ch); ctx->counters.indexChunks++;
+    sk->n += n; sk->maxChunkBins = std::max(sk->maxChunkBins, ch->totalBins);
+    g0 = g1;
+    if (sk->nGenomes == 0) break;
+  }
+  sk->streaming = resident > 0 && (size_t)resident < sk->chunks.size();
+  sk->maxResident = sk->streaming ? resident : 0;
+  if (sk->streaming) {
+    // the sketch takes the records over: owned parts as they are, the others copied (the chunks' pieces point into them)
+    for (RecordPart &pt : parts) {
+      if (!pt.rec || !pt.n) continue;
+      if (pt.owned) { sk->kept.push_back(pt.rec); pt.rec = nullptr; continue; }     // taken over: the caller's cleanup finds nothing to free
+      uint32_t *cp = nullptr;
+      HIP_TRY(pool_malloc((void **)&cp, pt.n * 12));
+      sk->kept.push_back(cp);
+      HIP_TRY(hipMemcpyAsync(cp, pt.rec, pt.n * 12, hipMemcpyDeviceToDevice, ctx->stream));
+      for (IndexChunk *ch : sk->chunks) for (RecordPiece &pc : ch->pieces)
+        if (pc.rec >= pt.rec && pc.rec < pt.rec + 3 * pt.n) pc.rec = cp + (pc.rec - pt.rec);
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  } else {
+    std::vector<int32_t> partLastUse(parts.size(), -1);
+    for (int32_t g = 0; g < sk->nGenomes; g++) partLastUse[genomePart[g]] = g;
+    for (size_t c = 0; c < sk->chunks.size(); c++) {
+      IndexChunk *ch = sk->chunks[c];
+      TRY(build_chunk_index(ctx, &sk->params, ch));
+      ch->pieces.clear();                              // the records may go away now
+      for (size_t pi = 0; pi < parts.size(); pi++)
+        if (parts[pi].owned && parts[pi].rec && partLastUse[pi] < ch->g0 + ch->nGenomes) { pool_free(parts[pi].rec); parts[pi].rec = nullptr; }
+    }
+  }
+  sk->nUnique = 0;
+  for (IndexChunk *ch : sk->chunks) sk->nUnique += ch->nUnique;
+  sk->uniqueExact = sk->chunks.size() <= 1 && !sk->streaming;
+  ctx->counters.refBases += sk->totalLen; ctx->counters.refUniqueHashes += sk->nUnique;
+  return upload_luts(sk, 512);
+}
+
+// distinct hashes over all chunks = sum of the chunks' own counts - hashes that already occur in an earlier chunk
+int exact_unique(ani_sketch *sk)
+{
+  if (sk->uniqueExact) return ANI_OK;
+  ani_ctx *ctx = sk->ctx;
+  uint64_t dup = 0;
+  for (size_t c = 1; c < sk->chunks.size(); c++) {
+    IndexChunk *C = sk->chunks[c];
+    if (!C->n) continue;
+    TRY(ensure_chunk(sk, c));
+    uint8_t *seen = nullptr;
+    HIP_TRY(pool_malloc((void **)&seen, C->n));
+    hipError_t e = hipMemsetAsync(seen, 0, C->n, ctx->stream);
+    for (size_t x = 0; x < c && e == hipSuccess; x++) {
+      IndexChunk *E = sk->chunks[x];
+      if (!E->n) continue;
+      { const int rcE = ensure_chunk(sk, x, (int)c); if (rcE != ANI_OK) { pool_free(seen); return rcE; } }
+      hipLaunchKernelGGL(k_index_mark_shared, dim3(grid_for(C->n, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)C->sHash, C->n, (const TableSlot *)E->table,
+                         E->tableSlots, sk->params.windowSize, seen);
+    }
+    int rc = e == hipSuccess ? zero_counters(ctx) : fail(ANI_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    unsigned long long host[CNT_N];
+    if (rc == ANI_OK) {
+      hipLaunchKernelGGL(k_count_flags, dim3(grid_for(C->n, 256, 4096)), dim3(256), 0, ctx->stream, (const uint8_t *)seen, C->n, cnt_ptr(ctx, CNT_UNIQ));
+      rc = read_counters(ctx, host);
+    }
+    pool_free(seen);
+    TRY(rc);
+    dup += host[CNT_UNIQ];
+  }
+  sk->nUnique = 0;                 // (a streamed set knows a chunk's own count only once the chunk has been built: every chunk has been, above)
+  for (IndexChunk *ch : sk->chunks) { if (!ch->everBuilt && ch->n) return fail(ANI_ERR_INTERNAL, "index chunk never built"); sk->nUnique += ch->nUnique; }
+  sk->nUnique -= dup; sk->uniqueExact = true;
+  return ANI_OK;
+}
+
+}  // namespace anih
+
+extern "C" {
+
+int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *devRecords, size_t n, const int32_t *contigLen, int32_t nContigs,
+                            const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  if (!ctx || !out || (n && !devRecords) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
+    return fail(ANI_ERR_ARG, "invalid argument");
+  if (genomeContigStart[0] != 0 || genomeContigStart[nGenomes] != nContigs) return fail(ANI_ERR_ARG, "genomeContigStart does not cover the contig table");
+  TRY(check_params(p));
+  HIP_TRY(hipSetDevice(ctx->device));
+  ani_sketch *sk = new_sketch(ctx, p, contigLen, nContigs, genomeContigStart, nGenomes);
+  std::vector<RecordPart> parts(1);
+  parts[0].rec = (uint32_t *)devRecords; parts[0].n = n; parts[0].g0 = 0; parts[0].g1 = nGenomes; parts[0].owned = false;
+  const int rc = add_chunks(ctx, sk, parts);
+  if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
+  *out = sk;
+  return ANI_OK;
+}
+
+namespace {
+int sketch_from_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords, const uint64_t *n,
+                      const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                      const int32_t *genomeContigStart, int32_t nGenomes, bool adopt, ani_sketch **out, bool *consumed);
+}
+int ani_sketch_from_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords, const uint64_t *n,
+                                 const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                                 const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  bool consumed = false;
+  return sketch_from_parts(ctx, p, nParts, devRecords, n, partGenomeStart, contigLen, nContigs, genomeContigStart, nGenomes, false, out, &consumed);
+}
+int ani_sketch_adopt_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, void *const *devRecords, const uint64_t *n,
+                                  const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                                  const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
+{
+  bool consumed = false;
+  const int rc = sketch_from_parts(ctx, p, nParts, devRecords, n, partGenomeStart, contigLen, nContigs, genomeContigStart, nGenomes, true, out, &consumed);
+  if (!consumed && ctx && devRecords && nParts > 0) {        // rejected before anything was taken over: the buffers are the library's all the same
+    (void)hipSetDevice(ctx->device);
+    for (int32_t i = 0; i < nParts; i++) if (devRecords[i]) pool_free(devRecords[i]);
+  }
+  return rc;
+}
+namespace {
+int sketch_from_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const void *const *devRecords, const uint64_t *n,
+                      const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
+                      const int32_t *genomeContigStart, int32_t nGenomes, bool adopt, ani_sketch **out, bool *consumed)
+{
+  if (!ctx || !out || nParts < 0 || (nParts && (!devRecords || !n || !partGenomeStart)) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
+    return fail(ANI_ERR_ARG, "invalid argument");
+  if (genomeContigStart[0] != 0 || genomeContigStart[nGenomes] != nContigs) return fail(ANI_ERR_ARG, "genomeContigStart does not cover the contig table");
+  if (nParts && (partGenomeStart[0] != 0 || partGenomeStart[nParts] != nGenomes)) return fail(ANI_ERR_ARG, "partGenomeStart does not cover the genomes");
+  if (!nParts && nGenomes) return fail(ANI_ERR_ARG, "no record parts for %d genomes", nGenomes);
+  TRY(check_params(p));
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<RecordPart> parts((size_t)nParts);
+  for (int32_t i = 0; i < nParts; i++) {
+    if (partGenomeStart[i + 1] < partGenomeStart[i] || (n[i] && !devRecords[i])) return fail(ANI_ERR_ARG, "record part %d is malformed", i);
+    parts[i].rec = (uint32_t *)devRecords[i]; parts[i].n = (size_t)n[i]; parts[i].g0 = partGenomeStart[i]; parts[i].g1 = partGenomeStart[i + 1]; parts[i].owned = false;
+  }
+  // adopted buffers: a streamed set keeps them as they are (no copy of the records: a set near the device's capacity has no room
+  // for one), a resident set releases each as soon as the chunks that need it are built; whatever add_chunks did not take goes back here
+  for (auto &q : parts) q.owned = adopt;
+  *consumed = true;
+  ani_sketch *sk = new_sketch(ctx, p, contigLen, nContigs, genomeContigStart, nGenomes);
+  const int rc = add_chunks(ctx, sk, parts);
+  if (adopt) for (auto &q : parts) if (q.rec) { pool_free(q.rec); q.rec = nullptr; }
+  if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
+  *out = sk;
+  return ANI_OK;
+}
+}  // namespace
+
+int ani_sketch_build(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *refs, ani_sketch **out)
+{
+  if (!ctx || !out) return fail(ANI_ERR_ARG, "null argument");
+  TRY(check_params(p)); TRY(check_batch(refs));
+  HIP_TRY(hipSetDevice(ctx->device));
+  // references are sketched in slices of genomes so that the temporary pools stay small; the slices' records (position order,
+  // global seqIds) are then cut into index chunks at genome borders
+  std::vector<RecordPart> parts;
+  auto cleanup = [&]() { for (auto &q : parts) if (q.rec && q.owned) pool_free(q.rec); };
+  int32_t g0 = 0;
+  while (g0 < refs->nGenomes) {
+    int32_t g1 = g0; uint64_t bases = 0;
+    while (g1 < refs->nGenomes && (g1 == g0 || bases < (1ull << 30))) {
+      for (int32_t c = refs->genomeContigStart[g1]; c < refs->genomeContigStart[g1 + 1]; c++) bases += (uint64_t)refs->contigLen[c];
+      g1++;
+    }
+    DeviceBatch db;
+    int rc = upload_batch(ctx, refs, g0, g1, &db);
+    RecordPart pt; pt.g0 = g0; pt.g1 = g1;
+    if (rc == ANI_OK) rc = sketch_records(ctx, p, db, refs->genomeContigStart[g0], &pt.rec, &pt.n);
+    if (rc != ANI_OK) { cleanup(); return rc; }
+    parts.push_back(pt);
+    g0 = g1;
+  }
+  ani_sketch *sk = new_sketch(ctx, p, refs->contigLen, refs->nContigs, refs->genomeContigStart, refs->nGenomes);
+  const int rc = add_chunks(ctx, sk, parts);
+  cleanup();
+  if (rc != ANI_OK) { free_sketch_device(sk); delete sk; return rc; }
+  *out = sk;
+  return ANI_OK;
+}
+
+void ani_sketch_destroy(ani_sketch *sk)
+{
+  if (!sk) return;
+  (void)hipSetDevice(sk->device);       // the context may be gone already: device memory goes back to the per-device pools
+  free_sketch_device(sk);
+  delete sk;
+}
+
+int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n)
+{
+  if (!sk || !out || !n) return fail(ANI_ERR_ARG, "null argument");
+  ani_ctx *ctx = sk->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  *n = (size_t)sk->n;
+  *out = (ani_minimizer_t *)malloc((sk->n ? (size_t)sk->n : 1) * sizeof(ani_minimizer_t));
+  if (!*out) return fail(ANI_ERR_NOMEM, "host allocation failed");
+  size_t o = 0;
+  for (const IndexChunk *ch : sk->chunks) {
+    if (ch->n == 0) continue;
+    if (!ch->resident) {                     // streamed set: the chunk's records are at hand in the export layout already
+      for (const RecordPiece &pc : ch->pieces) {
+        const hipError_t ec = hipMemcpy(*out + o, pc.rec, pc.n * 12, hipMemcpyDeviceToHost);
+        if (ec != hipSuccess) { free(*out); *out = nullptr; HIP_TRY(ec); }
+        o += pc.n;
+      }
+      continue;
+    }
+    uint32_t *tmp = nullptr;
+    hipError_t e = pool_malloc((void **)&tmp, (size_t)ch->n * 12);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(ch->n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash, ch->mSeq, ch->mWpos, ch->n, (uint32_t)ch->c0, tmp);
+      e = hipMemcpyAsync(*out + o, tmp, (size_t)ch->n * 12, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (tmp) pool_free(tmp);
+    if (e != hipSuccess || e2 != hipSuccess) { free(*out); *out = nullptr; HIP_TRY(e); HIP_TRY(e2); }
+    o += ch->n;
+  }
+  return ANI_OK;
+}
+
+int ani_sketch_stats(const ani_sketch *skc, uint64_t *nMinimizers, uint64_t *nUnique, uint64_t *totalLength, int32_t *nContigs, int32_t *nGenomes)
+{
+  if (!skc) return fail(ANI_ERR_ARG, "null sketch");
+  ani_sketch *sk = const_cast<ani_sketch *>(skc);
+  if (nUnique) {
+    HIP_TRY(hipSetDevice(sk->device));
+    TRY(exact_unique(sk));          // several index chunks: hashes shared between chunks are counted once (lazily, here)
+    *nUnique = sk->nUnique;
+  }
+  if (nMinimizers) *nMinimizers = sk->n;
+  if (totalLength) *totalLength = sk->totalLen;
+  if (nContigs) *nContigs = sk->nContigs;
+  if (nGenomes) *nGenomes = sk->nGenomes;
+  return ANI_OK;
+}
+
+int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGenome, int32_t cap)
+{
+  if (!sk || !nChunks) return fail(ANI_ERR_ARG, "null argument");
+  *nChunks = (int32_t)sk->chunks.size();
+  if (firstGenome) for (int32_t i = 0; i < cap && i < *nChunks; i++) firstGenome[i] = sk->chunks[i]->g0;
+  return ANI_OK;
+}
+
+int ani_sketch_residency(const ani_sketch *sk, int32_t *streaming, int32_t *maxResident, int32_t *residentNow)
+{
+  if (!sk) return fail(ANI_ERR_ARG, "null sketch");
+  if (streaming) *streaming = sk->streaming ? 1 : 0;
+  if (maxResident) *maxResident = sk->streaming ? sk->maxResident : (int32_t)sk->chunks.size();
+  if (residentNow) { int32_t r = 0; for (const IndexChunk *ch : sk->chunks) r += ch->resident; *residentNow = r; }
+  return ANI_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Persistent sketch file (the reference rebuilds its sketch in every run and every thread).
+//   header (4096 B) : magic "ANISKTCH", version, the parameters the sketch depends on, counts, section offsets
+//   contigLen        int32[nContigs]
+//   genomeContigStart int32[nGenomes + 1]
+//   genomeRecStart   uint64[nGenomes + 1]   first record of every genome: a reader can take any genome range (one rank's shard)
+//   names            nGenomes NUL-terminated strings (may be empty)
+//   records          12-byte (hash, seqId, wpos) minimizer records, position order, global seqIds = skch::MinimizerInfo, the
+//                    layout of ani_sketch_records / ani_sketch_from_records
+// Sections start on 4096-byte boundaries, so the file can be mmap'ed and the record section handed to hipMemcpy as it is.  The
+// hash-ordered index is not stored: rebuilding it on the device (radix sort) is faster than reading it back.
+// -----------------------------------------------------------------------------------------------------
+namespace {
+struct SketchFileHeader {
+  char magic[8]; uint32_t version, headerBytes;
+  int32_t kmerSize, windowSize, fragLen; float percentageIdentity;
+  int32_t nContigs, nGenomes; uint64_t nRecords;
+  uint64_t offContigLen, offGcs, offGenomeRec, offNames, namesBytes, offRecords;
+};
+constexpr uint64_t kFileAlign = 4096;
+inline uint64_t align_up(uint64_t x) { return (x + kFileAlign - 1) / kFileAlign * kFileAlign; }
+bool write_all(int fd, const void *p, size_t n) { const char *c = (const char *)p; while (n) { const ssize_t w = ::write(fd, c, n); if (w <= 0) return false; c += w; n -= (size_t)w; } return true; }
+bool pad_to(int fd, uint64_t *pos, uint64_t target) { static const char z[4096] = {0}; while (*pos < target) { const size_t n = (size_t)std::min<uint64_t>(4096, target - *pos); if (!write_all(fd, z, n)) return false; *pos += n; } return true; }
+}  // namespace
+
+int ani_sketch_save(const ani_sketch *sk, const char *path, const char *const *genomeNames)
+{
+  if (!sk || !path) return fail(ANI_ERR_ARG, "null argument");
+  ani_ctx *ctx = sk->ctx;
+  HIP_TRY(hipSetDevice(sk->device));
+  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return fail(ANI_ERR_ARG, "cannot create %s", path);
+  std::string names;
+  for (int32_t g = 0; g < sk->nGenomes; g++) { names += genomeNames && genomeNames[g] ? genomeNames[g] : (g < (int32_t)sk->genomeNames.size() ? sk->genomeNames[g].c_str() : ""); names.push_back('\0'); }
+  const std::vector<uint64_t> &genomeRec = sk->genomeRecStart;      // first record of every genome (add_chunks)
+  if (genomeRec.size() != (size_t)sk->nGenomes + 1) { ::close(fd); return fail(ANI_ERR_INTERNAL, "sketch without its genome record table"); }
+  SketchFileHeader h; memset(&h, 0, sizeof h);
+  memcpy(h.magic, "ANISKTCH", 8); h.version = 1; h.headerBytes = (uint32_t)kFileAlign;
+  h.kmerSize = sk->params.kmerSize; h.windowSize = sk->params.windowSize; h.fragLen = sk->params.fragLen; h.percentageIdentity = sk->params.percentageIdentity;
+  h.nContigs = sk->nContigs; h.nGenomes = sk->nGenomes; h.nRecords = sk->n;
+  h.offContigLen = kFileAlign;
+  h.offGcs = align_up(h.offContigLen + (uint64_t)sk->nContigs * 4);
+  h.offGenomeRec = align_up(h.offGcs + ((uint64_t)sk->nGenomes + 1) * 4);
+  h.offNames = align_up(h.offGenomeRec + ((uint64_t)sk->nGenomes + 1) * 8);
+  h.namesBytes = names.size();
+  h.offRecords = align_up(h.offNames + names.size());
+  uint64_t pos = 0;
+  bool ok = write_all(fd, &h, sizeof h); pos += sizeof h;
+  ok = ok && pad_to(fd, &pos, h.offContigLen) && write_all(fd, sk->contigLen.data(), (size_t)sk->nContigs * 4); pos += (uint64_t)sk->nContigs * 4;
+  ok = ok && pad_to(fd, &pos, h.offGcs) && write_all(fd, sk->genomeContigStart.data(), ((size_t)sk->nGenomes + 1) * 4); pos += ((uint64_t)sk->nGenomes + 1) * 4;
+  ok = ok && pad_to(fd, &pos, h.offGenomeRec) && write_all(fd, genomeRec.data(), genomeRec.size() * 8); pos += genomeRec.size() * 8;
+  ok = ok && pad_to(fd, &pos, h.offNames) && write_all(fd, names.data(), names.size()); pos += names.size();
+  ok = ok && pad_to(fd, &pos, h.offRecords);
+  // records: joined on the device into 12-byte records, through page-locked staging, 64 M records at a time
+  const size_t kPiece = (size_t)64 << 20;
+  for (const IndexChunk *ch : sk->chunks) {
+    if (!ch->resident) {                     // streamed set: written from the records the sketch keeps
+      for (const RecordPiece &pc : ch->pieces)
+        for (size_t o = 0; ok && o < pc.n; o += kPiece) {
+          const size_t m = std::min<size_t>(kPiece, pc.n - o);
+          void *host = nullptr;
+          if (pinned_buffer(ctx, 0, m * 12, &host) != ANI_OK) { ok = false; break; }
+          ok = hipMemcpy(host, pc.rec + 3 * o, m * 12, hipMemcpyDeviceToHost) == hipSuccess && write_all(fd, host, m * 12);
+        }
+      continue;
+    }
+    for (size_t o = 0; ok && o < ch->n; o += kPiece) {
+      const size_t m = std::min<size_t>(kPiece, ch->n - o);
+      uint32_t *tmp = nullptr; void *host = nullptr;
+      if (pool_malloc((void **)&tmp, m * 12) != hipSuccess || pinned_buffer(ctx, 0, m * 12, &host) != ANI_OK) { if (tmp) pool_free(tmp); ok = false; break; }
+      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(m, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash + o, ch->mSeq + o, ch->mWpos + o, (uint32_t)m, (uint32_t)ch->c0, tmp);
+      hipError_t e = hipMemcpyAsync(host, tmp, m * 12, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      pool_free(tmp);
+      ok = e == hipSuccess && write_all(fd, host, m * 12);
+    }
+  }
+  if (::close(fd) != 0) ok = false;
+  if (!ok) { ::unlink(path); return fail(ANI_ERR_DEVICE, "writing %s failed", path); }
+  return ANI_OK;
+}
+
+// genomes [g0, g1) of a sketch file (g1 < 0: to the end) -> a sketch on this context; seqIds / genome ids are renumbered from 0
+int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_sketch **out)
+{
+  if (!ctx || !path || !out) return fail(ANI_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) return fail(ANI_ERR_ARG, "cannot open %s", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < sizeof(SketchFileHeader)) { ::close(fd); return fail(ANI_ERR_ARG, "%s is not a sketch file", path); }
+  const size_t fileBytes = (size_t)st.st_size;
+  const uint8_t *base = (const uint8_t *)mmap(nullptr, fileBytes, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (base == MAP_FAILED) return fail(ANI_ERR_NOMEM, "mmap of %s failed", path);
+  struct Unmap { const uint8_t *p; size_t n; ~Unmap() { munmap((void *)p, n); } } unmap{base, fileBytes};
+  SketchFileHeader h; memcpy(&h, base, sizeof h);
+  if (memcmp(h.magic, "ANISKTCH", 8) != 0 || h.version != 1) return fail(ANI_ERR_ARG, "%s is not a version-1 sketch file", path);
+  // section extents without overflow: a section [off, off + count * size) lies inside the file iff off <= fileBytes and count <= (fileBytes - off) / size
+  auto inside = [&](uint64_t off, uint64_t count, uint64_t size) { return off <= fileBytes && count <= (fileBytes - off) / size; };
+  if (h.nContigs < 0 || h.nGenomes < 0 || !inside(h.offRecords, h.nRecords, 12) || !inside(h.offNames, h.namesBytes, 1) ||
+      !inside(h.offGenomeRec, (uint64_t)h.nGenomes + 1, 8) || !inside(h.offGcs, (uint64_t)h.nGenomes + 1, 4) || !inside(h.offContigLen, (uint64_t)h.nContigs, 4) ||
+      (h.offRecords | h.offGenomeRec | h.offGcs | h.offContigLen) % 4 != 0 || h.offGenomeRec % 8 != 0)
+    return fail(ANI_ERR_ARG, "%s is truncated", path);
+  {
+    // the tables are used as copy offsets and sizes below: validate them instead of trusting the file
+    const int32_t *gcsT = (const int32_t *)(base + h.offGcs), *clenT = (const int32_t *)(base + h.offContigLen);
+    const uint64_t *grecT = (const uint64_t *)(base + h.offGenomeRec);
+    bool ok = gcsT[0] == 0 && gcsT[h.nGenomes] == h.nContigs && grecT[0] == 0 && grecT[h.nGenomes] == h.nRecords;
+    for (int32_t g = 0; ok && g < h.nGenomes; g++) ok = gcsT[g] <= gcsT[g + 1] && grecT[g] <= grecT[g + 1];
+    for (int32_t c = 0; ok && c < h.nContigs; c++) ok = clenT[c] >= 0;
+    if (!ok) return fail(ANI_ERR_ARG, "%s has inconsistent genome / contig tables", path);
+  }
+  if (g1 < 0) g1 = h.nGenomes;
+  if (g0 < 0 || g0 > g1 || g1 > h.nGenomes) return fail(ANI_ERR_ARG, "genome range [%d, %d) outside the file's %d genomes", g0, g1, h.nGenomes);
+  ani_params_t p; p.kmerSize = h.kmerSize; p.windowSize = h.windowSize; p.fragLen = h.fragLen; p.percentageIdentity = h.percentageIdentity;
+  TRY(check_params(&p));
+  const int32_t *gcsF = (const int32_t *)(base + h.offGcs), *clenF = (const int32_t *)(base + h.offContigLen);
+  const uint64_t *grec = (const uint64_t *)(base + h.offGenomeRec);
+  const int32_t c0 = gcsF[g0], c1 = gcsF[g1], nG = g1 - g0;
+  std::vector<int32_t> gcs((size_t)nG + 1);
+  for (int32_t g = 0; g <= nG; g++) gcs[g] = gcsF[g0 + g] - c0;
+  ani_sketch *sk = new_sketch(ctx, &p, clenF + c0, c1 - c0, gcs.data(), nG);
+  { const char *nm = (const char *)(base + h.offNames), *end = nm + h.namesBytes;
+    for (int32_t g = 0; g < h.nGenomes && nm < end; g++) { const size_t l = strnlen(nm, (size_t)(end - nm)); if (g >= g0 && g < g1) sk->genomeNames.emplace_back(nm, l); nm += l + 1; } }
+  // records to the device in pieces of whole genomes (<= 64 M records), seqIds rebased to the range's first contig
+  std::vector<RecordPart> parts;
+  auto bail = [&](int rc) { for (auto &q : parts) if (q.rec) pool_free(q.rec); free_sketch_device(sk); delete sk; return rc; };
+  const uint64_t kPiece = (uint64_t)64 << 20;
+  int32_t ga = g0;
+  while (ga < g1) {
+    int32_t gb = ga + 1;
+    while (gb < g1 && grec[gb + 1] - grec[ga] <= kPiece) gb++;
+    RecordPart pt; pt.g0 = ga - g0; pt.g1 = gb - g0; pt.n = (size_t)(grec[gb] - grec[ga]);
+    if (pt.n) {
+      if (pool_malloc((void **)&pt.rec, pt.n * 12) != hipSuccess) return bail(fail(ANI_ERR_NOMEM, "device allocation of %zu records failed", pt.n));
+      parts.push_back(pt);
+      hipError_t e = hipMemcpyAsync(pt.rec, base + h.offRecords + grec[ga] * 12, pt.n * 12, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess && c0) hipLaunchKernelGGL(ani::k_records_rebase, dim3(grid_for(pt.n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, pt.rec, (uint64_t)pt.n, c0);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "copying records to the device failed: %s", hipGetErrorString(e)));
+    } else parts.push_back(pt);
+    ga = gb;
+  }
+  if (parts.empty()) { RecordPart pt; pt.g0 = 0; pt.g1 = nG; parts.push_back(pt); }
+  const int rc = add_chunks(ctx, sk, parts);
+  for (auto &q : parts) if (q.rec) { pool_free(q.rec); q.rec = nullptr; }
+  if (rc != ANI_OK) return bail(rc);
+  *out = sk;
+  return ANI_OK;
+}
+
+int ani_sketch_file_info(const char *path, ani_params_t *p, int32_t *nContigs, int32_t *nGenomes, uint64_t *nMinimizers)
+{
+  if (!path) return fail(ANI_ERR_ARG, "null argument");
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(ANI_ERR_ARG, "cannot open %s", path);
+  SketchFileHeader h;
+  const size_t got = fread(&h, 1, sizeof h, f);
+  fclose(f);
+  if (got != sizeof h || memcmp(h.magic, "ANISKTCH", 8) != 0 || h.version != 1) return fail(ANI_ERR_ARG, "%s is not a version-1 sketch file", path);
+  if (p) { p->kmerSize = h.kmerSize; p->windowSize = h.windowSize; p->fragLen = h.fragLen; p->percentageIdentity = h.percentageIdentity; }
+  if (nContigs) *nContigs = h.nContigs;
+  if (nGenomes) *nGenomes = h.nGenomes;
+  if (nMinimizers) *nMinimizers = h.nRecords;
+  return ANI_OK;
+}
+
+// genome name / contig lengths of a (loaded) sketch: what the command line needs to print results without the FASTA files
+const char *ani_sketch_genome_name(const ani_sketch *sk, int32_t g) { return (sk && g >= 0 && g < (int32_t)sk->genomeNames.size()) ? sk->genomeNames[g].c_str() : ""; }
+int ani_sketch_tables(const ani_sketch *sk, const int32_t **contigLen, const int32_t **genomeContigStart)
+{
+  if (!sk) return fail(ANI_ERR_ARG, "null sketch");
+  if (contigLen) *contigLen = sk->contigLen.data();
+  if (genomeContigStart) *genomeContigStart = sk->genomeContigStart.data();
+  return ANI_OK;
+}
+
+
+}  // extern "C"

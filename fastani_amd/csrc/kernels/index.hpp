@@ -48,7 +48,7 @@ __host__ __device__ __forceinline__ int32_t dup_next(const DupLinks &d, uint32_t
   return -1;
 }
 
-__global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
+static __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
                              uint32_t n, uint32_t seqBase, uint32_t *__restrict__ records)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -64,7 +64,7 @@ __global__ void k_index_join(const uint32_t *__restrict__ mHash, const int32_t *
 //   window start) may trail by less than the gap to its successor: possible iff wpos[j] - wpos[j'] <= cmw + (wpos[j'+1] - wpos[j']).
 // Entries without a link behave as plain set members in L2 (links of non-near pairs would only ever be compared against the bounds of
 // one window).  `nPairs` counts every pair; a pair beyond `pairCap` is not stored (the host reruns the kernel with room for all).
-__global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t *__restrict__ sSW, uint32_t n,
+static __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t *__restrict__ sSW, uint32_t n,
                               const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin, int32_t cmw,
                               uint64_t *__restrict__ pairs, uint32_t pairCap, unsigned int *__restrict__ nPairs,
                               uint32_t *__restrict__ dupBits, uint32_t *__restrict__ mWin, unsigned long long *__restrict__ nUnique)
@@ -140,7 +140,7 @@ __host__ __device__ __forceinline__ uint32_t table_slot(uint32_t h, int w, uint3
 
 // pass 1: per block of kTableBlock entries of the hash-sorted index: number of distinct hashes that start in it, and
 // max(slot - index inside the block) over them (INT_MIN if none)
-__global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__restrict__ sHash, uint32_t n, int w, uint32_t nSlots,
+static __global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__restrict__ sHash, uint32_t n, int w, uint32_t nSlots,
                                                              int32_t *__restrict__ blockCnt, int32_t *__restrict__ blockBest)
 {
   __shared__ int ws[16];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__r
 
 // pass 2: the distinct hashes into their slots.  carryCnt[b] = distinct hashes before block b, carryBest[b] = max(slot - global
 // index) over them (both finished on the host from pass 1)
-__global__ __launch_bounds__(kTPB) void k_table_scatter(const uint32_t *__restrict__ sHash, uint32_t n, int w, uint32_t nSlots,
+static __global__ __launch_bounds__(kTPB) void k_table_scatter(const uint32_t *__restrict__ sHash, uint32_t n, int w, uint32_t nSlots,
                                                         const int32_t *__restrict__ carryCnt, const int32_t *__restrict__ carryBest,
                                                         TableSlot *__restrict__ table)
 {
@@ -222,7 +222,7 @@ __device__ __forceinline__ void table_probe(const TableSlot *__restrict__ table,
 }
 
 // contigFirstMin[c] = first position-ordered entry with seqId >= c, for c = 0..nContigs
-__global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t n, int32_t nContigs,
+static __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t n, int32_t nContigs,
                                      int32_t *__restrict__ contigFirstMin)
 {
   for (int32_t c = blockIdx.x * blockDim.x + threadIdx.x; c <= nContigs; c += gridDim.x * blockDim.x) {
@@ -248,7 +248,7 @@ __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, uint32_t 
 // coalesce.
 constexpr int kWinHalo = 768;             // positions staged in LDS on either side of a workgroup's entries (~3 typical spans)
 constexpr int kWinBlock = 1024;           // entries per workgroup (four per thread: the halo is read once per 1024 entries, 2.5 x the data instead of 7 x)
-__global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
+static __global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
                                                             const int32_t *__restrict__ contigFirstMin, uint32_t n,
                                                             int32_t cmw1, int32_t expect /* entries per cmw positions */, uint32_t *__restrict__ mWin)
 {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__res
 
 // 12-byte records in position order with GLOBAL seqIds: out[c] = first record with seqId >= seqIdBase + c, c = 0..nContigs.
 // Used to cut a record stream into index chunks at genome borders.
-__global__ void k_records_contig_first(const uint32_t *__restrict__ records, uint64_t n, int32_t seqIdBase, int32_t nContigs,
+static __global__ void k_records_contig_first(const uint32_t *__restrict__ records, uint64_t n, int32_t seqIdBase, int32_t nContigs,
                                        uint64_t *__restrict__ out)
 {
   for (int32_t c = blockIdx.x * blockDim.x + threadIdx.x; c <= nContigs; c += gridDim.x * blockDim.x) {
@@ -311,14 +311,14 @@ __global__ void k_records_contig_first(const uint32_t *__restrict__ records, uin
 }
 
 // records read from a sketch file for a genome range that does not start at contig 0: seqIds relative to the range
-__global__ void k_records_rebase(uint32_t *__restrict__ records, uint64_t n, int32_t c0)
+static __global__ void k_records_rebase(uint32_t *__restrict__ records, uint64_t n, int32_t c0)
 {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) records[3 * i + 1] -= (uint32_t)c0;
 }
 
 // Exact number of distinct hashes over several index chunks (Sketch::sanityCheck needs it, winSketch.hpp:298-318): every
 // distinct hash of chunk C (its first entry in hash order) is looked up in one earlier chunk E; seen[r] is set when found.
-__global__ void k_index_mark_shared(const uint32_t *__restrict__ sHashC, uint32_t nC, const TableSlot *__restrict__ tableE, uint32_t nSlotsE, int w,
+static __global__ void k_index_mark_shared(const uint32_t *__restrict__ sHashC, uint32_t nC, const TableSlot *__restrict__ tableE, uint32_t nSlotsE, int w,
                                     uint8_t *__restrict__ seen)
 {
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nC; r += gridDim.x * blockDim.x) {
@@ -330,7 +330,7 @@ __global__ void k_index_mark_shared(const uint32_t *__restrict__ sHashC, uint32_
     if (cnt) seen[r] = 1;
   }
 }
-__global__ void k_count_flags(const uint8_t *__restrict__ flags, uint32_t n, unsigned long long *__restrict__ total)
+static __global__ void k_count_flags(const uint8_t *__restrict__ flags, uint32_t n, unsigned long long *__restrict__ total)
 {
   unsigned long long c = 0;
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) c += flags[r] != 0;
@@ -344,7 +344,7 @@ __global__ void k_count_flags(const uint8_t *__restrict__ flags, uint32_t n, uns
 // search inside one 256-position bin (~20 entries = one or two cache lines; k_l2_ranges is HBM-bound on exactly these lines)
 // instead of over the whole contig.
 constexpr int kPosSampleShift = 8;
-__global__ void k_index_pos_sample(const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
+static __global__ void k_index_pos_sample(const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
                                    const uint32_t *__restrict__ posBase, int32_t nContigs, uint32_t totalBins, uint32_t n,
                                    uint32_t *__restrict__ posSample)
 {

@@ -183,7 +183,7 @@ __device__ inline void l1_emit_candidates_stream(const L1Args &a, int f, int H, 
 // as a lane had a single probe in flight.  So a workgroup takes kL1ProbeFrags fragments at once and every lane runs that many
 // independent chains side by side.  Writes (first, cnt) per sketch hash and H per fragment.
 constexpr int kL1ProbeFrags = 4;      // (2 and 8 measure the same 10.3-11.0 ms per step: with 65 GB of table lines fetched per step the kernel runs at 6 TB/s)
-__global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
+static __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
 {
   __shared__ unsigned long long wsum[kTPB / kWave];
   const int i0 = xcd_item(blockIdx.x, gridDim.x) * kL1ProbeFrags;
@@ -327,7 +327,7 @@ __device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, ui
   } else if (lane == 0) a.fragCandOff[f] = 0;
   if (lane == 0) a.fragCandCnt[f] = nG;
 }
-__global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
+static __global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
 {
   __shared__ uint64_t hits[kL1TinyFrags][kL1HitCapTiny];
   __shared__ int V[kL1TinyFrags][kL1HitCapTiny];
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
 // still costs its dispatch — ~9 ns each with 24 KiB of LDS to reserve, 13 of the 17 ms k_l1<0, 2048> took for the 1.67 M fragment
 // visits of one rank of an 8-GPU job (profiles/r04h_bench_sim8.json.log).  One thread per fragment: fragments without hits get their
 // zero counts here, class-S fragments are appended in order (one atomic per workgroup).
-__global__ __launch_bounds__(kTPB) void k_l1_list(L1Args a, int32_t *__restrict__ list, unsigned int *__restrict__ cursor)
+static __global__ __launch_bounds__(kTPB) void k_l1_list(L1Args a, int32_t *__restrict__ list, unsigned int *__restrict__ cursor)
 {
   __shared__ unsigned int wcount[kTPB / kWave], sBase;
   const int i = blockIdx.x * kTPB + threadIdx.x;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_list(L1Args a, int32_t *__restrict_
 // look-up per hit — five more barrier-separated phases and 20 more registers (5 instead of 6 workgroups per CU): k_l1<0,2048> went
 // from 30.7 to 41.2 ms per step, bit-exact.)
 template <int HLO, int HCAP>
-__global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict__ list)
+static __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict__ list)
 {
   __shared__ uint64_t hits[HCAP];
   __shared__ int V[HCAP];
@@ -496,13 +496,13 @@ struct L1BigArgs {
   int n; int shiftSeq, shiftRank;       // key = rank << shiftRank | seqId << shiftSeq | wpos
 };
 
-__global__ void k_l1_big_info(const int32_t *__restrict__ list, uint32_t n, const int32_t *__restrict__ fragS, const int32_t *__restrict__ fragHits, int32_t *__restrict__ out)
+static __global__ void k_l1_big_info(const int32_t *__restrict__ list, uint32_t n, const int32_t *__restrict__ fragS, const int32_t *__restrict__ fragHits, int32_t *__restrict__ out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const int f = list[i]; out[2 * i] = fragS[f]; out[2 * i + 1] = fragHits[f]; }
 }
 
-__global__ __launch_bounds__(kTPB) void k_l1_big_offsets(L1Args a, L1BigArgs g)
+static __global__ __launch_bounds__(kTPB) void k_l1_big_offsets(L1Args a, L1BigArgs g)
 {
   __shared__ int ws[16];
   const int i = blockIdx.x;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_offsets(L1Args a, L1BigArgs g)
   block_array_excl_scan(ho, s, ws);
 }
 
-__global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, L1BigArgs g)
+static __global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, L1BigArgs g)
 {
   __shared__ int sho[kFragHashCapL1];
   __shared__ int sFrag;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_gather(L1Args a, L1BigArgs g)
   }
 }
 
-__global__ void k_l1_big_unpack(uint64_t *__restrict__ keys, uint64_t n, int shiftSeq, int shiftRank)
+static __global__ void k_l1_big_unpack(uint64_t *__restrict__ keys, uint64_t n, int shiftSeq, int shiftRank)
 {
   const uint64_t mSeq = (1ull << (shiftRank - shiftSeq)) - 1, mPos = (1ull << shiftSeq) - 1;
   for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (uint64_t)gridDim.x * blockDim.x) {
@@ -557,7 +557,7 @@ __global__ void k_l1_big_unpack(uint64_t *__restrict__ keys, uint64_t n, int shi
   }
 }
 
-__global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, L1BigArgs g, int *__restrict__ V)
+static __global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, L1BigArgs g, int *__restrict__ V)
 {
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(kTPB) void k_l1_big_candidates(L1Args a, L1BigArgs 
 // Reorder candidates into the reference's callback order — fragment ascending, then (seqId, start) as produced — or, for a batch
 // of several genomes, into the fragments' processing order (`order`; the candidates of one fragment stay together either way).
 // fragCandCnt and orderedOff are indexed by position in that order.
-__global__ void k_l1_order(const uint32_t *__restrict__ fragCandOff, const int32_t *__restrict__ fragCandCnt,
+static __global__ void k_l1_order(const uint32_t *__restrict__ fragCandOff, const int32_t *__restrict__ fragCandCnt,
                            const uint32_t *__restrict__ orderedOff, const int32_t *__restrict__ order, int32_t nFrag,
                            const int32_t *__restrict__ inSeq, const int32_t *__restrict__ inStart, const int32_t *__restrict__ inEnd,
                            int32_t *__restrict__ outFrag, int32_t *__restrict__ outSeq, int32_t *__restrict__ outStart,

@@ -207,7 +207,7 @@ struct L2Args {
   unsigned long long *sumEntries, *sumSteps, *sumQ;
 };
 
-__global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__restrict__ list, int32_t listCount, int32_t listBase)
+static __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__restrict__ list, int32_t listCount, int32_t listBase)
 {
   const int32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   const int32_t li = listBase + lane;
@@ -267,7 +267,7 @@ struct L2FastArgs {
   int32_t allowFast;               // test knob ANI_L2_PATH: 0 = everything to the general kernel, 2 = everything to class B
 };
 
-__global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
+static __global__ __launch_bounds__(kTPB) void k_l2_ranges(L2FastArgs a)
 {
   const int32_t c = a.c0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.c1) return;
@@ -329,7 +329,7 @@ __device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32
 // bucket holds at most two of them except in rare cases, which a wave vote sends to a binary search.
 constexpr int kL2StageEvents = 2048;        // events per wave window (4 KiB)
 constexpr int kL2CandBatch = 40;            // candidates whose descriptors are fetched at once
-__global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
+static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
   __shared__ uint32_t qs[kL2FastMaxS + 2];
   __shared__ uint32_t st2[kL2RankBuckets];
@@ -546,7 +546,7 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
 // wave vote.  Positions are not tracked at all: the window start of an evaluation is "entry number delCount", and the two
 // positions the result needs are read from the index when the stream is done.
 template <class G>
-__global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_t *__restrict__ list, const unsigned int *__restrict__ listCount)
+static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_t *__restrict__ list, const unsigned int *__restrict__ listCount)
 {
   __shared__ uint32_t lds[(kL2SimTPB / kWave) * G::kWords * kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_
 
 // candidates of the chunk that must take the general kernel -> list (order irrelevant)
 // after both simulation classes ran: slowFlag 1 = outside the fast-path limits, 3 = gap counter overflow, 0 / 8 = done
-__global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t *__restrict__ list,
+static __global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t *__restrict__ list,
                                   unsigned int *__restrict__ count, unsigned long long *__restrict__ reasons /* [4] */)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -692,7 +692,7 @@ __global__ void k_l2_collect_slow(int32_t c0, int32_t n, const int32_t *__restri
 // Candidates of a chunk ordered by the length of their code stream (counting sort on codeCount / 16): the 64 lanes of a wave
 // then run about the same number of steps instead of waiting for the longest of 64 random candidates.
 constexpr int kL2LenBuckets = 1024;      // codeCount <= 2 * 16384 -> bucket = codeCount >> 5
-__global__ __launch_bounds__(kTPB) void k_l2_len_hist(const int32_t *__restrict__ codeCount, int32_t n, unsigned int *__restrict__ hist)
+static __global__ __launch_bounds__(kTPB) void k_l2_len_hist(const int32_t *__restrict__ codeCount, int32_t n, unsigned int *__restrict__ hist)
 {
   __shared__ unsigned int h[kL2LenBuckets];
   for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) h[i] = 0;
@@ -704,12 +704,12 @@ __global__ __launch_bounds__(kTPB) void k_l2_len_hist(const int32_t *__restrict_
   block_barrier();
   for (int i = threadIdx.x; i < kL2LenBuckets; i += kTPB) if (h[i]) atomicAdd(&hist[i], h[i]);
 }
-__global__ __launch_bounds__(kTPB) void k_l2_len_scan(unsigned int *__restrict__ hist)     // one workgroup: exclusive scan in place
+static __global__ __launch_bounds__(kTPB) void k_l2_len_scan(unsigned int *__restrict__ hist)     // one workgroup: exclusive scan in place
 {
   __shared__ int ws[16];
   block_array_excl_scan((int *)hist, kL2LenBuckets, ws);
 }
-__global__ __launch_bounds__(kTPB) void k_l2_len_scatter(const int32_t *__restrict__ codeCount, int32_t c0, int32_t n,
+static __global__ __launch_bounds__(kTPB) void k_l2_len_scatter(const int32_t *__restrict__ codeCount, int32_t c0, int32_t n,
                                                          unsigned int *__restrict__ cursor, int32_t *__restrict__ order)
 {
   // one global atomic per (workgroup, bucket): ranks inside the workgroup come from LDS atomics
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kTPB) void k_l2_len_scatter(const int32_t *__restri
 }
 
 // class-B candidates of the chunk (slowFlag == 4) -> dense list
-__global__ void k_l2_collect_class(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t flag, int32_t *__restrict__ list,
+static __global__ void k_l2_collect_class(int32_t c0, int32_t n, const int32_t *__restrict__ slowFlag, int32_t flag, int32_t *__restrict__ list,
                                    unsigned int *__restrict__ count)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

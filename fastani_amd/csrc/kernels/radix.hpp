@@ -111,7 +111,7 @@ __device__ __forceinline__ void radix_status_store(unsigned long long *p, unsign
 // Digit histograms of every pass in ONE read of the keys: hist[pass * 256 + digit] (64-bit, zeroed by the host).  The index build
 // passes `soa` = true: the same read writes the position-ordered SoA arrays of the chunk (mHash / mSeq / mWpos at `soaBase + i`).
 template <class KeyT, class Src>
-__global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64_t n, int endBit, int nPasses, unsigned long long *__restrict__ hist,
+static __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64_t n, int endBit, int nPasses, unsigned long long *__restrict__ hist,
                                                           uint32_t *__restrict__ mHash, int32_t *__restrict__ mSeq, int32_t *__restrict__ mWpos)
 {
   // one copy of the counters per wave: the top digit of minimizer hashes takes a few dozen values, and 64 lanes adding to a handful of
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64_t n, i
 }
 
 // exclusive scan of every pass's 256 digit counts, in place (one workgroup, thread d = digit d)
-__global__ __launch_bounds__(kTPB) void k_radix_scan(unsigned long long *__restrict__ hist, int nPasses)
+static __global__ __launch_bounds__(kTPB) void k_radix_scan(unsigned long long *__restrict__ hist, int nPasses)
 {
   __shared__ unsigned long long part[kTPB / kWave];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kTPB) void k_radix_scan(unsigned long long *__restr
 // VGPRs) — not instruction-level tricks: 256 x 16 (the same tile, 105 VGPRs, 16 waves per CU) measured 4.7 ms per pass of 4 x 10^8
 // records against 2.7 ms for rocPRIM's onesweep (profiles/r04c_radix_kernel_stats.csv).
 template <class KeyT, class ValT, class Src>
-__global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restrict__ keysOut, ValT *__restrict__ valsOut, uint64_t n, int shift, int endBit,
+static __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restrict__ keysOut, ValT *__restrict__ valsOut, uint64_t n, int shift, int endBit,
                                                           const unsigned long long *__restrict__ digitBase, unsigned long long *__restrict__ status,
                                                           unsigned int *__restrict__ tileCounter, uint32_t tileBase, unsigned int *__restrict__ errFlag)
 {

@@ -30,7 +30,7 @@ struct FinishArgs {
   uint32_t *idBits;         // nucIdentity bits, 0 if filtered out
 };
 
-__global__ void k_finish_candidates(FinishArgs a)
+static __global__ void k_finish_candidates(FinishArgs a)
 {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.nCand) return;
@@ -54,7 +54,7 @@ struct OneWayArgs {
 };
 
 // one lane per candidate; the first candidate of each (fragment, genome) group resolves the group
-__global__ void k_oneway_bins(OneWayArgs a)
+static __global__ void k_oneway_bins(OneWayArgs a)
 {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.nCand) return;
@@ -88,7 +88,7 @@ struct PairArgs {
 // One wave per (query genome, reference genome) pair.  The genome's bins are read 64 at a time (coalesced); the float sum has
 // to follow bin order, so the non-empty lanes of each 64-bin slab are added one after the other through v_readlane — unrelated
 // pairs (nearly all of them) have no or a handful of non-empty bins and cost 27 loads + ballots per 5 Mbp reference.
-__global__ __launch_bounds__(kTPB) void k_pair_reduce(PairArgs a)
+static __global__ __launch_bounds__(kTPB) void k_pair_reduce(PairArgs a)
 {
   const long long p = ((long long)blockIdx.x * kTPB + threadIdx.x) >> 6;      // wave-uniform
   if (p >= (long long)a.nQuery * a.nRefGenomes) return;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kTPB) void k_pair_reduce(PairArgs a)
 }
 
 // mapping export for ani_map_query: compacted, candidate order preserved by a prior scan of the keep flags
-__global__ void k_emit_mappings(int32_t nCand, const int32_t *__restrict__ candFrag, const int32_t *__restrict__ candSeq,
+static __global__ void k_emit_mappings(int32_t nCand, const int32_t *__restrict__ candFrag, const int32_t *__restrict__ candSeq,
                                 const int32_t *__restrict__ refStart, const uint32_t *__restrict__ idBits,
                                 const int32_t *__restrict__ best, const int32_t *__restrict__ fragS,
                                 const int32_t *__restrict__ fragQuerySeqId, const uint32_t *__restrict__ outOff, int L,
@@ -131,14 +131,14 @@ __global__ void k_emit_mappings(int32_t nCand, const int32_t *__restrict__ candF
   m[9] = (uint32_t)fragS[f]; m[10] = (uint32_t)best[c];
 }
 
-__global__ void k_keep_flags(int32_t n, const uint32_t *__restrict__ idBits, int32_t *__restrict__ flags)
+static __global__ void k_keep_flags(int32_t n, const uint32_t *__restrict__ idBits, int32_t *__restrict__ flags)
 {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < n) flags[c] = idBits[c] != 0;
 }
 
 // out[i] = candidates of the i-th fragment in processing order (order == nullptr: fragment i)
-__global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ order, int32_t *__restrict__ out)
+static __global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, const int32_t *__restrict__ order, int32_t *__restrict__ out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -147,7 +147,7 @@ __global__ void k_clamp_counts(int32_t n, const int32_t *__restrict__ in, const 
 }
 
 // Processing order of the fragments of a multi-genome batch (see map_stage): sort key = running fragment id inside the genome
-__global__ void k_frag_order_keys(const int32_t *__restrict__ fragQSeq, int32_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
+static __global__ void k_frag_order_keys(const int32_t *__restrict__ fragQSeq, int32_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
 {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f < n) { key[f] = (uint64_t)(uint32_t)fragQSeq[f]; idx[f] = (uint32_t)f; }

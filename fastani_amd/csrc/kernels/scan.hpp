@@ -8,7 +8,7 @@ namespace ani {
 constexpr int kScanPerThread = 8;
 constexpr int kScanPerBlock = kTPB * kScanPerThread;   // 2048
 
-__global__ __launch_bounds__(kTPB) void k_scan_blocks(const int32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
+static __global__ __launch_bounds__(kTPB) void k_scan_blocks(const int32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
                                                       int32_t *__restrict__ blockTotals)
 {
   __shared__ int ws[16];
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kTPB) void k_scan_blocks(const int32_t *__restrict_
   if (threadIdx.x == 0) blockTotals[blockIdx.x] = tot;
 }
 
-__global__ void k_scan_add(uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ blockOffsets)
+static __global__ void k_scan_add(uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ blockOffsets)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] += blockOffsets[i / kScanPerBlock];

@@ -269,7 +269,7 @@ __device__ __forceinline__ void tile_winnow(const void *seq, int64_t off, int32_
 // ------------------------------------------------------------------------------------------------
 // Reference sketch, pass 1: one workgroup per tile; records go to a temporary pool in tile-arrival order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTPB) void k_sketch_tiles(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
+static __global__ __launch_bounds__(kTPB) void k_sketch_tiles(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
                                                        const int64_t *__restrict__ contigOff, const int32_t *__restrict__ contigLen,
                                                        const uint8_t *__restrict__ contigMode /* 1 = 2-bit packed, 0 = raw bytes */,
                                                        const TileDesc *__restrict__ tiles, int k, int w,
@@ -317,7 +317,7 @@ __device__ __forceinline__ int32_t owner_of(const uint32_t *__restrict__ start, 
   return lo;
 }
 
-__global__ void k_expand_tiles(const uint32_t *__restrict__ tileStart, int32_t nContigs, uint32_t nTiles, int32_t stride, TileDesc *__restrict__ tiles)
+static __global__ void k_expand_tiles(const uint32_t *__restrict__ tileStart, int32_t nContigs, uint32_t nTiles, int32_t stride, TileDesc *__restrict__ tiles)
 {
   const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
   if (T >= nTiles) return;
@@ -327,7 +327,7 @@ __global__ void k_expand_tiles(const uint32_t *__restrict__ tileStart, int32_t n
 
 // pass 2: decide, per tile, whether its provisional first record repeats the argmin that the nearest earlier
 // non-empty tile of the same contig ended with (then it is not a new minimizer, commonFunc.hpp:155).
-__global__ void k_sketch_tile_counts(const TileDesc *__restrict__ tiles, const TileMeta *__restrict__ meta, int nTiles,
+static __global__ void k_sketch_tile_counts(const TileDesc *__restrict__ tiles, const TileMeta *__restrict__ meta, int nTiles,
                                      int32_t *__restrict__ outCnt /* [nTiles] */, uint8_t *__restrict__ dropFirst)
 {
   int T = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,7 +346,7 @@ __global__ void k_sketch_tile_counts(const TileDesc *__restrict__ tiles, const T
 }
 
 // pass 3: gather the tile-ordered records into position order as 12-byte skch::MinimizerInfo records.
-__global__ __launch_bounds__(kTPB) void k_sketch_gather(const TileDesc *__restrict__ tiles, const TileMeta *__restrict__ meta,
+static __global__ __launch_bounds__(kTPB) void k_sketch_gather(const TileDesc *__restrict__ tiles, const TileMeta *__restrict__ meta,
                                                         const uint8_t *__restrict__ dropFirst, const uint32_t *__restrict__ outOff,
                                                         const uint32_t *__restrict__ poolHash, const int32_t *__restrict__ poolWpos,
                                                         int32_t seqIdBase, uint32_t *__restrict__ records /* 3 words each */)
@@ -374,7 +374,7 @@ struct FragDesc {
   int32_t start;      // first base of the fragment inside the contig (i * fragLen)
 };
 
-__global__ void k_expand_frags(const uint32_t *__restrict__ fragStart, const int32_t *__restrict__ contigGenomeLocal,
+static __global__ void k_expand_frags(const uint32_t *__restrict__ fragStart, const int32_t *__restrict__ contigGenomeLocal,
                                const int32_t *__restrict__ contigQSeqBase, int32_t nContigs, uint32_t nFrags, int32_t fragLen,
                                FragDesc *__restrict__ frags, int32_t *__restrict__ fragGenome, int32_t *__restrict__ fragQSeq)
 {
@@ -454,7 +454,7 @@ __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ se
 // SINGLE: the fragment fits one tile (fragLen - k + 1 <= kTile, the default 3 kb fragments): the minimizer staging buffer then
 // reuses the window-key array, which is dead once the tile is winnowed — 26 KiB of LDS per workgroup instead of 42.
 template <bool SINGLE>
-__global__ __launch_bounds__(kTPB, SINGLE ? 4 : 3) void k_fragment_sketch(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
+static __global__ __launch_bounds__(kTPB, SINGLE ? 4 : 3) void k_fragment_sketch(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
                                                           const int64_t *__restrict__ contigOff, const uint8_t *__restrict__ contigMode,
                                                           const FragDesc *__restrict__ frags, int fragLen, int k, int w,
                                                           uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
@@ -486,7 +486,7 @@ struct FusedInfo {
   int32_t fragLocal0;   // local position of the fragment's first base
 };
 
-__global__ void k_expand_fused(const uint32_t *__restrict__ tileStart, const uint32_t *__restrict__ fragStart, int32_t nContigs, uint32_t nTiles,
+static __global__ void k_expand_fused(const uint32_t *__restrict__ tileStart, const uint32_t *__restrict__ fragStart, int32_t nContigs, uint32_t nTiles,
                                int32_t fragLen, int32_t w, int32_t stride, TileDesc *__restrict__ tiles, FusedInfo *__restrict__ info)
 {
   const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
@@ -530,7 +530,7 @@ __device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool over
 }
 
 // one wave per fragment: its sketch from the striped pool to its place in the packed pool; fragOff is rewritten
-__global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, uint32_t *__restrict__ fragOff, const int32_t *__restrict__ s, const uint32_t *__restrict__ newOff,
+static __global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, uint32_t *__restrict__ fragOff, const int32_t *__restrict__ s, const uint32_t *__restrict__ newOff,
                                      uint32_t nFrag, uint32_t *__restrict__ out)
 {
   const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -610,7 +610,7 @@ __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, in
   fragment_finish(hbuf, overflow ? kFragHashCap : total, overflow, fi.frag, qPool, qCap, qCount, fragOff, fragS, maxS, ws, sBasePtr);
 }
 
-__global__ __launch_bounds__(kTPB, 3) void k_sketch_fused(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
+static __global__ __launch_bounds__(kTPB, 3) void k_sketch_fused(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
                                                           const int64_t *__restrict__ contigOff, const int32_t *__restrict__ contigLen, const uint8_t *__restrict__ contigMode,
                                                           const TileDesc *__restrict__ tiles, const FusedInfo *__restrict__ info, int k, int w, int fragLen,
                                                           uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap, unsigned long long *__restrict__ poolCount,

@@ -171,7 +171,7 @@ int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGeno
 
 /* Reference sets larger than the device memory (BASELINE configs[4]; the reference's own answer is the database split of
  * computeCoreIdentity.hpp:457-487 / scripts/splitDatabase.sh with every query mapped against every split): when the index
- * (~45 bytes per minimizer) does not fit beside a working-set reserve — or when ANI_MAX_RESIDENT_CHUNKS says so — the sketch keeps
+ * (~36 bytes per minimizer) does not fit beside a working-set reserve — or when ANI_MAX_RESIDENT_CHUNKS says so — the sketch keeps
  * the 12-byte minimizer records and at most `maxResident` chunks' index arrays; the mapping entry points then walk the set chunk by
  * chunk (build, map every query sub-batch, drop).  Results are identical.  Reports the mode. */
 int ani_sketch_residency(const ani_sketch *sk, int32_t *streaming, int32_t *maxResident, int32_t *residentNow);

@@ -114,7 +114,7 @@ def test_limits(emu_engine):
 
 
 def test_l2_code_overflow_halves_the_chunk(monkeypatch):
-    """a chunk whose 16-bit code stream would pass the offset limit is cut in half and redone (ani_abi.hip, L2 chunk loop);
+    """a chunk whose 16-bit code stream would pass the offset limit is cut in half and redone (engine_map.hip, L2 chunk loop);
     the limit is lowered through a test knob so that small inputs reach the branch"""
     e = _emu_engine_with(monkeypatch, ANI_L2_CODE_LIMIT=6000, ANI_L2_CHUNK=64)
     e.reset_counters()

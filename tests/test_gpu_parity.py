@@ -372,3 +372,14 @@ def test_same_hash_links_rerun(monkeypatch):
     pc.case_low_complexity(e)
     pc.case_gap_counter_overflow(e)
     e.close()
+
+
+@pytest.mark.gpu
+def test_l2_without_the_side_stream(monkeypatch):
+    """since round 4 the L2 simulation of a chunk runs on the side stream beside the next chunk's ranges / codes kernels; ANI_L2_OVERLAP=0
+    is the serial order of rounds 1-3: same results (tiny L2 chunks: many hand-overs between the two streams)"""
+    for ov in ("0", "1"):
+        e = _engine_with(monkeypatch, ANI_L2_OVERLAP=ov, ANI_L2_CHUNK=97)
+        pc.case_synthetic_cluster(e, 60000)
+        pc.case_tandem_repeats(e)
+        e.close()

@@ -42,6 +42,12 @@ if has quick; then
   timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify 2> "$OUT/quick.err" | tee "$OUT/quick.json.log" | cut -c1-900
   tail -3 "$OUT/quick.err"
 fi
+if has overlap; then
+  echo "== bench with ANI_L2_OVERLAP=1 / =0 (A/B on one box)"
+  for v in 1 0 1 0; do
+    ANI_L2_OVERLAP=$v timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('overlap=$v', d['ms_per_step'], d['stage_ms_per_step_rank0'])" | tee -a "$OUT/overlap_ab.txt"
+  done
+fi
 if has bench; then
   echo "== bench" | tee "$OUT/bench.log"
   timeout 900 python bench.py --steps 10 --warmup 2 2> "$OUT/bench.err" | tee "$OUT/bench.json.log" | cut -c1-900
@@ -93,7 +99,7 @@ if has c4; then
 fi
 if has c5; then
   echo "== c5: ${C5_GENOMES:-30000} references (streamed index) x 300 queries"
-  ANI_POOL_TRACE=${C5_TRACE:-} timeout 1500 python bench.py --config c5 --genomes ${C5_GENOMES:-30000} --queries 300 --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --oracle-pairs 60 2> "$OUT/bench_c5.err" | tee "$OUT/bench_c5.json.log" | cut -c1-900
+  timeout 1500 python bench.py --config c5 --genomes ${C5_GENOMES:-30000} --queries 300 --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --oracle-pairs 60 2> "$OUT/bench_c5.err" | tee "$OUT/bench_c5.json.log" | cut -c1-900
   tail -3 "$OUT/bench_c5.err"
 fi
 if has o2m; then

@@ -1,6 +1,6 @@
 """Static view of one kernel's device assembly: basic blocks with their instruction mix (VALU / SALU / LDS / VMEM / multiplies).
 usage: python tools/isa_blocks.py <dev.s> <kernel name substring> [min instructions]
-(dev.s: hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only ani_abi.hip).  The integer kernels of this library are
+(dev.s: hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only engine_map.hip — or whichever unit launches the kernel).  The integer kernels of this library are
 instruction-issue-bound, so the instruction count of the hot blocks is the figure of merit that can be read
 without a GPU."""
 import collections
