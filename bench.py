@@ -612,10 +612,12 @@ def step_single(R):
 
 def step_ring(R):
     """reference-sharded all-vs-all (fastani_amd/multi_gpu.py): this rank's genomes hashed once for both roles, indexed here and
-    nowhere else; then N ring steps, each mapping one rank's fragment set against the shard while the next one arrives.
+    nowhere else; the ranks' packed fragment sets are all-gathered (ONE collective) while the rank maps its own set, then the N - 1
+    foreign sets are mapped as one merged set (ANI_BENCH_EXCHANGE=ring: the round-3 ring, one hop and one mapping call per set).
     STRONG scaling: the job (NR x NR pairs) is fixed, every stage of it shards."""
     from fastani_amd.api import Sketch
-    from fastani_amd.multi_gpu import ring_map
+    from fastani_amd.multi_gpu import gather_map, ring_map
+    exchange = ring_map if os.environ.get("ANI_BENCH_EXCHANGE", "gather") == "ring" else gather_map
     e, p, T = R.e, R.p, R.timers
     t_a = time.perf_counter()
     ptr, n, frags = e.sketch_records_self(p, R.my_refs, 0)
@@ -625,7 +627,7 @@ def step_ring(R):
         e.device_free(ptr)
     t_d = time.perf_counter()
     rt = {}
-    rows = ring_map(e, sk, frags, R.part_g0, R.lo, R.dist, R.rank, R.world, ring_alloc_fn(R), lambda: dev_sync(R), rt)
+    rows = exchange(e, sk, frags, R.part_g0, R.lo, R.dist, R.rank, R.world, ring_alloc_fn(R), lambda: dev_sync(R), rt)
     frags.close()
     sk.close()
     T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3
@@ -677,27 +679,31 @@ def step_gather(R):
 
 
 def prepare_simulation(R):
-    """--simulate-world W: the fragment sets the other W - 1 ranks would send, made here (untimed) and packed the way the ring moves them"""
+    """--simulate-world W: the fragment sets the other W - 1 ranks would contribute to the all-gather, made here (untimed) and packed
+    into the slots of one buffer the way the collective leaves them"""
     from fastani_amd.api import DeviceGenomes
     e, p = R.e, R.p
-    R.sim_bufs = []
+    sets = []
     for x in range(R.W):
         g0, g1 = int(R.part_g0[x]), int(R.part_g0[x + 1])
         ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(R.ref_buf.data_ptr(), R.NR, R.L, first=g0, count=g1 - g0), 0)
         if n:
             e.device_free(ptr)
-        nb = fr.packed_bytes()
-        t = R.torch.empty(nb, dtype=R.torch.uint8, device=R.dev)
-        fr.pack_into(t.data_ptr(), nb)
+        sets.append(fr)
+    R.sim_cap = (max(fr.packed_bytes() for fr in sets) + 255) // 256 * 256
+    R.sim_buf = R.torch.empty(R.sim_cap * R.W, dtype=R.torch.uint8, device=R.dev)
+    for x, fr in enumerate(sets):
+        fr.pack_into(R.sim_buf.data_ptr() + x * R.sim_cap, R.sim_cap)
         fr.close()
-        R.sim_bufs.append((t, nb))
     dev_sync(R)
 
 
 def step_simulate(R):
-    """the compute of rank r of a W-rank ring job, alone on this GPU: its shard sketched and indexed, its own set packed, then W
-    mapping calls — its own set and the W - 1 sets the ring would deliver (they are already here: no communication is timed)"""
+    """the compute of rank r of a W-rank job, alone on this GPU: its shard sketched and indexed, its own set packed into its slot and
+    mapped, then the W - 1 foreign sets — already in their slots: no communication is timed — mapped as one merged set
+    (ANI_BENCH_EXCHANGE=ring: one mapping call per set, the round-3 ring)"""
     from fastani_amd.api import FragmentSet, Sketch
+    import numpy as np
     e, p, T = R.e, R.p, R.timers
     t_a = time.perf_counter()
     ptr, n, frags = e.sketch_records_self(p, R.my_refs, 0)
@@ -706,25 +712,30 @@ def step_simulate(R):
     if n:
         e.device_free(ptr)
     t_d = time.perf_counter()
-    own_t, own_nb = R.sim_bufs[R.r]
-    frags.pack_into(own_t.data_ptr(), own_nb)
-    frags.close()
+    base = R.sim_buf.data_ptr()
+    frags.pack_into(base + R.r * R.sim_cap, R.sim_cap)
     dev_sync(R)
     t_p = time.perf_counter()
     out = []
-    for s in range(R.W):
-        src = (R.r - s) % R.W
-        t, nb = R.sim_bufs[src]
-        view = FragmentSet.unpack(e, t.data_ptr(), nb, keepalive=t)
-        rows = sk.map_cgi_fragset(view, int(R.part_g0[src]))
-        view.close()
-        rows["refGenomeId"] += R.lo
-        out.append(rows)
+    if os.environ.get("ANI_BENCH_EXCHANGE", "gather") == "ring":
+        frags.close()
+        for s in range(R.W):
+            src = (R.r - s) % R.W
+            view = FragmentSet.unpack(e, base + src * R.sim_cap, R.sim_cap, keepalive=R.sim_buf)
+            out.append(sk.map_cgi_fragset(view, int(R.part_g0[src])))
+            view.close()
+    else:
+        out.append(sk.map_cgi_fragset(frags, int(R.part_g0[R.r])))
+        frags.close()
+        merged = FragmentSet.unpack_merged(e, base, R.sim_cap, [int(R.part_g0[s]) if s != R.r else -1 for s in range(R.W)], keepalive=R.sim_buf)
+        out.append(sk.map_cgi_fragset(merged, 0))
+        merged.close()
     t_e = time.perf_counter()
     sk.close()
+    rows = np.concatenate(out)
+    rows["refGenomeId"] += R.lo
     T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["ring_pack_ms"] += (t_p - t_d) * 1e3; T["map_ms"] += (t_e - t_p) * 1e3
-    import numpy as np
-    return np.concatenate(out)
+    return rows
 
 
 STEPS = {"single": step_single, "ring": step_ring, "gather": step_gather, "simulate": step_simulate}
@@ -784,7 +795,7 @@ def gather_rank_info(R, res, steps, mode):
     gathered = torch.empty(R.world * nv, dtype=torch.float64, device=R.dev)
     dist.all_gather_into_tensor(gathered, mine_info)
     g = gathered.view(R.world, nv).tolist()
-    info = {"ranks_seen_by_rccl": dist.get_world_size(), "mode": "reference-sharded ring (fastani_amd/multi_gpu.py)" if mode == "ring" else "query-sharded, reference records all-gathered",
+    info = {"ranks_seen_by_rccl": dist.get_world_size(), "mode": ("reference-sharded, fragment sets all-gathered (fastani_amd/multi_gpu.py: gather_map)" if os.environ.get("ANI_BENCH_EXCHANGE", "gather") != "ring" else "reference-sharded ring (fastani_amd/multi_gpu.py: ring_map)") if mode == "ring" else "query-sharded, reference records all-gathered",
             "timeline_note": "per rank, ms per step: ref_records = sketching the rank's references, fragsketch = its queries' fragment sketches (runs while the records are "
                              "all-gathered), allgather = the part of the gather not hidden behind it, index = index build, map = mapping + reduce + rows to the host, "
                              "ring_pack / ring_wait = packing the fragment set / waiting for the next set of the ring, other = the rest of the step",
@@ -792,7 +803,7 @@ def gather_rank_info(R, res, steps, mode):
     for i, k in enumerate(TIMER_KEYS + ["other_ms"]):
         info[k] = [round(x[1 + i], 2) for x in g]
     info["rows"] = [int(x[-1]) for x in g]
-    info["bytes_moved_per_rank"] = (int(getattr(R.e, "_ring_bufs", (("", 0),))[0][1]) * (R.world - 1)) if mode == "ring" else int((R.slot + 1) * 12 * (R.world - 1))
+    info["bytes_moved_per_rank"] = (int(getattr(R.e, "_ring_bufs", (("", 0, 0),))[0][1]) * (R.world - 1)) if mode == "ring" else int((R.slot + 1) * 12 * (R.world - 1))
     return info
 
 
@@ -935,7 +946,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
     if sim:
         how = "; SIMULATED rank %d of a %d-rank reference-sharded ring job on one GPU (its compute only, no communication)" % (R.r, R.W)
     elif world > 1 or R.multi:
-        how = ("; STRONG scaling: references sharded %d ways, query fragment sketches ring-passed over RCCL" % world if mode == "ring"
+        how = ("; STRONG scaling: references sharded %d ways, query fragment sketches all-gathered over RCCL" % world if mode == "ring"
                else "; WEAK scaling: queries sharded %d ways (%d per GPU), reference sketch all-gathered over RCCL" % (world, nq_local))
     out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -952,9 +963,9 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
                                                                           "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments", "l1TinyFragments")},
            "roofline": roof}
     if sim:
-        out["simulated"] = {"world": R.W, "rank": R.r, "what": "value = %d x %d pairs / the time ONE rank of a %d-GPU strong-scaling job computes (sketch + index of its %d genomes, %d mapping calls); "
-                                                              "the ring's transfers (one packed fragment set per hop, %d bytes) overlap the mapping and are not in it"
-                                                              % (NR, NR, R.W, R.hi - R.lo, R.W, R.sim_bufs[R.r][1]),
+        out["simulated"] = {"world": R.W, "rank": R.r, "what": "value = %d x %d pairs / the time ONE rank of a %d-GPU strong-scaling job computes (sketch + index of its %d genomes, %d mapping calls: its own set, the others merged); "
+                                                              "the all-gather of the packed fragment sets (%d bytes per rank) runs under the mapping of the rank's own set and is not in it"
+                                                              % (NR, NR, R.W, R.hi - R.lo, 2, R.sim_cap),
                             "n_gpus_simulated": R.W}
     if getattr(R, "last_residency", None):
         out["config"]["residency"] = R.last_residency

@@ -99,6 +99,7 @@ def _bind(lib):
         "ani_fragset_pack_bytes": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
         "ani_fragset_pack": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
         "ani_fragset_unpack": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(vp)]),
+        "ani_fragset_unpack_merged": (C.c_int, [vp, vp, C.c_size_t, C.c_int32, vp, C.POINTER(vp)]),
         "ani_sketch_residency": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "ani_map_cgi_batch": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
@@ -343,6 +344,15 @@ class FragmentSet:
         """view of a packed set at dev_ptr (the arrays stay in that buffer: pass its owner as keepalive)"""
         h = C.c_void_p()
         engine._chk(engine.lib.ani_fragset_unpack(engine.h, dev_ptr, nbytes, C.byref(h)))
+        return FragmentSet(engine, h, keepalive)
+
+    @staticmethod
+    def unpack_merged(engine, dev_ptr, slot_bytes, slot_query_base, keepalive=None):
+        """ONE set over the packed sets at dev_ptr + i * slot_bytes (an all-gather's output); slot_query_base[i] = query id of slot i's
+        first genome, or -1 to leave the slot out.  Map it with first_query_id = 0."""
+        q = np.ascontiguousarray(slot_query_base, dtype=np.int32)
+        h = C.c_void_p()
+        engine._chk(engine.lib.ani_fragset_unpack_merged(engine.h, dev_ptr, slot_bytes, len(q), q.ctypes.data, C.byref(h)))
         return FragmentSet(engine, h, keepalive)
 
     def close(self):

@@ -406,7 +406,7 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &f
 
 // the dense table of a sub-batch (all chunks reduced) -> rows in (query, reference genome) order, appended to `rows`
 // (`block`: the table is the compact one of that chunk — reference genome = block->g0 + column)
-int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows, const IndexChunk *block = nullptr)
+int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows, const IndexChunk *block = nullptr, const int32_t *queryIds = nullptr)
 {
   const int32_t nCols = block ? block->nGenomes : set->nGenomes, col0 = block ? block->g0 : 0;
   const size_t nPairs = (size_t)nQuery * (size_t)nCols;
@@ -424,7 +424,7 @@ int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuer
     const uint32_t *cnt = dense + (size_t)qi * (size_t)nCols, *idb = cnt + nPairs;
     for (int32_t g = 0; g < nCols; g++) {
       if (!cnt[g]) continue;
-      ani_cgi_t r; r.refGenomeId = col0 + g; r.qryGenomeId = firstQueryId + qi; r.countSeq = (int32_t)cnt[g];
+      ani_cgi_t r; r.refGenomeId = col0 + g; r.qryGenomeId = firstQueryId + (queryIds ? queryIds[qi] : qi); r.countSeq = (int32_t)cnt[g];
       r.totalQueryFragments = fs.genomeFragments[qi];
       memcpy(&r.identity, &idb[g], 4);
       *out++ = r;
@@ -435,7 +435,7 @@ int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuer
 }
 
 // Map + reduce for the fragments of `fs` (a whole set or a slice of one) against every index chunk (all resident); rows appended
-int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows)
+int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows, const int32_t *queryIds = nullptr)
 {
   TRY(upload_luts(sk, fs.maxS));
   for (IndexChunk *ch : sk->chunks) {
@@ -443,7 +443,7 @@ int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery,
     TRY(map_stage(ctx, sk, ch, fs, &nCand));
     TRY(reduce_stage(ctx, sk, ch, fs, nCand, nQuery));
   }
-  return collect_rows(ctx, sk, fs, nQuery, firstQueryId, rows);
+  return collect_rows(ctx, sk, fs, nQuery, firstQueryId, rows, nullptr, queryIds);
 }
 
 // Sub-batches of kept fragment sets, mapped against a whole reference set.  A resident set is walked sub-batch by sub-batch (every
@@ -451,7 +451,7 @@ int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery,
 // map every sub-batch of every set against it, drop it — so that each chunk is built once per call however many query genomes
 // there are (the reference's own loop has the same shape: per reference split, all queries; core_genome_identity.cpp:55-106);
 // the rows of a sub-batch then come chunk by chunk and are put back into (query, reference) order at the end.
-struct SubBatch { const ani_fragset *set; int32_t g0, g1, firstQueryId; FragSet v; };
+struct SubBatch { const ani_fragset *set; int32_t g0, g1, firstQueryId; FragSet v; const int32_t *queryIds; };   // queryIds: per genome, relative to firstQueryId (merged sets), else consecutive
 int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_fragset *> &sets, const std::vector<int32_t> &firstQueryIds, RowBuf *rows)
 {
   std::vector<SubBatch> sub;
@@ -471,7 +471,9 @@ int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_frags
                                                                  ((uint64_t)2 << 30) / (8ull * (uint64_t)std::max<int32_t>(sk->nGenomes, 1))));
       while (g1 < nG && (g1 == g0 || ((uint64_t)(f->genomeFragStart[g1] - f->genomeFragStart[g0]) < ctx->subBatchFragments && (uint64_t)(g1 - g0) < maxQ))) g1++;
       const int64_t fA = f->genomeFragStart[g0], fB = f->genomeFragStart[g1];
-      SubBatch sb; sb.set = f; sb.g0 = g0; sb.g1 = g1; sb.firstQueryId = firstQueryIds[si] + g0;
+      SubBatch sb; sb.set = f; sb.g0 = g0; sb.g1 = g1;
+      sb.queryIds = f->genomeQueryId.empty() ? nullptr : f->genomeQueryId.data() + g0;
+      sb.firstQueryId = firstQueryIds[si] + (sb.queryIds ? 0 : g0);
       FragSet &v = sb.v;                                       // slice [g0, g1) of the kept set
       v.nFrag = (int32_t)(fB - fA); v.maxS = f->fs.maxS; v.poolSize = f->fs.poolSize;
       v.genomeFragments.assign(f->fs.genomeFragments.begin() + g0, f->fs.genomeFragments.begin() + g1);
@@ -483,7 +485,7 @@ int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_frags
     }
   }
   if (!sk->streaming) {
-    for (const SubBatch &sb : sub) TRY(map_fragset(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, rows));
+    for (const SubBatch &sb : sub) TRY(map_fragset(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, rows, sb.queryIds));
     return ANI_OK;
   }
   TRY(upload_luts(sk, maxS));
@@ -496,7 +498,7 @@ int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_frags
       int32_t nCand = 0;
       TRY(map_stage(ctx, sk, ch, sb.v, &nCand));
       TRY(reduce_stage(ctx, sk, ch, sb.v, nCand, sb.g1 - sb.g0, true));
-      TRY(collect_rows(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, &part[i], ch));
+      TRY(collect_rows(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, &part[i], ch, sb.queryIds));
     }
   }
   // a sub-batch's rows are (chunk, query, reference)-ordered and a chunk's references all precede the next chunk's: a stable
@@ -508,10 +510,12 @@ int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_frags
     ani_cgi_t *out = rows->grow(pb.n);
     if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", pb.n);
     const int32_t q0 = sub[i].firstQueryId, nq = sub[i].g1 - sub[i].g0;
+    const int32_t *ids = sub[i].queryIds;          // a merged set: the genomes' query ids (ascending), relative to q0; else consecutive
+    auto slot_of = [&](int32_t id) -> size_t { return ids ? (size_t)(std::lower_bound(ids, ids + nq, id - q0) - ids) : (size_t)(id - q0); };
     std::vector<size_t> start((size_t)nq + 1, 0);
-    for (size_t r = 0; r < pb.n; r++) start[(size_t)(pb.p[r].qryGenomeId - q0) + 1]++;
+    for (size_t r = 0; r < pb.n; r++) start[slot_of(pb.p[r].qryGenomeId) + 1]++;
     for (int32_t q = 0; q < nq; q++) start[(size_t)q + 1] += start[(size_t)q];
-    for (size_t r = 0; r < pb.n; r++) out[start[(size_t)(pb.p[r].qryGenomeId - q0)]++] = pb.p[r];
+    for (size_t r = 0; r < pb.n; r++) out[start[slot_of(pb.p[r].qryGenomeId)]++] = pb.p[r];
     rows->n += pb.n;
     free(pb.p); pb.p = nullptr; pb.n = pb.cap = 0;                  // host memory of a big run: give each part back as soon as it is merged
   }

@@ -259,8 +259,9 @@ int fragment_stage(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, F
 
 void fragset_release(ani_fragset *f)
 {
-  void *ptrs[] = {f->arr.fragOff, f->arr.fragS, f->arr.fragGenome, f->arr.fragQSeq, f->qPool};
-  if (!f->borrowed) for (void *q : ptrs) if (q) pool_free(q);
+  void *tables[] = {f->arr.fragOff, f->arr.fragS, f->arr.fragGenome, f->arr.fragQSeq};
+  if (!f->borrowed || f->ownTables) for (void *q : tables) if (q) pool_free(q);
+  if (!f->borrowed && f->qPool) pool_free(f->qPool);
   delete f;
 }
 void fragset_finish(ani_fragset *f)
@@ -481,6 +482,75 @@ int ani_fragset_unpack(ani_ctx *ctx, const void *devBuf, size_t bytes, ani_frags
   f->arr.fragGenome = (int32_t *)(b + h.offFragGenome); f->arr.fragQSeq = (int32_t *)(b + h.offFragQSeq);
   f->qPool = (uint32_t *)(b + h.offPool);
   f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq; f->fs.qPool = f->qPool; f->fs.genomeBase = 0;
+  fragset_finish(f);
+  *out = f;
+  return ANI_OK;
+}
+
+// ONE set over several packed sets that lie in one device buffer at a fixed pitch — what an all-gather of the ranks' packed sets
+// delivers.  The hash pools stay where they are (the merged pool IS the buffer: sketch offsets are rebased, so the buffer must span
+// less than 2^32 hashes); the per-fragment tables are copied into tables of the set's own.  slotQueryBase[i] = query id of slot i's
+// first genome, or < 0 to leave the slot out (a rank's own slot).  Mapping the merged set costs one pass of the L1 / L2 kernels where
+// the sets one by one cost one pass each — and a set that meets a foreign reference shard is all launch latency.
+int ani_fragset_unpack_merged(ani_ctx *ctx, const void *devBuf, size_t slotBytes, int32_t nSlots, const int32_t *slotQueryBase, ani_fragset **out)
+{
+  if (!ctx || !devBuf || !out || nSlots < 0 || (nSlots && !slotQueryBase)) return fail(ANI_ERR_ARG, "null argument");
+  if (slotBytes % 256 != 0 || slotBytes < 256) return fail(ANI_ERR_ARG, "slot pitch must be a multiple of 256 bytes");
+  if ((uint64_t)slotBytes * (uint64_t)nSlots / 4 > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "gathered fragment sets span more than 2^32 hashes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const uint8_t *base = (const uint8_t *)devBuf;
+  std::vector<FragWireHeader> hs((size_t)nSlots);
+  for (int32_t i = 0; i < nSlots; i++) if (slotQueryBase[i] >= 0) HIP_TRY(hipMemcpyAsync(&hs[i], base + (size_t)i * slotBytes, sizeof(FragWireHeader), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ani_fragset *f = new ani_fragset();
+  f->ctx = ctx; f->device = ctx->device; f->borrowed = true; f->ownTables = true;
+  auto bail = [&](int rc) { fragset_release(f); return rc; };
+  uint64_t nF = 0; int32_t nG = 0; bool first = true;
+  for (int32_t i = 0; i < nSlots; i++) {
+    if (slotQueryBase[i] < 0) continue;
+    const FragWireHeader &h = hs[i];
+    if (memcmp(h.magic, "ANIFRAGS", 8) != 0 || h.version != 1 || h.nFrag < 0 || h.nGenomes < 0 || h.totalBytes > slotBytes || h.nHashes > h.poolSize) return bail(fail(ANI_ERR_ARG, "slot %d is not a packed fragment set", i));
+    ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen; tmp.params.percentageIdentity = h.percentageIdentity;
+    tmp.fs.nFrag = h.nFrag; tmp.fs.poolSize = h.poolSize; tmp.fs.genomeFragments.assign((size_t)h.nGenomes, 0);
+    const FragWireHeader want = wire_header(&tmp);
+    if (want.offFragOff != h.offFragOff || want.offFragS != h.offFragS || want.offFragGenome != h.offFragGenome || want.offFragQSeq != h.offFragQSeq || want.offPool != h.offPool || want.totalBytes != h.totalBytes)
+      return bail(fail(ANI_ERR_ARG, "slot %d: packed fragment set is malformed", i));
+    if (first) { f->params = tmp.params; const int rc = check_params(&f->params); if (rc != ANI_OK) return bail(rc); first = false; }
+    else if (f->params.kmerSize != h.kmerSize || f->params.windowSize != h.windowSize || f->params.fragLen != h.fragLen) return bail(fail(ANI_ERR_ARG, "slot %d was sketched with other parameters", i));
+    nF += (uint64_t)h.nFrag; nG += h.nGenomes;
+    if (nF > 0x3fffffffull) return bail(fail(ANI_ERR_LIMIT, "too many fragments in the merged set"));
+  }
+  if (first) { f->params.kmerSize = 16; f->params.windowSize = 1; f->params.fragLen = 3000; f->params.percentageIdentity = 80.0f; }      // nothing to merge: an empty set
+  f->fs.nFrag = (int32_t)nF; f->fs.poolSize = (uint64_t)slotBytes * (uint64_t)nSlots / 4; f->fs.genomeBase = 0;
+  f->qPool = (uint32_t *)const_cast<void *>(devBuf); f->fs.qPool = f->qPool;
+  if (nF) {
+    hipError_t e = pool_malloc((void **)&f->arr.fragOff, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragS, nF * 4);
+    if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragGenome, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragQSeq, nF * 4);
+    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "tables of the merged fragment set: %s", hipGetErrorString(e)));
+  }
+  uint64_t fAt = 0; int32_t gAt = 0;
+  std::vector<int32_t> gf;
+  for (int32_t i = 0; i < nSlots; i++) {
+    if (slotQueryBase[i] < 0) continue;
+    const FragWireHeader &h = hs[i];
+    const uint8_t *b = base + (size_t)i * slotBytes;
+    gf.assign((size_t)h.nGenomes, 0);
+    if (h.nGenomes) { const hipError_t e = hipMemcpy(gf.data(), b + h.offGenomeFragments, (size_t)h.nGenomes * 4, hipMemcpyDeviceToHost); if (e != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "reading slot %d: %s", i, hipGetErrorString(e))); }
+    int64_t sum = 0;
+    for (int32_t v : gf) { if (v < 0) { sum = -1; break; } sum += v; }
+    if (sum != (int64_t)h.nFrag) return bail(fail(ANI_ERR_ARG, "slot %d: genome table does not add up to the fragment count", i));
+    for (int32_t g = 0; g < h.nGenomes; g++) { f->fs.genomeFragments.push_back(gf[g]); f->genomeQueryId.push_back(slotQueryBase[i] + g); }
+    if (h.nFrag) {
+      const uint32_t addOff = (uint32_t)(((size_t)i * slotBytes + h.offPool) / 4);
+      hipLaunchKernelGGL(k_fragset_rebase, dim3(std::min<unsigned>(grid_for((size_t)h.nFrag), 65535u)), dim3(256), 0, ctx->stream, (uint32_t)h.nFrag, (const uint32_t *)(b + h.offFragOff), (const int32_t *)(b + h.offFragS),
+                         (const int32_t *)(b + h.offFragGenome), (const int32_t *)(b + h.offFragQSeq), addOff, gAt,
+                         f->arr.fragOff + fAt, f->arr.fragS + fAt, f->arr.fragGenome + fAt, f->arr.fragQSeq + fAt);
+    }
+    f->fs.maxS = std::max(f->fs.maxS, h.maxS); f->fs.nHashes += h.nHashes;
+    fAt += (uint64_t)h.nFrag; gAt += h.nGenomes;
+  }
+  { const hipError_t e = hipGetLastError(); const hipError_t e2 = hipStreamSynchronize(ctx->stream); if (e != hipSuccess || e2 != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "merging fragment sets failed")); }
+  f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq;
   fragset_finish(f);
   *out = f;
   return ANI_OK;

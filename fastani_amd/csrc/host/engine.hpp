@@ -426,6 +426,8 @@ struct ani_fragset {
   FragArrays arr; uint32_t *qPool = nullptr;
   bool borrowed = false;           // the arrays live in a caller's buffer (ani_fragset_unpack): not freed with the set
   std::vector<int64_t> genomeFragStart;     // prefix of fs.genomeFragments
+  std::vector<int32_t> genomeQueryId;       // merged sets (ani_fragset_unpack_merged): the query id of every genome, relative to the call's firstQueryId
+  bool ownTables = false;                   // ... whose per-fragment tables are the set's own while the pool is borrowed
 };
 
 

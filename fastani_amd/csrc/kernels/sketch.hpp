@@ -533,13 +533,24 @@ __device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool over
 static __global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, uint32_t *__restrict__ fragOff, const int32_t *__restrict__ s, const uint32_t *__restrict__ newOff,
                                      uint32_t nFrag, uint32_t *__restrict__ out)
 {
-  const uint32_t f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const uint32_t f = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;      // (64-bit: 64 threads per fragment pass 2^32 at 2^26 fragments)
   if (f >= nFrag) return;
   const uint32_t src = fragOff[f], dst = newOff[f];
   const int n = s[f];
   for (int i = (int)lane; i < n; i += 64) out[dst + i] = pool[src + i];
   ANI_WAVE_SYNC();                                  // every lane has read fragOff[f]
   if (lane == 0) fragOff[f] = dst;
+}
+
+// the per-fragment tables of one packed fragment set (ani_fragset_pack) into their place in the tables of a merged set: sketch
+// offsets rebased to the merged pool, genome numbers to the merged genome list
+static __global__ void k_fragset_rebase(uint32_t n, const uint32_t *__restrict__ srcOff, const int32_t *__restrict__ srcS, const int32_t *__restrict__ srcGenome,
+                                        const int32_t *__restrict__ srcQSeq, uint32_t addOff, int32_t addGenome,
+                                        uint32_t *__restrict__ dstOff, int32_t *__restrict__ dstS, int32_t *__restrict__ dstGenome, int32_t *__restrict__ dstQSeq)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    dstOff[i] = srcOff[i] + addOff; dstS[i] = srcS[i]; dstGenome[i] = srcGenome[i] + addGenome; dstQSeq[i] = srcQSeq[i];
+  }
 }
 
 template <bool PACKED>

@@ -1,5 +1,12 @@
 """Reference-sharded many-to-many over the GPUs of one node (one process per GPU; torch.distributed: "nccl" = RCCL over xGMI).
 
+Two forms of the same exchange.  gather_map (round 4, what bench.py runs): ONE all-gather of the ranks' packed fragment sets, started
+before the rank maps its own set and waited for after it; the N - 1 foreign sets are then mapped in ONE call as a merged set
+(ani_fragset_unpack_merged).  ring_map (round 3): the sets go round a ring, one hop and one mapping call per step.  A fragment set
+that meets a foreign shard is almost all launch latency (~107 chance seed hits and 0.7 candidates per fragment against 125 genomes),
+so seven small passes of the L1 / L2 kernels cost more than one pass over seven sets: per rank of an 8-GPU 1000 x 1000 job 51 -> 45 ms
+(bench.py --simulate-world 8).
+
 The query-sharded form of SURVEY.md section 8e (every GPU holds the whole reference index) stops scaling where the index stops
 fitting: N GPUs hold exactly as many references as one, and every rank repeats the whole index build.  Here the REFERENCES are
 sharded: rank r sketches and indexes genomes [g0[r], g0[r+1]) only (1/N of the index memory and of the build), and what travels
@@ -73,3 +80,51 @@ def ring_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, al
         t["wait_ms"] += (t3 - t2) * 1e3
         cur = 1 - cur
     return np.concatenate(out) if out else np.zeros(0, dtype=rows.dtype)
+
+
+def gather_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, alloc, sync, timers=None):
+    """Same contract as ring_map.  The packed sets are all-gathered (slot = the largest set, agreed by one tiny all-reduce) while this
+    rank maps its own set; the foreign sets are mapped as ONE merged set over the gather buffer."""
+    import torch
+    t = timers if timers is not None else {}
+    for k in ("pack_ms", "map_ms", "wait_ms"):
+        t.setdefault(k, 0.0)
+    t0 = time.perf_counter()
+    nb = frags.packed_bytes()
+    cap = nb
+    if world > 1:
+        m = torch.tensor([nb], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            m = m.cuda()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        cap = int(m.item())
+    cap = (cap + 255) // 256 * 256
+    key = ("gather_buf", cap, world)
+    bufs = getattr(engine, "_ring_bufs", None)
+    if bufs is None or bufs[0] != key:
+        bufs = (key, [alloc(cap * world)])
+        engine._ring_bufs = bufs
+    buf, ptr = bufs[1][0]
+    mine = buf[rank * cap:(rank + 1) * cap]
+    frags.pack_into(ptr + rank * cap, cap)
+    sync()
+    work = dist.all_gather_into_tensor(buf, mine, async_op=True) if world > 1 else None      # the one collective of the path ...
+    t1 = time.perf_counter()
+    out = [sk.map_cgi_fragset(frags, int(first_query_ids[rank]))]                              # ... under the mapping of the rank's own set
+    t2 = time.perf_counter()
+    if work is not None:
+        work.wait()
+        sync()
+        t3 = time.perf_counter()
+        base = [int(first_query_ids[s]) if s != rank else -1 for s in range(world)]
+        merged = FragmentSet.unpack_merged(engine, ptr, cap, base, keepalive=buf)
+        out.append(sk.map_cgi_fragset(merged, 0))
+        merged.close()
+        t4 = time.perf_counter()
+        t["wait_ms"] += (t3 - t2) * 1e3
+        t["map_ms"] += (t4 - t3) * 1e3
+    t["pack_ms"] += (t1 - t0) * 1e3
+    t["map_ms"] += (t2 - t1) * 1e3
+    rows = np.concatenate(out)
+    rows["refGenomeId"] += ref_base
+    return rows

@@ -248,6 +248,14 @@ int ani_fragset_info(const ani_fragset *frags, int32_t *nGenomes, int64_t *nFrag
 int ani_fragset_pack_bytes(const ani_fragset *frags, size_t *bytes);
 int ani_fragset_pack(ani_ctx *ctx, const ani_fragset *frags, void *devBuf, size_t cap, size_t *bytes);
 int ani_fragset_unpack(ani_ctx *ctx, const void *devBuf, size_t bytes, ani_fragset **out);
+/* ONE set over several packed sets that lie in one device buffer at a fixed pitch (slot i at devBuf + i * slotBytes) — what an
+ * all-gather of the ranks' packed sets delivers.  slotQueryBase[i] = query id of slot i's first genome (ascending over the slots),
+ * or < 0 to leave the slot out (the rank's own); rows come back with qryGenomeId = firstQueryId + that id.  The hash pools stay in
+ * devBuf (which must outlive the set and span < 2^32 hashes); only the per-fragment tables are copied.  Mapping the merged set is one
+ * pass of the kernels instead of one per set — the reference's loop has this shape too: per reference split, ALL queries
+ * (core_genome_identity.cpp:55-106). */
+int ani_fragset_unpack_merged(ani_ctx *ctx, const void *devBuf, size_t slotBytes, int32_t nSlots, const int32_t *slotQueryBase,
+                              ani_fragset **out);
 
 /* ---- reducer: replaces cgi::computeCGI (computeCoreIdentity.hpp:166-298) for one query genome ---- */
 int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *sk, const ani_mapping_t *mappings, size_t n,

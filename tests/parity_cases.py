@@ -406,6 +406,30 @@ def case_fragset_wire(engine, alloc):
             raise AssertionError("a truncated buffer must be rejected")
         except AniError as e:
             assert e.code == -1
+    # several packed sets in the slots of one buffer (an all-gather's output) as ONE merged set: slot 1 left out (the rank's own), an
+    # empty slot in between, query ids from the slots' bases — the rows of the included genomes, under those ids
+    parts = [genomes[:2], genomes[2:3], [[b"ACGT"]], genomes[3:]]
+    sets = [engine.fragment_set(p, g) for g in parts]
+    pitch = (max(x.packed_bytes() for x in sets) + 255) // 256 * 256
+    mbuf, mptr = alloc(pitch * len(sets) + 1024)
+    mptr = (mptr + 255) // 256 * 256
+    for i, x in enumerate(sets):
+        x.pack_into(mptr + i * pitch, pitch)
+        x.close()
+    bases = [0, -1, 50, 3]                           # genomes 0,1 -> ids 0,1; slot 1 out; the 4-base genome -> id 50 (no fragments); genomes 3,4 -> ids 3,4
+    mv = FragmentSet.unpack_merged(engine, mptr, pitch, bases, keepalive=mbuf)
+    assert mv.info()["genomes"] == 5
+    got = sk.map_cgi_fragset(mv, 0)
+    want = rows0[rows0["qryGenomeId"] != 2]
+    assert np.array_equal(got, want), (got, want)
+    got100 = sk.map_cgi_fragset(mv, 100)
+    assert np.array_equal(got100["qryGenomeId"], want["qryGenomeId"] + 100) and np.array_equal(got100["identity"], want["identity"])
+    mv.close()
+    try:
+        FragmentSet.unpack_merged(engine, mptr + 256, pitch, bases)
+        raise AssertionError("slots that do not start with a packed set must be rejected")
+    except AniError as e:
+        assert e.code == -1
     # an empty set travels too
     f0 = engine.fragment_set(p, [[b"ACGT"]])
     n0 = f0.pack_into(ptr, nb)

@@ -61,7 +61,7 @@ def _worker(rank, world, port, out_dir, n_genomes):
     dist.destroy_process_group()
 
 
-def _ring_worker(rank, world, port, out_dir, n_genomes):
+def _ring_worker(rank, world, port, out_dir, n_genomes, exchange="ring"):
     """the reference-sharded step of bench.py --config c4 (fastani_amd/multi_gpu.py): every rank sketches and indexes ITS genomes
     only (fused all-vs-all pass: reference records + kept fragment sketches), the packed fragment sets go round the ring and every
     rank maps every set against its shard"""
@@ -71,7 +71,7 @@ def _ring_worker(rank, world, port, out_dir, n_genomes):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from fastani_amd.api import Engine, HostGenomes, Sketch
-    from fastani_amd.multi_gpu import ring_map
+    from fastani_amd.multi_gpu import gather_map, ring_map
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -92,20 +92,21 @@ def _ring_worker(rank, world, port, out_dir, n_genomes):
         t = torch.zeros(nbytes, dtype=torch.uint8)
         return t, t.data_ptr()
     timers = {}
-    rows = ring_map(e, sk, frags, part_g0, lo, dist, rank, world, alloc, lambda: None, timers)
+    rows = (ring_map if exchange == "ring" else gather_map)(e, sk, frags, part_g0, lo, dist, rank, world, alloc, lambda: None, timers)
     frags.close()
     np.save(os.path.join(out_dir, "ring%d.npy" % rank), rows)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_genomes", [(2, 5), (4, 3)])
-def test_reference_sharded_ring_matches_single_process(tmp_path, emu_engine, world, n_genomes):
-    """world 4 with 3 genomes: rank 0 has no genome at all — an empty index and an empty fragment set still travel the ring"""
+@pytest.mark.parametrize("world,n_genomes,exchange", [(2, 5, "ring"), (4, 3, "ring"), (2, 5, "gather"), (4, 3, "gather"), (4, 5, "gather")])
+def test_reference_sharded_ring_matches_single_process(tmp_path, emu_engine, world, n_genomes, exchange):
+    """world 4 with 3 genomes: rank 0 has no genome at all — an empty index and an empty fragment set still take part in the exchange
+    (ring: one hop and one mapping call per set; gather: ONE all-gather, the foreign sets mapped as one merged set)"""
     import torch.multiprocessing as mp
     from fastani_amd.api import Sketch
-    port = 29900 + (os.getpid() % 400) + 10 * world + n_genomes
-    mp.spawn(_ring_worker, args=(world, port, str(tmp_path), n_genomes), nprocs=world, join=True)
+    port = 29900 + (os.getpid() % 400) + 10 * world + n_genomes + (50 if exchange == "gather" else 0)
+    mp.spawn(_ring_worker, args=(world, port, str(tmp_path), n_genomes, exchange), nprocs=world, join=True)
     genomes = _genomes(n_genomes)
     p = emu_engine.params()
     single = Sketch(emu_engine, p, genomes).map_cgi_batch(genomes, 0)
@@ -173,7 +174,7 @@ def test_bench_orchestration_two_ranks(config, scaling, emu_engine, tmp_path):
     strong = not (config == "many-to-many" and scaling == "weak")
     assert out["scaling"] == ("strong" if strong else "weak")
     if strong:
-        assert out["config"]["query_genomes"] == 6 and sum(ranks["rows"]) == 36 and "ring" in ranks["mode"]
+        assert out["config"]["query_genomes"] == 6 and sum(ranks["rows"]) == 36 and "reference-sharded" in ranks["mode"]
         assert ranks["bytes_moved_per_rank"] > 0
         if config == "many-to-many":
             wl = out["weak_scaling_leg"]

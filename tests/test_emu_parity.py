@@ -150,3 +150,14 @@ def test_same_hash_links_rerun(monkeypatch):
     pc.case_low_complexity(e)
     pc.case_gap_counter_overflow(e)
     e.close()
+
+
+def test_merged_fragment_sets_on_a_streamed_reference_set(monkeypatch):
+    """a merged set (ani_fragset_unpack_merged: non-consecutive query ids) mapped against a reference set that is streamed chunk by
+    chunk: the rows of a sub-batch come chunk by chunk and are put back into (query, reference) order through the id table"""
+    def alloc(nbytes):
+        a = np.zeros(nbytes // 4 + 4, dtype=np.uint32)
+        return a, a.ctypes.data
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=1, ANI_SUBBATCH_FRAGS=9)
+    pc.case_fragset_wire(e, alloc)
+    e.close()

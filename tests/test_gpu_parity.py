@@ -383,3 +383,17 @@ def test_l2_without_the_side_stream(monkeypatch):
         pc.case_synthetic_cluster(e, 60000)
         pc.case_tandem_repeats(e)
         e.close()
+
+
+@pytest.mark.gpu
+def test_merged_fragment_sets_on_a_streamed_reference_set(monkeypatch):
+    """a merged set (ani_fragset_unpack_merged: non-consecutive query ids) mapped against a reference set that is streamed chunk by
+    chunk: the rows of a sub-batch come chunk by chunk and are put back into (query, reference) order through the id table"""
+    import torch
+
+    def alloc(nbytes):
+        t = torch.zeros(nbytes // 4 + 4, dtype=torch.int32, device="cuda:0")
+        return t, t.data_ptr()
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=1, ANI_SUBBATCH_FRAGS=9)
+    pc.case_fragset_wire(e, alloc)
+    e.close()

@@ -56,7 +56,7 @@ def test_bench_over_rccl_one_rank(gpu_engine, tmp_path, config, scaling):
     assert out["rows_identical_across_steps"] and out["data"] == "synthetic"
     strong = not (config == "many-to-many" and scaling == "weak")
     assert out["scaling"] == ("strong" if strong else "weak") and out["config"]["mode"] == ("ring" if strong else "gather")
-    assert ("ring" in ranks["mode"]) == strong
+    assert ("reference-sharded" in ranks["mode"]) == strong
     got = _sorted(np.load(dump + ".rank0.npy"))
     assert np.array_equal(got, single)
     assert out["parity_timed_rows"]["ok"] and out["parity_timed_rows"]["vs_oracle"]["pairs_with_rows"] > 0        # and the oracle agrees, bit for bit
