@@ -914,8 +914,10 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
             roof["frac_note"] = "achieved / frac = the L2 stage as a whole (its kernels share one set of algorithmic bytes); kernel_achieved / kernel_frac = the dominant kernel alone; whole_job = the step"
     roof["int_ops"] = int_ops_block(c, args.steps, fused)
     roof["bound_note"] = ("'hbm' by the algorithmic-byte accounting of SURVEY.md section 8d (12 B per reference minimizer in a candidate range); what "
-                          "limits k_l2_sim is vector instruction issue: its VALU wave-instructions x 4 cycles are 86 % of the kernel's SIMD cycles at 2.5 "
-                          "waves per SIMD (LDS-bound occupancy), profiles/r02X_pmc_sq_summary.txt; its HBM traffic is roofline.traffic, a third of the algorithmic bytes")
+                          "limits k_l2_sim and k_l2_codes is vector instruction issue (k_l2_sim: VALU wave-instructions x 4 cycles = 86 % of its SIMD cycles at 2.5 "
+                          "waves per SIMD, profiles/r02X_pmc_sq_summary.txt); since round 4 the simulation of a chunk runs on a side stream beside the next chunk's "
+                          "codes kernel (ANI_L2_OVERLAP=0 serialises them: stage +3.6 ms), so the two kernels' own durations — HIP events here, rocprofv3 in "
+                          "profiles/ — are those of kernels that share the machine and add up to more than the stage; the stage figure (achieved / frac) is the one to read")
     # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
     # + WRITE_SIZE, per launch) — only quoted when it is this default workload
     try:
@@ -933,7 +935,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
                     break
     except Exception:
         pass
-    if dom == "ani::k_l2_sim":
+    if dom in ("ani::k_l2_sim", "ani::k_l2_codes"):          # one launch of each per L2 chunk
         launches = max(1, c["l2Launches"])
         roof.update({"launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
                      "algorithmic_bytes_per_launch": round(nbytes / launches, 1)})
