@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--simulate-rank", type=int, default=0)
     ap.add_argument("--dump-rows", default="", help="write the rows of the last timed step to <path>[.rank<r>].npy (tests)")
     ap.add_argument("--slice-genomes", type=int, default=1000, help="c5: genomes generated and sketched per slice")
+    ap.add_argument("--ref-block", type=int, default=0, help="c5: reference genomes indexed and mapped together (0 = as many as keep the records in a third of the device memory)")
     ap.add_argument("--genomes", type=int, default=0, help="reference genomes (0 = the config's: 1000, c4: 10000, c5: 30000)")
     ap.add_argument("--queries", type=int, default=0, help="query genomes per GPU (0 = the config's)")
     ap.add_argument("--genome-len", type=int, default=5_000_000)
@@ -474,6 +475,14 @@ def make_inputs(R):
             raise SystemExit("--config c5 is a single-GPU run (on N GPUs configs[4] is the reference-sharded ring of --config c4 with more genomes)")
         R.nq_local = min(a.queries or 300, NR)
         R.slice_n = min(a.slice_genomes, NR)
+        R.ref_block = a.ref_block
+        if R.ref_block <= 0:
+            # ~ 2 L / (w + 1) minimizers of 12 bytes per genome; a third of the device memory for the records leaves room for an
+            # index chunk (36 bytes per minimizer of the chunk), the mapping pools and the slice buffers
+            per_genome = 12.0 * 2.0 * L / 25.0 * 1.05
+            total = torch.cuda.get_device_properties(R.dev).total_memory if not R.emu else 1 << 40
+            R.ref_block = max(R.slice_n, int(total / 3 / per_genome) // R.slice_n * R.slice_n)
+        R.ref_block = min(R.ref_block, NR)
         R.ref_buf = torch.empty(R.slice_n * words + 64, dtype=torch.int32, device=R.dev)
         R.qry_buf = torch.empty(R.nq_local * words + 64, dtype=torch.int32, device=R.dev)
         e.synth_packed(a.seed, 0, R.nq_local, L, R.qry_buf.data_ptr(), variant=0, cluster_size=a.cluster_size)
@@ -557,6 +566,7 @@ def ring_alloc_fn(R):
 # ---------------------------------------------------------------------------------------------------------------------------
 def step_single(R):
     """one GPU: reference sketch + index (skch::Sketch), every query mapped (skch::Map) and reduced (cgi::computeCGI)"""
+    import numpy as np
     from fastani_amd.api import DeviceGenomes, Sketch
     e, p, T = R.e, R.p, R.timers
     t_a = time.perf_counter()
@@ -565,29 +575,46 @@ def step_single(R):
         # a large set in slices of 1000 genomes (a slice's minimizers and sketch hashes are 32-bit counts): record parts (+ kept
         # fragment sets when the genomes are queries too), ONE index over the parts — handed over to the library, so a streamed set
         # keeps them without a copy — and ONE mapping call (a streamed set builds each chunk once)
-        parts, sets, firsts = [], [], []
         c5 = R.args.config == "c5"
         step_n = R.slice_n if c5 else R.self_slice
-        for s0 in range(0, R.NR, step_n):
-            s1 = min(R.NR, s0 + step_n)
-            if c5:
-                e.synth_packed(R.args.seed, s0, s1 - s0, R.L, R.ref_buf.data_ptr(), variant=0, cluster_size=R.args.cluster_size)
-                ptr, n = e.sketch_records(p, DeviceGenomes(R.ref_buf.data_ptr(), s1 - s0, R.L), s0)
-            else:
-                ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(R.ref_buf.data_ptr(), R.NR, R.L, first=s0, count=s1 - s0), s0)
-                sets.append(fr); firsts.append(s0)
-            parts.append((ptr, n, s0))
-        t_b = time.perf_counter()
-        sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [R.NR], R.contig_len, R.gcs), adopt=True)
-        t_d = time.perf_counter()
-        rows = sk.map_cgi_batch(R.qrys, R.first_query_id) if c5 else sk.map_cgi_fragsets(sets, firsts)
-        t_e = time.perf_counter()
-        R.last_residency = sk.residency()
-        for fr in sets:
-            fr.close()
-        sk.close()
-        T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
-        return rows
+        # c5 beyond the memory that holds the set's RECORDS (12 bytes per minimizer: 60 000 genomes of 5 Mbp fill the GPU): the set
+        # is taken in blocks of --ref-block genomes, each block sketched, indexed (streamed chunk by chunk), mapped by every query
+        # and dropped — a (query, reference) result does not depend on what else is indexed, and the reference
+        # does the same with its database splits (core_genome_identity.cpp:55-121, computeCoreIdentity.hpp:457-487)
+        block = R.ref_block if c5 else R.NR
+        out = []
+        R.last_residency = None
+        R.blocks_last_step = 0
+        for b0 in range(0, R.NR, block):
+            b1 = min(R.NR, b0 + block)
+            parts, sets, firsts = [], [], []
+            t_a = time.perf_counter()
+            for s0 in range(b0, b1, step_n):
+                s1 = min(b1, s0 + step_n)
+                if c5:
+                    e.synth_packed(R.args.seed, s0, s1 - s0, R.L, R.ref_buf.data_ptr(), variant=0, cluster_size=R.args.cluster_size)
+                    ptr, n = e.sketch_records(p, DeviceGenomes(R.ref_buf.data_ptr(), s1 - s0, R.L), s0 - b0)
+                else:
+                    ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(R.ref_buf.data_ptr(), R.NR, R.L, first=s0, count=s1 - s0), s0)
+                    sets.append(fr); firsts.append(s0)
+                parts.append((ptr, n, s0 - b0))
+            t_b = time.perf_counter()
+            sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [b1 - b0],
+                                            R.contig_len[:b1 - b0], R.gcs[:b1 - b0 + 1]), adopt=True)
+            t_d = time.perf_counter()
+            rows = sk.map_cgi_batch(R.qrys, R.first_query_id) if c5 else sk.map_cgi_fragsets(sets, firsts)
+            rows["refGenomeId"] += b0
+            out.append(rows)
+            t_e = time.perf_counter()
+            res = sk.residency()
+            R.last_residency = res if R.last_residency is None else dict(streaming=res["streaming"] or R.last_residency["streaming"],
+                                                                         max_resident=max(res["max_resident"], R.last_residency["max_resident"]), resident_now=res["resident_now"])
+            R.blocks_last_step += 1
+            for fr in sets:
+                fr.close()
+            sk.close()
+            T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
+        return out[0] if len(out) == 1 else np.concatenate(out)
     if R.self_mode:
         # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
         ptr, n, frags = e.sketch_records_self(p, R.refs, 0)
@@ -943,7 +970,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
     wl = {"many-to-many": "many-to-many %dx%d" % (NR, n_queries_total), "one-to-many": "one-to-many 1x%d (query = cluster 0 member 1)" % NR,
           "c4": "many-to-many %dx%d (configs[3] shape, all-vs-all%s)" % (NR, n_queries_total, "" if n_queries_total == NR else ", query count bounded by --queries"),
           "c5": "many-to-many %dx%d (configs[4] shape: a reference set beyond the device memory's index capacity, streamed; the set is generated and sketched slice by slice, "
-                "only its minimizer records stay resident)" % (NR, n_queries_total)}[cfg]
+                "only the minimizer records of one block of references stay resident)" % (NR, n_queries_total)}[cfg]
     how = ""
     if sim:
         how = "; SIMULATED rank %d of a %d-rank reference-sharded ring job on one GPU (its compute only, no communication)" % (R.r, R.W)
@@ -971,6 +998,9 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
                             "n_gpus_simulated": R.W}
     if getattr(R, "last_residency", None):
         out["config"]["residency"] = R.last_residency
+    if cfg == "c5":
+        out["config"]["ref_block"] = {"genomes": R.ref_block, "blocks": getattr(R, "blocks_last_step", 1),
+                                      "what": "the reference set is indexed and mapped in blocks of this many genomes (records of one block resident at a time)"}
     if rank_info:
         out["ranks"] = rank_info
     if weak_leg:

@@ -242,6 +242,17 @@ __device__ inline int block_array_excl_scan(int *a, int n, int *ws)
 #define ANI_WAVE_SYNC() (void)__ballot(1)
 #endif
 
+// A value that is the same in every lane of the wave, moved to a scalar register: comparisons against it take it as the scalar
+// operand, branches on it are scalar branches and a loop that carries it carries no vector copies.  (The compiler cannot know that
+// something read from LDS or derived from threadIdx.x >> 6 is wave-uniform; the CPU stand-in needs nothing.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+#else
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return x; }
+#endif
+__device__ __forceinline__ int32_t wave_uniform(int32_t x) { return (int32_t)wave_uniform((uint32_t)x); }
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t x) { return (uint64_t)wave_uniform((uint32_t)x) | ((uint64_t)wave_uniform((uint32_t)(x >> 32)) << 32); }
+
 // Bitonic sort of n2 (power of two) keys in LDS, ascending, by the whole workgroup.
 // Two consecutive stages (strides 2h and h) are fused: a thread loads the four elements i0 + {0, h, 2h, 3h}, runs the four
 // compare-exchanges of both stages in registers and stores them back — half the LDS passes of the plain network.

@@ -331,7 +331,7 @@ static __global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
 {
   __shared__ uint64_t hits[kL1TinyFrags][kL1HitCapTiny];
   __shared__ int V[kL1TinyFrags][kL1HitCapTiny];
-  const int wv = threadIdx.x >> 6;
+  const int wv = wave_uniform((int32_t)(threadIdx.x >> 6));                  // the wave's fragment, its counts and offsets: scalar registers
   const int i = xcd_item(blockIdx.x, gridDim.x) * kL1TinyFrags + wv;
   if (i >= a.nFrag) return;
   const int f = a.fragOrder ? a.fragOrder[i] : i;

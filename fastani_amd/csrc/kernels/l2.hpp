@@ -332,11 +332,11 @@ constexpr int kL2CandBatch = 40;            // candidates whose descriptors are 
 static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
 {
   __shared__ uint32_t qs[kL2FastMaxS + 2];
-  __shared__ uint32_t st2[kL2RankBuckets];
+  __shared__ __attribute__((aligned(16))) uint32_t st2[kL2RankBuckets];
   __shared__ __attribute__((aligned(16))) uint16_t stageAll[(kTPB / kWave) * kL2StageEvents];
   __shared__ L2Range cRange[kL2CandBatch];         // the candidates' descriptors, fetched side by side (nEvents < 0: no stream)
   __shared__ uint64_t cOff[kL2CandBatch];
-  uint16_t *st = stageAll;                         // the plain rank table is only needed to build st2 (2050 of the 8192 entries)
+  __shared__ int cRangeScan[8];                    // scratch of the workgroup scan
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive fragments of a query map to overlapping
   // reference ranges, so XCD x takes a contiguous eighth of the chunk's fragments: neighbours share their reference reads in L2.
   const int32_t per = (int32_t)(gridDim.x >> 3);
@@ -363,22 +363,41 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     }
   };
   fetch_cands(cA);
-  for (int i = threadIdx.x; i < s; i += kTPB) qs[i] = q[i];
-  if (threadIdx.x < 2) qs[s + threadIdx.x] = 0xffffffffu;             // the two-entry probe may read one or two slots past the sketch
-  // rank table: st[b] = #{q : bucket(q) < b}; st2[b] = st[b] | entries of bucket b << 16
+  // Rank table: st2[b] = #{q : bucket(q) < b} | entries of bucket b << 16.  Counted and scanned (one LDS atomic per sketch hash on
+  // 16-bit counters packed in pairs, eight buckets per thread, one workgroup scan) — the first form walked, per sketch hash, the
+  // buckets up to the next hash: a loop as long as the longest gap among the 64 hashes of a wave.
+  static_assert(kL2FastMaxS <= 2 * kTPB && kL2RankBuckets == 8 * kTPB, "two sketch hashes and eight buckets per thread");
   const int sh = a.g.rankShift;
-  for (int i = threadIdx.x; i <= s; i += kTPB) {
-    const int b0 = i > 0 ? l2_rank_bucket(q[i - 1], sh) + 1 : 0;
-    const int b1 = i < s ? l2_rank_bucket(q[i], sh) : kL2RankBuckets;
-    for (int b = b0; b <= b1; b++) st[b] = (uint16_t)i;
-  }
+  uint32_t *cnt2 = (uint32_t *)stageAll;           // kL2RankBuckets / 2 dwords of the windows, which are free until the waves start
+  { uint4 z; z.x = z.y = z.z = z.w = 0u; ((uint4 *)cnt2)[threadIdx.x] = z; }
+  const int i0 = (int)threadIdx.x, i1 = (int)threadIdx.x + kTPB;
+  const uint32_t q0 = i0 < s ? q[i0] : 0xffffffffu, q1 = i1 < s ? q[i1] : 0xffffffffu;
+  if (i0 < s) qs[i0] = q0;
+  if (i1 < s) qs[i1] = q1;
+  if (threadIdx.x < 2) qs[s + threadIdx.x] = 0xffffffffu;             // the two-entry probe may read one or two slots past the sketch
   block_barrier();
-  for (int b = threadIdx.x; b < kL2RankBuckets; b += kTPB) st2[b] = (uint32_t)st[b] | ((uint32_t)(st[b + 1] - st[b]) << 16);
-  block_barrier();                                 // from here on the waves go their own ways; `st` is dead, the windows are free
+  if (i0 < s) { const int b = l2_rank_bucket(q0, sh); atomicAdd(&cnt2[b >> 1], 1u << ((b & 1) << 4)); }
+  if (i1 < s) { const int b = l2_rank_bucket(q1, sh); atomicAdd(&cnt2[b >> 1], 1u << ((b & 1) << 4)); }
+  block_barrier();
+  {
+    const uint4 c4 = ((const uint4 *)cnt2)[threadIdx.x];               // buckets 8 t .. 8 t + 7
+    const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
+    uint32_t n[8], loc[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { n[j] = (j & 1) ? (cw[j >> 1] >> 16) : (cw[j >> 1] & 0xffffu); loc[j] = sum; sum += n[j]; }
+    int tot;
+    const uint32_t base = (uint32_t)block_excl_scan((int)sum, (int *)cRangeScan, &tot);
+    uint4 o0, o1;
+    o0.x = (base + loc[0]) | (n[0] << 16); o0.y = (base + loc[1]) | (n[1] << 16); o0.z = (base + loc[2]) | (n[2] << 16); o0.w = (base + loc[3]) | (n[3] << 16);
+    o1.x = (base + loc[4]) | (n[4] << 16); o1.y = (base + loc[5]) | (n[5] << 16); o1.z = (base + loc[6]) | (n[6] << 16); o1.w = (base + loc[7]) | (n[7] << 16);
+    ((uint4 *)st2)[2 * threadIdx.x] = o0; ((uint4 *)st2)[2 * threadIdx.x + 1] = o1;
+  }
+  block_barrier();                                 // from here on the waves go their own ways; the counters are dead, the windows are free
 
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1), wv = wave_uniform((int32_t)(threadIdx.x >> 6));
   uint16_t *stage = stageAll + wv * kL2StageEvents;
-  // Work items of this wave = (candidate, pass of 4 * 64 entries), in order.
+  // Work items of this wave = (candidate, pass of 4 * 64 entries), in order.  Everything in an item is wave-uniform and kept in
+  // scalar registers (wave_uniform): the item loop then branches on scalars and the per-entry bounds tests take scalar operands.
   struct Item {
     int32_t c; uint32_t jb;                          // candidate, first entry of the pass
     char *ob; const char *hb, *wb;                   // wave-uniform bases: event stream, hashes, window links (32-bit byte offsets per lane)
@@ -388,10 +407,12 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   int32_t batch0 = cA, batch1 = cA + kL2CandBatch < cB ? cA + kL2CandBatch : cB;      // candidates whose descriptors are in LDS
   auto open_cand = [&](int32_t c, Item &it) -> bool {          // first candidate >= c of this wave (within the batch) that has a stream
     for (; c < batch1; c += kTPB / kWave) {
-      const L2Range r = cRange[c - batch0];
+      L2Range r = cRange[c - batch0];
+      r.nEvents = wave_uniform(r.nEvents);
       if (r.nEvents < 0) continue;
+      r.beg0 = wave_uniform(r.beg0); r.end0 = wave_uniform(r.end0); r.last = wave_uniform(r.last);
       it.c = c; it.jb = 0;
-      it.ob = (char *)((uint16_t *)a.codes + cOff[c - batch0]);
+      it.ob = (char *)((uint16_t *)a.codes + wave_uniform(cOff[c - batch0]));
       it.hb = (const char *)(a.g.mHash + r.beg0); it.wb = (const char *)(a.g.mWin + r.beg0);
       it.m = (uint32_t)(r.last - r.beg0);
       it.nInit = (uint32_t)(r.end0 - r.beg0); it.nInsAll = it.m - 1;          // inserts (first window included) are the entries [0, m-1)
@@ -449,22 +470,30 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
     }
     // Two events per entry, stored without control flow: an event that does not exist (entries beyond the range, the never-inserted
     // last entry, entries that never leave) goes to the pad slot behind the stream (k_l2_ranges reserves one).
+    uint32_t pi[4], pd[4]; uint16_t ci[4], cdl[4];
+    const uint32_t dumpSlot = cur.dump;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const uint32_t x = cur.jb + lane + e * kWave;
       const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
-      const uint32_t dIns = 2u - (rk[e] & 1u);                                          // field change of the insert; the delete's is its negative (3-bit two's complement)
+      // field change of the event, 3-bit two's complement: insert +2 (010), of a query hash +1 (001); delete -2 (110) / -1 (111)
+      const uint32_t mq = 0u - (rk[e] & 1u);                                            // all ones for a query hash
       // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
       const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
-      const uint32_t pi = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : cur.dump;
-      const uint16_t ci = (uint16_t)(cd | kL2InsBit | (x + 1 < cur.nInit ? kL2NoEvalBit : 0u) | (dIns << kL2DeltaShift));
+      pi[e] = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dumpSlot;
+      ci[e] = (uint16_t)((cd | kL2InsBit | (2u << kL2DeltaShift) | ((int32_t)x < (int32_t)cur.nInit - 1 ? kL2NoEvalBit : 0u)) ^ (mq & (3u << kL2DeltaShift)));
       // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
       // window's)
       const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
-      const uint32_t pd = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : cur.dump;
-      const uint16_t cdl = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (((8u - dIns) & 7u) << kL2DeltaShift));   // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
-      if (cur.staged) { stage[pi] = ci; stage[pd] = cdl; }                              // wave-uniform choice
-      else { *(uint16_t *)(cur.ob + pi * 2u) = ci; *(uint16_t *)(cur.ob + pd * 2u) = cdl; }
+      pd[e] = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : dumpSlot;
+      cdl[e] = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));   // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+    }
+    if (cur.staged) {                                                                   // wave-uniform choice
+#pragma unroll
+      for (int e = 0; e < 4; e++) { stage[pi[e]] = ci[e]; stage[pd[e]] = cdl[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { *(uint16_t *)(cur.ob + pi[e] * 2u) = ci[e]; *(uint16_t *)(cur.ob + pd[e] * 2u) = cdl[e]; }
     }
     if (cur.staged && cur.lastPass) {                // the candidate's stream is complete in the window: write it out
       ANI_WAVE_SYNC();

@@ -198,3 +198,30 @@ def test_bench_orchestration_two_ranks(config, scaling, emu_engine, tmp_path):
     else:
         # rank 0 maps variant 0 (= the references themselves), rank 1 variant 1 with query ids 6..11
         assert np.array_equal(got[got["qryGenomeId"] < 6], single) and len(got) == 72
+
+
+def test_bench_c5_reference_blocks(emu_engine, tmp_path):
+    """bench.py --config c5 with the reference set taken in BLOCKS (--ref-block: each block of genomes sketched slice by slice,
+    indexed, mapped by every query and dropped — how a set whose records exceed the device memory runs on one GPU): the rows equal
+    those of one index over the whole set, whatever the block and slice sizes."""
+    import json
+    import subprocess
+    from fastani_amd.api import DeviceGenomes, Sketch
+    L, n, nq = 24000, 7, 3
+    words = (L + 15) // 16
+    buf = np.zeros(n * words + 64, dtype=np.uint32)
+    emu_engine.synth_packed(20260925, 0, n, L, buf.ctypes.data)
+    p = emu_engine.params()
+    single = Sketch(emu_engine, p, DeviceGenomes(buf.ctypes.data, n, L)).map_cgi_batch(DeviceGenomes(buf.ctypes.data, nq, L), 0)
+    assert len(single) >= 2 * nq
+    for block, slc in ((3, 2), (4, 4), (7, 3)):
+        dump = os.path.join(str(tmp_path), "rows_%d_%d" % (block, slc))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "c5", "--genomes", str(n), "--queries", str(nq),
+                            "--genome-len", str(L), "--ref-block", str(block), "--slice-genomes", str(slc), "--dump-rows", dump],
+                           capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=1200)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+        assert out["config"]["ref_block"]["genomes"] == block and out["config"]["ref_block"]["blocks"] == -(-n // block)
+        got = np.load(dump + ".npy")
+        got = got[np.lexsort((got["refGenomeId"], got["qryGenomeId"]))]
+        assert np.array_equal(got, single)
