@@ -318,13 +318,20 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
             e2e_out = os.path.join(td, "e2e.out")
             threads = min(hi["logical_cpus"], 64)
             t0 = time.time()
-            r = subprocess.run([cli, "--ql", lst, "--rl", lst, "-t", str(threads), "-o", e2e_out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                               env=dict(os.environ, ANI_CLI_TRACE="1"))
+            r = subprocess.Popen([cli, "--ql", lst, "--rl", lst, "-t", str(threads), "-o", e2e_out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                 env=dict(os.environ, ANI_CLI_TRACE="1"))
+            err_lines, stamps = [], []
+            for raw in r.stderr:                                  # the arrival time of every line: what lies before main() and behind its last line
+                err_lines.append(raw.decode(errors="replace").rstrip("\n")); stamps.append(time.time() - t0)
+            r.wait()
             t_e2e = time.time() - t0
             e2e = {"seconds": round(t_e2e, 2), "pairs_per_s": round(n_refs * n_refs / t_e2e, 1), "threads": threads, "returncode": r.returncode,
                    "what": "fastani_amd/fastANI --ql all --rl all (%d x %d FASTA files, %.1f GB, local disk) -> output file; first FASTA byte to output closed"
                            % (n_refs, n_refs, out["fasta_set"]["bytes"] / 1e9)}
-            err_lines = r.stderr.decode(errors="replace").splitlines()
+            marks = [(st, float(ln.split()[2])) for ln, st in zip(err_lines, stamps) if ln.startswith("[fastANI trace]")]
+            if marks:
+                e2e["outside_main"] = {"process_start_to_main_s": round(max(0.0, marks[0][0] - marks[0][1]), 3), "last_mark_to_exit_s": round(t_e2e - marks[-1][0], 3),
+                                       "what": "the launcher's clock against the command line's own phase marks: loading the HIP runtime before main(), and the process going away (device and page-locked memory released by the driver) after the output is closed"}
             tl = [ln for ln in err_lines if "Time spent sketching" in ln or "Time spent writing" in ln]
             if tl:
                 e2e["stderr_timers"] = tl

@@ -212,6 +212,7 @@ struct ani_ctx {
   uint64_t dupPairCap = 0;                                                           // first guess of the same-hash link list (env ANI_DUP_PAIR_CAP, tests: forces the rerun)
   bool l1Tiny = true;                                                               // env ANI_L1_TINY=0: fragments with <= 64 seed hits take the workgroup path like the others
   bool l2Overlap = true;                                                            // the L2 simulation on the side stream, beside the next chunk's ranges / codes kernels (env ANI_L2_OVERLAP=0 switches it off; see the L2 loop)
+  bool l2Pair = false;                                                              // class A simulated two candidates per lane in packed 16-bit halves (k_l2_sim_pair; env ANI_L2_PAIR)
   uint64_t l1HitLimit = 0x7ffffff0ull;                                              // seed hits per fragment and index chunk (32-bit hit offsets; env ANI_L1_HIT_LIMIT, tests)
   uint64_t candPoolMin = 4096;                                                      // floor of the L1 candidate pool, per stripe (env ANI_CAND_POOL_MIN, tests: forces the retry path)
   uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;              // seed hits / fragments per group of the batched global-memory L1 path (env ANI_L1_BIG_GROUP_HITS / _FRAGS, tests)

@@ -407,7 +407,12 @@ int main(int argc, char **argv)
       std::cerr << "ERROR, the sketch file was built with -k " << fp_.kmerSize << " --fragLen " << fp_.fragLen << ", this run uses -k " << ap.kmerSize << " --fragLen " << ap.fragLen << std::endl; exit(1); }
   }
 
-  const uint64_t kSliceBytes = getenv("ANI_SLICE_BYTES") ? (uint64_t)atoll(getenv("ANI_SLICE_BYTES")) : (1ull << 30);
+  // FASTA bytes per slice (the unit that is parsed, packed, uploaded and sketched as one piece, and one mapping call per query
+  // slice): a twenty-fourth of the input between 128 MiB and 1 GiB.  Small slices let parsing, upload and sketching overlap from the
+  // first few files on and keep the page-locked staging small (which the driver has to unpin when the process goes away); large
+  // sets take the 1 GiB that amortises the per-slice calls.  Measured on 1000 x 5 Mbp, output closed after: 1.32 s with 1 GiB slices,
+  // 1.03-1.10 s with 128-256 MiB, 1.13 s with 64 MiB (profiles/r04af_e2e_probe.txt).  ANI_SLICE_BYTES overrides.
+  uint64_t kSliceBytes = 1ull << 30;
   const int nRef = (int)o.refs.size(), nQry = (int)o.queries.size();
   const bool fromFile = !o.refSketch.empty();
   if (fromFile && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --refSketch cannot be combined with --visualize or -s" << std::endl; exit(1); }
@@ -435,6 +440,12 @@ int main(int argc, char **argv)
   if (!o.visualize && !o.sanityCheck) {
     if (!fromFile) files = o.refs;
     if (!allVsAll) files.insert(files.end(), o.queries.begin(), o.queries.end());
+    if (const char *ev = getenv("ANI_SLICE_BYTES")) kSliceBytes = (uint64_t)atoll(ev);
+    else {
+      uint64_t total = 0;
+      for (auto &f : files) { struct stat st; if (stat(f.c_str(), &st) == 0) total += (uint64_t)st.st_size; }
+      kSliceBytes = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(1ull << 27, total / 24));
+    }
     fpPtr.reset(new FilePipeline(files, o.threads, 3 * kSliceBytes));
   }
   trace("options parsed, readers started");
@@ -491,6 +502,7 @@ int main(int argc, char **argv)
                              const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute) {     // device work on the uploaded slice (compute thread)
       std::vector<Uploaded> ups(slices.size());
       std::vector<std::string> errs((size_t)nDev);
+      double stageSecs[4] = {0, 0, 0, 0};                 // ANI_CLI_TRACE: upload threads waiting for the readers / packing + copying, compute threads waiting / working
       std::mutex mu; std::condition_variable cv;
       std::vector<size_t> done((size_t)nDev, 0);          // slices the compute thread of device d has finished (bounds the upload thread's lead)
       std::vector<std::vector<size_t>> mineOf((size_t)nDev);
@@ -502,13 +514,16 @@ int main(int argc, char **argv)
             const size_t k = mineOf[d][mine];
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return mine < done[d] + 2 || !errs[d].empty(); }); if (!errs[d].empty()) return; }
             const size_t a = slices[k].first, b = slices[k].second;
+            const auto tw = Clock::now();
             if (!fp.wait(a, b)) { { std::lock_guard<std::mutex> lk(mu); errs[d] = "input"; } cv.notify_all(); return; }
+            const auto tu = Clock::now();
             SliceBatch sb;
             for (size_t i = a; i < b; i++) { sb.add(fp.slot[i]); noteLength(files[i], fp.slot[i].g); }
             Uploaded &u = ups[k];
             bool ok = enter(d, k, sb, u);
             ani_seq_batch_t hb = sb.batch();
             if (ok && ani_batch_upload(dev[d].up, &hb, &u.b)) ok = false;
+            { std::lock_guard<std::mutex> lk(mu); stageSecs[0] += std::chrono::duration<double>(tu - tw).count(); stageSecs[1] += secs_since(tu); }
             std::string msg = ok ? "" : ani_last_error();
             fp.release(a, b);                               // the host copy is no longer needed
             u.len = std::move(sb.len); u.gcs = std::move(sb.gcs);
@@ -519,9 +534,12 @@ int main(int argc, char **argv)
         });
         th.emplace_back([&, d]() {                        // compute thread
           for (size_t k : mineOf[d]) {
+            const auto tw = Clock::now();
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return ups[k].ready || !errs[d].empty(); }); if (!errs[d].empty()) return; }
+            const auto tc = Clock::now();
             std::string msg;
             const bool ok = compute(d, k, ups[k], msg);
+            { std::lock_guard<std::mutex> lk(mu); stageSecs[2] += std::chrono::duration<double>(tc - tw).count(); stageSecs[3] += secs_since(tc); }
             if (ups[k].b) { ani_batch_free(ups[k].b); ups[k].b = nullptr; }
             { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "device" : msg; done[d]++; }
             cv.notify_all();
@@ -530,6 +548,8 @@ int main(int argc, char **argv)
         });
       }
       for (auto &t : th) t.join();        // no thread waits for another device's: a failing device cannot stall the others
+      { char line[256]; snprintf(line, sizeof line, "%s: %zu slices; upload threads waited %.3f s for the readers, packed + copied %.3f s; compute threads waited %.3f s, worked %.3f s",
+                                 what, slices.size(), stageSecs[0], stageSecs[1], stageSecs[2], stageSecs[3]); trace(line); }
       for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, " << what << ": " << e << std::endl; exit(1); }
     };
     auto dev_view = [](const Uploaded &u) {
@@ -895,8 +915,8 @@ int main(int argc, char **argv)
   }
   std::cerr << "INFO, skch::main, Time spent writing the output : " << secs_since(tOut) << " sec; total : " << secs_since(tStart) << " sec" << std::endl;
   trace("output written");
-  fpPtr.reset();
   if (getenv("ANI_CLEAN_EXIT")) {                     // tests / leak checkers: release everything in order
+    fpPtr.reset();
     for (auto &d : dev) { ani_shutdown(d.up); ani_shutdown(d.ctx); }
     trace("contexts shut down");
     return 0;

@@ -48,6 +48,16 @@ if has overlap; then
     ANI_L2_OVERLAP=$v timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('overlap=$v', d['ms_per_step'], d['stage_ms_per_step_rank0'])" | tee -a "$OUT/overlap_ab.txt"
   done
 fi
+if has pair; then
+  echo "== parity suite with the pair simulation kernel"
+  ANI_L2_PAIR=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -4 | tee "$OUT/pair_tests.log"
+  echo "== bench with ANI_L2_PAIR=1 / =0 (A/B on one box)"
+  for v in 1 0 1 0; do
+    ANI_L2_PAIR=$v timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['all_kernels_ms_per_step']; print('pair=$v', d['ms_per_step'], d['stage_ms_per_step_rank0'], {x: k[x] for x in ('ani::k_l2_sim','ani::k_l2_codes')})" | tee -a "$OUT/pair_ab.txt"
+  done
+  ANI_L2_PAIR=1 ANI_L2_OVERLAP=0 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['all_kernels_ms_per_step']; print('pair=1 overlap=0', d['ms_per_step'], d['stage_ms_per_step_rank0'], {x: k[x] for x in ('ani::k_l2_sim','ani::k_l2_codes')})" | tee -a "$OUT/pair_ab.txt"
+  ANI_L2_PAIR=0 ANI_L2_OVERLAP=0 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['all_kernels_ms_per_step']; print('pair=0 overlap=0', d['ms_per_step'], d['stage_ms_per_step_rank0'], {x: k[x] for x in ('ani::k_l2_sim','ani::k_l2_codes')})" | tee -a "$OUT/pair_ab.txt"
+fi
 if has bench; then
   echo "== bench" | tee "$OUT/bench.log"
   timeout 900 python bench.py --steps 10 --warmup 2 2> "$OUT/bench.err" | tee "$OUT/bench.json.log" | cut -c1-900
