@@ -20,6 +20,8 @@
 #include <atomic>
 #include <thread>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <cstdarg>
 #include <cstdint>
@@ -173,18 +175,52 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
-// host-side parallel loop for the ingest path (ANI_HOST_THREADS overrides the thread count; small jobs stay serial)
+// host-side parallel loop for the ingest path (ANI_HOST_THREADS overrides the thread count; small jobs stay serial).
+// The workers are started once and live as long as the process: a slice of the command line's input is one call, and sixty-four
+// thread creations per call — each an mmap and an munmap of a stack, in an address space whose reader threads map and unmap sequence
+// buffers all the time — cost more than the packing they were created for.
+struct HostPool {
+  std::mutex mu, runMu; std::condition_variable cvWork, cvDone;
+  std::function<void(size_t)> job; size_t n = 0; std::atomic<size_t> next{0}; unsigned wanted = 0, started = 0, active = 0; uint64_t epoch = 0;
+  std::vector<std::thread> th;
+  void worker(unsigned id)
+  {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cvWork.wait(lk, [&]() { return epoch != seen && id < wanted; });
+        seen = epoch;
+      }
+      for (size_t i; (i = next.fetch_add(1)) < n;) job(i);
+      { std::lock_guard<std::mutex> lk(mu); active--; }
+      cvDone.notify_all();
+    }
+  }
+  void run(size_t count, unsigned nt, const std::function<void(size_t)> &f)
+  {
+    std::lock_guard<std::mutex> one(runMu);             // one loop at a time (a second caller waits its turn)
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      while (started + 1 < nt) { const unsigned id = started++; th.emplace_back([this, id]() { worker(id); }); th.back().detach(); }
+      job = f; n = count; next = 0; wanted = nt - 1; active = nt - 1; epoch++;
+    }
+    cvWork.notify_all();
+    for (size_t i; (i = next.fetch_add(1)) < count;) f(i);                    // the caller works too
+    std::unique_lock<std::mutex> lk(mu);
+    cvDone.wait(lk, [&]() { return active == 0; });
+    wanted = 0;
+  }
+};
+inline HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; }      // never destroyed: its threads are detached
 template <class F>
 void parallel_for(size_t n, uint64_t work, F f)
 {
-  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 64) nt = 64;
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 32) nt = 32;     // (beside 32 reader threads: 16-32 packers measured best, 64 starve the readers; profiles/r04ak_e2e_probe.txt)
   if (const char *ev = getenv("ANI_HOST_THREADS")) { int v = atoi(ev); if (v >= 1) nt = (unsigned)v; }
   if (nt > n) nt = (unsigned)n;
   if (nt <= 1 || work < (1u << 22)) { for (size_t i = 0; i < n; i++) f(i); return; }
-  std::atomic<size_t> next{0};
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; t++) th.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); });
-  for (auto &x : th) x.join();
+  host_pool().run(n, nt, std::function<void(size_t)>(f));
 }
 
 // 1-D grid for n work items.  Kernels without a grid-stride loop are launched with the default (uncapped: gridDim.x may reach

@@ -283,6 +283,7 @@ struct FilePipeline {
   std::vector<uint64_t> sizeEst, sizePrefix;
   std::mutex mu; std::condition_variable cv;
   size_t next = 0; uint64_t releasedBytes = 0, window; bool failed = false;
+  std::vector<std::vector<uint8_t>> spare;      // sequence buffers of released files, reused by the readers
   int active = 8;                    // readers allowed to work: a few until the devices are initialised (set_active), then all
   std::vector<std::thread> th;
   FilePipeline(const std::vector<std::string> &p, int threads, uint64_t windowBytes) : paths(p), slot(p.size()), ready(p.size(), 0), sizeEst(p.size()), sizePrefix(p.size() + 1, 0), window(windowBytes)
@@ -311,6 +312,7 @@ struct FilePipeline {
         i = next++;
       }
       FileData fd;
+      { std::lock_guard<std::mutex> g(mu); if (!spare.empty()) { fd.data = std::move(spare.back()); spare.pop_back(); fd.data.clear(); } }
       const bool ok = readFile(paths[i], fd);
       { std::lock_guard<std::mutex> g(mu); slot[i] = std::move(fd); ready[i] = 1; if (!ok) failed = true; }
       cv.notify_all();
@@ -324,10 +326,15 @@ struct FilePipeline {
     return !failed;
   }
   // the consumer is done with files [a, b): free them and let the readers move on
+  // (the sequence buffers go back to the readers instead of to the allocator: a 5 MB vector is an mmap of its own, and unmapping
+  // one — with the inter-processor interrupts to every core that runs a thread of this process — took 150 us, forty per slice, as
+  // long as packing and copying the slice; profiles/r04aj_e2e_probe.txt.  What is left when the last file has been read goes with
+  // the pipeline.)
   void release(size_t a, size_t b)
   {
-    for (size_t i = a; i < b; i++) slot[i].clear();
-    { std::lock_guard<std::mutex> g(mu); releasedBytes = std::max(releasedBytes, sizePrefix[b]); }
+    std::vector<std::vector<uint8_t>> keep;
+    for (size_t i = a; i < b; i++) { if (slot[i].data.capacity()) keep.push_back(std::move(slot[i].data)); slot[i].clear(); }
+    { std::lock_guard<std::mutex> g(mu); for (auto &v : keep) spare.push_back(std::move(v)); releasedBytes = std::max(releasedBytes, sizePrefix[b]); }
     cv.notify_all();
   }
 };
@@ -502,7 +509,7 @@ int main(int argc, char **argv)
                              const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute) {     // device work on the uploaded slice (compute thread)
       std::vector<Uploaded> ups(slices.size());
       std::vector<std::string> errs((size_t)nDev);
-      double stageSecs[4] = {0, 0, 0, 0};                 // ANI_CLI_TRACE: upload threads waiting for the readers / packing + copying, compute threads waiting / working
+      double stageSecs[7] = {0, 0, 0, 0, 0, 0, 0};                 // ANI_CLI_TRACE: upload threads waiting for the readers / packing + copying, compute threads waiting / working
       std::mutex mu; std::condition_variable cv;
       std::vector<size_t> done((size_t)nDev, 0);          // slices the compute thread of device d has finished (bounds the upload thread's lead)
       std::vector<std::vector<size_t>> mineOf((size_t)nDev);
@@ -512,6 +519,7 @@ int main(int argc, char **argv)
         th.emplace_back([&, d]() {                        // upload thread
           for (size_t mine = 0; mine < mineOf[d].size(); mine++) {
             const size_t k = mineOf[d][mine];
+            const auto tl = Clock::now();
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return mine < done[d] + 2 || !errs[d].empty(); }); if (!errs[d].empty()) return; }
             const size_t a = slices[k].first, b = slices[k].second;
             const auto tw = Clock::now();
@@ -522,10 +530,13 @@ int main(int argc, char **argv)
             Uploaded &u = ups[k];
             bool ok = enter(d, k, sb, u);
             ani_seq_batch_t hb = sb.batch();
+            const auto tp = Clock::now();
             if (ok && ani_batch_upload(dev[d].up, &hb, &u.b)) ok = false;
-            { std::lock_guard<std::mutex> lk(mu); stageSecs[0] += std::chrono::duration<double>(tu - tw).count(); stageSecs[1] += secs_since(tu); }
+            const auto tr = Clock::now();
             std::string msg = ok ? "" : ani_last_error();
             fp.release(a, b);                               // the host copy is no longer needed
+            { std::lock_guard<std::mutex> lk(mu); stageSecs[0] += std::chrono::duration<double>(tu - tw).count(); stageSecs[1] += std::chrono::duration<double>(tr - tp).count();
+              stageSecs[4] += std::chrono::duration<double>(tw - tl).count(); stageSecs[5] += std::chrono::duration<double>(tp - tu).count(); stageSecs[6] += secs_since(tr); }
             u.len = std::move(sb.len); u.gcs = std::move(sb.gcs);
             { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "upload" : msg; u.ready = true; }
             cv.notify_all();
@@ -548,8 +559,8 @@ int main(int argc, char **argv)
         });
       }
       for (auto &t : th) t.join();        // no thread waits for another device's: a failing device cannot stall the others
-      { char line[256]; snprintf(line, sizeof line, "%s: %zu slices; upload threads waited %.3f s for the readers, packed + copied %.3f s; compute threads waited %.3f s, worked %.3f s",
-                                 what, slices.size(), stageSecs[0], stageSecs[1], stageSecs[2], stageSecs[3]); trace(line); }
+      { char line[400]; snprintf(line, sizeof line, "%s: %zu slices; upload threads waited %.3f s for the readers, %.3f s for the compute threads, entered the slices %.3f s, packed + copied %.3f s, released the host copies %.3f s; compute threads waited %.3f s, worked %.3f s",
+                                 what, slices.size(), stageSecs[0], stageSecs[4], stageSecs[5], stageSecs[1], stageSecs[6], stageSecs[2], stageSecs[3]); trace(line); }
       for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, " << what << ": " << e << std::endl; exit(1); }
     };
     auto dev_view = [](const Uploaded &u) {
