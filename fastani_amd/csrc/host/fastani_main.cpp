@@ -284,7 +284,7 @@ struct FilePipeline {
   std::mutex mu; std::condition_variable cv;
   size_t next = 0; uint64_t releasedBytes = 0, window; bool failed = false;
   std::vector<std::vector<uint8_t>> spare;      // sequence buffers of released files, reused by the readers
-  int active = 8;                    // readers allowed to work: a few until the devices are initialised (set_active), then all
+  int active = getenv("ANI_CLI_INIT_READERS") ? atoi(getenv("ANI_CLI_INIT_READERS")) : 8;      // readers allowed to work: a few until the devices are initialised (set_active), then all
   std::vector<std::thread> th;
   FilePipeline(const std::vector<std::string> &p, int threads, uint64_t windowBytes) : paths(p), slot(p.size()), ready(p.size(), 0), sizeEst(p.size()), sizePrefix(p.size() + 1, 0), window(windowBytes)
   {
