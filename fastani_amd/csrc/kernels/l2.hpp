@@ -574,6 +574,16 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
 // longest stream of the wave is done (lanes are ordered by stream length), the rare same-hash-neighbour look-ups sit behind a
 // wave vote.  Positions are not tracked at all: the window start of an evaluation is "entry number delCount", and the two
 // positions the result needs are read from the index when the stream is done.
+// eight event codes in four words.  (A vector value, not HIP's uint4 struct: a conditional copy of a whole uint4 made the compiler
+// keep the block in scratch memory and store it there once per block — 29 GB of writes per benchmark step that nothing ever read
+// back — and member-wise assignment split the 16-byte load into four.)
+typedef uint32_t L2Block __attribute__((vector_size(16)));
+__device__ __forceinline__ L2Block l2_block_zero() { const L2Block b = {0u, 0u, 0u, 0u}; return b; }
+__device__ __forceinline__ L2Block l2_block_load(bool on, const uint4 *p, L2Block otherwise)
+{
+  if (on) otherwise = *(const L2Block *)p;
+  return otherwise;
+}
 template <class G>
 static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const int32_t *__restrict__ list, const unsigned int *__restrict__ listCount)
 {
@@ -606,13 +616,12 @@ static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const
   // A lane without a candidate of this class (class-B and general-path candidates sit in the same length-ordered list: about every
   // tenth lane) reads no stream: its words stay zero — event 0 is "delete a non-query hash from field 0 and evaluate", harmless on
   // its own cleared state — so that it counts as PLAIN below instead of sending its whole wave through the general form for good.
-  uint4 cur; cur.x = cur.y = cur.z = cur.w = 0u;
-  if (mine) cur = p[0];
+  L2Block cur = l2_block_load(mine, p, l2_block_zero());
   // one block = 8 events.  PLAIN: every lane of the wave has all 8 events and none of them is flagged nearDup (two wave votes per
   // block decide) — then an event needs no bounds test and no look-up path; otherwise the block takes the general form.
-  auto run_block = [&](auto plainTag, int blk, const uint4 &blkWords) {
+  auto run_block = [&](auto plainTag, int blk, const L2Block &blkWords) {
     constexpr bool PLAIN = decltype(plainTag)::value;
-    const uint32_t wd[4] = {blkWords.x, blkWords.y, blkWords.z, blkWords.w};
+    const uint32_t wd[4] = {blkWords[0], blkWords[1], blkWords[2], blkWords[3]};
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const uint32_t code = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffffu);
@@ -655,15 +664,14 @@ static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const
   {
     constexpr uint32_t kFillPair = (kL2InsBit | kL2NoEvalBit) * 0x10001u, kDupPair = kL2DupBit * 0x10001u;
     for (; __any(mine); blk++) {
-      const uint32_t andw = cur.x & cur.y & cur.z & cur.w, orw = cur.x | cur.y | cur.z | cur.w;
+      const uint32_t andw = cur[0] & cur[1] & cur[2] & cur[3], orw = cur[0] | cur[1] | cur[2] | cur[3];
       const bool fill = 8 * blk + 8 <= n && (andw & kFillPair) == kFillPair;
       if (!__all(fill || !mine)) break;
       const int nb = blk + 1 < nBlk ? blk + 1 : blk;
-      uint4 nxt = cur;
-      if (mine) nxt = p[nb];
+      const L2Block nxt = l2_block_load(mine, p + nb, cur);
       const bool anyDup = __any(mine && (orw & kDupPair) != 0);         // rare: an entry with a same-hash neighbour nearby
       if (mine) {
-        const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+        const uint32_t wd[4] = {cur[0], cur[1], cur[2], cur[3]};
 #pragma unroll
         for (int e = 0; e < 8; e++) {
           const uint32_t code = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffffu);
@@ -692,9 +700,8 @@ static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const
   }
   for (; __any(blk < nBlk); blk++) {
     const int nb = blk + 1 < nBlk ? blk + 1 : blk;                     // never beyond the lane's own stream
-    uint4 nxt = cur;
-    if (mine) nxt = p[nb];
-    const uint32_t orw = cur.x | cur.y | cur.z | cur.w;
+    const L2Block nxt = l2_block_load(mine, p + nb, cur);
+    const uint32_t orw = cur[0] | cur[1] | cur[2] | cur[3];
     const bool plain = !mine || (8 * blk + 8 <= n && (orw & (kL2DupBit | (kL2DupBit << 16))) == 0);
     if (__all(plain)) run_block(std::true_type(), blk, cur);
     else run_block(std::false_type(), blk, cur);
@@ -818,7 +825,7 @@ static __global__ __launch_bounds__(kWave) void k_l2_sim_pair(L2FastArgs a, cons
   const unsigned int slot0 = (blockIdx.x * (unsigned int)kWave + (unsigned int)lane) * 2u;     // neighbours in the length order
 #pragma unroll
   for (int x = 0; x < 2 * G::kStateWords; x++) lds[x * kWave + lane] = 0u;
-  bool mine[2]; int32_t c[2], ci[2]; L2Range r[2]; int n[2], nBlk[2], sq[2]; const uint4 *p[2]; uint4 cur[2];
+  bool mine[2]; int32_t c[2], ci[2]; L2Range r[2]; int n[2], nBlk[2], sq[2]; const uint4 *p[2]; L2Block cur[2];
   int iS[2], tot[2], sh[2]; uint32_t ovf = 0;
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -831,8 +838,7 @@ static __global__ __launch_bounds__(kWave) void k_l2_sim_pair(L2FastArgs a, cons
     n[h] = r[h].nEvents; nBlk[h] = (n[h] + 7) >> 3;
     sq[h] = mine[h] ? a.g.fragS[a.g.candFrag[c[h]]] : 1;
     p[h] = (const uint4 *)((const uint16_t *)a.codes + (mine[h] ? a.codeOff[ci[h]] : 0u));
-    cur[h].x = cur[h].y = cur[h].z = cur[h].w = 0u;                   // a half without a candidate: zero events (see k_l2_sim)
-    if (mine[h]) cur[h] = p[h][0];
+    cur[h] = l2_block_load(mine[h], p[h], l2_block_zero());          // a half without a candidate: zero events (see k_l2_sim)
     iS[h] = sq[h]; tot[h] = sq[h]; sh[h] = 0;
   }
   // Phase A (see k_l2_sim): the first super-window's inserts are field updates only; while every candidate of the wave has a whole
@@ -844,7 +850,7 @@ static __global__ __launch_bounds__(kWave) void k_l2_sim_pair(L2FastArgs a, cons
       bool fill = true, dupHere = false;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const uint32_t andw = cur[h].x & cur[h].y & cur[h].z & cur[h].w, orw = cur[h].x | cur[h].y | cur[h].z | cur[h].w;
+        const uint32_t andw = cur[h][0] & cur[h][1] & cur[h][2] & cur[h][3], orw = cur[h][0] | cur[h][1] | cur[h][2] | cur[h][3];
         fill = fill && (!mine[h] || (8 * blk + 8 <= n[h] && (andw & kFillPair) == kFillPair));
         dupHere = dupHere || (mine[h] && (orw & kDupPair) != 0);
       }
@@ -852,11 +858,11 @@ static __global__ __launch_bounds__(kWave) void k_l2_sim_pair(L2FastArgs a, cons
       const bool anyDup = __any(dupHere);                                // rare: an entry with a same-hash neighbour nearby
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        uint4 nxt = cur[h];
+        L2Block nxt = cur[h];
         if (mine[h]) {
           const int nb = blk + 1 < nBlk[h] ? blk + 1 : blk;
-          nxt = p[h][nb];
-          const uint32_t wd[4] = {cur[h].x, cur[h].y, cur[h].z, cur[h].w};
+          nxt = l2_block_load(true, p[h] + nb, cur[h]);
+          const uint32_t wd[4] = {cur[h][0], cur[h][1], cur[h][2], cur[h][3]};
 #pragma unroll
           for (int e = 0; e < 8; e++) {
             const uint32_t code = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffffu);
@@ -892,15 +898,15 @@ static __global__ __launch_bounds__(kWave) void k_l2_sim_pair(L2FastArgs a, cons
   const int blkMain = blk;
   const int nBlkMax = nBlk[0] > nBlk[1] ? nBlk[0] : nBlk[1];
   for (; __any(blk < nBlkMax); blk++) {
-    uint4 nxt[2]; bool plain = true;
+    L2Block nxt[2]; bool plain = true;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      nxt[h] = cur[h];
-      if (mine[h]) { int nb = blk + 1 < nBlk[h] ? blk + 1 : nBlk[h] - 1; nb = nb < 0 ? 0 : nb; nxt[h] = p[h][nb]; }
-      const uint32_t orw = cur[h].x | cur[h].y | cur[h].z | cur[h].w;
+      int nb = blk + 1 < nBlk[h] ? blk + 1 : nBlk[h] - 1; nb = nb < 0 ? 0 : nb;
+      nxt[h] = l2_block_load(mine[h], p[h] + nb, cur[h]);
+      const uint32_t orw = cur[h][0] | cur[h][1] | cur[h][2] | cur[h][3];
       plain = plain && (!mine[h] || (8 * blk + 8 <= n[h] && (orw & (kL2DupBit | (kL2DupBit << 16))) == 0));
     }
-    const uint32_t w0[4] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w}, w1[4] = {cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+    const uint32_t w0[4] = {cur[0][0], cur[0][1], cur[0][2], cur[0][3]}, w1[4] = {cur[1][0], cur[1][1], cur[1][2], cur[1][3]};
     if (__all(plain)) {
 #pragma unroll
       for (int e = 0; e < 8; e++) {
