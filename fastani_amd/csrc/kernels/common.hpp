@@ -181,6 +181,17 @@ __device__ __forceinline__ void block_barrier_mem()
   __syncthreads();
 }
 
+// A value that is the same in every lane of the wave, moved to a scalar register: comparisons against it take it as the scalar
+// operand, branches on it are scalar branches and a loop that carries it carries no vector copies.  (The compiler cannot know that
+// something read from LDS or derived from threadIdx.x >> 6 is wave-uniform; the CPU stand-in needs nothing.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+#else
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return x; }
+#endif
+__device__ __forceinline__ int32_t wave_uniform(int32_t x) { return (int32_t)wave_uniform((uint32_t)x); }
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t x) { return (uint64_t)wave_uniform((uint32_t)x) | ((uint64_t)wave_uniform((uint32_t)(x >> 32)) << 32); }
+
 // exclusive scan of one int per thread across the workgroup; *total = sum over all threads.
 // `ws` = LDS scratch of at least 8 ints.  Contains barriers: every thread of the block must call it.
 __device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total)
@@ -193,7 +204,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total)
   int base = 0, tot = 0;
 #pragma unroll
   for (int i = 0; i < kTPB / kWave; i++) { int x = ws[i]; if (i < wv) base += x; tot += x; }
-  *total = tot;
+  *total = wave_uniform(tot);            // the same in every thread: a scalar for the loops and branches it bounds
   return base + incl - v;
 }
 
@@ -241,17 +252,6 @@ __device__ inline int block_array_excl_scan(int *a, int n, int *ws)
 #else
 #define ANI_WAVE_SYNC() (void)__ballot(1)
 #endif
-
-// A value that is the same in every lane of the wave, moved to a scalar register: comparisons against it take it as the scalar
-// operand, branches on it are scalar branches and a loop that carries it carries no vector copies.  (The compiler cannot know that
-// something read from LDS or derived from threadIdx.x >> 6 is wave-uniform; the CPU stand-in needs nothing.)
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-#else
-__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return x; }
-#endif
-__device__ __forceinline__ int32_t wave_uniform(int32_t x) { return (int32_t)wave_uniform((uint32_t)x); }
-__device__ __forceinline__ uint64_t wave_uniform(uint64_t x) { return (uint64_t)wave_uniform((uint32_t)x) | ((uint64_t)wave_uniform((uint32_t)(x >> 32)) << 32); }
 
 // Bitonic sort of n2 (power of two) keys in LDS, ascending, by the whole workgroup.
 // Two consecutive stages (strides 2h and h) are fused: a thread loads the four elements i0 + {0, h, 2h, 3h}, runs the four

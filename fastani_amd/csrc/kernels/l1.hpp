@@ -466,7 +466,7 @@ static __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__r
       }
     }
     block_barrier();
-    n = sKeep;
+    n = wave_uniform(sKeep);
   }
   block_sort<uint64_t>(hits, n);                    // :320 (starts with a barrier: the gather is complete)
 

@@ -444,61 +444,109 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   while (have) {
     const bool haveNext = next_item(cur, nxt);
     if (haveNext) load_item(nxt, hn, wn);
-    // Rank = entries of the sketch below h.  The two sketch entries at the bucket's start decide it unless the bucket holds more
-    // than two and both are below h: entries behind the bucket's own belong to later buckets, i.e. are larger than any hash of
-    // this bucket, so they need no "is it in the bucket" test (the sketch is followed by two 0xffffffff sentinels).
-    uint32_t rk[4];
-    uint32_t deep = 0;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];            // first sketch entry of the bucket | entries in it << 16
-      const uint32_t lo = sp & 0xffffu;
-      const uint32_t q0 = qs[lo], q1 = qs[lo + 1];
-      rk[e] = ((lo + (uint32_t)(q0 < h[e]) + (uint32_t)(q1 < h[e])) << 1) | (uint32_t)((q0 == h[e]) | (q1 == h[e]));
-      deep |= (uint32_t)(q1 < h[e]) & (uint32_t)(sp > 0x2ffffu);
-    }
-    if (__any(deep != 0)) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];
-        int lo = (int)(sp & 0xffffu), hi = lo + (int)(sp >> 16);
-        if (hi - lo > 2) {
-          while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h[e]) lo = mid + 1; else hi = mid; }
-          rk[e] = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h[e]);    // == q_rank(qs, s, h)
+    // A pass ranks up to four entries per lane; the last pass of a candidate takes only as many as are left (a candidate of the
+    // benchmark has ~600 entries: 256 + 256 + 92 — at four per lane whatever is left, a fifth of all the work was done on entries
+    // beyond the range).  E is wave-uniform: a scalar branch picks the variant.
+    auto pass_body = [&](auto eTag) {
+      constexpr int E = decltype(eTag)::value;
+      // Rank = entries of the sketch below h.  The two sketch entries at the bucket's start decide it unless the bucket holds more
+      // than two and both are below h: entries behind the bucket's own belong to later buckets, i.e. are larger than any hash of
+      // this bucket, so they need no "is it in the bucket" test (the sketch is followed by two 0xffffffff sentinels).
+      uint32_t rk[4];
+      uint32_t deep = 0;
+  #pragma unroll
+      for (int e = 0; e < E; e++) {
+        const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];            // first sketch entry of the bucket | entries in it << 16
+        const uint32_t lo = sp & 0xffffu;
+        const uint32_t q0 = qs[lo], q1 = qs[lo + 1];
+        rk[e] = ((lo + (uint32_t)(q0 < h[e]) + (uint32_t)(q1 < h[e])) << 1) | (uint32_t)((q0 == h[e]) | (q1 == h[e]));
+        deep |= (uint32_t)(q1 < h[e]) & (uint32_t)(sp > 0x2ffffu);
+      }
+#ifdef ANI_ABL_RANK2
+  #pragma unroll
+      for (int e = 0; e < E; e++) {
+        const uint32_t h2 = h[e] ^ 0x5bd1e995u;
+        const uint32_t sp = st2[l2_rank_bucket(h2, sh)];
+        const uint32_t lo = sp & 0xffffu;
+        const uint32_t q0 = qs[lo], q1 = qs[lo + 1];
+        const uint32_t r2 = ((lo + (uint32_t)(q0 < h2) + (uint32_t)(q1 < h2)) << 1) | (uint32_t)((q0 == h2) | (q1 == h2));
+        asm volatile("" :: "v"(r2));
+      }
+#endif
+      if (__any(deep != 0)) {
+  #pragma unroll
+        for (int e = 0; e < E; e++) {
+          const uint32_t sp = st2[l2_rank_bucket(h[e], sh)];
+          int lo = (int)(sp & 0xffffu), hi = lo + (int)(sp >> 16);
+          if (hi - lo > 2) {
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (qs[mid] < h[e]) lo = mid + 1; else hi = mid; }
+            rk[e] = ((uint32_t)lo << 1) | (uint32_t)(lo < s && qs[lo] == h[e]);    // == q_rank(qs, s, h)
+          }
         }
       }
-    }
-    // Two events per entry, stored without control flow: an event that does not exist (entries beyond the range, the never-inserted
-    // last entry, entries that never leave) goes to the pad slot behind the stream (k_l2_ranges reserves one).
-    uint32_t pi[4], pd[4]; uint16_t ci[4], cdl[4];
-    const uint32_t dumpSlot = cur.dump;
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const uint32_t x = cur.jb + lane + e * kWave;
-      const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
-      // field change of the event, 3-bit two's complement: insert +2 (010), of a query hash +1 (001); delete -2 (110) / -1 (111)
-      const uint32_t mq = 0u - (rk[e] & 1u);                                            // all ones for a query hash
-      // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
-      const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
-      pi[e] = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dumpSlot;
-      ci[e] = (uint16_t)((cd | kL2InsBit | (2u << kL2DeltaShift) | ((int32_t)x < (int32_t)cur.nInit - 1 ? kL2NoEvalBit : 0u)) ^ (mq & (3u << kL2DeltaShift)));
-      // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
-      // window's)
-      const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
-      pd[e] = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : dumpSlot;
-      cdl[e] = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));   // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
-    }
-    if (cur.staged) {                                                                   // wave-uniform choice
-#pragma unroll
-      for (int e = 0; e < 4; e++) { stage[pi[e]] = ci[e]; stage[pd[e]] = cdl[e]; }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; e++) { *(uint16_t *)(cur.ob + pi[e] * 2u) = ci[e]; *(uint16_t *)(cur.ob + pd[e] * 2u) = cdl[e]; }
+      // Two events per entry, stored without control flow: an event that does not exist (entries beyond the range, the never-inserted
+      // last entry, entries that never leave) goes to the pad slot behind the stream (k_l2_ranges reserves one).
+      uint32_t pi[4], pd[4]; uint16_t ci[4], cdl[4];
+      const uint32_t dumpSlot = cur.dump;
+  #pragma unroll
+      for (int e = 0; e < E; e++) {
+        const uint32_t x = cur.jb + lane + e * kWave;
+        const uint32_t cd = rk[e] | ((wl[e] >> 21) & kL2DupBit);                          // kWinDupBit (bit 31) -> kL2DupBit (bit 10)
+        // field change of the event, 3-bit two's complement: insert +2 (010), of a query hash +1 (001); delete -2 (110) / -1 (111)
+        const uint32_t mq = 0u - (rk[e] & 1u);                                            // all ones for a query hash
+        // insert of entry x: after the inserts of the entries before it and the deletes of the entries up to x - B - 2
+        const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;                 // deletes that precede it
+        pi[e] = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dumpSlot;
+        ci[e] = (uint16_t)((cd | kL2InsBit | (2u << kL2DeltaShift) | ((int32_t)x < (int32_t)cur.nInit - 1 ? kL2NoEvalBit : 0u)) ^ (mq & (3u << kL2DeltaShift)));
+        // delete of entry x: after the deletes of the entries before it and the inserts of the entries below x + A (at least the first
+        // window's)
+        const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
+        pd[e] = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : dumpSlot;
+        cdl[e] = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));   // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+      }
+#ifdef ANI_ABL_VALU2
+  #pragma unroll
+      for (int e = 0; e < E; e++) {
+        const uint32_t x = cur.jb + lane + e * kWave + 7u;
+        const uint32_t cd = rk[e] | ((wl[e] >> 20) & kL2DupBit);
+        const uint32_t mq = 0u - (rk[e] & 1u);
+        const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;
+        const uint32_t pi2 = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dumpSlot;
+        const uint32_t ci2 = ((cd | kL2InsBit | (2u << kL2DeltaShift) | ((int32_t)x < (int32_t)cur.nInit - 1 ? kL2NoEvalBit : 0u)) ^ (mq & (3u << kL2DeltaShift)));
+        const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
+        const uint32_t pd2 = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : dumpSlot;
+        const uint32_t cdl2 = (cd | ((wl[e] >> 17) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));
+        asm volatile("" :: "v"(pi2), "v"(ci2), "v"(pd2), "v"(cdl2));
+      }
+#endif
+      if (cur.staged) {                                                                   // wave-uniform choice
+  #pragma unroll
+        for (int e = 0; e < E; e++) { stage[pi[e]] = ci[e]; stage[pd[e]] = cdl[e]; }
+#ifdef ANI_ABL_STAGE2
+        asm volatile("" ::: "memory");
+  #pragma unroll
+        for (int e = 0; e < E; e++) { stage[pi[e]] = ci[e]; stage[pd[e]] = cdl[e]; }
+#endif
+      } else {
+  #pragma unroll
+        for (int e = 0; e < E; e++) { *(uint16_t *)(cur.ob + pi[e] * 2u) = ci[e]; *(uint16_t *)(cur.ob + pd[e] * 2u) = cdl[e]; }
+      }
+    };
+    {
+      const uint32_t left = cur.m - cur.jb;          // entries from the first of this pass to the end of the range (>= 1)
+      if (left > 3u * kWave) pass_body(std::integral_constant<int, 4>());
+      else if (left > 2u * kWave) pass_body(std::integral_constant<int, 3>());
+      else if (left > (uint32_t)kWave) pass_body(std::integral_constant<int, 2>());
+      else pass_body(std::integral_constant<int, 1>());
     }
     if (cur.staged && cur.lastPass) {                // the candidate's stream is complete in the window: write it out
       ANI_WAVE_SYNC();
       const uint32_t nOut = (cur.dump + 8u) & ~7u;   // = codeCount: the stream and its pad, whole 16-byte pieces
       for (uint32_t o = (uint32_t)lane * 8u; o < nOut; o += kWave * 8u) *(uint4 *)(cur.ob + o * 2u) = *(const uint4 *)(stage + o);
+#ifdef ANI_ABL_FLUSH2
+      asm volatile("" ::: "memory");
+      for (uint32_t o = (uint32_t)lane * 8u; o < nOut; o += kWave * 8u) *(uint4 *)(cur.ob + o * 2u) = *(const uint4 *)(stage + o);
+#endif
       ANI_WAVE_SYNC();                               // the window is reused by the next candidate
     }
     have = haveNext;
