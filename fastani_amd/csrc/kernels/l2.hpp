@@ -462,17 +462,6 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
         rk[e] = ((lo + (uint32_t)(q0 < h[e]) + (uint32_t)(q1 < h[e])) << 1) | (uint32_t)((q0 == h[e]) | (q1 == h[e]));
         deep |= (uint32_t)(q1 < h[e]) & (uint32_t)(sp > 0x2ffffu);
       }
-#ifdef ANI_ABL_RANK2
-  #pragma unroll
-      for (int e = 0; e < E; e++) {
-        const uint32_t h2 = h[e] ^ 0x5bd1e995u;
-        const uint32_t sp = st2[l2_rank_bucket(h2, sh)];
-        const uint32_t lo = sp & 0xffffu;
-        const uint32_t q0 = qs[lo], q1 = qs[lo + 1];
-        const uint32_t r2 = ((lo + (uint32_t)(q0 < h2) + (uint32_t)(q1 < h2)) << 1) | (uint32_t)((q0 == h2) | (q1 == h2));
-        asm volatile("" :: "v"(r2));
-      }
-#endif
       if (__any(deep != 0)) {
   #pragma unroll
         for (int e = 0; e < E; e++) {
@@ -504,29 +493,9 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
         pd[e] = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : dumpSlot;
         cdl[e] = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));   // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
       }
-#ifdef ANI_ABL_VALU2
-  #pragma unroll
-      for (int e = 0; e < E; e++) {
-        const uint32_t x = cur.jb + lane + e * kWave + 7u;
-        const uint32_t cd = rk[e] | ((wl[e] >> 20) & kL2DupBit);
-        const uint32_t mq = 0u - (rk[e] & 1u);
-        const int32_t db = (int32_t)x - (int32_t)(wl[e] & kWinMask) - 1;
-        const uint32_t pi2 = x < cur.nInsAll ? x + (uint32_t)(db < 0 ? 0 : db) : dumpSlot;
-        const uint32_t ci2 = ((cd | kL2InsBit | (2u << kL2DeltaShift) | ((int32_t)x < (int32_t)cur.nInit - 1 ? kL2NoEvalBit : 0u)) ^ (mq & (3u << kL2DeltaShift)));
-        const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
-        const uint32_t pd2 = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : dumpSlot;
-        const uint32_t cdl2 = (cd | ((wl[e] >> 17) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));
-        asm volatile("" :: "v"(pi2), "v"(ci2), "v"(pd2), "v"(cdl2));
-      }
-#endif
       if (cur.staged) {                                                                   // wave-uniform choice
   #pragma unroll
         for (int e = 0; e < E; e++) { stage[pi[e]] = ci[e]; stage[pd[e]] = cdl[e]; }
-#ifdef ANI_ABL_STAGE2
-        asm volatile("" ::: "memory");
-  #pragma unroll
-        for (int e = 0; e < E; e++) { stage[pi[e]] = ci[e]; stage[pd[e]] = cdl[e]; }
-#endif
       } else {
   #pragma unroll
         for (int e = 0; e < E; e++) { *(uint16_t *)(cur.ob + pi[e] * 2u) = ci[e]; *(uint16_t *)(cur.ob + pd[e] * 2u) = cdl[e]; }
@@ -543,10 +512,6 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
       ANI_WAVE_SYNC();
       const uint32_t nOut = (cur.dump + 8u) & ~7u;   // = codeCount: the stream and its pad, whole 16-byte pieces
       for (uint32_t o = (uint32_t)lane * 8u; o < nOut; o += kWave * 8u) *(uint4 *)(cur.ob + o * 2u) = *(const uint4 *)(stage + o);
-#ifdef ANI_ABL_FLUSH2
-      asm volatile("" ::: "memory");
-      for (uint32_t o = (uint32_t)lane * 8u; o < nOut; o += kWave * 8u) *(uint4 *)(cur.ob + o * 2u) = *(const uint4 *)(stage + o);
-#endif
       ANI_WAVE_SYNC();                               // the window is reused by the next candidate
     }
     have = haveNext;
