@@ -181,3 +181,27 @@ def test_merged_fragment_sets_on_a_streamed_reference_set(monkeypatch):
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=1, ANI_SUBBATCH_FRAGS=9)
     pc.case_fragset_wire(e, alloc)
     e.close()
+
+
+def test_host_pool_packing(monkeypatch):
+    """the ingest packing loop on the persistent host thread pool (host/engine.hpp: HostPool; only batches of >= 2^22 bases take
+    it): several calls on one pool with different thread counts, contigs that are not pure ACGT among them (raw second pass) — the
+    minimizer stream must be the oracle's"""
+    import orc
+    rng = np.random.default_rng(5)
+    genomes = []
+    for g in range(4):
+        s = orc.synth_genome(5, g, 1_100_000).copy()
+        if g == 2:
+            s[500_000:500_040] = ord("N")                     # one impure contig: copied raw in the second pass
+        genomes.append([s, orc.synth_genome(6, g, 30_000)])   # two contigs per genome
+    osk = orc.Sketch(genomes, 16, 24)
+    want = osk.minimizers()
+    for nt in ("3", "7", "2"):
+        e = _emu_engine_with(monkeypatch, ANI_HOST_THREADS=nt)
+        from fastani_amd.api import Sketch
+        for _ in range(2):
+            sk = Sketch(e, e.params(), genomes)
+            assert np.array_equal(sk.minimizers(), want)
+            sk.close()
+        e.close()
