@@ -22,8 +22,10 @@ Workloads (config.workload):
               per-rank time behind the predicted W-GPU figure.
   one-to-many = configs[1]: 1 query genome (cluster 0, member 1) against the 1000-genome set; a step still sketches and
       indexes the references (the reference does too); the map-only latency is reported beside it.
-  c5 = configs[4] in miniature: a reference set that does not stay resident (default 30 000 x 5 Mbp, generated and sketched slice by
-      slice; only the 12-byte minimizer records stay, the index is streamed chunk by chunk) x --queries genomes (default 300).
+  c5 = configs[4]'s reference side: a reference set that does not stay resident (default 30 000 x 5 Mbp, --genomes 90000 for the
+      full count; generated and sketched slice by slice; only the 12-byte minimizer records of one BLOCK of references stay
+      (--ref-block, default: a third of the device memory), the block's index is streamed chunk by chunk, every query is mapped
+      against every block) x --queries genomes (default 300).
   c4 = configs[3]: 10000 x 10000 (all-vs-all, 500 clusters).
       N = 1 : the reference set held as several index chunks (streamed through the device when they do not fit); --queries bounds
               the query count.
