@@ -40,8 +40,8 @@ Prints ONE JSON line on rank 0 (see the driver contract): value = whole-job pair
   parity_timed_rows — the rows of the LAST TIMED STEP compared with the untouched reference binary (every reference x
                  the CPU-baseline queries) and with the C oracle on >= 200 random pairs;
   cpu_baseline — oracle/_ref/fastANI_ref (the untouched reference, built by oracle/Makefile) timed on this box's host cores
-                 on a bounded sample of the same workload: ALL references x 8 queries, -t 16 = its fastest thread count on the
-                 128-core host (rank 0, N = 1);
+                 on a bounded sample of the same workload: ALL references x 24 queries in ONE run at -t 16 (its fastest thread
+                 count on the 128-core host), fixed and per-query cost read from its own stderr timers (rank 0, N = 1);
   end_to_end   — the drop-in CLI (fastani_amd/fastANI) on the same FASTA files on local disk -> output file, wall clock.
 """
 import argparse
@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--simulate-world", type=int, default=0, help="ONE GPU computes what one rank of a W-GPU strong-scaling (ring) job computes, without the communication: "
                                                                   "the measured per-rank time behind the predicted W-GPU figure (DESIGN.md section 5)")
     ap.add_argument("--simulate-rank", type=int, default=0)
+    ap.add_argument("--dry-collectives", action="store_true", help="N > 1: run ONLY the collectives of the multi-rank step — the one-word all-reduce, the in-place all-gather with the "
+                    "real slot size of the workload, the barrier — 10 times, print per-rank seconds and GB/s as one JSON line and leave (tells a hang from a slow link in ~30 s)")
     ap.add_argument("--dump-rows", default="", help="write the rows of the last timed step to <path>[.rank<r>].npy (tests)")
     ap.add_argument("--slice-genomes", type=int, default=1000, help="c5: genomes generated and sketched per slice")
     ap.add_argument("--ref-block", type=int, default=0, help="c5: reference genomes indexed and mapped together (0 = as many as keep the records in a third of the device memory)")
@@ -91,7 +93,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-self", action="store_true", help="all-vs-all: sketch the query role separately (as for unrelated query sets)")
-    ap.add_argument("--cpu-queries", type=int, default=10, help="query genomes of the larger of the two fastANI_ref samples (the smaller one takes 2)")
+    ap.add_argument("--cpu-queries", type=int, default=24, help="query genomes of the fastANI_ref sample (one run; fixed and marginal cost from its own stderr timers)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="fastANI_ref -t: 16 is where the reference is fastest on the 128-core benchmark host (1 x 1000: 39.6 s at 16, 51.9 at 32, "
                          "83.5 at 64, 117.4 at 128 threads — every thread builds its own hash-map index; profiles/r02_refscale.txt)")
@@ -241,6 +243,39 @@ def oracle_spot_check(orc, args, rows_by_pair, n_refs, query_ids, L, window, pai
             "queries": len(q_ids), "refs": len(ref_ids), "oracle_seconds": round(time.time() - t0, 1)}
 
 
+def ref_timeline(cmd, n_queries):
+    """Runs the reference binary once and reads its cost model out of its own stderr (every line stamped on arrival):
+    thread 0 prints 'Time spent sketching the reference', then per query 'Start Map i', 'Time spent mapping fragments in query #i',
+    'Time spent post mapping' (core_genome_identity.cpp:60-105), and the process prints 'parallel_for execution finished' when the
+    slowest thread is through its queries (:119)."""
+    import statistics
+    t0 = time.time()
+    r = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    lines = []
+    for raw in r.stderr:
+        lines.append((time.time() - t0, raw.decode(errors="replace").rstrip("\n")))
+    r.wait()
+    wall = time.time() - t0
+    if r.returncode != 0:
+        raise SystemExit("fastANI_ref failed (%d):\n%s" % (r.returncode, "\n".join(ln for _, ln in lines[-20:])))
+    sketch_timer = next((float(ln.split(":")[-1].split()[0]) for _, ln in lines if "Time spent sketching the reference" in ln), None)
+    t_start_map1 = next((st for st, ln in lines if ln.rstrip().endswith("Start Map 1")), None)
+    t_loop_done = next((st for st, ln in lines if "parallel_for execution finished" in ln), None)
+    t_map = [float(ln.split(":")[-1].split()[0]) for _, ln in lines if "Time spent mapping fragments in query" in ln]
+    t_post = [float(ln.split(":")[-1].split()[0]) for _, ln in lines if "Time spent post mapping" in ln]
+    per_q = [a + b for a, b in zip(t_map, t_post)]
+    if t_start_map1 is None or t_loop_done is None or len(per_q) != n_queries:
+        raise SystemExit("fastANI_ref: unexpected stderr (%d per-query timers for %d queries)" % (len(per_q), n_queries))
+    m_loop = (t_loop_done - t_start_map1) / n_queries
+    m_t0 = statistics.median(per_q)
+    srt = sorted(per_q)
+    return {"queries": n_queries, "wall_s": round(wall, 2), "thread0_sketch_timer_s": round(sketch_timer, 2) if sketch_timer is not None else None,
+            "start_map1_at_s": round(t_start_map1, 2), "loop_done_at_s": round(t_loop_done, 2), "after_loop_s": round(wall - t_loop_done, 2),
+            "marginal_s_per_query": m_loop, "fixed_s": wall - m_loop * n_queries,
+            "thread0_per_query_s": {"median": round(m_t0, 3), "min": round(srt[0], 3), "p25": round(srt[len(srt) // 4], 3), "p75": round(srt[(3 * len(srt)) // 4], 3), "max": round(srt[-1], 3)},
+            "marginal_crosscheck_ratio": round(m_t0 / m_loop, 3) if m_loop > 0 else None}
+
+
 def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
     """rank 0, N = 1: FASTA copies of the set on local disk, the reference binary on a bounded sample, the drop-in CLI end to
     end, and the parity of the timed step's rows against both the reference's output and the oracle."""
@@ -266,43 +301,37 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
         paths = write_fasta_set(orc, args.seed, ids, L, td, hi["logical_cpus"], args.cluster_size)
         out["fasta_set"] = {"files": len(paths), "bytes": int(sum(os.path.getsize(p) for p in paths)), "seconds": round(time.time() - t0, 1), "dir": "local disk (%s)" % td}
         index_of = {p: i for i, p in enumerate(paths)}
-        # ---- reference binary: every reference x a few query genomes, at TWO query counts.  The reference's cost is
+        # ---- reference binary: every reference x a sample of the query genomes, ONE run.  The reference's cost is
         # T(Nq) = F + m * Nq: F = every thread sketches and indexes its split of the references, plus the serial re-read of all files for
-        # the genome lengths (computeCoreIdentity.hpp:48-92); m = one query mapped against every split.  A single small sample
-        # amortises F over a handful of queries and understates the reference several times over (profiles/r02_refscale.txt), so
-        # `value` is the extrapolation to the workload's own query count, F + m * Nq_workload. ----
+        # the genome lengths (computeCoreIdentity.hpp:48-92) and the writers; m = one query mapped against every split.  Both come out of
+        # the run's own stderr lines (core_genome_identity.cpp:60-70 "Time spent sketching the reference", :93-105 "Time spent mapping
+        # fragments in query #i" / "Time spent post mapping") and their arrival times — see ref_timeline().  Rounds 3-4 took the slope
+        # between two runs (2 and 10 queries), whose common 40-50 s sketch phase moved by more than the 15 s the slope was read from. ----
         if want_ref:
             all_q = [q for q in query_ids if q < len(paths)]
             q_hi = all_q[:args.cpu_queries]
-            q_lo = q_hi[:max(1, min(2, len(q_hi) - 1))] if len(q_hi) > 1 else q_hi
             rl = os.path.join(td, "rl.txt")
             open(rl, "w").write("\n".join(paths[:n_cpu_refs]) + "\n")
             threads = max(1, min(args.cpu_threads, hi["physical_cores"]))
-
-            def run_ref(qs, tag):
-                ql = os.path.join(td, "ql_%s.txt" % tag)
-                open(ql, "w").write("\n".join(paths[q] for q in qs) + "\n")
-                ro = os.path.join(td, "ref_%s.out" % tag)
-                t0 = time.time()
-                subprocess.check_call([orc.REF_BIN, "--ql", ql, "--rl", rl, "-t", str(threads), "-o", ro], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                return time.time() - t0, ro
-            t_hi, ref_out = run_ref(q_hi, "hi")
-            if len(q_lo) < len(q_hi):
-                t_lo, _ = run_ref(q_lo, "lo")
-                m_q = max(0.0, (t_hi - t_lo) / (len(q_hi) - len(q_lo)))
-                fixed = max(0.0, t_lo - m_q * len(q_lo))
-            else:                                               # one-to-many: the workload IS the sample
-                t_lo, m_q, fixed = t_hi, 0.0, t_hi
-            t_full = fixed + m_q * n_queries if len(q_lo) < len(q_hi) else t_hi
+            ql = os.path.join(td, "ql_ref.txt")
+            open(ql, "w").write("\n".join(paths[q] for q in q_hi) + "\n")
+            ref_out = os.path.join(td, "ref.out")
+            tl = ref_timeline([orc.REF_BIN, "--ql", ql, "--rl", rl, "-t", str(threads), "-o", ref_out], len(q_hi))
+            m_q, fixed, t_hi = tl["marginal_s_per_query"], tl["fixed_s"], tl["wall_s"]
+            t_full = fixed + m_q * n_queries
+            tl["pairs_per_s_of_the_sample_itself"] = round(len(q_hi) * n_cpu_refs / t_hi, 1)
+            tl["marginal_s_per_query"], tl["fixed_s"] = round(m_q, 4), round(fixed, 2)
             out["cpu_baseline"] = {"value": round(n_queries * n_cpu_refs / t_full, 3), "unit": "pairs/s", "cores": threads, "kind": "reference",
                                    "cpu_model": hi["cpu_model"], "logical_cpus": hi["logical_cpus"], "physical_cores": hi["physical_cores"],
                                    "fixed_s": round(fixed, 2), "marginal_s_per_query": round(m_q, 3), "extrapolated_full_workload_s": round(t_full, 1),
-                                   "measured": {"queries": [len(q_lo), len(q_hi)], "wall_s": [round(t_lo, 2), round(t_hi, 2)],
-                                                "pairs_per_s_of_the_samples_themselves": [round(len(q_lo) * n_cpu_refs / t_lo, 1), round(len(q_hi) * n_cpu_refs / t_hi, 1)]},
+                                   "measured": tl,
+                                   "rule": "value = Nq x Nr / (F + m x Nq) with Nq = the workload's %d queries; m = (arrival of 'parallel_for execution finished' - arrival of thread 0's "
+                                           "'Start Map 1') / sampled queries = what one more query costs the slowest thread; F = wall - m x sampled queries (reference sketch + index per "
+                                           "thread, genome lengths re-read, writers); cross-check m_thread0 = median of thread 0's own per-query 'mapping' + 'post mapping' timers" % n_queries,
                                    "threads_note": "-t %d: the thread count at which the reference is fastest on this host class (profiles/r03_refscale.txt)" % threads,
-                                   "sample": "fastANI_ref -t %d on %d and %d query genomes x %d references of the same clustered %d bp set (FASTA on local disk), wall %.1f s + %.1f s incl. FASTA parse; "
-                                             "value = %d x %d pairs / (fixed %.1f s + %d x %.2f s per query)"
-                                             % (threads, len(q_lo), len(q_hi), n_cpu_refs, L, t_lo, t_hi, n_queries, n_cpu_refs, fixed, n_queries, m_q)}
+                                   "sample": "fastANI_ref -t %d, ONE run on %d query genomes x %d references of the same clustered %d bp set (80-column FASTA on local disk), wall %.1f s incl. FASTA parse; "
+                                             "value = %d x %d pairs / (fixed %.1f s + %d x %.3f s per query)"
+                                             % (threads, len(q_hi), n_cpu_refs, L, t_hi, n_queries, n_cpu_refs, fixed, n_queries, m_q)}
             q_ids = q_hi
             if not args.no_verify:
                 parity["vs_reference_binary"] = compare_with_reference(rows_by_pair, read_ref_out(ref_out, index_of), set(q_ids), n_cpu_refs, L)
@@ -420,6 +449,12 @@ def setup_runtime(args):
     R.dev = torch.device("cpu") if R.emu else torch.device("cuda", R.local)
     if not R.emu:
         torch.cuda.set_device(R.dev)
+    # host threads per rank: N ranks share the host, so each takes cores / N (the library's packing pool reads ANI_HOST_THREADS; torch's
+    # intra-op pool would otherwise start one thread per core in every rank).  ANI_BENCH_THREADS_PER_RANK overrides.
+    R.threads_per_rank = max(1, int(os.environ.get("ANI_BENCH_THREADS_PER_RANK", "0")) or (os.cpu_count() or 1) // max(1, R.world))
+    if R.world > 1:
+        os.environ.setdefault("ANI_HOST_THREADS", str(min(64, R.threads_per_rank)))
+        torch.set_num_threads(max(1, min(R.threads_per_rank, 16)))
     import fastani_amd
     if R.emu:
         import ctypes
@@ -774,6 +809,42 @@ def step_simulate(R):
     return rows
 
 
+def dry_collectives(R, reps=10):
+    """--dry-collectives: the collectives of the strong-scaling step with nothing around them.  Slot size = the packed fragment set of
+    this rank's shard (~1.6 MB per 5 Mbp genome: 4 bytes per sketch hash + tables), agreed by the same one-word all-reduce the step
+    uses; the all-gather is the in-place form of fastani_amd/multi_gpu.py: gather_map."""
+    torch, dist = R.torch, R.dist
+    est = int((R.hi - R.lo) * (R.L / 3000.0) * (240 * 4 + 16) + 4096)         # ~240 sketch hashes per 3 kb fragment
+    times = {"all_reduce_s": [], "all_gather_s": [], "barrier_s": []}
+    m = torch.tensor([est], dtype=torch.int64, device=R.dev)
+    t0 = time.perf_counter(); dist.all_reduce(m, op=dist.ReduceOp.MAX); dev_sync(R); first_allreduce = time.perf_counter() - t0
+    cap = (int(m.item()) + 255) // 256 * 256
+    buf = torch.empty(cap * R.world, dtype=torch.uint8, device=R.dev)
+    buf[R.rank * cap:(R.rank + 1) * cap].fill_(R.rank + 1)
+    ok = True
+    for i in range(reps):
+        dev_sync(R)
+        t0 = time.perf_counter(); dist.all_reduce(m, op=dist.ReduceOp.MAX); dev_sync(R); t1 = time.perf_counter()
+        work = dist.all_gather_into_tensor(buf, buf[R.rank * cap:(R.rank + 1) * cap], async_op=True); work.wait(); dev_sync(R); t2 = time.perf_counter()
+        dist.barrier(); dev_sync(R); t3 = time.perf_counter()
+        times["all_reduce_s"].append(t1 - t0); times["all_gather_s"].append(t2 - t1); times["barrier_s"].append(t3 - t2)
+        if i == 0:
+            ok = all(int(buf[s * cap]) == s + 1 and int(buf[(s + 1) * cap - 1]) == s + 1 for s in range(R.world))
+    mine = torch.tensor([min(times["all_reduce_s"]), min(times["all_gather_s"]), sorted(times["all_gather_s"])[len(times["all_gather_s"]) // 2], min(times["barrier_s"]), float(ok), first_allreduce],
+                        dtype=torch.float64, device=R.dev)
+    allv = torch.empty(R.world * mine.numel(), dtype=torch.float64, device=R.dev)
+    dist.all_gather_into_tensor(allv, mine)
+    g = allv.view(R.world, -1).tolist()
+    recv = cap * (R.world - 1)
+    if R.rank == 0:
+        print(json.dumps({"dry_collectives": True, "n_gpus": R.world, "slot_bytes": cap, "bytes_received_per_rank": recv, "reps": reps,
+                          "first_all_reduce_s": [round(x[5], 4) for x in g], "all_reduce_min_s": [round(x[0], 6) for x in g],
+                          "all_gather_min_s": [round(x[1], 6) for x in g], "all_gather_median_s": [round(x[2], 6) for x in g],
+                          "all_gather_GBps_received_per_rank": [round(recv / x[1] / 1e9, 2) if x[1] > 0 else None for x in g],
+                          "barrier_min_s": [round(x[3], 6) for x in g], "slots_arrived_intact": [bool(x[4]) for x in g],
+                          "threads_per_rank": R.threads_per_rank}), flush=True)
+
+
 STEPS = {"single": step_single, "ring": step_ring, "gather": step_gather, "simulate": step_simulate}
 
 
@@ -850,6 +921,13 @@ def main():
     e, p, cfg = R.e, R.p, args.config
     make_inputs(R)
     mode, NR, L, world, rank = R.mode, R.NR, R.L, R.world, R.rank
+    if args.dry_collectives:
+        if R.dist is None:
+            raise SystemExit("--dry-collectives needs a process group (launch with torch.distributed.run, or ANI_BENCH_FORCE_DIST=1 for one rank)")
+        dry_collectives(R)
+        e.close()
+        R.dist.destroy_process_group()
+        return
     if mode == "simulate":
         prepare_simulation(R)
     res = timed_loop(R, STEPS[mode], args.steps, args.warmup)
@@ -986,7 +1064,10 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
     elif world > 1 or R.multi:
         how = ("; STRONG scaling: references sharded %d ways, query fragment sketches all-gathered over RCCL" % world if mode == "ring"
                else "; WEAK scaling: queries sharded %d ways (%d per GPU), reference sketch all-gathered over RCCL" % (world, nq_local))
+    # `value` is the contract's figure: whole-job throughput with the inputs already resident in HBM when the timed region starts
+    # (2-bit packed genomes); the wall-clock figure of SURVEY.md section 8d (first FASTA byte -> output file closed) is `end_to_end`
     out = {"metric": "ANI pairs/sec, many-to-many NxN ~5 Mbp genomes", "value": round(value, 1), "unit": "pairs/s",
+           "value_is": "device-resident inputs (2-bit packed genomes in HBM at the start of the timed region; rows on the host at its end); end_to_end.pairs_per_s = FASTA on disk -> output file",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
            "higher_is_better": True, "scaling": "weak" if mode == "gather" else "strong", "vs_baseline": None, "dtype": "u32",
            "data": "synthetic" if not R.emu else "synthetic; CPU EMULATION OF THE KERNELS (test of the orchestration, not a measurement)",

@@ -142,7 +142,7 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_L1_BIG_GROUP_FRAGS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupFrags = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev); if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
   if (const char *ev = getenv("ANI_STREAM_CHUNK_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->streamChunkMinimizers = (uint64_t)v; }
-  for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); }
+  for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evIndex[i], hipEventDisableTiming)); }
   int rc = c->dCounters.ensure(kCounterWords * 8);
   if (rc != ANI_OK) { delete c; return rc; }
   *out = c;
@@ -161,7 +161,7 @@ void ani_shutdown(ani_ctx *c)
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); }
+  for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); if (c->evIndex[i]) (void)hipEventDestroy(c->evIndex[i]); }
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   for (int i = 0; i < 5; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -121,7 +121,7 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
     { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
     SK_HIP(hipMemsetAsync(sk->dupBits, 0, bitWords * 4, ctx->stream));
     // Main stream: the index sort (radix.hpp) — its histogram read of the records writes the position-ordered SoA arrays, its passes
-    // are bound by memory bandwidth.  Side stream, as soon as the SoA arrays exist (evSimA[0]): everything that needs positions only —
+    // are bound by memory bandwidth.  Side stream, as soon as the SoA arrays exist (evIndex[0]; the index build has its own events — the L2 stage's evSimA belong to map_stage): everything that needs positions only —
     // contig slices, the window links of the L2 event stream (binary searches over LDS-staged positions: latency- and LDS-bound),
     // the sampled position index — runs underneath the sort's passes instead of after them.
     struct SideJoin { ani_ctx *c; ~SideJoin() { (void)hipStreamSynchronize(c->stream2); } } sideJoin{ctx};   // also on the error paths below
@@ -131,7 +131,7 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
       for (const RecordPiece &pc : sk->pieces) if (pc.n) { recs.push_back(pc.rec); cnts.push_back(pc.n); }
       size_t tb = 0;
       int rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, nullptr, &tb, ctx->stream, nullptr, nullptr);
-      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, ctx->evSimA[0], ctx->stream2); }
+      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, ctx->evIndex[0], ctx->stream2); }
       if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
       sorting = true;                               // the passes are in flight; stream2 waits for the SoA arrays
     }
@@ -142,13 +142,20 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
     if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
                                     sk->totalPosBins, (uint32_t)n, sk->posSample);
     if (sorting) {
-      const int rc = ani_sort_check(ctx->sortTmp.p, ctx->stream);
+      // (ctx->sortTmp holds the status and error words of the passes in flight: nothing may touch it between ani_sort_index and here)
+      int rc = ani_sort_check(ctx->sortTmp.p, ctx->stream);
+      if (rc == 9001) {                             // a look-back gave up (a scheduling surprise, sort_device.hip): once more, without the side stream
+        std::vector<const void *> recs; std::vector<size_t> cnts;
+        for (const RecordPiece &pc : sk->pieces) if (pc.n) { recs.push_back(pc.rec); cnts.push_back(pc.n); }
+        size_t tb = ctx->sortTmp.cap;
+        rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, nullptr, nullptr);
+      }
       if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
     }
     pool_free(tmpK); pool_free(tmpV);
     SK_HIP(hipGetLastError());
-    SK_HIP(hipEventRecord(ctx->evSimA[1], ctx->stream2));
-    SK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evSimA[1], 0));            // the links kernel needs the contig slices and ORs into the window links
+    SK_HIP(hipEventRecord(ctx->evIndex[1], ctx->stream2));
+    SK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evIndex[1], 0));            // the links kernel needs the contig slices and ORs into the window links
     // same-hash links of near duplicates (index.hpp: DupLinks) and the number of distinct hashes
     unsigned long long host[CNT_N];
     host[CNT_UNIQ] = 0;

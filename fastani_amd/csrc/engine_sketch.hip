@@ -418,6 +418,20 @@ FragWireHeader wire_header(const ani_fragset *f)
   h.totalBytes = wire_align(h.offPool + h.poolSize * 4);
   return h;
 }
+// One check for every header that arrives in a buffer (ani_fragset_unpack, every slot of ani_fragset_unpack_merged — those come from
+// peers): magic, version, counts in range, and EVERY offset equal to what the layout rule gives for these counts, so that no field of
+// the header is used as a device offset unchecked.  Returns nullptr or what is wrong.
+const char *validate_wire_header(const FragWireHeader &h, uint64_t bytesAvailable)
+{
+  if (memcmp(h.magic, "ANIFRAGS", 8) != 0 || h.version != 1) return "not a packed fragment set";
+  if (h.nFrag < 0 || h.nGenomes < 0 || h.maxS < 0 || h.poolSize > 0xfffffff0ull || h.nHashes > h.poolSize) return "inconsistent counts";
+  ani_fragset tmp; tmp.fs.nFrag = h.nFrag; tmp.fs.poolSize = h.poolSize; tmp.fs.genomeFragments.assign((size_t)h.nGenomes, 0);
+  const FragWireHeader want = wire_header(&tmp);       // the layout follows from the counts: the offsets in the buffer must be these
+  if (want.offGenomeFragments != h.offGenomeFragments || want.offFragOff != h.offFragOff || want.offFragS != h.offFragS || want.offFragGenome != h.offFragGenome ||
+      want.offFragQSeq != h.offFragQSeq || want.offPool != h.offPool || want.totalBytes != h.totalBytes || h.totalBytes > bytesAvailable)
+    return "truncated or malformed";
+  return nullptr;
+}
 }  // namespace
 
 int ani_fragset_pack_bytes(const ani_fragset *f, size_t *bytes)
@@ -458,15 +472,10 @@ int ani_fragset_unpack(ani_ctx *ctx, const void *devBuf, size_t bytes, ani_frags
   if (bytes < 256) return fail(ANI_ERR_ARG, "not a packed fragment set");
   FragWireHeader h;
   HIP_TRY(hipMemcpy(&h, devBuf, sizeof h, hipMemcpyDeviceToHost));
-  if (memcmp(h.magic, "ANIFRAGS", 8) != 0 || h.version != 1) return fail(ANI_ERR_ARG, "not a packed fragment set");
+  if (const char *why = validate_wire_header(h, bytes)) return fail(ANI_ERR_ARG, "packed fragment set: %s", why);
   ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen; tmp.params.percentageIdentity = h.percentageIdentity;
   TRY(check_params(&tmp.params));
-  if (h.nFrag < 0 || h.nGenomes < 0 || h.maxS < 0 || h.poolSize > 0xfffffff0ull || h.nHashes > h.poolSize) return fail(ANI_ERR_ARG, "packed fragment set with inconsistent counts");
   tmp.fs.nFrag = h.nFrag; tmp.fs.maxS = h.maxS; tmp.fs.nHashes = h.nHashes; tmp.fs.poolSize = h.poolSize; tmp.fs.genomeFragments.assign((size_t)h.nGenomes, 0);
-  const FragWireHeader want = wire_header(&tmp);       // the layout follows from the counts: the offsets in the buffer must be these
-  if (want.offFragOff != h.offFragOff || want.offFragS != h.offFragS || want.offFragGenome != h.offFragGenome || want.offFragQSeq != h.offFragQSeq ||
-      want.offPool != h.offPool || want.totalBytes != h.totalBytes || h.totalBytes > bytes)
-    return fail(ANI_ERR_ARG, "packed fragment set is truncated or malformed");
   ani_fragset *f = new ani_fragset();
   f->ctx = ctx; f->device = ctx->device; f->params = tmp.params; f->borrowed = true;
   f->fs = tmp.fs;
@@ -505,18 +514,19 @@ int ani_fragset_unpack_merged(ani_ctx *ctx, const void *devBuf, size_t slotBytes
   ani_fragset *f = new ani_fragset();
   f->ctx = ctx; f->device = ctx->device; f->borrowed = true; f->ownTables = true;
   auto bail = [&](int rc) { fragset_release(f); return rc; };
-  uint64_t nF = 0; int32_t nG = 0; bool first = true;
+  uint64_t nF = 0; int32_t nG = 0; bool first = true; int64_t nextQueryId = 0;
   for (int32_t i = 0; i < nSlots; i++) {
     if (slotQueryBase[i] < 0) continue;
     const FragWireHeader &h = hs[i];
-    if (memcmp(h.magic, "ANIFRAGS", 8) != 0 || h.version != 1 || h.nFrag < 0 || h.nGenomes < 0 || h.totalBytes > slotBytes || h.nHashes > h.poolSize) return bail(fail(ANI_ERR_ARG, "slot %d is not a packed fragment set", i));
+    if (const char *why = validate_wire_header(h, slotBytes)) return bail(fail(ANI_ERR_ARG, "slot %d: %s (a peer that packed nothing, or a stale buffer?)", i, why));
+    // the streamed re-order of map_fragsets finds a query's set by a lower bound over the genomes' query ids: the used slots must
+    // come in ascending, non-overlapping query-id order (ranks own contiguous genome ranges in rank order)
+    if ((int64_t)slotQueryBase[i] < nextQueryId) return bail(fail(ANI_ERR_ARG, "slot %d: query ids must ascend over the used slots (slot starts at %d, the slots before it end at %lld)", i, slotQueryBase[i], (long long)nextQueryId));
+    nextQueryId = (int64_t)slotQueryBase[i] + h.nGenomes;
     ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen; tmp.params.percentageIdentity = h.percentageIdentity;
-    tmp.fs.nFrag = h.nFrag; tmp.fs.poolSize = h.poolSize; tmp.fs.genomeFragments.assign((size_t)h.nGenomes, 0);
-    const FragWireHeader want = wire_header(&tmp);
-    if (want.offFragOff != h.offFragOff || want.offFragS != h.offFragS || want.offFragGenome != h.offFragGenome || want.offFragQSeq != h.offFragQSeq || want.offPool != h.offPool || want.totalBytes != h.totalBytes)
-      return bail(fail(ANI_ERR_ARG, "slot %d: packed fragment set is malformed", i));
     if (first) { f->params = tmp.params; const int rc = check_params(&f->params); if (rc != ANI_OK) return bail(rc); first = false; }
-    else if (f->params.kmerSize != h.kmerSize || f->params.windowSize != h.windowSize || f->params.fragLen != h.fragLen) return bail(fail(ANI_ERR_ARG, "slot %d was sketched with other parameters", i));
+    else if (f->params.kmerSize != h.kmerSize || f->params.windowSize != h.windowSize || f->params.fragLen != h.fragLen || f->params.percentageIdentity != h.percentageIdentity)
+      return bail(fail(ANI_ERR_ARG, "slot %d was sketched with other parameters", i));
     nF += (uint64_t)h.nFrag; nG += h.nGenomes;
     if (nF > 0x3fffffffull) return bail(fail(ANI_ERR_LIMIT, "too many fragments in the merged set"));
   }

@@ -67,6 +67,17 @@ struct DevicePool {
   hipError_t alloc(void **out, size_t bytes)
   {
     if (bytes == 0) bytes = 1;
+    // Size classes for large blocks (round 5): a request of >= 64 MiB is rounded up to a multiple of 2^(floor(log2 bytes) - 5), i.e.
+    // 1/32 .. 1/64 of its size (<= 3 % slack).  The index chunks of a streamed reference set are cut at genome borders and differ by
+    // a few 10^-4 of their size: without classes a chunk that is a little LARGER than the one just dropped finds no cached block
+    // (lower_bound), takes ~36 GB of fresh memory, and the dropped chunk's blocks stay cached until the device is full — the 39 chunk
+    // builds of the 90 000-genome run spent as long in first-touch memory and hipFree as in kernels (profiles/r04c5b).
+    static const bool classes = !(getenv("ANI_POOL_CLASSES") && !strcmp(getenv("ANI_POOL_CLASSES"), "0"));
+    if (classes && bytes >= ((size_t)64 << 20)) {
+      int lg = 63; while (!((bytes >> lg) & 1)) lg--;
+      const size_t gran = (size_t)1 << (lg - 5);
+      bytes = (bytes + gran - 1) / gran * gran;
+    }
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.lower_bound(bytes);
     // reuse only a closely fitting block: a looser fit lets a long-lived buffer capture the block a per-sketch array of a
@@ -257,7 +268,7 @@ struct ani_ctx {
   std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
   void *pinned[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t pinnedCap[5] = {0, 0, 0, 0, 0};   // page-locked staging: 0/1 result reads, 2 prefix-sum block totals, 3/4 ingest (packed / raw bytes)
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
-  hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr};
+  hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr}, evIndex[2] = {nullptr, nullptr};   // evIndex: build_chunk_index's own (sort -> side work -> join)
   // stage timers: event pairs are recorded as the launches go out and read back lazily (flush_timers), never by blocking the host
   std::vector<hipEvent_t> timerEvents; size_t timerUsed = 0;
   struct PendingTimer { size_t a, b; double *acc; };

@@ -426,6 +426,7 @@ int main(int argc, char **argv)
   if (!o.saveSketch.empty() && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --saveSketch cannot be combined with --visualize or -s (those modes sketch per reference split)" << std::endl; exit(1); }
   const bool allVsAll = !fromFile && (o.queries == o.refs) && !o.visualize && !o.sanityCheck;
   if (o.visualize || o.sanityCheck) o.devices.resize(1);            // the per-split / per-mapping paths are single-device
+  if (!o.saveSketch.empty() && o.devices.size() > 1) { std::cerr << "ERROR, --saveSketch writes the sketch of one device: run it with --gpus 1" << std::endl; exit(1); }   // before anything is read or sketched
 
   std::unordered_map<std::string, uint64_t> genomeLengths;          // computeCoreIdentity.hpp:48-92, filled while the files pass through
   std::mutex lenMu;
@@ -639,8 +640,7 @@ int main(int argc, char **argv)
       std::cerr << "INFO [thread 0], skch::main, Time spent sketching the reference : " << secs_since(t0) << " sec" << std::endl;
     }
 
-    if (!o.saveSketch.empty()) {
-      if (nDev > 1) { std::cerr << "ERROR, --saveSketch writes the sketch of one device: run it with --gpus 1" << std::endl; exit(1); }
+    if (!o.saveSketch.empty()) {                     // (one device: checked with the options)
       std::vector<const char *> nm; for (auto &r : o.refs) nm.push_back(r.c_str());
       if (ani_sketch_save(shard[0].sk, o.saveSketch.c_str(), nm.data())) die("ani_sketch_save");
       trace("sketch file written");
@@ -676,16 +676,37 @@ int main(int argc, char **argv)
           return true;
         });
     } else {
+      // The query slices are taken in WAVES: the fragment sketches of one wave's slices are made, (packed,) mapped against every shard
+      // and freed before the next wave's are made, so the device holds O(wave) query data, not O(all queries) (a fragment set is about a
+      // third of its genomes' bases in bytes: 1.6 MB per 5 Mbp genome).  A wave is as large as its budget allows, because a streamed
+      // shard rebuilds every index chunk once per wave.  All-vs-all: the sets exist already (fused pass) — one wave.
+      uint64_t waveBytes = 96ull << 30;                                                       // input bytes per wave (=> ~30 GB of fragment sets)
+      if (const char *ev = getenv("ANI_CLI_QUERY_WAVE_BYTES")) waveBytes = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
+      size_t nWaves = 0;
+      for (size_t w0 = 0, w1 = 0; w0 < qrySlices.size(); w0 = w1) {
+      if (allVsAll) w1 = qrySlices.size();
+      else {
+        uint64_t bytes = 0;
+        for (w1 = w0; w1 < qrySlices.size(); w1++) {
+          uint64_t sb = 0; for (size_t i = qrySlices[w1].first; i < qrySlices[w1].second; i++) sb += fp.sizeEst[i];
+          if (w1 > w0 && bytes + sb > waveBytes) break;
+          bytes += sb;
+        }
+      }
+      nWaves++;
       // 1. the query side's fragment sketches, slice by slice, on the device that reads the slice (all-vs-all: made by the fused pass)
-      if (!allVsAll)
-        run_two_stage(qrySlices, "query sketch", [&](size_t k) { return (int)(k % (size_t)nDev); },
+      if (!allVsAll) {
+        const std::vector<std::pair<size_t, size_t>> waveSlices(qrySlices.begin() + (std::ptrdiff_t)w0, qrySlices.begin() + (std::ptrdiff_t)w1);
+        run_two_stage(waveSlices, "query sketch", [&](size_t kk) { return (int)((kk + w0) % (size_t)nDev); },
           [&](int, size_t, SliceBatch &, Uploaded &) { return true; },
-          [&](int d, size_t k, Uploaded &u, std::string &msg) {
+          [&](int d, size_t kk, Uploaded &u, std::string &msg) {
+            const size_t k = kk + w0;
             ani_seq_batch_t db = dev_view(u);
             if (ani_fragset_build(dev[d].ctx, &ap, &db, &qsets[k].f)) { msg = ani_last_error(); return false; }
             qsets[k].dev = d; qsets[k].firstQuery = (int32_t)(qrySlices[k].first - nRefFiles);
             return true;
           });
+      }
       // 2. several devices: every set as one buffer the other devices can pull
       if (nDev > 1)
         for (auto &q : qsets) {
@@ -737,6 +758,8 @@ int main(int argc, char **argv)
       for (auto &w : workers) w.join();
       for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, mapping: " << e << std::endl; exit(1); }
       for (auto &q : qsets) { if (q.f) ani_fragset_free(q.f); if (q.packed) ani_device_free(dev[q.dev].ctx, q.packed); q.f = nullptr; q.packed = nullptr; }
+      }                                              // next wave
+      if (nWaves > 1) std::cerr << "INFO, skch::main, query genomes mapped in " << nWaves << " waves" << std::endl;
     }
     trace("queries mapped");
     for (auto &v : sliceRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }

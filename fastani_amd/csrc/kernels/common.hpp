@@ -453,7 +453,8 @@ template <class K, int KPT> __device__ __forceinline__ void wave_sort_regs(K (&k
   }
 }
 
-// Sorts a[0 .. n) ascending, n <= 4096 (the caller's array has room for next_pow2(max(n, 64)) keys; the tail is padded with ~0).
+constexpr int kBlockSortMax = 4096;
+// Sorts a[0 .. n) ascending, n <= kBlockSortMax (the caller's array has room for next_pow2(max(n, 64)) keys; the tail is padded with ~0).
 // Frames itself with workgroup barriers: the keys are complete before, the sorted sequence is visible after.
 __host__ __device__ __forceinline__ int next_pow2_dev(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 template <class K>
@@ -473,7 +474,8 @@ __device__ __forceinline__ void block_sort(K *a, int n)      // (inlined: an out
     case 512: block_sort_regs<K, 2, kTPB / kWave>(a); break;
     case 1024: block_sort_regs<K, 4, kTPB / kWave>(a); break;
     case 2048: block_sort_regs<K, 8, kTPB / kWave>(a); break;
-    default: block_sort_regs<K, 16, kTPB / kWave>(a); break;
+    case 4096: block_sort_regs<K, 16, kTPB / kWave>(a); break;
+    default: __builtin_trap();                            // n > kBlockSortMax: the caller's class limits rule it out — never sort a prefix silently
   }
   block_barrier();
 }

@@ -23,6 +23,7 @@ constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgro
 constexpr int kL1HitCapMax = kL1HitCapMid;   // beyond: the batched global-memory path.  (A class L of 8192 hits — 96 KiB of LDS, one workgroup
                                              // per CU — existed until round 3: 0.43 us per fragment where the batched path takes 0.33, measured at
                                              // 493 k such fragments per step of the cluster-size-100 benchmark.)
+static_assert(kL1HitCapMax <= kBlockSortMax, "block_sort (common.hpp) sorts at most kBlockSortMax keys");
 constexpr int kL1FilterMinHits = 300;   // below this the sort is cheaper than the noise filter
 template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 14 : 15; }   // log2(8 * HCAP) occupancy counters per tiling
 
@@ -336,7 +337,7 @@ static __global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
   if (i >= a.nFrag) return;
   const int f = a.fragOrder ? a.fragOrder[i] : i;
   const int s = a.fragS[f], H = a.fragHits[f];
-  if (s <= 0 || s > kL1MaxS || H <= 0 || H > kL1HitCapTiny) return;        // the workgroup classes / the batched path / nothing to do (k_l1<0, 2048> or k_l1_list writes the zero counts)
+  if (s <= 0 || s > kL1MaxS || H <= 0 || H > kL1HitCapTiny || H > a.ldsHitCap) return;   // the workgroup classes / the batched path (same class predicate as k_l1_probe: H > ldsHitCap is bigList's) / nothing to do (k_l1<0, 2048> or k_l1_list writes the zero counts)
   l1_tiny(a, f, s, H, hits[wv], V[wv]);
 }
 

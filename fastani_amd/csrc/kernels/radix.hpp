@@ -158,13 +158,14 @@ static __global__ __launch_bounds__(kTPB) void k_radix_scan(unsigned long long *
   }
 }
 
-// One pass over `n` elements that form the tiles [tileBase, tileBase + ceil(n / 4096)) of the whole sequence (the index chunk's
+// One pass over `n` elements that form the tiles [tileBase, tileBase + ceil(n / kRadixTile)) of the whole sequence (kRadixTile = 6144 keys) (the index chunk's
 // records come as several buffers: one launch per buffer, the look-back runs across them).
 //   digitBase  [256] exclusive digit offsets of this pass (k_radix_scan)
 //   status     [(all tiles) * 256], zeroed;  tileCounter zeroed per launch;  errFlag: set when a look-back gave up
 // 512 threads x 12 keys: the tile's life is a string of latencies (key loads, one LDS round trip per ranked key, the look-back's
-// round trips past the L2, value loads) and what hides them is waves — 8 per workgroup, 4 workgroups per CU (38 KiB of LDS, ~70
-// VGPRs) — not instruction-level tricks: 256 x 16 (the same tile, 105 VGPRs, 16 waves per CU) measured 4.7 ms per pass of 4 x 10^8
+// round trips past the L2, value loads) and what hides them is waves — 8 per workgroup; LDS per workgroup = the staging tile (6144 x max(key, value)
+// bytes: 48 KiB for the index's u32 / u64 pass, 24 KiB for u32-only) + 8 KiB of per-wave digit counters + 1 KiB of run bases ≈ 57 KiB for
+// the index pass, i.e. 2 workgroups = 16 waves per CU of 160 KiB — not instruction-level tricks: 256 x 16 (the same tile, 105 VGPRs, 16 waves per CU) measured 4.7 ms per pass of 4 x 10^8
 // records against 2.7 ms for rocPRIM's onesweep (profiles/r04c_radix_kernel_stats.csv).
 template <class KeyT, class ValT, class Src>
 static __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restrict__ keysOut, ValT *__restrict__ valsOut, uint64_t n, int shift, int endBit,

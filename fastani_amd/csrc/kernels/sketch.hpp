@@ -388,6 +388,7 @@ static __global__ void k_expand_frags(const uint32_t *__restrict__ fragStart, co
 }
 
 constexpr int kFragHashCap = 4096;   // minimizers one fragment may produce before sort/unique (LDS staging)
+static_assert(kFragHashCap <= kBlockSortMax, "block_sort (common.hpp) sorts at most kBlockSortMax keys");
 
 template <bool PACKED>
 __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ seq, const int64_t *__restrict__ contigOff,

@@ -6,7 +6,9 @@
 // Workspace = [digit histograms / offsets: 8 x 256 x u64][tile counters: 64 x u32][error flag][look-back status: tiles x 256 x u64]
 // [ping-pong buffer for sorts of more than one pass].  The calls return when the sort is done (they check the error flag).
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 
@@ -45,8 +47,19 @@ int finish(const Workspace &w, hipStream_t stream)
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  // test knob: ANI_SORT_FAIL_EVERY=<k> makes every k-th completed sort of the process report a given-up look-back (k = 2: every
+  // sort fails once and succeeds when it is repeated)
+  if (const char *ev = getenv("ANI_SORT_FAIL_EVERY")) {
+    static std::atomic<unsigned> done{0};
+    const int k = atoi(ev);
+    if (k > 0 && (done.fetch_add(1) + 1) % (unsigned)k == 0) return 9001;
+  }
   return err ? 9001 : 0;                                    // a look-back gave up (kRadixSpinLimit): the output is incomplete
 }
+// A look-back that gives up (9001) is a scheduling surprise — the device shared with another process, a pre-empted queue, a debugger —
+// not a property of the data: the sort is run ONCE more (histograms, counters, status words and the error flag are re-zeroed by every
+// run; the inputs are only read) before the caller sees the error.
+constexpr int kSortAttempts = 2;
 
 // generic: keys (and values) in arrays, bits [0, endBit) significant
 template <class KeyT, class ValT>
@@ -65,22 +78,28 @@ int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *val
   if (*tmpBytes < need) return 9003;
   Workspace w = carve(tmp, tiles);
   KeyT *pongK = (KeyT *)w.pong; ValT *pongV = (ValT *)(w.pong + keyBytes);
-  hipError_t e = hipMemsetAsync(w.hist, 0, align256(kHistBytes) + align256(kCtrBytes), stream);
-  if (e != hipSuccess) return (int)e;
-  const unsigned hg = (unsigned)std::min<uint64_t>((n + kTPB * 8 - 1) / (kTPB * 8), 4096);
-  ArraySrc<KeyT, ValT> in{keysIn, valsIn};
-  hipLaunchKernelGGL((k_radix_histogram<KeyT, ArraySrc<KeyT, ValT>>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, in, (uint64_t)n, endBit, P, w.hist, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-  hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kTPB), 0, stream, w.hist, P);
-  for (int p = 0; p < P; p++) {
-    const bool toOut = ((P - 1 - p) & 1) == 0;
-    ArraySrc<KeyT, ValT> src = p == 0 ? in : (toOut ? ArraySrc<KeyT, ValT>{pongK, pongV} : ArraySrc<KeyT, ValT>{keysOut, valsOut});
-    KeyT *dk = toOut ? keysOut : pongK; ValT *dv = toOut ? valsOut : pongV;
-    e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
+  const bool rerunnable = (const void *)keysIn != (const void *)keysOut && (!kHasVal || (const void *)valsIn != (const void *)valsOut);
+  int rc = 0;
+  for (int attempt = 0; attempt < kSortAttempts; attempt++) {
+    hipError_t e = hipMemsetAsync(w.hist, 0, align256(kHistBytes) + align256(kCtrBytes), stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_radix_pass<KeyT, ValT, ArraySrc<KeyT, ValT>>), dim3((unsigned)tiles), dim3(kRadixTPB), 0, stream, src, dk, dv, (uint64_t)n, p * kRadixBits, endBit,
-                       (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + p, 0u, w.err);
+    const unsigned hg = (unsigned)std::min<uint64_t>((n + kTPB * 8 - 1) / (kTPB * 8), 4096);
+    ArraySrc<KeyT, ValT> in{keysIn, valsIn};
+    hipLaunchKernelGGL((k_radix_histogram<KeyT, ArraySrc<KeyT, ValT>>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, in, (uint64_t)n, endBit, P, w.hist, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kTPB), 0, stream, w.hist, P);
+    for (int p = 0; p < P; p++) {
+      const bool toOut = ((P - 1 - p) & 1) == 0;
+      ArraySrc<KeyT, ValT> src = p == 0 ? in : (toOut ? ArraySrc<KeyT, ValT>{pongK, pongV} : ArraySrc<KeyT, ValT>{keysOut, valsOut});
+      KeyT *dk = toOut ? keysOut : pongK; ValT *dv = toOut ? valsOut : pongV;
+      e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
+      if (e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL((k_radix_pass<KeyT, ValT, ArraySrc<KeyT, ValT>>), dim3((unsigned)tiles), dim3(kRadixTPB), 0, stream, src, dk, dv, (uint64_t)n, p * kRadixBits, endBit,
+                         (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + p, 0u, w.err);
+    }
+    rc = finish(w, stream);
+    if (rc != 9001 || !rerunnable) break;
   }
-  return finish(w, stream);
+  return rc;
 }
 }  // namespace
 
@@ -118,6 +137,9 @@ extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN,
   if (*tmpBytes < need) return 9003;
   if (nPieces + P > kMaxLaunches) return 9004;
   Workspace w = carve(tmp, tiles);
+  const bool async = soaReady && sideStream;
+  int rc = 0;
+  for (int attempt = 0; attempt < (async ? 1 : kSortAttempts); attempt++) {       // (a caller with a side stream repeats the call without one when ani_sort_check reports 9001)
   hipError_t e = hipMemsetAsync(w.hist, 0, align256(kHistBytes) + align256(kCtrBytes), stream);
   if (e != hipSuccess) return (int)e;
   size_t o = 0;
@@ -129,7 +151,7 @@ extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN,
     o += pieceN[i];
   }
   // the SoA arrays are complete: work that only needs positions may start on the caller's side stream, underneath the passes
-  if (soaReady && sideStream) {
+  if (async) {
     e = hipEventRecord(soaReady, stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(sideStream, soaReady, 0);
     if (e != hipSuccess) return (int)e;
@@ -155,7 +177,11 @@ extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN,
                        (uint64_t)n, p * kRadixBits, 32, (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + launch, 0u, w.err);
     launch++;
   }
-  return (soaReady && sideStream) ? 0 : finish(w, stream);     // with a side stream the caller queues its side work first, then ani_sort_check
+  if (async) return 0;                                         // with a side stream the caller queues its side work first, then ani_sort_check
+  rc = finish(w, stream);
+  if (rc != 9001) break;
+  }
+  return rc;
 }
 
 // completes an ani_sort_index call that was given a side stream: waits for the sort and checks its error flag

@@ -105,6 +105,13 @@ def gather_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, 
         bufs = (key, [alloc(cap * world)])
         engine._ring_bufs = bufs
     buf, ptr = bufs[1][0]
+    # the in-place form of the all-gather (input = this rank's slot of the output) is only valid at offset rank * cap of a buffer of
+    # exactly cap * world elements, and the merged view needs the ranks' query ranges in rank order (ani_fragset_unpack_merged checks
+    # the order again on the headers that arrive)
+    if buf.numel() * buf.element_size() != cap * world:
+        raise RuntimeError("gather buffer of %d bytes for %d slots of %d" % (buf.numel() * buf.element_size(), world, cap))
+    if any(int(first_query_ids[i]) > int(first_query_ids[i + 1]) for i in range(world - 1)):
+        raise ValueError("first_query_ids must be non-decreasing by rank: %r" % (list(first_query_ids),))
     mine = buf[rank * cap:(rank + 1) * cap]
     frags.pack_into(ptr + rank * cap, cap)
     sync()

@@ -416,7 +416,13 @@ def case_fragset_wire(engine, alloc):
     for i, x in enumerate(sets):
         x.pack_into(mptr + i * pitch, pitch)
         x.close()
-    bases = [0, -1, 50, 3]                           # genomes 0,1 -> ids 0,1; slot 1 out; the 4-base genome -> id 50 (no fragments); genomes 3,4 -> ids 3,4
+    bases = [0, -1, 2, 3]                            # genomes 0,1 -> ids 0,1; slot 1 out; the 4-base genome -> id 2 (no fragments); genomes 3,4 -> ids 3,4
+    for bad in ([0, -1, 50, 3], [3, -1, 2, 0], [0, -1, 1, 3]):    # query ids must ascend over the used slots, without overlap
+        try:
+            FragmentSet.unpack_merged(engine, mptr, pitch, bad)
+            raise AssertionError("slot bases %r must be rejected" % bad)
+        except AniError as e:
+            assert e.code == -1
     mv = FragmentSet.unpack_merged(engine, mptr, pitch, bases, keepalive=mbuf)
     assert mv.info()["genomes"] == 5
     got = sk.map_cgi_fragset(mv, 0)

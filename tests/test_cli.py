@@ -119,7 +119,11 @@ def _run_streaming_variants(binary, tmp, full=True):
             ({"ANI_SLICE_BYTES": "40000"}, ["--devices", "0,0"]), ({"ANI_SLICE_BYTES": "80000", "ANI_MAX_INDEX_MINIMIZERS": "7000"}, ["--devices", "0,0,0"]),
             # reference set streamed through the device: one index chunk resident at a time (what a set beyond the HBM gets)
             ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, []),
-            ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "5000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, ["--devices", "0,0"])]
+            ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "5000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, ["--devices", "0,0"]),
+            # the query slices in waves (fragment sketches of one wave made, mapped against every shard, freed): one slice per wave
+            # over two contexts, two slices per wave against a streamed set
+            ({"ANI_SLICE_BYTES": "40000", "ANI_CLI_QUERY_WAVE_BYTES": "1"}, ["--devices", "0,0"]),
+            ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000", "ANI_MAX_RESIDENT_CHUNKS": "1", "ANI_CLI_QUERY_WAVE_BYTES": "80000"}, [])]
     if not full:                    # CPU build: the two streamed variants (one of them chunked over two contexts)
         envs = [envs[5], envs[6]]
     for env, extra in envs:
@@ -133,6 +137,8 @@ def _run_streaming_variants(binary, tmp, full=True):
                 assert open(rout + ".matrix").read() == open(out + ".matrix").read(), (env, extra)
             err = rb.stderr.decode()
             assert "Time spent sketching the reference" in err and "Time spent mapping fragments in query" in err and "Time spent post mapping" in err
+            if "ANI_CLI_QUERY_WAVE_BYTES" in env and name == "qr":
+                assert "query genomes mapped in" in err and "waves" in err, err[-800:]
     # persistent reference sketch: written by one run, used instead of --rl by the next (same rows, file names from the sketch)
     skf = os.path.join(tmp, "refs.anisk")
     args, rout = ref["qr"]
@@ -146,6 +152,9 @@ def _run_streaming_variants(binary, tmp, full=True):
         assert _lines(rout) == _lines(out), extra
     rb = subprocess.run([binary, "--ql", ql, "--refSketch", skf, "-k", "14", "-o", out], capture_output=True)
     assert rb.returncode == 1 and b"sketch file was built with" in rb.stderr
+    # --saveSketch on several devices is refused when the options are read, not after the whole reference set has been sketched
+    rb = subprocess.run([binary] + args + ["-o", out, "--saveSketch", skf + ".2", "--devices", "0,0"], capture_output=True)
+    assert rb.returncode == 1 and b"--saveSketch writes the sketch of one device" in rb.stderr and b"Time spent sketching" not in rb.stderr
 
 
 @pytest.mark.skipif(not orc.have_ref(), reason="oracle/_ref not built")

@@ -200,6 +200,21 @@ def test_bench_orchestration_two_ranks(config, scaling, emu_engine, tmp_path):
         assert np.array_equal(got[got["qryGenomeId"] < 6], single) and len(got) == 72
 
 
+def test_bench_dry_collectives_two_ranks(tmp_path):
+    """bench.py --dry-collectives: only the collectives of the strong-scaling step (one-word all-reduce, in-place all-gather with the
+    real slot size, barrier), the line a first run on an 8-GPU node starts with"""
+    import json
+    import subprocess
+    port = 29650 + (os.getpid() % 300)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-collectives", "--genomes", "6", "--genome-len", "24000"],
+                       capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert out["dry_collectives"] and out["n_gpus"] == 2 and out["slots_arrived_intact"] == [True, True]
+    assert out["slot_bytes"] % 256 == 0 and out["bytes_received_per_rank"] == out["slot_bytes"] and len(out["all_gather_GBps_received_per_rank"]) == 2
+
+
 def test_bench_c5_reference_blocks(emu_engine, tmp_path):
     """bench.py --config c5 with the reference set taken in BLOCKS (--ref-block: each block of genomes sketched slice by slice,
     indexed, mapped by every query and dropped — how a set whose records exceed the device memory runs on one GPU): the rows equal

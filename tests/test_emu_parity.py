@@ -142,6 +142,43 @@ def test_l1_tiny_path_off(monkeypatch):
     e.close()
 
 
+def test_l1_lds_cap_below_the_wave_class(monkeypatch):
+    """with ANI_L1_LDS_MAX between 1 and 255 a fragment with ldsHitCap < H <= 256 seed hits belongs to the batched path
+    alone — k_l1_tiny must use k_l1_probe's class predicate, or the fragment's candidates enter the pool twice"""
+    cands = []
+    for env in ({}, dict(ANI_L1_LDS_MAX=100, ANI_L1_BIG_GROUP_HITS=200000)):
+        e = _emu_engine_with(monkeypatch, **env)
+        e.reset_counters()
+        pc.case_synthetic_cluster(e, 30000)
+        pc.case_tandem_repeats(e)
+        # distant relatives only (12-15 % divergence): a few dozen seed hits per fragment, the wave kernel's class under either setting
+        a0 = pc.rng_genome(31, 24000)
+        far = [[a0], [pc.mutate(a0, 0.12, 32)]]
+        pp, sk, osk = pc.check_sketch(e, far)
+        pc.check_queries(e, pp, sk, osk, [[pc.mutate(a0, 0.15, 33)]])
+        c = e.counters()
+        cands.append(c["l1Candidates"])
+        if env:
+            assert c["l1BigFragments"] > 0 and c["l1TinyFragments"] > 0
+        e.close()
+    assert cands[0] == cands[1], cands            # every candidate emitted once
+
+
+def test_sort_is_repeated_once_when_a_look_back_gives_up(monkeypatch):
+    """a look-back that gives up (spin bound; a scheduling surprise, not a property of the data) repeats the sort once
+    before the call fails — with ANI_SORT_FAIL_EVERY=2 every sort of the process reports that once and passes when repeated (the
+    index build's side-stream form, the fragment order, the batched L1 path's hit sort, the same-hash links)"""
+    e = _emu_engine_with(monkeypatch, ANI_SORT_FAIL_EVERY=2, ANI_L1_LDS_MAX=0)
+    pc.case_synthetic_cluster(e, 24000)
+    pc.case_tandem_repeats(e)
+    e.close()
+    e = _emu_engine_with(monkeypatch, ANI_SORT_FAIL_EVERY=1)          # never passes: the error surfaces
+    from fastani_amd.api import AniError
+    with pytest.raises(AniError):
+        pc.case_synthetic_cluster(e, 24000)
+    e.close()
+
+
 def test_l2_pair_kernel(monkeypatch):
     """k_l2_sim_pair (l2.hpp; ANI_L2_PAIR=1, an experiment that is off by default): two candidates per lane, the window state in
     packed 16-bit halves — same mapping records, same counters (evaluated windows included) as the one-candidate kernel"""

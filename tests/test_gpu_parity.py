@@ -384,6 +384,29 @@ def test_l1_tiny_path_off(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_l1_lds_cap_below_the_wave_class(monkeypatch):
+    """with ANI_L1_LDS_MAX between 1 and 255 a fragment with ldsHitCap < H <= 256 seed hits belongs to the batched path
+    alone — k_l1_tiny must use k_l1_probe's class predicate, or the fragment's candidates enter the pool twice"""
+    cands = []
+    for env in ({}, dict(ANI_L1_LDS_MAX=100, ANI_L1_BIG_GROUP_HITS=200000)):
+        e = _engine_with(monkeypatch, **env)
+        e.reset_counters()
+        pc.case_synthetic_cluster(e, 30000)
+        pc.case_tandem_repeats(e)
+        # distant relatives only (12-15 % divergence): a few dozen seed hits per fragment, the wave kernel's class under either setting
+        a0 = pc.rng_genome(31, 24000)
+        far = [[a0], [pc.mutate(a0, 0.12, 32)]]
+        pp, sk, osk = pc.check_sketch(e, far)
+        pc.check_queries(e, pp, sk, osk, [[pc.mutate(a0, 0.15, 33)]])
+        c = e.counters()
+        cands.append(c["l1Candidates"])
+        if env:
+            assert c["l1BigFragments"] > 0 and c["l1TinyFragments"] > 0
+        e.close()
+    assert cands[0] == cands[1], cands            # every candidate emitted once
+
+
+@pytest.mark.gpu
 def test_same_hash_links_rerun(monkeypatch):
     """the list of same-hash links (index.hpp: DupLinks) is sized from a guess; a repetitive reference (tandem repeats, one k-mer on
     thousands of contigs) holds more near-duplicate pairs than that and the links kernel runs again with room for all"""

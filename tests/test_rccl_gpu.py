@@ -77,3 +77,16 @@ def test_simulated_ranks_add_up(gpu_engine, tmp_path):
         assert out["config"]["mode"] == "simulate" and out["simulated"]["world"] == 4 and out["rows_identical_across_steps"]
         parts.append(np.load(dump + ".npy"))
     assert np.array_equal(_sorted(np.concatenate(parts)), single)
+
+
+@pytest.mark.gpu
+def test_dry_collectives_over_rccl_one_rank():
+    """bench.py --dry-collectives over RCCL (one rank is what one GPU allows): the all-reduce, the in-place all-gather at the real slot
+    size of the 1000-genome workload's shard, the barrier — the 30-second check an 8-GPU run starts with"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(29350 + (os.getpid() % 200)),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-collectives"]
+    r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, ANI_BENCH_FORCE_DIST="1"), timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert out["dry_collectives"] and out["n_gpus"] == 1 and out["slots_arrived_intact"] == [True]
+    assert out["slot_bytes"] > 10 ** 9                      # 1000 genomes x ~1.6 MB of packed fragment sketches

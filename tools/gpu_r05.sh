@@ -1,0 +1,116 @@
+#!/bin/bash
+# One GPU-box visit of round 5.  usage: tools/gpu_r05.sh <tag> [stage ...]
+#   stages: tests bench3 quick prof c4sim8 c4one c5warm disk ubench overlap sim8 ab pmc cli90k
+# Writes everything under gpurun_out/<tag>/ (copy what is to be judged into profiles/).
+set -u
+exec < /dev/null
+TAG=${1:-r05}; shift || true
+STAGES=${*:-tests quick}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+line() { python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1])
+k = d.get('roofline', {}).get('all_kernels_ms_per_step', {})
+print('$1', d.get('value'), d.get('ms_per_step'), d.get('stage_ms_per_step_rank0'), {x: k[x] for x in ('ani::k_l2_sim', 'ani::k_l2_codes', 'ani::k_l1_probe', 'ani::k_l1') if x in k}, 'l2Steps', d.get('counters_per_step_rank0', {}).get('l2Steps'), 'rows_ok', d.get('rows_identical_across_steps'))
+"; }
+QUICK="--steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify"
+
+if has disk; then
+  { echo "== disk"; df -h "$REPO" /tmp /dev/shm 2>&1; nproc; free -g | head -2
+    timeout 120 dd if=/dev/zero of=/tmp/ddtest bs=1M count=6000 oflag=direct 2>&1 | tail -1
+    timeout 120 dd if=/tmp/ddtest of=/dev/null bs=1M iflag=direct 2>&1 | tail -1; rm -f /tmp/ddtest; } | tee "$OUT/disk.txt"
+fi
+if has tests; then
+  { echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+    echo "== pytest -m gpu"; timeout 1800 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tail -30; } | tee "$OUT/tests.log"
+fi
+if has paritytests; then
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -5 | tee "$OUT/paritytests.log"
+fi
+if has quick; then
+  echo "== bench (no cpu legs)"
+  timeout 600 python bench.py $QUICK 2> "$OUT/quick.err" | tee "$OUT/quick.json.log" | line quick
+  tail -3 "$OUT/quick.err"
+fi
+if has bench3; then
+  # the full default line three times on this box with ONE FASTA set: cpu_baseline must agree within +-15 %
+  mkdir -p /tmp/ani_bench_wd
+  for i in 1 2 3; do
+    echo "== bench run $i"
+    timeout 900 python bench.py --workdir /tmp/ani_bench_wd 2> "$OUT/bench$i.err" > "$OUT/bench$i.json.log"
+    python - "$OUT/bench$i.json.log" <<'EOF' | tee -a "$OUT/bench3_summary.txt"
+import sys, json
+d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')][-1])
+cb, e2e = d.get('cpu_baseline') or {}, d.get('end_to_end') or {}
+print('value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline'].get('frac'), 'cpu', cb.get('value'), 'F', cb.get('fixed_s'), 'm', cb.get('marginal_s_per_query'),
+      'xcheck', (cb.get('measured') or {}).get('marginal_crosscheck_ratio'), 'e2e', e2e.get('seconds'), 'parity', (d.get('parity_timed_rows') or {}).get('ok'))
+EOF
+  done
+  rm -rf /tmp/ani_bench_wd
+fi
+if has prof; then
+  echo "== rocprofv3 kernel stats (same command, no cpu legs)"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench --output-format csv -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/prof_bench.log" 2>&1)
+  f=$(find "$OUT/prof" -name "*kernel_stats*.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv" && head -28 "$f" | cut -c1-160
+  rm -rf "$OUT/prof"
+fi
+if has c4sim8; then
+  echo "== configs[3] in its multi-rank form: rank 0 of 8 at 10 000 x 10 000 (1250-genome shard, own set + merged 8750-genome foreign set)"
+  timeout 1500 python bench.py --config c4 --simulate-world 8 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --oracle-pairs 60 2> "$OUT/c4sim8.err" | tee "$OUT/c4sim8.json.log" | cut -c1-1500
+  tail -3 "$OUT/c4sim8.err"
+fi
+if has c4one; then
+  echo "== configs[3] on one GPU, warm (for the ratio)"
+  timeout 1500 python bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --oracle-pairs 60 2> "$OUT/c4one.err" | tee "$OUT/c4one.json.log" | cut -c1-1500
+  tail -3 "$OUT/c4one.err"
+fi
+if has sim8; then
+  for g in ${SIM_GENOMES:-1000}; do
+    for w in ${SIM_WORLDS:-8}; do
+      echo "== simulate-world $w, $g genomes"
+      timeout 900 python bench.py --simulate-world $w --genomes $g --steps 5 --warmup 2 --no-verify 2> "$OUT/sim${w}_$g.err" | tee "$OUT/sim${w}_$g.json.log" | line "sim$w/$g"
+    done
+    echo "== one GPU, $g genomes"
+    timeout 900 python bench.py --genomes $g --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-verify 2> "$OUT/one_$g.err" | tee "$OUT/one_$g.json.log" | line "one/$g"
+  done
+fi
+if has c5warm; then
+  echo "== configs[4] reference side, warm: 90 000 x 5 Mbp references x 1000 queries, --steps 2 --warmup 1"
+  ANI_POOL_TRACE=1 timeout 1500 python bench.py --config c5 --genomes 90000 --queries 1000 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --oracle-pairs 60 2> "$OUT/c5warm.err" | tee "$OUT/c5warm.json.log" | cut -c1-1500
+  grep -c "hipMalloc" "$OUT/c5warm.err"; grep "hipMalloc" "$OUT/c5warm.err" | awk '{mb+=$4; ms+=$6} END {print "fresh device memory:", mb/1024, "GB,", ms/1000, "s inside hipMalloc"}' | tee "$OUT/c5warm_pool.txt"
+  grep -n "timed step" "$OUT/c5warm.err" | head; grep "hipMalloc" "$OUT/c5warm.err" | sort -k6 -n -r | head -12 >> "$OUT/c5warm_pool.txt"
+  gzip -f "$OUT/c5warm.err"
+fi
+if has ubench; then
+  echo "== random reads / writes" | tee "$OUT/ubench_gather.txt"
+  timeout 300 tools/ubench/gather 2>&1 | tee -a "$OUT/ubench_gather.txt"
+fi
+if has overlap; then
+  echo "== L1 of one sub-batch beside L2 of another: two contexts on one device" | tee "$OUT/overlap_probe.txt"
+  timeout 600 python tools/overlap_probe.py --slices 2 4 8 --reps 4 2>&1 | tail -30 | tee -a "$OUT/overlap_probe.txt"
+fi
+if has ab; then
+  # A/B/A/B of an environment switch on one box: AB_VAR=<name> AB_VALUES="1 0"
+  for v in ${AB_VALUES:-1 0} ${AB_VALUES:-1 0}; do
+    env ${AB_VAR:-ANI_L2_TRIM}=$v timeout 300 python bench.py $QUICK 2>/dev/null | line "${AB_VAR:-ANI_L2_TRIM}=$v" | tee -a "$OUT/ab_${AB_VAR:-ANI_L2_TRIM}.txt"
+  done
+fi
+if has pmc; then
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"; do
+    name=$(echo $set | cut -d' ' -f1)
+    (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace -d "$OUT/pmc_$name" -o pmc --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/pmc_$name.log" 2>&1)
+    f=$(find "$OUT/pmc_$name" -name "*counter_collection*.csv" | head -1)
+    [ -n "$f" ] && python "$REPO/tools/pmc_summary.py" "$f" > "$OUT/pmc_${name}_summary.txt" 2>&1 && head -30 "$OUT/pmc_${name}_summary.txt" | cut -c1-200
+    rm -rf "$OUT/pmc_$name"
+  done
+fi
+if has cli90k; then
+  echo "== the command line on a 90 000-genome sketch file"
+  timeout 2400 python tools/c5_cli.py ${CLI90K_ARGS:-} 2>&1 | tail -40 | tee "$OUT/cli90k.txt"
+fi
+echo "== done: $STAGES"

@@ -25,6 +25,21 @@ __global__ __launch_bounds__(256) void k_gather(const uint2 *__restrict__ t, uin
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// Random 8-byte WRITES (round 5): what a bucketed ("merge-join") seed probe would pay to put its (first, count) results back into
+// sketch order — the scatter that follows the L2-resident table walk.
+template <int MLP>
+__global__ __launch_bounds__(256) void k_scatter(uint2 *__restrict__ t, uint64_t mask, int rounds)
+{
+  uint64_t x = (blockIdx.x * 256ull + threadIdx.x) * 0x9e3779b97f4a7c15ull + 12345;
+  for (int r = 0; r < rounds; r++) {
+#pragma unroll
+    for (int q = 0; q < MLP; q++) {
+      x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 32;
+      t[x & mask] = make_uint2((uint32_t)x, (uint32_t)r);
+    }
+  }
+}
+
 int main()
 {
   const uint64_t nEntries = 1ull << 29;       // 4 GiB of 8-byte entries
@@ -47,6 +62,19 @@ int main()
       }
       printf("%7llu MiB %6d %14.3e %12.2f\n", (unsigned long long)(wBytes >> 20), mlp, reads / (best * 1e-3), 4e8 / (reads / (best * 1e-3)) * 1e3);
     }
+  }
+  printf("\nrandom 8-byte writes\n%10s %14s %12s\n", "window", "writes/s", "ms per 4e8");
+  for (uint64_t wBytes = 8ull << 20; wBytes <= 4ull << 30; wBytes <<= 3) {
+    const int rounds = 16, blocks = 256 * 32;
+    const double writes = (double)blocks * 256 * rounds * 4;
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k_scatter<4>, dim3(blocks), dim3(256), 0, 0, t, wBytes / 8 - 1, rounds);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    printf("%7llu MiB %14.3e %12.2f\n", (unsigned long long)(wBytes >> 20), writes / (best * 1e-3), 4e8 / (writes / (best * 1e-3)) * 1e3);
   }
   return 0;
 }
