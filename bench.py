@@ -266,14 +266,19 @@ def ref_timeline(cmd, n_queries):
     per_q = [a + b for a, b in zip(t_map, t_post)]
     if t_start_map1 is None or t_loop_done is None or len(per_q) != n_queries:
         raise SystemExit("fastANI_ref: unexpected stderr (%d per-query timers for %d queries)" % (len(per_q), n_queries))
+    # what one more query costs a thread: the median of thread 0's own per-query timers (mapping + post mapping).  The loop-level figure
+    # (arrival of 'parallel_for execution finished' - arrival of thread 0's 'Start Map 1') / queries is kept as a cross-check only: it
+    # also holds the imbalance of the threads' SKETCH phases (the slowest thread starts its first query up to ~10 s after thread 0),
+    # which is a fixed cost — read as a per-query cost of a 24-query sample it moved the extrapolation by +-15 % between runs on one box
+    # (profiles/r05a_bench3_summary.txt), the median by +-2 %.
     m_loop = (t_loop_done - t_start_map1) / n_queries
     m_t0 = statistics.median(per_q)
     srt = sorted(per_q)
     return {"queries": n_queries, "wall_s": round(wall, 2), "thread0_sketch_timer_s": round(sketch_timer, 2) if sketch_timer is not None else None,
             "start_map1_at_s": round(t_start_map1, 2), "loop_done_at_s": round(t_loop_done, 2), "after_loop_s": round(wall - t_loop_done, 2),
-            "marginal_s_per_query": m_loop, "fixed_s": wall - m_loop * n_queries,
-            "thread0_per_query_s": {"median": round(m_t0, 3), "min": round(srt[0], 3), "p25": round(srt[len(srt) // 4], 3), "p75": round(srt[(3 * len(srt)) // 4], 3), "max": round(srt[-1], 3)},
-            "marginal_crosscheck_ratio": round(m_t0 / m_loop, 3) if m_loop > 0 else None}
+            "marginal_s_per_query": m_t0, "fixed_s": wall - m_t0 * n_queries,
+            "thread0_per_query_s": {"median": round(m_t0, 3), "mean": round(sum(per_q) / len(per_q), 3), "min": round(srt[0], 3), "p25": round(srt[len(srt) // 4], 3), "p75": round(srt[(3 * len(srt)) // 4], 3), "max": round(srt[-1], 3)},
+            "loop_level_s_per_query": round(m_loop, 4), "marginal_crosscheck_ratio": round(m_t0 / m_loop, 3) if m_loop > 0 else None}
 
 
 def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
@@ -325,9 +330,10 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
                                    "cpu_model": hi["cpu_model"], "logical_cpus": hi["logical_cpus"], "physical_cores": hi["physical_cores"],
                                    "fixed_s": round(fixed, 2), "marginal_s_per_query": round(m_q, 3), "extrapolated_full_workload_s": round(t_full, 1),
                                    "measured": tl,
-                                   "rule": "value = Nq x Nr / (F + m x Nq) with Nq = the workload's %d queries; m = (arrival of 'parallel_for execution finished' - arrival of thread 0's "
-                                           "'Start Map 1') / sampled queries = what one more query costs the slowest thread; F = wall - m x sampled queries (reference sketch + index per "
-                                           "thread, genome lengths re-read, writers); cross-check m_thread0 = median of thread 0's own per-query 'mapping' + 'post mapping' timers" % n_queries,
+                                   "rule": "value = Nq x Nr / (F + m x Nq) with Nq = the workload's %d queries; m = median of thread 0's own per-query 'Time spent mapping fragments' + "
+                                           "'Time spent post mapping' timers = what one more query costs a thread; F = wall - m x sampled queries (reference sketch + index per thread and "
+                                           "their imbalance, genome lengths re-read, writers); cross-check: loop_level_s_per_query = (arrival of 'parallel_for execution finished' - arrival "
+                                           "of thread 0's 'Start Map 1') / sampled queries, which also holds the sketch-phase imbalance" % n_queries,
                                    "threads_note": "-t %d: the thread count at which the reference is fastest on this host class (profiles/r03_refscale.txt)" % threads,
                                    "sample": "fastANI_ref -t %d, ONE run on %d query genomes x %d references of the same clustered %d bp set (80-column FASTA on local disk), wall %.1f s incl. FASTA parse; "
                                              "value = %d x %d pairs / (fixed %.1f s + %d x %.3f s per query)"
@@ -991,6 +997,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
         "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes - (12.0 * c["l2WindowEntriesB"] + 4.0 * c["l2QueryHashesB"]),
                           "class-A launches (k_l2_sim<L2Geom<255>>): 12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per class-A candidate"),
         "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate (the SAME bytes as k_l2_sim: the two kernels share one set of algorithmic bytes, see roofline.stage)"),
+        "ani::k_l2_trim_eval+apply": (c["msL2Trim"], 4.0 * 240.0 * c["l2TrimmedCandidates"], "range trimming: ~240 reference hashes of the probed super-window per trimmed candidate (its time is part of the L2 stage)"),
         "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
         "ani::k_l1_probe": (c["msL1Probe"], 4.0 * c["l1Probes"], "4 B x fragment sketch hashes probed (per index chunk)"),
         "ani::k_l1<0,2048>": (c["msL1Main"], 8.0 * c["seedHits"], "8 B x seed hits (all LDS classes; the small class handles nearly all fragments)"),
@@ -1079,7 +1086,8 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
            "stage_ms_per_step_rank0": stages, "host_timeline_ms_per_step_rank0": host_timeline, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
            "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                           "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
-                                                                          "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments", "l1TinyFragments")},
+                                                                          "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments", "l1TinyFragments",
+                                                                          "l2TrimmedEntries", "l2TrimmedCandidates")},
            "roofline": roof}
     if sim:
         out["simulated"] = {"world": R.W, "rank": R.r, "what": "value = %d x %d pairs / the time ONE rank of a %d-GPU strong-scaling job computes (sketch + index of its %d genomes, %d mapping calls: its own set, the others merged); "

@@ -3,7 +3,7 @@
     from fastani_amd import engine
     e = engine()                         # loads csrc/libfastani_amd.so (HIP, gfx950); raises if missing / no GPU
 """
-from .api import (AniError, CGI_DT, DeviceGenomes, Engine, FragmentSet, HostGenomes, MAPPING_DT, MINIMIZER_DT, Params, Sketch, UploadedGenomes)
+from .api import (AniError, CGI_DT, DeviceGenomes, Engine, FragmentSet, HostGenomes, MAPPING_DT, MINIMIZER_DT, Params, Sketch, SketchWriter, UploadedGenomes)
 
 
 def engine(device=0):

@@ -47,7 +47,8 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
                                           "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
                                           "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "indexChunks", "l1Probes", "l2ChunkHalvings", "indexChunkBuilds", "l1BigFragments", "l1MidFragments", "l1TinyFragments")] + \
-               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main", "msL1Big", "msL1Tiny")]
+               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main", "msL1Big", "msL1Tiny")] + \
+               [("l2TrimmedEntries", C.c_uint64), ("l2TrimmedCandidates", C.c_uint64), ("msL2Trim", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -87,6 +88,10 @@ def _bind(lib):
         "ani_compute_cgi": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_sketch_save": (C.c_int, [vp, C.c_char_p, vp]),
         "ani_sketch_load": (C.c_int, [vp, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(vp)]),
+        "ani_sketch_writer_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "ani_sketch_writer_add": (C.c_int, [vp, vp, vp]),
+        "ani_sketch_writer_close": (C.c_int, [vp]),
+        "ani_device_memory": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "ani_sketch_file_info": (C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
         "ani_sketch_genome_name": (C.c_char_p, [vp, C.c_int32]),
         "ani_sketch_tables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -365,6 +370,27 @@ class FragmentSet:
             self.close()
         except Exception:
             pass
+
+
+class SketchWriter:
+    """one sketch file from several sketches added one after the other (ani_sketch_writer_*): a reference set whose records exceed the
+    device memory is written block by block"""
+    def __init__(self, engine, path):
+        self.e = engine
+        h = C.c_void_p()
+        engine._chk(engine.lib.ani_sketch_writer_open(str(path).encode(), C.byref(h)))
+        self.h = h
+
+    def add(self, sketch, names=None):
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[n.encode() if isinstance(n, str) else n for n in names])
+        self.e._chk(self.e.lib.ani_sketch_writer_add(self.h, sketch.h, arr))
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, None
+            self.e._chk(self.e.lib.ani_sketch_writer_close(h))
 
 
 class Sketch:

@@ -24,7 +24,7 @@ constexpr uint32_t kMurmurSeed = 42;  // commonFunc.hpp:32
 // Statistics counters (sums only, never cursors) are striped over kStatStripes copies of the counter block so that the
 // per-wave atomics of a large grid do not serialise on one address; the host adds the stripes up.
 constexpr int kStatStripes = 32;
-constexpr int kStatStripeWords = 24;   // 64-bit words per stripe (= number of counters)
+constexpr int kStatStripeWords = 26;   // 64-bit words per stripe (= number of counters)
 __device__ __forceinline__ unsigned long long *stat_slot(unsigned long long *base) { return base + (blockIdx.x & (kStatStripes - 1)) * kStatStripeWords; }
 
 // Bump allocation out of a pool, one request per workgroup.  A returning atomicAdd on ONE address costs 12 ns on MI355X however many
@@ -157,6 +157,24 @@ __device__ __forceinline__ int wave_incl_scan(int v)
   return v;
 }
 
+// The same scan over the DPP data path (gfx9 wave64: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast:15 into rows 1 and
+// 3, row_bcast:31 into rows 2 and 3): six v_add_u32_dpp instead of six ds_bpermute round trips with their selects.  Lanes without a
+// source (bound_ctrl off, `old` = 0) add nothing.  Checked against wave_incl_scan on the hardware by tools/ubench/lanexor.hip.
+__device__ __forceinline__ int wave_incl_scan_dpp(int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+  return v;
+#else
+  return wave_incl_scan(v);
+#endif
+}
+
 // Workgroup barrier.  HIP's __syncthreads() is fence(release) + s_barrier + fence(acquire), and the compiler of ROCm 7.2 was seen
 // to drop the s_waitcnt lgkmcnt(0) that the release fence needs in front of a barrier at a loop header (the back edge of the bitonic
 // sort's pass loop: four ds_write_b64 in flight, then s_barrier): a wave then passes the barrier with its LDS writes still queued
@@ -190,6 +208,12 @@ __device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return x; }
 #endif
 __device__ __forceinline__ int32_t wave_uniform(int32_t x) { return (int32_t)wave_uniform((uint32_t)x); }
+// the value lane `l` (wave-uniform, usually a constant) holds, as a scalar
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int32_t lane_value(int32_t x, int l) { return __builtin_amdgcn_readlane(x, l); }
+#else
+__device__ __forceinline__ int32_t lane_value(int32_t x, int l) { return __shfl(x, l); }
+#endif
 __device__ __forceinline__ uint64_t wave_uniform(uint64_t x) { return (uint64_t)wave_uniform((uint32_t)x) | ((uint64_t)wave_uniform((uint32_t)(x >> 32)) << 32); }
 
 // exclusive scan of one int per thread across the workgroup; *total = sum over all threads.

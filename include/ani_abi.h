@@ -125,6 +125,10 @@ typedef struct {
   double msL1Probe, msL1Main; /* ani::k_l1_probe; ani::k_l1<0, 2048> (the small-class gather + filter + sort + candidate kernel) */
   double msL1Big;             /* the batched global-memory L1 path (gather + device sort + candidates) */
   double msL1Tiny;            /* ani::k_l1_tiny */
+  /* round 5 (appended: the fields above keep their offsets) */
+  uint64_t l2TrimmedEntries;  /* reference minimizers removed from candidate ranges by the hit-profile bound (still counted in l2WindowEntries) */
+  uint64_t l2TrimmedCandidates;   /* candidates whose range was shortened */
+  double msL2Trim;            /* ani::k_l2_trim_eval + ani::k_l2_trim_apply */
 } ani_counters_t;
 
 /* ---- life cycle ---- */
@@ -138,6 +142,9 @@ int ani_device_copy(ani_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* device memory of this context (released with ani_device_free) and a copy between two contexts' devices — the host side of a
  * multi-GPU run stages minimizer records with these (peer-to-peer over xGMI when the devices can access each other) */
 int ani_device_alloc(ani_ctx *ctx, size_t bytes, void **out);
+/* free / total memory of the context's device in bytes (the command line sizes the blocks of a reference sketch file with it;
+ * no counterpart in the reference, which splits its database by hand: scripts/splitDatabase.sh) */
+int ani_device_memory(ani_ctx *ctx, size_t *freeBytes, size_t *totalBytes);
 int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void *src, size_t bytes);
 /* Ingest: classify + 2-bit pack host sequences on host threads into page-locked staging, copy them to the
  * device and keep them there.  The handle can be passed to every entry point that takes a sequence batch (layout
@@ -208,6 +215,13 @@ int ani_sketch_adopt_record_parts(ani_ctx *ctx, const ani_params_t *p, int32_t n
  * ani_sketch_load takes a genome range [g0, g1) (g1 < 0: all), so every rank of a multi-GPU job can read its own share. */
 int ani_sketch_save(const ani_sketch *sk, const char *path, const char *const *genomeNames /* [nGenomes] or NULL */);
 int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_sketch **out);
+/* One file from several sketches, added one after the other (their genomes are appended): how a reference set whose minimizer
+ * records exceed the device memory is written block by block.  ani_sketch_save = open + add + close.  A failed or empty writer
+ * removes its file at close. */
+typedef struct ani_sketch_writer ani_sketch_writer;
+int ani_sketch_writer_open(const char *path, ani_sketch_writer **out);
+int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char *const *genomeNames /* [sk's genomes] or NULL */);
+int ani_sketch_writer_close(ani_sketch_writer *w);
 int ani_sketch_file_info(const char *path, ani_params_t *p, int32_t *nContigs, int32_t *nGenomes, uint64_t *nMinimizers);
 const char *ani_sketch_genome_name(const ani_sketch *sk, int32_t genome);
 int ani_sketch_tables(const ani_sketch *sk, const int32_t **contigLen, const int32_t **genomeContigStart);

@@ -526,6 +526,32 @@ def case_sketch_file(engine, tmpdir):
     ref = Sketch(engine, p, genomes[1:4])
     assert np.array_equal(part.minimizers(), ref.minimizers()) and part.genome_names() == names[1:4]
     assert np.array_equal(part.map_cgi_batch(genomes, 0), ref.map_cgi_batch(genomes, 0))
+    # one file from several sketches (ani_sketch_writer_*: a reference set beyond the device memory is written block by block): the
+    # same file contents as the one-sketch file, whatever the cut — the second and third sketch's contig and record numbers carry on
+    from fastani_amd.api import SketchWriter
+    for cuts in ((2,), (1, 4), (3, 5)):
+        path2 = os.path.join(str(tmpdir), "refs_parts.anisk")
+        w = SketchWriter(engine, path2)
+        lo = 0
+        for hi in list(cuts) + [len(genomes)]:
+            blk = Sketch(engine, p, genomes[lo:hi])
+            w.add(blk, names[lo:hi])
+            blk.close()
+            lo = hi
+        w.close()
+        sk3 = Sketch(engine, p, file=path2)
+        assert np.array_equal(sk3.minimizers(), sk.minimizers()) and sk3.stats() == sk.stats() and sk3.genome_names() == names, cuts
+        assert np.array_equal(sk3.map_cgi_batch(genomes, 0), sk.map_cgi_batch(genomes, 0)), cuts
+        part3 = Sketch(engine, p, file=path2, genome_range=(1, 4))
+        assert np.array_equal(part3.minimizers(), ref.minimizers()), cuts
+        for x in (sk3, part3):
+            x.close()
+    w = SketchWriter(engine, os.path.join(str(tmpdir), "empty.anisk"))
+    try:
+        w.close()
+        raise AssertionError("a sketch file without a sketch must be refused")
+    except AniError as e:
+        assert e.code == -1 and not os.path.exists(os.path.join(str(tmpdir), "empty.anisk"))
     open(path, "r+b").write(b"XXXX")
     try:
         Sketch(engine, p, file=path)

@@ -150,6 +150,16 @@ def _run_streaming_variants(binary, tmp, full=True):
         rb = subprocess.run([binary, "--ql", ql, "--refSketch", skf, "-t", "2", "-o", out, "--matrix"] + extra, capture_output=True)
         assert rb.returncode == 0, rb.stderr.decode()[-1500:]
         assert _lines(rout) == _lines(out), extra
+    # a sketch file whose records do not fit the device at once is taken in BLOCKS of genomes (load a genome range, map every query,
+    # drop it): same rows, whatever the block size, on one context and on two, with the queries in one wave or in several
+    for env, extra in (({"ANI_CLI_REF_BLOCK_BYTES": "60000"}, []), ({"ANI_CLI_REF_BLOCK_BYTES": "25000", "ANI_SLICE_BYTES": "40000", "ANI_CLI_QUERY_WAVE_BYTES": "80000"}, []),
+                       ({"ANI_CLI_REF_BLOCK_BYTES": "30000", "ANI_MAX_INDEX_MINIMIZERS": "5000", "ANI_MAX_RESIDENT_CHUNKS": "1"}, ["--devices", "0,0"])):
+        out = os.path.join(tmp, "sk3.out")
+        rb = subprocess.run([binary, "--ql", ql, "--refSketch", skf, "-t", "2", "-o", out, "--matrix"] + extra, capture_output=True, env=dict(os.environ, **env))
+        assert rb.returncode == 0, rb.stderr.decode()[-1500:]
+        assert _lines(rout) == _lines(out), (env, extra)
+        assert b"blocks of genomes per device" in rb.stderr and b"reference block 2 of" in rb.stderr, rb.stderr.decode()[-1500:]
+        assert open(os.path.join(tmp, "sk2.out.matrix")).read() == open(out + ".matrix").read(), (env, extra)
     rb = subprocess.run([binary, "--ql", ql, "--refSketch", skf, "-k", "14", "-o", out], capture_output=True)
     assert rb.returncode == 1 and b"sketch file was built with" in rb.stderr
     # --saveSketch on several devices is refused when the options are read, not after the whole reference set has been sketched

@@ -41,7 +41,8 @@ if has bench3; then
   mkdir -p /tmp/ani_bench_wd
   for i in 1 2 3; do
     echo "== bench run $i"
-    timeout 900 python bench.py --workdir /tmp/ani_bench_wd 2> "$OUT/bench$i.err" > "$OUT/bench$i.json.log"
+    extra=""; [ $i -gt 1 ] && extra="--no-e2e"          # (the command-line leg once)
+    timeout 900 python bench.py --workdir /tmp/ani_bench_wd $extra 2> "$OUT/bench$i.err" > "$OUT/bench$i.json.log"
     python - "$OUT/bench$i.json.log" <<'EOF' | tee -a "$OUT/bench3_summary.txt"
 import sys, json
 d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')][-1])
@@ -101,7 +102,8 @@ if has ab; then
   done
 fi
 if has pmc; then
-  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"; do
+  IFS=';' read -ra SETS <<< "${PMC_SETS:-FETCH_SIZE;WRITE_SIZE;SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS}"
+  for set in "${SETS[@]}"; do
     name=$(echo $set | cut -d' ' -f1)
     (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace -d "$OUT/pmc_$name" -o pmc --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/pmc_$name.log" 2>&1)
     f=$(find "$OUT/pmc_$name" -name "*counter_collection*.csv" | head -1)
@@ -111,6 +113,6 @@ if has pmc; then
 fi
 if has cli90k; then
   echo "== the command line on a 90 000-genome sketch file"
-  timeout 2400 python tools/c5_cli.py ${CLI90K_ARGS:-} 2>&1 | tail -40 | tee "$OUT/cli90k.txt"
+  timeout 2400 python tests/scale/c5_cli.py ${CLI90K_ARGS:-} 2>&1 | tail -40 | tee "$OUT/cli90k.txt"
 fi
 echo "== done: $STAGES"

@@ -17,6 +17,13 @@ __global__ void k(uint32_t *out)
   out[4 * 64 + threadIdx.x] = lane_xor<16>(x);
   out[5 * 64 + threadIdx.x] = lane_xor<32>(x);
 }
+// wave_incl_scan_dpp (row_shr / row_bcast DPP adds) against the shuffle form, four waves with different data
+__global__ void k_scan(int *out)
+{
+  const int v = (int)((threadIdx.x * 2654435761u) >> 24) + (threadIdx.x & 3);
+  out[threadIdx.x] = wave_incl_scan_dpp(v);
+  out[256 + threadIdx.x] = wave_incl_scan(v);
+}
 template <class K> __global__ __launch_bounds__(kTPB) void k_sort(K *data, const int *n, int cap)
 {
   __shared__ K a[4096];
@@ -50,6 +57,9 @@ int main()
   int bad = 0;
   for (int m = 0; m < 6; m++) for (int l = 0; l < 64; l++) { uint32_t e = (uint32_t)((l ^ (1 << m)) * 3 + 7); if (h[m * 64 + l] != e) { if (bad < 10) printf("m=%d lane %d got %u want %u\n", 1 << m, l, h[m * 64 + l], e); bad++; } }
   printf("lane_xor: bad=%d\n", bad);
+  { int *ds; (void)hipMalloc(&ds, 512 * 4); k_scan<<<1, 256>>>(ds); int hs[512]; (void)hipMemcpy(hs, ds, sizeof hs, hipMemcpyDeviceToHost);
+    int sb = 0; for (int i = 0; i < 256; i++) if (hs[i] != hs[256 + i]) { if (sb < 10) printf("scan lane %d: dpp %d shuffle %d\n", i, hs[i], hs[256 + i]); sb++; }
+    printf("wave_incl_scan_dpp: bad=%d\n", sb); bad += sb; }
   const int b32 = check_sort<uint32_t>(), b64 = check_sort<uint64_t>();
   printf("block_sort: wrong size classes u32=%d u64=%d\n", b32, b64);
   return (bad | b32 | b64) != 0;
