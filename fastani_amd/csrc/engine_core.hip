@@ -60,6 +60,18 @@ int pinned_buffer(ani_ctx *c, int slot, size_t bytes, void **out)
   return ANI_OK;
 }
 
+void add_counters(ani_counters_t *d, const ani_counters_t *s)
+{
+#define ADD(f) d->f += s->f
+  ADD(refBases); ADD(refMinimizers); ADD(refUniqueHashes); ADD(queryGenomes); ADD(queryFragments); ADD(queryBases); ADD(querySketchHashes); ADD(seedHits); ADD(l1Candidates);
+  ADD(l2WindowEntries); ADD(l2Steps); ADD(l2QueryHashes); ADD(l2WindowEntriesB); ADD(l2QueryHashesB); ADD(l2Launches); ADD(l2FastCandidates); ADD(l2SlowCandidates);
+  ADD(l2SlowLimit); ADD(l2SlowDup); ADD(l2SlowOverflow); ADD(mappings); ADD(cgiRows); ADD(indexChunks); ADD(l1Probes); ADD(l2ChunkHalvings); ADD(indexChunkBuilds);
+  ADD(l1BigFragments); ADD(l1MidFragments); ADD(l1TinyFragments);
+  ADD(msSketch); ADD(msIndex); ADD(msFragSketch); ADD(msL1); ADD(msL2); ADD(msReduce); ADD(msL2Kernel); ADD(msL2Ranges); ADD(msL2Codes); ADD(msL2Slow); ADD(msL2SimB);
+  ADD(msL1Probe); ADD(msL1Main); ADD(msL1Big); ADD(msL1Tiny); ADD(l2TrimmedEntries); ADD(l2TrimmedCandidates); ADD(msL2Trim);
+#undef ADD
+}
+
 void flush_timers(ani_ctx *c)
 {
   if (c->timerPending.empty()) { c->timerUsed = 0; return; }
@@ -217,20 +229,6 @@ int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void
   HIP_TRY(hipStreamSynchronize(dstCtx->stream));
   return ANI_OK;
 }
-
-namespace anih {
-void add_counters(ani_counters_t *d, const ani_counters_t *s)
-{
-#define ADD(f) d->f += s->f
-  ADD(refBases); ADD(refMinimizers); ADD(refUniqueHashes); ADD(queryGenomes); ADD(queryFragments); ADD(queryBases); ADD(querySketchHashes); ADD(seedHits); ADD(l1Candidates);
-  ADD(l2WindowEntries); ADD(l2Steps); ADD(l2QueryHashes); ADD(l2WindowEntriesB); ADD(l2QueryHashesB); ADD(l2Launches); ADD(l2FastCandidates); ADD(l2SlowCandidates);
-  ADD(l2SlowLimit); ADD(l2SlowDup); ADD(l2SlowOverflow); ADD(mappings); ADD(cgiRows); ADD(indexChunks); ADD(l1Probes); ADD(l2ChunkHalvings); ADD(indexChunkBuilds);
-  ADD(l1BigFragments); ADD(l1MidFragments); ADD(l1TinyFragments);
-  ADD(msSketch); ADD(msIndex); ADD(msFragSketch); ADD(msL1); ADD(msL2); ADD(msReduce); ADD(msL2Kernel); ADD(msL2Ranges); ADD(msL2Codes); ADD(msL2Slow); ADD(msL2SimB);
-  ADD(msL1Probe); ADD(msL1Main); ADD(msL1Big); ADD(msL1Tiny); ADD(l2TrimmedEntries); ADD(l2TrimmedCandidates); ADD(msL2Trim);
-#undef ADD
-}
-}  // namespace anih
 
 int ani_get_counters(ani_ctx *c, ani_counters_t *out)
 {

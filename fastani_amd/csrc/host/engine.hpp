@@ -261,8 +261,10 @@ struct ani_ctx {
   bool l2Overlap = true;                                                            // the L2 simulation on the side stream, beside the next chunk's ranges / codes kernels (env ANI_L2_OVERLAP=0 switches it off; see the L2 loop)
   bool l2Trim = false;                                                              // L2 ranges trimmed by the hit profiles of L1 (l2.hpp: k_l2_trim_eval / _apply; env ANI_L2_TRIM=1).  Exact, removes 42 % of the
                                                                                     // placements of the benchmark — and costs more than it saves (profiles/r05h_trim_ab_no_overlap.txt): off by default, kept with its tests
-  bool mapPipeline = true;                                                          // sub-batches of a resident set mapped by two host threads on two contexts of this device, so that one's L1 kernels
-                                                                                    // (memory-paced) meet the other's L2 kernels (issue-bound); env ANI_MAP_PIPELINE=0 switches it off (map_fragsets)
+  bool mapPipeline = false;                                                         // sub-batches of a resident set mapped by two host threads on two contexts of this device, so that one's L1 kernels
+                                                                                    // (memory-paced) meet the other's L2 kernels (issue-bound); env ANI_MAP_PIPELINE=1 (map_fragsets).  Measured: the 1000 x 1000
+                                                                                    // step 200.7 -> 197.9 ms (profiles/r05i_map_pipeline_ab.txt) — the kernels slow each other by nearly what they overlap, and the
+                                                                                    // per-stage event timers become sums over overlapping kernels; off by default, kept with its tests
   uint64_t mapPipelineMinFrags = (uint64_t)1 << 18;                                 // ... for calls with at least this many fragments (env ANI_MAP_PIPELINE_MIN_FRAGS: tests)
   ani_ctx *helper = nullptr;                                                        // ... the second context (created on first use, shut down with this one)
   std::atomic<int> *l1Done = nullptr;                                               // ... set by map_stage when a sub-batch's L1 kernels are through (the second thread starts behind the first one's L1)

@@ -652,14 +652,15 @@ int main(int argc, char **argv)
         }
       }
     {
-      uint64_t occ = 0, uniq = 0; int32_t nChunks = 0;
+      uint64_t occ = 0, uniq = 0; int32_t nChunks = 0; bool blkStreamed = false;
       for (int d = 0; d < nDev; d++) {
         uint64_t oc = 0; int32_t nc = 0, st = 0;
         ani_sketch_stats(shard[d].sk, &oc, nullptr, nullptr, nullptr, nullptr);
         ani_sketch_chunks(shard[d].sk, &nc, nullptr, 0);
         ani_sketch_residency(shard[d].sk, &st, nullptr, nullptr);
-        occ += oc; nChunks += nc; streamed = streamed || st != 0;
+        occ += oc; nChunks += nc; blkStreamed = blkStreamed || st != 0;
       }
+      streamed = streamed || blkStreamed;
       occAll += occ; chunksAll += nChunks;
       if (blk == 0) {
         std::cerr << "INFO [thread 0], skch::Sketch::build, minimizers picked from reference = " << (nBlocks > 1 ? fileMinimizers : occ) << std::endl;
@@ -669,7 +670,7 @@ int main(int argc, char **argv)
       }
       if (nBlocks > 1)
         std::cerr << "INFO [thread 0], skch::Sketch::index, reference block " << blk + 1 << " of " << nBlocks << ": " << occ << " minimizers, " << nChunks << " index chunks on " << nDev << " device(s)"
-                  << (streamed ? ", streamed" : "") << "; loaded at " << secs_since(t0) << " sec" << std::endl;
+                  << (blkStreamed ? ", streamed" : "") << "; loaded at " << secs_since(t0) << " sec" << std::endl;
     }
     };                                               // prepare_block
     prepare_block(0);
