@@ -325,8 +325,6 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         // of kernels that share the machine for part of their run; the stage time (msL2, bracketed on the main stream, which waits for
         // both) is what the headline roofline fraction is computed from.
         const bool overlap = ctx->l2Overlap;
-        bool pairSim = ctx->l2Pair;                                       // experiment, off by default (l2.hpp: k_l2_sim_pair); read per call so that tests can switch it
-        if (const char *ev = getenv("ANI_L2_PAIR")) pairSim = strcmp(ev, "0") != 0;
         hipStream_t simStream = ctx->stream;
         if (overlap) {
           HIP_TRY(hipEventRecord(ctx->evSimA[p], ctx->stream));            // codes of this chunk are written
@@ -335,11 +333,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1, simStream);
-          if (pairSim)
-            hipLaunchKernelGGL((k_l2_sim_pair<L2GeomA>), dim3(grid_for((n + 1) / 2, kWave)), dim3(kWave), 0, simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
-                               (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
-          else
-            hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
+          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
                                (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
         }
         ctx->counters.l2Launches++;

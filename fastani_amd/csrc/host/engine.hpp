@@ -268,7 +268,6 @@ struct ani_ctx {
   uint64_t mapPipelineMinFrags = (uint64_t)1 << 18;                                 // ... for calls with at least this many fragments (env ANI_MAP_PIPELINE_MIN_FRAGS: tests)
   ani_ctx *helper = nullptr;                                                        // ... the second context (created on first use, shut down with this one)
   std::atomic<int> *l1Done = nullptr;                                               // ... set by map_stage when a sub-batch's L1 kernels are through (the second thread starts behind the first one's L1)
-  bool l2Pair = false;                                                              // class A simulated two candidates per lane in packed 16-bit halves (k_l2_sim_pair; env ANI_L2_PAIR)
   uint64_t l1HitLimit = 0x7ffffff0ull;                                              // seed hits per fragment and index chunk (32-bit hit offsets; env ANI_L1_HIT_LIMIT, tests)
   uint64_t candPoolMin = 4096;                                                      // floor of the L1 candidate pool, per stripe (env ANI_CAND_POOL_MIN, tests: forces the retry path)
   uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;              // seed hits / fragments per group of the batched global-memory L1 path (env ANI_L1_BIG_GROUP_HITS / _FRAGS, tests)

@@ -975,244 +975,10 @@ static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const
   if (lane == 0 && (cntE | cntS | cntQ)) { atomicAdd(stat_slot(a.g.sumEntries), cntE); atomicAdd(stat_slot(a.g.sumSteps), cntS); atomicAdd(stat_slot(a.g.sumQ), cntQ); }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Two candidates per lane, state in packed 16-bit halves (class A).  k_l2_sim spends ~54 vector instructions per event, nearly all
-// of them arithmetic on numbers below 512; here the two candidates of a lane share every one of those instructions: a register
-// holds candidate 0 in its low and candidate 1 in its high half (v_pk_add_u16 / v_pk_sub_u16 / v_pk_ashrrev_i16 / v_pk_lshlrev_b16
-// and plain bit operations; a comparison is a subtraction's sign, spread over the half by an arithmetic shift, a selection is a
-// mask).  Only the four LDS addresses and accesses of an event stay per candidate.  The arithmetic is l2_apply's, line by line.
-// The price: twice the LDS per wave (32 KiB: 5 waves per CU instead of 10).
-typedef short pk16 __attribute__((vector_size(4)));
-typedef unsigned short pku16 __attribute__((vector_size(4)));
-__device__ __forceinline__ pk16 pk_from(uint32_t x) { pk16 r; __builtin_memcpy(&r, &x, 4); return r; }
-__device__ __forceinline__ uint32_t pk_bits(pk16 x) { uint32_t r; __builtin_memcpy(&r, &x, 4); return r; }
-__device__ __forceinline__ pk16 pk_pair(int lo, int hi) { return pk_from(((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16)); }
-__device__ __forceinline__ int pk_lo(pk16 x) { return (int)(int16_t)(pk_bits(x) & 0xffffu); }
-__device__ __forceinline__ int pk_hi(pk16 x) { return (int)(int16_t)(pk_bits(x) >> 16); }
-// A mask is used as a mask.  Left to itself the compiler recognises "sign bit spread over the half, then AND" as a selection, and a
-// selection between 16-bit halves as two compares, two selects and a byte permute: the packed arithmetic is gone again.  The empty
-// asm statement makes the mask a value of unknown origin.
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ pk16 pk_opaque(pk16 m) { asm("" : "+v"(m)); return m; }
-#else
-__device__ __forceinline__ pk16 pk_opaque(pk16 m) { return m; }
-#endif
-// all ones in a half whose bit `BIT` is set
-template <int BIT> __device__ __forceinline__ pk16 pk_bitmask(pk16 x) { pku16 u; __builtin_memcpy(&u, &x, 4); u = u << (15 - BIT); pk16 r; __builtin_memcpy(&r, &u, 4); return pk_opaque(r >> 15); }
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ pk16 pk_max0(pk16 x) { const pk16 z = {0, 0}; return __builtin_elementwise_max(x, z); }
-// the event codes number e (0..7) of the two candidates' blocks side by side: one byte permute
-__device__ __forceinline__ uint32_t pk_codes(uint32_t w0, uint32_t w1, bool odd) { return __builtin_amdgcn_perm(w1, w0, odd ? 0x07060302u : 0x05040100u); }
-#else
-__device__ __forceinline__ pk16 pk_max0(pk16 x) { return x & ~(x >> 15); }
-__device__ __forceinline__ uint32_t pk_codes(uint32_t w0, uint32_t w1, bool odd) { return odd ? ((w0 >> 16) | (w1 & 0xffff0000u)) : ((w0 & 0xffffu) | (w1 << 16)); }
-#endif
-__device__ __forceinline__ pk16 pk_sel(pk16 m, pk16 a, pk16 b) { return (a & m) | (b & ~m); }
-__device__ __forceinline__ pk16 pk_ltmask(pk16 a, pk16 b) { return pk_opaque((a - b) >> 15); }          // a < b, for |a - b| < 2^15
+// (Rounds 4 - 5 kept a second simulation kernel here, k_l2_sim_pair: two candidates per lane with the state in packed 16-bit halves —
+// 38.7 vector instructions per event instead of 54.4, bit-exact, and slower (65.7 vs 44.1 ms per step: twice the LDS per wave, half
+// the waves per SIMD; profiles/r04ad_pair_ab.txt, docs/history.md section 2.5).  Removed in round 5; the last commit that has it: 7bf79f3.)
 
-struct L2PairState { pk16 s, iStar, tot, shared, best, begAtBest, begAtLast, delCount, noEvals; uint32_t ovfAcc; };
-
-// one event of each of the lane's two candidates.  MASKED = false: both events exist and take effect (PLAIN blocks);
-// otherwise onm / effm are all ones in the half whose event exists / changes the window (l2_apply's `on`, k_l2_sim's `eff`).
-template <bool MASKED>
-__device__ __forceinline__ void l2_pair_event(uint8_t *F0, uint8_t *F1, L2PairState &r, pk16 P, pk16 onm, pk16 effm)
-{
-  const pk16 one = pk_pair(1, 1);
-  const pk16 isQm = pk_bitmask<0>(P);
-  pk16 idx = pk_from((pk_bits(P) >> 1) & 0x01ff01ffu);
-  if (MASKED) idx = idx & onm;                                       // an event that does not exist touches field 0 (and leaves it as it is)
-  pk16 d = P >> kL2DeltaShift;                                        // sign-extended 3-bit field
-  if (MASKED) d = d & effm;
-  const pk16 insm = pk_bitmask<11>(P);
-  static_assert(kL2InsBit == (1u << 11) && kL2NoEvalBit == (1u << 12), "bit positions of the event code");
-  const pk16 nins = ~insm;
-  const pk16 sg = nins | one;                                         // +1 insert, -1 delete
-  pk16 j = pk_max0(r.iStar + insm);                                   // pivot-adjacent field
-  const uint32_t ib = pk_bits(idx), jb = pk_bits(j);
-  uint8_t *pOwn0 = F0 + l2_field_off((int)(ib & 0xffffu)), *pOwn1 = F1 + l2_field_off((int)(ib >> 16));
-  const uint32_t own0 = *pOwn0, own1 = *pOwn1;
-  const uint32_t fj0 = F0[l2_field_off((int)(jb & 0xffffu))], fj1 = F1[l2_field_off((int)(jb >> 16))];
-  const pk16 nw = pk_from(own0 | (own1 << 16)) + d;
-  r.ovfAcc |= pk_bits(nw);
-  *pOwn0 = (uint8_t)pk_bits(nw); *pOwn1 = (uint8_t)(pk_bits(nw) >> 16);
-  pk16 fj = pk_from(fj0 | (fj1 << 16));
-  const pk16 eqm = pk_opaque(((idx ^ j) - one) >> 15);               // idx == j
-  fj = fj + (d & eqm);                                                // the event itself changed field[j]
-  const pk16 c1 = (fj >> 1) + one;
-  const pk16 ltm = pk_ltmask(idx, r.iStar);
-  pk16 t = sg & ltm;
-  if (MASKED) t = t & effm;
-  r.shared = r.shared + (t & isQm);
-  r.tot = r.tot + (t & ~isQm);
-  const pk16 reach = r.tot + (c1 & nins);
-  const pk16 overm = pk_ltmask(r.s, reach);                           // reach > s
-  const pk16 roomm = pk_ltmask(pk_sel(insm, idx, r.iStar), pk_sel(insm, r.iStar, r.s));
-  pk16 mvm = roomm & ~isQm & ~(overm ^ insm);
-  if (MASKED) mvm = mvm & effm;
-  const pk16 mone = sg & mvm;                                         // insert: -1 on everything, delete: +1
-  r.iStar = r.iStar - mone;
-  r.shared = r.shared - (mone & pk_bitmask<0>(fj));
-  r.tot = r.tot - (((c1 ^ nins) - nins) & mvm);                       // the pivot moved over q and the n[] non-query hashes next to it
-  // evaluate (computeMap.hpp:468-476) with the window starting at entry number delCount
-  r.delCount = r.delCount - (MASKED ? (nins & onm) : nins);
-  pk16 nevm = pk_bitmask<12>(P);
-  if (MASKED) nevm = nevm | ~onm;
-  const pk16 se = r.shared | nevm;                                    // -1: never compares (best >= 0)
-  const pk16 bm = pk_ltmask(r.best, se), lm = pk_ltmask(se, r.best);
-  r.best = pk_sel(bm, se, r.best);
-  r.begAtBest = pk_sel(bm, r.delCount, r.begAtBest);
-  r.begAtLast = pk_sel(lm, r.begAtLast, r.delCount);
-  r.noEvals = r.noEvals + nevm;                                       // -(events without evaluation)
-}
-
-template <class G>
-static __global__ __launch_bounds__(kWave) void k_l2_sim_pair(L2FastArgs a, const int32_t *__restrict__ list, const unsigned int *__restrict__ listCount)
-{
-  static_assert(G::kMaxS == 255, "class A");
-  constexpr int kColBytes = G::kWords * kWave * 4;                    // the state of one candidate per lane
-  __shared__ uint32_t lds[2 * G::kWords * kWave];
-  const int lane = threadIdx.x;
-  uint8_t *F[2] = {(uint8_t *)lds + lane, (uint8_t *)lds + kColBytes + lane};
-  const unsigned int nList = *listCount;
-  if (blockIdx.x * (unsigned int)(2 * kWave) >= nList) return;        // whole wave beyond the list
-  const unsigned int slot0 = (blockIdx.x * (unsigned int)kWave + (unsigned int)lane) * 2u;     // neighbours in the length order
-#pragma unroll
-  for (int x = 0; x < 2 * G::kStateWords; x++) lds[x * kWave + lane] = 0u;
-  bool mine[2]; int32_t c[2], ci[2]; L2Range r[2]; int n[2], nBlk[2], sq[2]; const uint4 *p[2]; L2Block cur[2];
-  int iS[2], tot[2], sh[2]; uint32_t ovf = 0;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    c[h] = slot0 + (unsigned int)h < nList ? list[slot0 + h] : a.c1;
-    const int flag = c[h] < a.c1 ? a.slowFlag[c[h] - a.c0] : 1;
-    mine[h] = flag == 0;
-    ci[h] = mine[h] ? c[h] - a.c0 : 0;
-    r[h].beg0 = 0; r[h].end0 = 0; r[h].last = 0; r[h].nEvents = 0;
-    if (mine[h]) r[h] = a.ranges[ci[h]];
-    n[h] = r[h].nEvents; nBlk[h] = (n[h] + 7) >> 3;
-    sq[h] = mine[h] ? a.g.fragS[a.g.candFrag[c[h]]] : 1;
-    p[h] = (const uint4 *)((const uint16_t *)a.codes + (mine[h] ? a.codeOff[ci[h]] : 0u));
-    cur[h] = l2_block_load(mine[h], p[h], l2_block_zero());          // a half without a candidate: zero events (see k_l2_sim)
-    iS[h] = sq[h]; tot[h] = sq[h]; sh[h] = 0;
-  }
-  // Phase A (see k_l2_sim): the first super-window's inserts are field updates only; while every candidate of the wave has a whole
-  // block of them.  Per candidate, unpacked: nine instructions an event leave nothing to share.
-  int blk = 0;
-  {
-    constexpr uint32_t kFillPair = (kL2InsBit | kL2NoEvalBit) * 0x10001u, kDupPair = kL2DupBit * 0x10001u;
-    for (; __any(mine[0] || mine[1]); blk++) {
-      bool fill = true, dupHere = false;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const uint32_t andw = cur[h][0] & cur[h][1] & cur[h][2] & cur[h][3], orw = cur[h][0] | cur[h][1] | cur[h][2] | cur[h][3];
-        fill = fill && (!mine[h] || (8 * blk + 8 <= n[h] && (andw & kFillPair) == kFillPair));
-        dupHere = dupHere || (mine[h] && (orw & kDupPair) != 0);
-      }
-      if (!__all(fill)) break;
-      const bool anyDup = __any(dupHere);                                // rare: an entry with a same-hash neighbour nearby
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        L2Block nxt = cur[h];
-        if (mine[h]) {
-          const int nb = blk + 1 < nBlk[h] ? blk + 1 : blk;
-          nxt = l2_block_load(true, p[h] + nb, cur[h]);
-          const uint32_t wd[4] = {cur[h][0], cur[h][1], cur[h][2], cur[h][3]};
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const uint32_t code = (e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffffu);
-            int d = (int)((code >> kL2DeltaShift) & 7u);
-            if (anyDup && (code & kL2DupBit) && dup_prev(a.g.dup, (uint32_t)(r[h].beg0 + 8 * blk + e)) >= r[h].beg0) d = 0;
-            uint8_t *pOwn = F[h] + l2_field_off((int)((code >> 1) & 0x1ffu));
-            const int nw = (int)*pOwn + d;
-            ovf |= (uint32_t)nw;
-            *pOwn = (uint8_t)nw;
-          }
-        }
-        cur[h] = nxt;
-      }
-    }
-    if (blk > 0) {                                                      // wave-uniform
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        int iSt = 0, tt = 0, shd = 0, acc = 0; bool open = mine[h];
-        for (int i = 1; __any(open && i <= sq[h]); i++) {
-          const int f = F[h][l2_field_off(i - 1)];                      // n[i-1] << 1 | b[i]
-          acc += f >> 1;
-          open = open && i <= sq[h] && i + acc <= sq[h];
-          iSt = open ? i : iSt; tt = open ? i + acc : tt; shd += open ? (f & 1) : 0;
-        }
-        if (mine[h]) { iS[h] = iSt; tot[h] = tt; sh[h] = shd; }
-      }
-    }
-  }
-  L2PairState R;
-  R.s = pk_pair(sq[0], sq[1]); R.iStar = pk_pair(iS[0], iS[1]); R.tot = pk_pair(tot[0], tot[1]); R.shared = pk_pair(sh[0], sh[1]);
-  R.best = pk_pair(0, 0); R.begAtBest = pk_pair(-1, -1); R.begAtLast = pk_pair(-1, -1); R.delCount = pk_pair(0, 0); R.noEvals = pk_pair(0, 0);
-  R.ovfAcc = (ovf & 0x100u) ? 0x01000100u : 0u;                        // (the fill phase's overflow is not told apart by candidate)
-  const int blkMain = blk;
-  const int nBlkMax = nBlk[0] > nBlk[1] ? nBlk[0] : nBlk[1];
-  for (; __any(blk < nBlkMax); blk++) {
-    L2Block nxt[2]; bool plain = true;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      int nb = blk + 1 < nBlk[h] ? blk + 1 : nBlk[h] - 1; nb = nb < 0 ? 0 : nb;
-      nxt[h] = l2_block_load(mine[h], p[h] + nb, cur[h]);
-      const uint32_t orw = cur[h][0] | cur[h][1] | cur[h][2] | cur[h][3];
-      plain = plain && (!mine[h] || (8 * blk + 8 <= n[h] && (orw & (kL2DupBit | (kL2DupBit << 16))) == 0));
-    }
-    const uint32_t w0[4] = {cur[0][0], cur[0][1], cur[0][2], cur[0][3]}, w1[4] = {cur[1][0], cur[1][1], cur[1][2], cur[1][3]};
-    if (__all(plain)) {
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const uint32_t P = pk_codes(w0[e >> 1], w1[e >> 1], (e & 1) != 0);
-        l2_pair_event<false>(F[0], F[1], R, pk_from(P), pk_pair(-1, -1), pk_pair(-1, -1));
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const uint32_t P = pk_codes(w0[e >> 1], w1[e >> 1], (e & 1) != 0);
-        const int ev = 8 * blk + e;                                     // events applied so far
-        bool on[2], eff[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) { on[h] = ev < n[h]; eff[h] = on[h]; }
-        const bool dupEv = (on[0] && (P & kL2DupBit)) || (on[1] && (P & (kL2DupBit << 16)));
-        if (__any(dupEv)) {
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            const uint32_t code = h ? (P >> 16) : (P & 0xffffu);
-            if (on[h] && (code & kL2DupBit)) {
-              const int delCount = h ? pk_hi(R.delCount) : pk_lo(R.delCount);
-              const int insCount = ev - delCount;                       // entries [delCount, insCount) are in the window
-              if (code & kL2InsBit) eff[h] = dup_prev(a.g.dup, (uint32_t)(r[h].beg0 + insCount)) < r[h].beg0 + delCount;
-              else { const int32_t nx = dup_next(a.g.dup, (uint32_t)(r[h].beg0 + delCount)); eff[h] = !(nx >= 0 && nx < r[h].beg0 + insCount); }
-            }
-          }
-        }
-        l2_pair_event<true>(F[0], F[1], R, pk_from(P), pk_pair(on[0] ? -1 : 0, on[1] ? -1 : 0), pk_pair(eff[0] ? -1 : 0, eff[1] ? -1 : 0));
-      }
-    }
-    cur[0] = nxt[0]; cur[1] = nxt[1];
-  }
-  unsigned long long cntE = 0, cntS = 0, cntQ = 0;
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    if (mine[h]) {
-      if ((R.ovfAcc >> (16 * h)) & 0x100u) a.slowFlag[ci[h]] = 3;
-      else {
-        const int best = h ? pk_hi(R.best) : pk_lo(R.best), begAtBest = h ? pk_hi(R.begAtBest) : pk_lo(R.begAtBest), begAtLast = h ? pk_hi(R.begAtLast) : pk_lo(R.begAtLast);
-        a.slowFlag[ci[h]] = 0;
-        a.g.outBest[c[h]] = best;
-        a.g.outFirst[c[h]] = begAtBest >= 0 ? a.g.mWpos[r[h].beg0 + begAtBest] : 0;
-        a.g.outLast[c[h]] = begAtLast >= 0 ? a.g.mWpos[r[h].beg0 + begAtLast] : 0;
-        // evaluations = events of the main loop's blocks that carried one (events beyond the stream count as "without")
-        const int steps = 8 * (blk - blkMain) + (h ? pk_hi(R.noEvals) : pk_lo(R.noEvals));
-        cntE += (unsigned long long)(r[h].last - r[h].beg0); cntS += (unsigned long long)steps; cntQ += (unsigned long long)sq[h];
-      }
-    }
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { cntE += __shfl_down(cntE, d); cntS += __shfl_down(cntS, d); cntQ += __shfl_down(cntQ, d); }
-  if (lane == 0 && (cntE | cntS | cntQ)) { atomicAdd(stat_slot(a.g.sumEntries), cntE); atomicAdd(stat_slot(a.g.sumSteps), cntS); atomicAdd(stat_slot(a.g.sumQ), cntQ); }
-}
 
 // candidates of the chunk that must take the general kernel -> list (order irrelevant)
 // after both simulation classes ran: slowFlag 1 = outside the fast-path limits, 3 = gap counter overflow, 0 / 8 = done

@@ -217,26 +217,6 @@ def test_pipelined_sub_batches(monkeypatch):
             monkeypatch.delenv(k)
 
 
-def test_l2_pair_kernel(monkeypatch):
-    """k_l2_sim_pair (l2.hpp; ANI_L2_PAIR=1, an experiment that is off by default): two candidates per lane, the window state in
-    packed 16-bit halves — same mapping records, same counters (evaluated windows included) as the one-candidate kernel"""
-    e = _emu_engine_with(monkeypatch, ANI_L2_PAIR=1)
-    e.reset_counters()
-    pc.case_synthetic_cluster(e, 30000)
-    paired = e.counters()
-    pc.case_tandem_repeats(e)
-    pc.case_gap_counter_overflow(e)
-    pc.case_evolved(e, 30000, 5)
-    pc.case_kmer12(e)
-    monkeypatch.setenv("ANI_L2_PAIR", "0")
-    e.reset_counters()
-    pc.case_synthetic_cluster(e, 30000)
-    plain = e.counters()
-    for k in ("l2Steps", "l2WindowEntries", "l2FastCandidates", "l2SlowCandidates"):
-        assert paired[k] == plain[k] and (plain[k] > 0 or k == "l2SlowCandidates"), k
-    e.close()
-
-
 def test_same_hash_links_rerun(monkeypatch):
     """the list of same-hash links (index.hpp: DupLinks) is sized from a guess; a repetitive reference (tandem repeats, one k-mer on
     thousands of contigs) holds more near-duplicate pairs than that and the links kernel runs again with room for all"""

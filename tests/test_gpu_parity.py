@@ -35,26 +35,6 @@ def test_l2_alternative_paths(gpu_engine, path, monkeypatch):
         assert c["l2SlowCandidates"] == 0 and c["l2FastCandidates"] > 0
 
 
-def test_l2_pair_kernel(gpu_engine, monkeypatch):
-    """k_l2_sim_pair (ANI_L2_PAIR=1; an experiment, off by default: DESIGN.md section 2.5): two candidates per lane in packed 16-bit
-    halves must give the records and the counters of the one-candidate kernel"""
-    monkeypatch.setenv("ANI_L2_PAIR", "1")
-    gpu_engine.reset_counters()
-    pc.case_synthetic_cluster(gpu_engine, 60000)
-    paired = gpu_engine.counters()
-    pc.case_tandem_repeats(gpu_engine)
-    pc.case_gap_counter_overflow(gpu_engine)
-    pc.case_evolved(gpu_engine)
-    pc.case_kmer12(gpu_engine)
-    assert pc.fuzz(gpu_engine, seed=11, iterations=6) == 6
-    monkeypatch.setenv("ANI_L2_PAIR", "0")
-    gpu_engine.reset_counters()
-    pc.case_synthetic_cluster(gpu_engine, 60000)
-    plain = gpu_engine.counters()
-    for k in ("l2Steps", "l2WindowEntries", "l2FastCandidates"):
-        assert paired[k] == plain[k] and plain[k] > 0, k
-
-
 def test_full_size_properties(gpu_engine):
     """BASELINE-size genomes (5 Mbp), device-resident 2-bit input: size-independent properties + oracle on two pairs."""
     import torch
