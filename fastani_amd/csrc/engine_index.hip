@@ -120,43 +120,33 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
     SK_HIP(pool_malloc((void **)&tmpK, n4));
     { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
     SK_HIP(hipMemsetAsync(sk->dupBits, 0, bitWords * 4, ctx->stream));
-    // Main stream: the index sort (radix.hpp) — its histogram read of the records writes the position-ordered SoA arrays, its passes
-    // are bound by memory bandwidth.  Side stream, as soon as the SoA arrays exist (evIndex[0]; the index build has its own events — the L2 stage's evSimA belong to map_stage): everything that needs positions only —
-    // contig slices, the window links of the L2 event stream (binary searches over LDS-staged positions: latency- and LDS-bound),
-    // the sampled position index — runs underneath the sort's passes instead of after them.
+    // Main stream: the index sort (radix.hpp: its histogram read of the records writes the position-ordered SoA arrays), then the
+    // same-hash links and the probe table.  Side stream: what needs positions only — the window links of the L2 event stream (binary
+    // searches over LDS-staged positions: latency- and LDS-bound) and the sampled position index.  Round 5: the side work starts
+    // BEHIND the sort's passes, beside the links / table kernels and the host round trips between them; under the passes (rounds 3 - 4)
+    // it cost the first pass what it took itself (6.8 ms instead of 3.0: the passes are occupancy-bound, profiles/r05m_kernel_stats.csv).
     struct SideJoin { ani_ctx *c; ~SideJoin() { (void)hipStreamSynchronize(c->stream2); } } sideJoin{ctx};   // also on the error paths below
-    bool sorting = false;
     if (n) {
       std::vector<const void *> recs; std::vector<size_t> cnts;
       for (const RecordPiece &pc : sk->pieces) if (pc.n) { recs.push_back(pc.rec); cnts.push_back(pc.n); }
       size_t tb = 0;
       int rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, nullptr, &tb, ctx->stream, nullptr, nullptr);
-      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, ctx->evIndex[0], ctx->stream2); }
+      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, nullptr, nullptr); }
       if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
-      sorting = true;                               // the passes are in flight; stream2 waits for the SoA arrays
     }
-    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    pool_free(tmpK); pool_free(tmpV);
+    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    SK_HIP(hipEventRecord(ctx->evIndex[0], ctx->stream));
+    SK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evIndex[0], 0));
     if (winLinks)
       hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + kWinBlock - 1) / kWinBlock)), dim3(256), 0, ctx->stream2, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
                          (const int32_t *)sk->contigFirstMin, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
     if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
                                     sk->totalPosBins, (uint32_t)n, sk->posSample);
-    if (sorting) {
-      // (ctx->sortTmp holds the status and error words of the passes in flight: nothing may touch it between ani_sort_index and here)
-      int rc = ani_sort_check(ctx->sortTmp.p, ctx->stream);
-      if (rc == 9001) {                             // a look-back gave up (a scheduling surprise, sort_device.hip): once more, without the side stream
-        std::vector<const void *> recs; std::vector<size_t> cnts;
-        for (const RecordPiece &pc : sk->pieces) if (pc.n) { recs.push_back(pc.rec); cnts.push_back(pc.n); }
-        size_t tb = ctx->sortTmp.cap;
-        rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, nullptr, nullptr);
-      }
-      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
-    }
-    pool_free(tmpK); pool_free(tmpV);
-    SK_HIP(hipGetLastError());
-    SK_HIP(hipEventRecord(ctx->evIndex[1], ctx->stream2));
-    SK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evIndex[1], 0));            // the links kernel needs the contig slices and ORs into the window links
+    SK_HIP(hipGetLastError());                                             // (joined at the end: the nearDup flags go into the window links there)
     // same-hash links of near duplicates (index.hpp: DupLinks) and the number of distinct hashes
+    uint64_t *dupPairs = nullptr; int dupKeyBits = 0;           // the unsorted half-records while their sort is in flight on the side stream
+    struct PairsGuard { uint64_t *&p; ani_ctx *c; ~PairsGuard() { if (p) { (void)hipStreamSynchronize(c->stream2); pool_free(p); p = nullptr; } } } pairsGuard{dupPairs, ctx};
     unsigned long long host[CNT_N];
     host[CNT_UNIQ] = 0;
     if (n) {
@@ -166,7 +156,7 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
         SK_HIP(pool_malloc((void **)&pairs, (size_t)pairCap * 16));
         { const int rz = zero_counters(ctx); if (rz != ANI_OK) { pool_free(pairs); return bail(rz); } }
         hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
-                           cmw, pairs, pairCap, (unsigned int *)cnt_ptr(ctx, CNT_NEG), sk->dupBits, winLinks ? sk->mWin : (uint32_t *)nullptr, cnt_ptr(ctx, CNT_UNIQ));
+                           cmw, pairs, pairCap, (unsigned int *)cnt_ptr(ctx, CNT_NEG), sk->dupBits, (uint32_t *)nullptr /* k_index_mark_dups sets the window links' flags */, cnt_ptr(ctx, CNT_UNIQ));
         { const int rr = read_counters(ctx, host); if (rr != ANI_OK) { pool_free(pairs); return bail(rr); } }
         const uint64_t nPairs = (uint32_t)host[CNT_NEG];
         if (nPairs > pairCap) {                                  // a repetitive reference: again with room for every pair (bits and flags are idempotent)
@@ -177,15 +167,20 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
         }
         sk->nDup = (uint32_t)(2 * nPairs);
         if (nPairs) {
-          // the half-records sorted by (entry, kind): bisection finds an entry's links (keys are unique: every key bit is significant up to the entry's)
+          // The half-records sorted by (entry, kind): bisection finds an entry's links.  (entry, kind) is unique, so only the bits from
+          // `kind` (31) up to the entry's top bit are sorted: four 8-bit passes for 4 x 10^8 entries instead of eight.  The sort goes to
+          // the SIDE stream, behind the window links, and is completed at the join below (round 5: on the main stream its small,
+          // look-back-latency-bound passes took 2.4 ms of the build's critical path, profiles/r05p_index_timeline.txt); nothing else
+          // touches ctx->sortTmp until then.
           int keyBits = 33; while (keyBits < 64 && (1ull << (keyBits - 32)) <= (uint64_t)n) keyBits++;
           SK_HIP(pool_malloc((void **)&sk->dupList, (size_t)sk->nDup * 8));
           size_t tb = 0;
-          int rc = ani_sort_keys_u64_bits(pairs, sk->dupList, sk->nDup, keyBits, nullptr, &tb, ctx->stream);
-          if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_keys_u64_bits(pairs, sk->dupList, sk->nDup, keyBits, ctx->sortTmp.p, &tb, ctx->stream); }
+          int rc = ani_sort_keys_u64_range(pairs, sk->dupList, sk->nDup, 31, keyBits, nullptr, &tb, ctx->stream2, 1);
+          if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) { SK_HIP(hipEventRecord(ctx->evIndex[0], ctx->stream)); SK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evIndex[0], 0));      // the links are written
+                                                                                  rc = ani_sort_keys_u64_range(pairs, sk->dupList, sk->nDup, 31, keyBits, ctx->sortTmp.p, &tb, ctx->stream2, 1); } }
           if (rc != 0) { pool_free(pairs); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(ANI_ERR_DEVICE, "radix sort of the same-hash links failed (%d)", rc)); }
-        }
-        pool_free(pairs);
+          dupPairs = pairs; dupKeyBits = keyBits;   // freed at the join
+        } else pool_free(pairs);
         break;
       }
     }
@@ -225,6 +220,17 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
       }
       const TableSlot sentinel{0xffffffffu, (uint32_t)n | 0x80000000u, 0u};
       SK_HIP(hipMemcpyAsync(sk->table + (alloc - 2), &sentinel, sizeof sentinel, hipMemcpyHostToDevice, ctx->stream));
+      // join the side stream (window links, position sample, the sort of the same-hash half-records); the nearDup flags of the
+      // entries with same-hash links go into the finished window links
+      if (dupPairs) {
+        int rc = ani_sort_check(ctx->sortTmp.p, ctx->stream2);
+        if (rc == 9001) { size_t tb = ctx->sortTmp.cap; rc = ani_sort_keys_u64_range(dupPairs, sk->dupList, sk->nDup, 31, dupKeyBits, ctx->sortTmp.p, &tb, ctx->stream2, 0); }     // a look-back gave up: once more, waiting for it
+        if (rc != 0) return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the same-hash links failed (%d)", rc));
+        pool_free(dupPairs); dupPairs = nullptr;
+      }
+      SK_HIP(hipEventRecord(ctx->evIndex[1], ctx->stream2));
+      SK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evIndex[1], 0));
+      if (winLinks && sk->nDup) hipLaunchKernelGGL(k_index_mark_dups, dim3(grid_for((size_t)sk->nDup)), dim3(256), 0, ctx->stream, (const uint64_t *)sk->dupList, sk->nDup, sk->mWin);
       SK_HIP(hipStreamSynchronize(ctx->stream));                             // cnt / best / sentinel are host memory
       sk->tableSlots = nSlots;
     }

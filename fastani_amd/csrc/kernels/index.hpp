@@ -116,6 +116,15 @@ static __global__ void k_index_links(const uint32_t *__restrict__ sHash, const u
   }
 }
 
+// The nearDup flag of the window links (bit 31 of mWin) for every entry that has a same-hash link: set from the sorted half-records
+// once both the links (main stream) and the window links (side stream) are there (round 5: k_index_links used to OR the bit into
+// mWin itself, which tied the two kernels into one order).
+static __global__ void k_index_mark_dups(const uint64_t *__restrict__ dupList, uint32_t nDup, uint32_t *__restrict__ mWin)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nDup) atomicOr(&mWin[(uint32_t)(dupList[i] >> 32)], kWinDupBit);
+}
+
 // Bucket key of a hash.  Minimizer hashes are minima over w k-mer hashes, so their density falls off like w (1 - v)^(w-1) over
 // the 32-bit range v = h / 2^32: buckets cut from the top bits of h would hold dozens of entries at the low end and none at the
 // high end.  The key is the CDF instead, ~ 2^32 (1 - (1 - v)^w) in 32-bit fixed point (square-and-multiply on the high halves

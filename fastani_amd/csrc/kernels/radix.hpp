@@ -111,7 +111,7 @@ __device__ __forceinline__ void radix_status_store(unsigned long long *p, unsign
 // Digit histograms of every pass in ONE read of the keys: hist[pass * 256 + digit] (64-bit, zeroed by the host).  The index build
 // passes `soa` = true: the same read writes the position-ordered SoA arrays of the chunk (mHash / mSeq / mWpos at `soaBase + i`).
 template <class KeyT, class Src>
-static __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64_t n, int endBit, int nPasses, unsigned long long *__restrict__ hist,
+static __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64_t n, int beginBit, int endBit, int nPasses, unsigned long long *__restrict__ hist,
                                                           uint32_t *__restrict__ mHash, int32_t *__restrict__ mSeq, int32_t *__restrict__ mWpos)
 {
   // one copy of the counters per wave: the top digit of minimizer hashes takes a few dozen values, and 64 lanes adding to a handful of
@@ -129,7 +129,7 @@ static __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64
         mHash[i] = (uint32_t)k; mSeq[i] = (int32_t)(v >> 32); mWpos[i] = (int32_t)(uint32_t)v;
       }
     }
-    for (int p = 0; p < nPasses; p++) atomicAdd(&mine[p * kRadixDigits + (int)radix_digit(k, p * kRadixBits, endBit)], 1u);
+    for (int p = 0; p < nPasses; p++) atomicAdd(&mine[p * kRadixDigits + (int)radix_digit(k, beginBit + p * kRadixBits, endBit)], 1u);   // pass p sorts the bits from beginBit + 8 p
   }
   block_barrier();
   for (int i = threadIdx.x; i < nPasses * kRadixDigits; i += kTPB) {

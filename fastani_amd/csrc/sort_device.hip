@@ -61,14 +61,17 @@ int finish(const Workspace &w, hipStream_t stream)
 // run; the inputs are only read) before the caller sees the error.
 constexpr int kSortAttempts = 2;
 
-// generic: keys (and values) in arrays, bits [0, endBit) significant
+// generic: keys (and values) in arrays, bits [beginBit, endBit) significant (the bits below beginBit travel with the key, unordered).
+// `async`: the call returns with the passes in flight (no retry); the caller completes it with ani_sort_check on the same stream
+// and must leave `tmp` alone until then.
 template <class KeyT, class ValT>
-int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *valsOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
+int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *valsOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream, bool async = false)
 {
   constexpr bool kHasVal = !std::is_same<ValT, RadixNoVal>::value;
-  if (endBit < 1) endBit = 1;
   if (endBit > (int)sizeof(KeyT) * 8) endBit = (int)sizeof(KeyT) * 8;
-  const int P = (endBit + kRadixBits - 1) / kRadixBits;
+  if (beginBit < 0) beginBit = 0;
+  if (endBit < beginBit + 1) endBit = beginBit + 1;
+  const int P = (endBit - beginBit + kRadixBits - 1) / kRadixBits;
   const uint64_t tiles = tiles_of(n);
   const size_t keyBytes = align256(n * sizeof(KeyT)), valBytes = kHasVal ? align256(n * sizeof(ValT)) : 0;
   const size_t need = workspace_bytes(tiles, P > 1 ? keyBytes + valBytes : 0);
@@ -85,7 +88,7 @@ int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *val
     if (e != hipSuccess) return (int)e;
     const unsigned hg = (unsigned)std::min<uint64_t>((n + kTPB * 8 - 1) / (kTPB * 8), 4096);
     ArraySrc<KeyT, ValT> in{keysIn, valsIn};
-    hipLaunchKernelGGL((k_radix_histogram<KeyT, ArraySrc<KeyT, ValT>>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, in, (uint64_t)n, endBit, P, w.hist, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL((k_radix_histogram<KeyT, ArraySrc<KeyT, ValT>>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, in, (uint64_t)n, beginBit, endBit, P, w.hist, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kTPB), 0, stream, w.hist, P);
     for (int p = 0; p < P; p++) {
       const bool toOut = ((P - 1 - p) & 1) == 0;
@@ -93,9 +96,10 @@ int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *val
       KeyT *dk = toOut ? keysOut : pongK; ValT *dv = toOut ? valsOut : pongV;
       e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL((k_radix_pass<KeyT, ValT, ArraySrc<KeyT, ValT>>), dim3((unsigned)tiles), dim3(kRadixTPB), 0, stream, src, dk, dv, (uint64_t)n, p * kRadixBits, endBit,
+      hipLaunchKernelGGL((k_radix_pass<KeyT, ValT, ArraySrc<KeyT, ValT>>), dim3((unsigned)tiles), dim3(kRadixTPB), 0, stream, src, dk, dv, (uint64_t)n, beginBit + p * kRadixBits, endBit,
                          (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + p, 0u, w.err);
     }
+    if (async) return 0;
     rc = finish(w, stream);
     if (rc != 9001 || !rerunnable) break;
   }
@@ -108,14 +112,22 @@ int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *val
 extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
                                       size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
 {
-  return sort_arrays<uint64_t, uint32_t>(keysIn, keysOut, valsIn, valsOut, n, endBit, tmp, tmpBytes, stream);
+  return sort_arrays<uint64_t, uint32_t>(keysIn, keysOut, valsIn, valsOut, n, 0, endBit, tmp, tmpBytes, stream);
 }
 
 // 64-bit keys, the low endBit bits significant (the batched L1 path packs (fragment, seqId, wpos) into as few bits as the index
 // chunk needs)
 extern "C" int ani_sort_keys_u64_bits(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
 {
-  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, endBit, tmp, tmpBytes, stream);
+  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, 0, endBit, tmp, tmpBytes, stream);
+}
+
+// 64-bit keys ordered by their bits [beginBit, endBit) only; `async` != 0: the passes stay in flight, ani_sort_check(tmp, stream)
+// completes the call.  (The same-hash half-records of the index: entry << 32 | kind << 31 | other are unique in (entry, kind), so the
+// 31 low bits need no pass — four passes instead of eight, on the side stream.)
+extern "C" int ani_sort_keys_u64_range(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream, int async)
+{
+  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, beginBit, endBit, tmp, tmpBytes, stream, async != 0);
 }
 
 // The index sort (Sketch::index, winSketch.hpp:181-193).  Input: the chunk's minimizer records as `nPieces` device buffers of
@@ -147,7 +159,7 @@ extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN,
     if (!pieceN[i]) continue;
     const unsigned hg = (unsigned)std::min<uint64_t>((pieceN[i] + kTPB * 8 - 1) / (kTPB * 8), 4096);
     RecordSrc src{(const uint32_t *)pieceRec[i], seqBase};
-    hipLaunchKernelGGL((k_radix_histogram<uint32_t, RecordSrc>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, src, (uint64_t)pieceN[i], 32, P, w.hist, mHash + o, mSeq + o, mWpos + o);
+    hipLaunchKernelGGL((k_radix_histogram<uint32_t, RecordSrc>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, src, (uint64_t)pieceN[i], 0, 32, P, w.hist, mHash + o, mSeq + o, mWpos + o);
     o += pieceN[i];
   }
   // the SoA arrays are complete: work that only needs positions may start on the caller's side stream, underneath the passes

@@ -60,6 +60,25 @@ if has prof; then
   [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv" && head -28 "$f" | cut -c1-160
   rm -rf "$OUT/prof"
 fi
+if has trace; then
+  echo "== kernel timeline of the last index build (rocprofv3 --kernel-trace)"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d "$OUT/trace" -o bench --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/trace_bench.log" 2>&1)
+  f=$(find "$OUT/trace" -name "*kernel_trace*.csv" | head -1)
+  [ -n "$f" ] && python - "$f" <<'EOF2' | tee "$OUT/index_timeline.txt"
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+last = max(i for i, r in enumerate(rows) if "k_radix_histogram<unsigned int, ani::RecordSrc" in r["Kernel_Name"])
+t0 = int(rows[last]["Start_Timestamp"])
+for r in rows[last:]:
+    n = r["Kernel_Name"].split("(")[0][:64]
+    a, b = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+    print("%9.3f %9.3f  %7.3f  q%s  %s" % (a, b, b - a, r.get("Queue_Id", "?"), n))
+    if "k_l1_probe" in n:
+        break
+EOF2
+  rm -rf "$OUT/trace"
+fi
 if has c4sim8; then
   echo "== configs[3] in its multi-rank form: rank 0 of 8 at 10 000 x 10 000 (1250-genome shard, own set + merged 8750-genome foreign set)"
   timeout 1500 python bench.py --config c4 --simulate-world 8 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --oracle-pairs 60 2> "$OUT/c4sim8.err" | tee "$OUT/c4sim8.json.log" | cut -c1-1500
