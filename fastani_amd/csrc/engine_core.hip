@@ -138,7 +138,14 @@ int ani_init(int device, ani_ctx **out)
   c->device = device;
   memset(&c->counters, 0, sizeof c->counters);
   HIP_TRY(hipStreamCreate(&c->stream));
-  HIP_TRY(hipStreamCreate(&c->stream2));
+  {
+    // ANI_SIDE_PRIORITY=low|high: queue priority of the side stream (index side work, the L2 simulation) — an A/B knob
+    const char *ev = getenv("ANI_SIDE_PRIORITY");
+    int least = 0, greatest = 0;
+    if (ev && (!strcmp(ev, "low") || !strcmp(ev, "high")) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+      HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamDefault, !strcmp(ev, "low") ? least : greatest));
+    else HIP_TRY(hipStreamCreate(&c->stream2));
+  }
   if (const char *ev = getenv("ANI_SUBBATCH_FRAGS")) { const long long v = atoll(ev); if (v > 0) c->subBatchFragments = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
   if (const char *ev = getenv("ANI_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }

@@ -149,7 +149,15 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
     struct PairsGuard { uint64_t *&p; ani_ctx *c; ~PairsGuard() { if (p) { (void)hipStreamSynchronize(c->stream2); pool_free(p); p = nullptr; } } } pairsGuard{dupPairs, ctx};
     unsigned long long host[CNT_N];
     host[CNT_UNIQ] = 0;
+    // (the probe table's block totals are queued right behind the links — the kernel takes the number of distinct hashes from the
+    //  device counter — so the counters and the totals come back in ONE round trip; block totals and carries live in page-locked
+    //  memory: with pageable vectors the two reads took 0.56 + 0.63 ms through the runtime's staging copy, profiles/r05q_index_timeline.txt)
+    const uint32_t nb = (uint32_t)((n + kTableBlock - 1) / kTableBlock);
+    int32_t *cnt = nullptr;
+    SK_TRY(pinned_buffer(ctx, 2, (size_t)(nb ? nb : 1) * 8, (void **)&cnt));
+    int32_t *best = cnt + (nb ? nb : 1);
     if (n) {
+      SK_TRY(ctx->scanTmpA.ensure((size_t)nb * 4)); SK_TRY(ctx->scanTmpB.ensure((size_t)nb * 4));
       uint32_t pairCap = (uint32_t)std::min<uint64_t>(n, ctx->dupPairCap ? ctx->dupPairCap : n / 64 + 4096);     // first guess; a repetitive reference reruns with the exact count
       for (int attempt = 0;; attempt++) {
         uint64_t *pairs = nullptr;
@@ -157,7 +165,14 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
         { const int rz = zero_counters(ctx); if (rz != ANI_OK) { pool_free(pairs); return bail(rz); } }
         hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
                            cmw, pairs, pairCap, (unsigned int *)cnt_ptr(ctx, CNT_NEG), sk->dupBits, (uint32_t *)nullptr /* k_index_mark_dups sets the window links' flags */, cnt_ptr(ctx, CNT_UNIQ));
-        { const int rr = read_counters(ctx, host); if (rr != ANI_OK) { pool_free(pairs); return bail(rr); } }
+        if (attempt == 0) {
+          hipLaunchKernelGGL(k_table_block_totals, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize,
+                             (const unsigned long long *)cnt_ptr(ctx, CNT_UNIQ), ctx->scanTmpA.as<int32_t>(), ctx->scanTmpB.as<int32_t>());
+          hipError_t ec = hipMemcpyAsync(cnt, ctx->scanTmpA.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream);
+          if (ec == hipSuccess) ec = hipMemcpyAsync(best, ctx->scanTmpB.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream);
+          if (ec != hipSuccess) { pool_free(pairs); SK_HIP(ec); }
+        }
+        { const int rr = read_counters(ctx, host); if (rr != ANI_OK) { pool_free(pairs); return bail(rr); } }     // (synchronises)
         const uint64_t nPairs = (uint32_t)host[CNT_NEG];
         if (nPairs > pairCap) {                                  // a repetitive reference: again with room for every pair (bits and flags are idempotent)
           pool_free(pairs);
@@ -187,17 +202,9 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
     // probe table: the distinct hashes in an order-preserving open-addressing table, load 0.5 (index.hpp)
     {
       sk->nUnique = host[CNT_UNIQ];                           // k_index_links counted the distinct hashes
-      const uint32_t nSlots = (uint32_t)std::min<uint64_t>(0x7ffffff0ull, std::max<uint64_t>(1024, (uint64_t)sk->nUnique * 2));
-      const uint32_t nb = (uint32_t)((n + kTableBlock - 1) / kTableBlock);
-      std::vector<int32_t> cnt(nb ? nb : 1), best(nb ? nb : 1);
+      const uint32_t nSlots = table_slots(sk->nUnique);
       int64_t lastP = -1;
       if (n) {
-        SK_TRY(ctx->scanTmpA.ensure((size_t)nb * 4)); SK_TRY(ctx->scanTmpB.ensure((size_t)nb * 4));
-        hipLaunchKernelGGL(k_table_block_totals, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize, nSlots,
-                           ctx->scanTmpA.as<int32_t>(), ctx->scanTmpB.as<int32_t>());
-        SK_HIP(hipMemcpyAsync(cnt.data(), ctx->scanTmpA.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-        SK_HIP(hipMemcpyAsync(best.data(), ctx->scanTmpB.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
-        SK_HIP(hipStreamSynchronize(ctx->stream));
         int64_t before = 0, run = INT32_MIN;                              // distinct hashes before the block; max(slot - global index) over them
         for (uint32_t b = 0; b < nb; b++) {
           const int32_t c = cnt[b], bb = best[b];
@@ -213,8 +220,8 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
       //  kernel 1.3 ms slower per 4 x 10^8 minimizers and saved 0.5 ms of fill: the device fills 9.6 GB in 0.65 ms)
       SK_HIP(hipMemsetAsync(sk->table, 0xff, alloc * sizeof(TableSlot), ctx->stream));
       if (n) {
-        SK_HIP(hipMemcpyAsync(ctx->scanTmpA.p, cnt.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
-        SK_HIP(hipMemcpyAsync(ctx->scanTmpB.p, best.data(), (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        SK_HIP(hipMemcpyAsync(ctx->scanTmpA.p, cnt, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        SK_HIP(hipMemcpyAsync(ctx->scanTmpB.p, best, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_table_scatter, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize, nSlots,
                            (const int32_t *)ctx->scanTmpA.as<int32_t>(), (const int32_t *)ctx->scanTmpB.as<int32_t>(), sk->table);
       }

@@ -72,36 +72,60 @@ static __global__ void k_index_join(const uint32_t *__restrict__ mHash, const in
 //   window start) may trail by less than the gap to its successor: possible iff wpos[j] - wpos[j'] <= cmw + (wpos[j'+1] - wpos[j']).
 // Entries without a link behave as plain set members in L2 (links of non-near pairs would only ever be compared against the bounds of
 // one window).  `nPairs` counts every pair; a pair beyond `pairCap` is not stored (the host reruns the kernel with room for all).
+// one same-hash pair (r - 1, r) of the sorted index: the link records if the two are near duplicates
+__device__ __forceinline__ void index_link_pair(uint32_t r, const uint64_t *__restrict__ sSW, const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
+                                                int32_t cmw, uint64_t *__restrict__ pairs, uint32_t pairCap, unsigned int *__restrict__ nPairs,
+                                                uint32_t *__restrict__ dupBits, uint32_t *__restrict__ mWin)
+{
+  const uint64_t a = sSW[r - 1], b = sSW[r];                   // a is positionally before b
+  if ((a >> 32) != (b >> 32)) return;                          // different contigs never share a window
+  const int32_t seq = (int32_t)(a >> 32), wa = (int32_t)(uint32_t)a, wb = (int32_t)(uint32_t)b;
+  // positional indices: binary search on wpos inside the contig's slice
+  int32_t lo = contigFirstMin[seq], hi = contigFirstMin[seq + 1];
+  const int32_t cHi = hi;
+  while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wa) lo = mid + 1; else hi = mid; }
+  const int32_t ia = lo;
+  const int32_t gap = (ia + 1 < cHi) ? mWpos[ia + 1] - wa : 0;
+  if (wb - wa > cmw + gap) return;
+  hi = cHi;
+  while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wb) lo = mid + 1; else hi = mid; }
+  const int32_t ib = lo;
+  const unsigned int slot = atomicAdd(nPairs, 1u);
+  if (slot < pairCap) {
+    pairs[2 * (size_t)slot] = ((uint64_t)(uint32_t)ia << 32) | (1ull << 31) | (uint32_t)ib;         // ia: its next near occurrence is ib
+    pairs[2 * (size_t)slot + 1] = ((uint64_t)(uint32_t)ib << 32) | (uint32_t)ia;                    // ib: its previous one is ia
+  }
+  atomicOr(&dupBits[ia >> 5], 1u << (ia & 31)); atomicOr(&dupBits[ib >> 5], 1u << (ib & 31));
+  if (mWin) { atomicOr(&mWin[ia], kWinDupBit); atomicOr(&mWin[ib], kWinDupBit); }
+}
+
+// (round 5: four consecutive entries per thread from one 16-byte load — one entry per thread and iteration was a chain of ~190
+//  dependent 4-byte loads per thread, 2.0 ms for the 1.6 GB of hashes.)
 static __global__ void k_index_links(const uint32_t *__restrict__ sHash, const uint64_t *__restrict__ sSW, uint32_t n,
                               const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin, int32_t cmw,
                               uint64_t *__restrict__ pairs, uint32_t pairCap, unsigned int *__restrict__ nPairs,
                               uint32_t *__restrict__ dupBits, uint32_t *__restrict__ mWin, unsigned long long *__restrict__ nUnique)
 {
   unsigned long long uniq = 0;
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-    const bool samePrev = r > 0 && sHash[r - 1] == sHash[r];
-    uniq += !samePrev;
-    if (!samePrev) continue;
-    const uint64_t a = sSW[r - 1], b = sSW[r];                   // a is positionally before b
-    if ((a >> 32) != (b >> 32)) continue;                        // different contigs never share a window
-    const int32_t seq = (int32_t)(a >> 32), wa = (int32_t)(uint32_t)a, wb = (int32_t)(uint32_t)b;
-    // positional indices: binary search on wpos inside the contig's slice
-    int32_t lo = contigFirstMin[seq], hi = contigFirstMin[seq + 1];
-    const int32_t cHi = hi;
-    while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wa) lo = mid + 1; else hi = mid; }
-    const int32_t ia = lo;
-    const int32_t gap = (ia + 1 < cHi) ? mWpos[ia + 1] - wa : 0;
-    if (wb - wa > cmw + gap) continue;
-    hi = cHi;
-    while (lo < hi) { int32_t mid = lo + ((hi - lo) >> 1); if (mWpos[mid] < wb) lo = mid + 1; else hi = mid; }
-    const int32_t ib = lo;
-    const unsigned int slot = atomicAdd(nPairs, 1u);
-    if (slot < pairCap) {
-      pairs[2 * (size_t)slot] = ((uint64_t)(uint32_t)ia << 32) | (1ull << 31) | (uint32_t)ib;         // ia: its next near occurrence is ib
-      pairs[2 * (size_t)slot + 1] = ((uint64_t)(uint32_t)ib << 32) | (uint32_t)ia;                    // ib: its previous one is ia
+  const uint32_t nQuads = (n + 3u) >> 2;
+  const bool vec = ((uintptr_t)sHash & 15u) == 0;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nQuads; t += gridDim.x * blockDim.x) {
+    const uint32_t r0 = t << 2;
+    uint32_t h[5];
+    h[0] = r0 ? sHash[r0 - 1] : 0u;
+    if (vec && r0 + 4u <= n) { const uint4 v = *(const uint4 *)(sHash + r0); h[1] = v.x; h[2] = v.y; h[3] = v.z; h[4] = v.w; }
+    else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h[1 + k] = r0 + k < n ? sHash[r0 + k] : 0u;
     }
-    atomicOr(&dupBits[ia >> 5], 1u << (ia & 31)); atomicOr(&dupBits[ib >> 5], 1u << (ib & 31));
-    if (mWin) { atomicOr(&mWin[ia], kWinDupBit); atomicOr(&mWin[ib], kWinDupBit); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t r = r0 + k;
+      if (r >= n) break;
+      const bool samePrev = r > 0 && h[k] == h[k + 1];
+      uniq += !samePrev;
+      if (samePrev) index_link_pair(r, sSW, mWpos, contigFirstMin, cmw, pairs, pairCap, nPairs, dupBits, mWin);
+    }
   }
   // one atomic per workgroup (the grid is small: a grid-stride loop covers the index)
   __shared__ unsigned long long part[8];
@@ -155,22 +179,46 @@ constexpr uint32_t kSlotEmpty = 0xffffffffu;
 constexpr int kTableBlock = kTPB * 8;
 __host__ __device__ __forceinline__ uint32_t table_slot(uint32_t h, int w, uint32_t nSlots) { return (uint32_t)(((uint64_t)bucket_key(h, w) * nSlots) >> 32); }
 
-// pass 1: per block of kTableBlock entries of the hash-sorted index: number of distinct hashes that start in it, and
-// max(slot - index inside the block) over them (INT_MIN if none)
-static __global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__restrict__ sHash, uint32_t n, int w, uint32_t nSlots,
-                                                             int32_t *__restrict__ blockCnt, int32_t *__restrict__ blockBest)
+// a thread's eight consecutive hashes of the sorted index from r0 (a multiple of 8; 0 beyond n) and which of them start a run
+// (round 5: two 16-byte loads and one 4-byte load instead of sixteen 4-byte loads at a 32-byte lane stride)
+__device__ __forceinline__ int table_load8(const uint32_t *__restrict__ sHash, uint32_t n, uint32_t r0, uint32_t (&h)[8], bool (&head)[8])
 {
-  __shared__ int ws[16];
-  const uint32_t r0 = blockIdx.x * (uint32_t)kTableBlock + threadIdx.x * 8u;
+  uint32_t prev = (r0 > 0 && r0 <= n) ? sHash[r0 - 1] : 0u;
+  if (r0 + 8u <= n && ((uintptr_t)sHash & 15u) == 0) {
+    const uint4 a = *(const uint4 *)(sHash + r0), b = *(const uint4 *)(sHash + r0 + 4);
+    h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w; h[4] = b.x; h[5] = b.y; h[6] = b.z; h[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = r0 + k < n ? sHash[r0 + k] : 0u;
+  }
   int cnt = 0;
-  uint32_t h[8]; bool head[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const uint32_t r = r0 + k;
-    h[k] = r < n ? sHash[r] : 0u;
-    head[k] = r < n && (r == 0 || sHash[r - 1] != h[k]);
+    head[k] = r < n && (r == 0 || prev != h[k]);
+    prev = h[k];
     cnt += head[k];
   }
+  return cnt;
+}
+
+// pass 1: per block of kTableBlock entries of the hash-sorted index: number of distinct hashes that start in it, and
+// max(slot - index inside the block) over them (INT_MIN if none)
+// The table size follows the number of distinct hashes, which k_index_links has just counted on the device: the kernel derives
+// nSlots from that counter (table_slots) so the host reads the counters and the block totals in ONE round trip.
+__host__ __device__ __forceinline__ uint32_t table_slots(unsigned long long nUnique)
+{
+  const unsigned long long v = nUnique * 2ull;
+  return (uint32_t)(v < 1024ull ? 1024ull : v > 0x7ffffff0ull ? 0x7ffffff0ull : v);
+}
+static __global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__restrict__ sHash, uint32_t n, int w, const unsigned long long *__restrict__ nUnique,
+                                                             int32_t *__restrict__ blockCnt, int32_t *__restrict__ blockBest)
+{
+  __shared__ int ws[16];
+  const uint32_t nSlots = table_slots(*nUnique);
+  const uint32_t r0 = blockIdx.x * (uint32_t)kTableBlock + threadIdx.x * 8u;
+  uint32_t h[8]; bool head[8];
+  const int cnt = table_load8(sHash, n, r0, h, head);
   int total; int idx = block_excl_scan(cnt, ws, &total);
   int best = INT32_MIN;
 #pragma unroll
@@ -188,15 +236,8 @@ static __global__ __launch_bounds__(kTPB) void k_table_scatter(const uint32_t *_
 {
   __shared__ int ws[kTPB + 16];
   const uint32_t r0 = blockIdx.x * (uint32_t)kTableBlock + threadIdx.x * 8u;
-  int cnt = 0;
   uint32_t h[8]; bool head[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const uint32_t r = r0 + k;
-    h[k] = r < n ? sHash[r] : 0u;
-    head[k] = r < n && (r == 0 || sHash[r - 1] != h[k]);
-    cnt += head[k];
-  }
+  const int cnt = table_load8(sHash, n, r0, h, head);
   int total; const int excl = block_excl_scan(cnt, ws, &total);
   const int g0 = carryCnt[blockIdx.x] + excl;       // global index of my first distinct hash
   int slot[8]; int best = INT32_MIN, g = g0;
@@ -278,37 +319,76 @@ static __global__ __launch_bounds__(256) void k_index_window_links(const int32_t
   for (int64_t x = w0 + threadIdx.x; x < w1; x += 256) sw[x - w0] = mWpos[x];
   block_barrier();
   auto wpos_at = [&](int32_t x) -> int32_t { return ((int64_t)x >= w0 && (int64_t)x < w1) ? sw[x - w0] : mWpos[x]; };
-  for (int q = 0; q < kWinBlock / 256; q++) {
-    const int64_t jj = j0 + q * 256 + threadIdx.x;
-    if (jj >= (int64_t)n) return;
-    const uint32_t j = (uint32_t)jj;
-    const int32_t sq = mSeq[j], wj = wpos_at((int32_t)j);
-    const int32_t cLo = contigFirstMin[sq], cHi = contigFirstMin[sq + 1];
-    // Both answers lie about `expect` entries away; a 64-entry bracket around that guess is tried first (two loads + 6 steps
-    // instead of 12 steps over the whole super-window), the full range only where the local density is unusual.
+  // Four CONSECUTIVE entries per thread (round 5; it was four entries 256 apart): both answers are non-decreasing in j inside a
+  // contig — the thresholds grow with wpos[j] and the range bounds with j — so only the thread's first entry (and the first of a
+  // contig) runs the two searches; the next ones advance the previous answers by the one or two entries the window has moved
+  // (up to kWinLinear steps, then the search on what is left).  5.1 -> ~2.5 ms per 4 x 10^8 entries.
+  constexpr int kPer = kWinBlock / 256, kWinLinear = 6;
+  const int64_t jj0 = j0 + (int64_t)threadIdx.x * kPer;
+  if (jj0 >= (int64_t)n) return;
+  int32_t sqv[kPer]; uint32_t out[kPer];
+  const bool full = jj0 + kPer <= (int64_t)n, vec = full && (((uintptr_t)mSeq | (uintptr_t)mWin) & 15u) == 0;
+  if (vec) { const uint4 v = *(const uint4 *)(mSeq + jj0); sqv[0] = (int32_t)v.x; sqv[1] = (int32_t)v.y; sqv[2] = (int32_t)v.z; sqv[3] = (int32_t)v.w; }
+  else {
+#pragma unroll
+    for (int q = 0; q < kPer; q++) sqv[q] = jj0 + q < (int64_t)n ? mSeq[jj0 + q] : -1;
+  }
+  static_assert(kPer == 4, "k_index_window_links: four entries per thread (one 16-byte load / store)");
+  int32_t prevSq = -1, prevB = 0, prevA = 0, cLo = 0, cHi = 0;
+  bool prevHasA = false;
+#pragma unroll
+  for (int q = 0; q < kPer; q++) {
+    if (jj0 + q >= (int64_t)n) break;
+    const int32_t j = (int32_t)(jj0 + q);
+    const int32_t sq = sqv[q], wj = wpos_at(j);
+    const bool cont = q > 0 && sq == prevSq;
+    if (!cont) { cLo = contigFirstMin[sq]; cHi = contigFirstMin[sq + 1]; }
     // u = first x in [max(cLo, j - cmw1), j] with wpos[x] > wj - cmw1   (wpos is strictly increasing: at most one entry per position)
-    int32_t lo = (int32_t)j - cmw1 > cLo ? (int32_t)j - cmw1 : cLo, hi = (int32_t)j;
-    {
-      const int32_t g0 = (int32_t)j - expect - 32, g1 = (int32_t)j - expect + 32;
+    int32_t lo = j - cmw1 > cLo ? j - cmw1 : cLo, hi = j;
+    bool search = true;
+    if (cont) {
+      lo = prevB > lo ? prevB : lo;
+      search = false;
+#pragma unroll 1
+      for (int st = 0; lo < hi && wpos_at(lo) <= wj - cmw1; lo++) if (++st > kWinLinear) { search = true; break; }
+    } else {
+      // Both answers lie about `expect` entries away; a 64-entry bracket around that guess is tried first (two loads + 6 steps
+      // instead of 12 steps over the whole super-window), the full range only where the local density is unusual.
+      const int32_t g0 = j - expect - 32, g1 = j - expect + 32;
       if (g0 >= lo && wpos_at(g0) <= wj - cmw1) lo = g0 + 1;
       if (g1 >= lo && g1 < hi && wpos_at(g1) > wj - cmw1) hi = g1;
     }
-    while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (wpos_at(mid) <= wj - cmw1) lo = mid + 1; else hi = mid; }
-    const uint32_t b = (uint32_t)((int32_t)j - lo);
+    if (search) while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (wpos_at(mid) <= wj - cmw1) lo = mid + 1; else hi = mid; }
+    prevB = lo;
+    const uint32_t b = (uint32_t)(j - lo);
     uint32_t a = 0, more = 0;
-    if ((int32_t)j + 1 < cHi) {
-      const int32_t tgt = wpos_at((int32_t)j + 1) + cmw1;
-      lo = (int32_t)j + 1; hi = (int32_t)j + 2 + cmw1 < cHi ? (int32_t)j + 2 + cmw1 : cHi;
-      {
-        const int32_t g0 = (int32_t)j + expect - 32, g1 = (int32_t)j + expect + 32;
+    const bool hasA = j + 1 < cHi;
+    if (hasA) {
+      const int32_t tgt = wpos_at(j + 1) + cmw1;
+      lo = j + 1; hi = j + 2 + cmw1 < cHi ? j + 2 + cmw1 : cHi;
+      search = true;
+      if (cont && prevHasA) {
+        lo = prevA > lo ? prevA : lo;           // (prevA <= the previous hi <= hi)
+        search = false;
+#pragma unroll 1
+        for (int st = 0; lo < hi && wpos_at(lo) < tgt; lo++) if (++st > kWinLinear) { search = true; break; }
+      } else {
+        const int32_t g0 = j + expect - 32, g1 = j + expect + 32;
         if (g0 >= lo && g0 < hi && wpos_at(g0) < tgt) lo = g0 + 1;
         if (g1 >= lo && g1 < hi && wpos_at(g1) >= tgt) hi = g1;
       }
-      while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (wpos_at(mid) < tgt) lo = mid + 1; else hi = mid; }
-      a = (uint32_t)(lo - (int32_t)j);
+      if (search) while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (wpos_at(mid) < tgt) lo = mid + 1; else hi = mid; }
+      prevA = lo;
+      a = (uint32_t)(lo - j);
       more = (lo < cHi && wpos_at(lo) == tgt) ? kWinMoreBit : 0u;
     }
-    mWin[j] = (a > kWinMask ? kWinMask : a) << kWinShiftA | (b > kWinMask ? kWinMask : b) | more;
+    prevHasA = hasA; prevSq = sq;
+    out[q] = (a > kWinMask ? kWinMask : a) << kWinShiftA | (b > kWinMask ? kWinMask : b) | more;
+  }
+  if (vec) { uint4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3]; *(uint4 *)(mWin + jj0) = v; }
+  else {
+#pragma unroll
+    for (int q = 0; q < kPer; q++) if (jj0 + q < (int64_t)n) mWin[jj0 + q] = out[q];
   }
 }
 
