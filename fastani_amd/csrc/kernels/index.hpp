@@ -322,7 +322,8 @@ static __global__ __launch_bounds__(256) void k_index_window_links(const int32_t
   // Four CONSECUTIVE entries per thread (round 5; it was four entries 256 apart): both answers are non-decreasing in j inside a
   // contig — the thresholds grow with wpos[j] and the range bounds with j — so only the thread's first entry (and the first of a
   // contig) runs the two searches; the next ones advance the previous answers by the one or two entries the window has moved
-  // (up to kWinLinear steps, then the search on what is left).  5.1 -> ~2.5 ms per 4 x 10^8 entries.
+  // (up to kWinLinear steps, then the search on what is left).  Measured beside the build's main stream: 5.1 ms per 4 x 10^8
+  // entries before and after (profiles/r05s, r05t_index_timeline.txt) — there the kernel is paced by what the other queue leaves it, not by its searches.
   constexpr int kPer = kWinBlock / 256, kWinLinear = 6;
   const int64_t jj0 = j0 + (int64_t)threadIdx.x * kPer;
   if (jj0 >= (int64_t)n) return;
