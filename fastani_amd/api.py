@@ -227,6 +227,20 @@ def _as_batch(g):
     return HostGenomes(g)
 
 
+class _OwnedBuffer:
+    """a buffer the library allocated (ani_free releases it), exposed through the array interface"""
+
+    def __init__(self, lib, address, n, dt):
+        self._lib, self._address = lib, address
+        self.__array_interface__ = dict(shape=(n,), typestr=dt.str, descr=dt.descr, data=(address, False), version=3)
+
+    def __del__(self):
+        try:
+            self._lib.ani_free(C.c_void_p(self._address))
+        except Exception:                       # interpreter shutdown: the process frees it
+            pass
+
+
 class Engine:
     """One ani_ctx: one device, one host thread."""
 
@@ -270,13 +284,13 @@ class Engine:
         self._chk(self.lib.ani_reset_counters(self.h))
 
     def _take(self, ptr, n, dt):
-        if n == 0:
-            out = np.zeros(0, dtype=dt)
-        else:
-            out = np.empty(n, dtype=dt)
-            C.memmove(out.ctypes.data, ptr, n * dt.itemsize)        # one copy; the library's buffer is released below
-        self.lib.ani_free(ptr)
-        return out
+        """the library's malloc'ed result buffer as a numpy array WITHOUT a copy: the array (and every view of it) keeps an owner
+        object alive that hands the buffer to ani_free when the last of them is gone.  (A copy of the 785 k result rows of the
+        1000 x 1000 job into a fresh array was 2 - 3 ms of page faults and memmove per step.)"""
+        if n == 0 or not ptr.value:
+            self.lib.ani_free(ptr)
+            return np.zeros(0, dtype=dt)
+        return np.asarray(_OwnedBuffer(self.lib, ptr.value, n, np.dtype(dt)))
 
     def query_sketch(self, params, genomes):
         g = _as_batch(genomes)

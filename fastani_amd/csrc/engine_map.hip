@@ -263,6 +263,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     struct SideJoin { ani_ctx *c; ~SideJoin() { (void)hipStreamSynchronize(c->stream2); } } sideJoin{ctx};   // also on the error paths below
     HIP_TRY(hipEventRecord(ctx->evSetDone[0], ctx->stream)); HIP_TRY(hipEventRecord(ctx->evSetDone[1], ctx->stream));   // both sets free, counters zeroed
     HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->evSetDone[1], 0));
+    // (measured, round 5: a small job — a rank's shard of a sharded all-vs-all, two chunks — cut into four so that more of the codes
+    //  are written beside a simulation: L2 stage 12.9 -> 13.4 ms, profiles/r05y_ab_l2_chunk_auto_sim8.txt; not kept)
     size_t chunk = CH;
     int nChunk = 0;
     for (size_t c0 = 0; c0 < nCand;) {

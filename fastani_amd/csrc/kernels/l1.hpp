@@ -295,7 +295,11 @@ static __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
       H64 = 0;
       for (int w = 0; w < kTPB / kWave; w++) H64 += wsum[w];
       const bool tooMany = H64 > a.hitLimit;
-      const int H = tooMany ? -1 : (int)H64;
+      int H = tooMany ? -1 : (int)H64;
+      // Fewer seed hits than a candidate region needs (minimumHits, computeMap.hpp:316-336) find nothing: such a fragment — a third
+      // of the visits of a fragment set to a foreign reference shard or index chunk, which collect two or three chance hits — counts
+      // as one without hits from here on (the LDS classes only: the batched path sizes its buffers from the probe counts).
+      if (H > 0 && s[q] <= kL1MaxS) { int m = s[q] <= a.lutMaxS ? a.minHitsLUT[s[q]] : 1; if (H < (m < 1 ? 1 : m)) H = 0; }
       a.fragHits[f] = H;
       if (H64) atomicAdd(stat_slot(a.sumHits), H64);
       if (tooMany) atomicAdd(a.overflowCount, 1u);

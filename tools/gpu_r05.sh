@@ -62,7 +62,7 @@ if has prof; then
 fi
 if has trace; then
   echo "== kernel timeline of the last index build (rocprofv3 --kernel-trace)"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d "$OUT/trace" -o bench --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/trace_bench.log" 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d "$OUT/trace" -o bench --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify $TRACE_ARGS > "$OUT/trace_bench.log" 2>&1)     # TRACE_ARGS: e.g. "--simulate-world 8"
   f=$(find "$OUT/trace" -name "*kernel_trace*.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'EOF2' | tee "$OUT/index_timeline.txt"
 import csv, sys
@@ -77,6 +77,39 @@ for r in rows[last:]:
     if "k_l1_probe" in n:
         break
 EOF2
+  # the whole last step: every interval of >= 40 us in which NO kernel of any queue runs, with the kernel before and after it,
+  # and the busy / idle totals (a step = from the last k_sketch_fused chain's first kernel to the last kernel of the trace)
+  [ -n "$f" ] && python - "$f" <<'EOF3' | tee "$OUT/step_gaps.txt"
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+name = lambda r: r["Kernel_Name"].split("(")[0][:56]
+idx = max(i for i, r in enumerate(rows) if "k_radix_histogram<unsigned int, ani::RecordSrc" in r["Kernel_Name"])
+# walk back to the start of the step: the first kernel after a gap of >= 5 ms before the index build's sketch kernels, or 60 ms back at most
+start = idx
+while start > 0 and int(rows[idx]["Start_Timestamp"]) - int(rows[start - 1]["Start_Timestamp"]) < 45e6 and "k_pair_reduce" not in rows[start - 1]["Kernel_Name"] and "k_oneway" not in rows[start - 1]["Kernel_Name"]:
+    start -= 1
+t0 = int(rows[start]["Start_Timestamp"])
+cur_end, prev, idle, gaps = int(rows[start]["End_Timestamp"]), rows[start], 0, []
+for r in rows[start + 1:]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if s > cur_end:
+        idle += s - cur_end
+        if s - cur_end >= 40000:
+            gaps.append(((cur_end - t0) / 1e6, (s - cur_end) / 1e6, name(prev), name(r)))
+    if e > cur_end:
+        cur_end, prev = e, r
+total = (cur_end - t0) / 1e6
+print("step of %.2f ms from %s: %.2f ms with no kernel running (%d gaps >= 40 us listed: at ms, length ms, after -> before)" % (total, name(rows[start]), idle / 1e6, len(gaps)))
+for g in gaps:
+    print("%9.3f  %6.3f  %s -> %s" % g)
+import os
+if os.environ.get("STEP_KERNELS"):
+    print("-- every kernel of the step (start, end, ms, queue)")
+    for r in rows[start:]:
+        a, b = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+        print("%9.3f %9.3f  %7.3f  q%s  %s" % (a, b, b - a, r.get("Queue_Id", "?"), name(r)))
+EOF3
   rm -rf "$OUT/trace"
 fi
 if has c4sim8; then
@@ -115,9 +148,9 @@ if has overlap; then
   timeout 600 python tools/overlap_probe.py --slices 2 4 8 --reps 4 2>&1 | tail -30 | tee -a "$OUT/overlap_probe.txt"
 fi
 if has ab; then
-  # A/B/A/B of an environment switch on one box: AB_VAR=<name> AB_VALUES="1 0"
+  # A/B/A/B of an environment switch on one box: AB_VAR=<name> AB_VALUES="1 0" [AB_ARGS="--simulate-world 8"]
   for v in ${AB_VALUES:-1 0} ${AB_VALUES:-1 0}; do
-    env ${AB_VAR:-ANI_L2_TRIM}=$v timeout 300 python bench.py $QUICK 2>/dev/null | line "${AB_VAR:-ANI_L2_TRIM}=$v" | tee -a "$OUT/ab_${AB_VAR:-ANI_L2_TRIM}.txt"
+    env ${AB_VAR:-ANI_L2_TRIM}=$v timeout 300 python bench.py $QUICK $AB_ARGS 2>/dev/null | line "${AB_VAR:-ANI_L2_TRIM}=$v" | tee -a "$OUT/ab_${AB_VAR:-ANI_L2_TRIM}.txt"
   done
 fi
 if has pmc; then
