@@ -82,6 +82,7 @@ def parse():
                     "real slot size of the workload, the barrier — 10 times, print per-rank seconds and GB/s as one JSON line and leave (tells a hang from a slow link in ~30 s)")
     ap.add_argument("--dump-rows", default="", help="write the rows of the last timed step to <path>[.rank<r>].npy (tests)")
     ap.add_argument("--slice-genomes", type=int, default=1000, help="c5: genomes generated and sketched per slice")
+    ap.add_argument("--query-slice", type=int, default=2000, help="c5: query genomes per kept fragment set")
     ap.add_argument("--ref-block", type=int, default=0, help="c5: reference genomes indexed and mapped together (0 = as many as keep the records in a third of the device memory)")
     ap.add_argument("--genomes", type=int, default=0, help="reference genomes (0 = the config's: 1000, c4: 10000, c5: 30000)")
     ap.add_argument("--queries", type=int, default=0, help="query genomes per GPU (0 = the config's)")
@@ -164,6 +165,33 @@ def read_ref_out(path, index_of):
         q, r, ani, cnt, tot = line.rstrip("\n").split("\t")
         rows[(index_of[q], index_of[r])] = (float(ani), int(cnt), int(tot))
     return rows
+
+
+class RowLookup:
+    """the rows of a step by (query genome, reference genome) -> (identity, countSeq, totalQueryFragments).  A query's rows are put
+    into a dict when the query is first asked for: 90 000 x 10 000 genomes leave 7 x 10^8 rows, and one dict over all of them (as
+    this was until round 5) took minutes and > 100 GB of host memory for a check that samples two dozen pairs."""
+
+    def __init__(self, rows):
+        self.rows, self._by_q, self._all = rows, {}, None
+
+    def _query(self, q):
+        d = self._by_q.get(q)
+        if d is None:
+            r = self.rows[self.rows["qryGenomeId"] == q]
+            d = {int(g): (float(a), int(c), int(t)) for g, a, c, t in zip(r["refGenomeId"], r["identity"], r["countSeq"], r["totalQueryFragments"])}
+            self._by_q[q] = d
+        return d
+
+    def get(self, key, default=None):
+        return self._query(int(key[0])).get(int(key[1]), default)
+
+    def items(self):
+        if self._all is None:
+            r = self.rows
+            self._all = {(int(q), int(g)): (float(a), int(c), int(t)) for q, g, a, c, t in
+                         zip(r["qryGenomeId"], r["refGenomeId"], r["identity"], r["countSeq"], r["totalQueryFragments"])}
+        return self._all.items()
 
 
 def compare_with_reference(rows_by_pair, ref_rows, queries, nrefs, L):
@@ -289,8 +317,7 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
     import orc   # oracle helpers (checker only): synthetic genome generator = CPU twin of ani_synth_packed, paths of oracle/_ref
     hi = host_info()
     out = {"host": hi}
-    rows_by_pair = {(int(q), int(r)): (float(a), int(c), int(t)) for q, r, a, c, t in
-                    zip(rows["qryGenomeId"], rows["refGenomeId"], rows["identity"], rows["countSeq"], rows["totalQueryFragments"])}
+    rows_by_pair = RowLookup(rows)
     parity = {}
     td = args.workdir or tempfile.mkdtemp(prefix="ani_bench_")
     os.makedirs(td, exist_ok=True)
@@ -525,6 +552,7 @@ def make_inputs(R):
             raise SystemExit("--config c5 is a single-GPU run (on N GPUs configs[4] is the reference-sharded ring of --config c4 with more genomes)")
         R.nq_local = min(a.queries or 300, NR)
         R.slice_n = min(a.slice_genomes, NR)
+        R.query_slice = max(1, a.query_slice)
         R.ref_block = a.ref_block
         if R.ref_block <= 0:
             # ~ 2 L / (w + 1) minimizers of 12 bytes per genome; a third of the device memory for the records leaves room for an
@@ -635,6 +663,17 @@ def step_single(R):
         out = []
         R.last_residency = None
         R.blocks_last_step = 0
+        qsets, qfirsts = [], []
+        if c5:
+            # the queries' fragment sketches, once per step, in sets of --query-slice genomes (a set's sketch hashes are a 32-bit
+            # count: 2000 genomes of 5 Mbp hold 8 x 10^8); every reference block maps all of them in ONE call, so a streamed block
+            # builds each of its index chunks once
+            t_q = time.perf_counter()
+            for q0 in range(0, R.nq_local, R.query_slice):
+                q1 = min(R.nq_local, q0 + R.query_slice)
+                qsets.append(e.fragment_set(p, DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, R.L, first=q0, count=q1 - q0)))
+                qfirsts.append(R.first_query_id + q0)
+            T["fragsketch_ms"] += (time.perf_counter() - t_q) * 1e3
         for b0 in range(0, R.NR, block):
             b1 = min(R.NR, b0 + block)
             parts, sets, firsts = [], [], []
@@ -652,7 +691,7 @@ def step_single(R):
             sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [b1 - b0],
                                             R.contig_len[:b1 - b0], R.gcs[:b1 - b0 + 1]), adopt=True)
             t_d = time.perf_counter()
-            rows = sk.map_cgi_batch(R.qrys, R.first_query_id) if c5 else sk.map_cgi_fragsets(sets, firsts)
+            rows = sk.map_cgi_fragsets(qsets, qfirsts) if c5 else sk.map_cgi_fragsets(sets, firsts)
             rows["refGenomeId"] += b0
             out.append(rows)
             t_e = time.perf_counter()
@@ -664,6 +703,10 @@ def step_single(R):
                 fr.close()
             sk.close()
             T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
+        for fr in qsets:
+            fr.close()
+        # (several blocks: the rows stay block-major — (query, reference) order inside a block.  Sorting the 7 x 10^8 rows of
+        #  90 000 x 10 000 on the host took longer than computing them: 55 of 104 s, profiles/r05c5_bench_c5_90000x10000.json.log)
         return out[0] if len(out) == 1 else np.concatenate(out)
     if R.self_mode:
         # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
@@ -886,7 +929,7 @@ def timed_loop(R, step, steps, warmup):
     sync(R)
     dt_local = time.perf_counter() - t0
     # outside the timed region: every step must have produced the same rows (run-to-run determinism)
-    crc = [zlib.crc32(np.ascontiguousarray(r).tobytes()) & 0xffffffff for r in rows_all]
+    crc = [zlib.crc32(np.ascontiguousarray(r).view(np.uint8)) & 0xffffffff for r in rows_all]          # (a view: no copy of the rows)
     del rows_all
     dt = dt_local
     if R.dist is not None:
@@ -1112,8 +1155,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
         # the rows of a one-rank ring / gather / simulated-rank run against the oracle, pair by pair
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
-        rows_by_pair = {(int(q), int(r)): (float(a), int(cn), int(t)) for q, r, a, cn, t in
-                        zip(rows["qryGenomeId"], rows["refGenomeId"], rows["identity"], rows["countSeq"], rows["totalQueryFragments"])}
+        rows_by_pair = RowLookup(rows)
         qids = list(range(NR)) if mode != "gather" else list(range(R.first_query_id, R.first_query_id + nq_local))
         out["parity_timed_rows"] = {"vs_oracle": oracle_spot_check(orc, args, rows_by_pair, R.hi - R.lo if mode != "gather" else NR, qids, L, p.windowSize, min(args.oracle_pairs, 120),
                                                                   ref_base=R.lo if mode != "gather" else 0)}

@@ -229,14 +229,14 @@ def test_bench_c5_reference_blocks(emu_engine, tmp_path):
     p = emu_engine.params()
     single = Sketch(emu_engine, p, DeviceGenomes(buf.ctypes.data, n, L)).map_cgi_batch(DeviceGenomes(buf.ctypes.data, nq, L), 0)
     assert len(single) >= 2 * nq
-    for block, slc in ((3, 2), (4, 4), (7, 3)):
+    for block, slc, qslc in ((3, 2, 2), (4, 4, 1), (7, 3, 2000)):        # (--query-slice: the queries as one or several kept fragment sets)
         dump = os.path.join(str(tmp_path), "rows_%d_%d" % (block, slc))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "c5", "--genomes", str(n), "--queries", str(nq),
-                            "--genome-len", str(L), "--ref-block", str(block), "--slice-genomes", str(slc), "--dump-rows", dump],
+                            "--genome-len", str(L), "--ref-block", str(block), "--slice-genomes", str(slc), "--query-slice", str(qslc), "--dump-rows", dump],
                            capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=1200)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
         assert out["config"]["ref_block"]["genomes"] == block and out["config"]["ref_block"]["blocks"] == -(-n // block)
         got = np.load(dump + ".npy")
-        got = got[np.lexsort((got["refGenomeId"], got["qryGenomeId"]))]
+        got = got[np.lexsort((got["refGenomeId"], got["qryGenomeId"]))]    # (several blocks arrive block-major)
         assert np.array_equal(got, single)

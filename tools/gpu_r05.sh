@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit of round 5.  usage: tools/gpu_r05.sh <tag> [stage ...]
-#   stages: tests bench3 quick prof c4sim8 c4one c5warm disk ubench overlap sim8 ab pmc cli90k
+#   stages: tests paritytests bench3 quick prof trace c4sim8 c4one c5warm c5big disk ubench overlap sim8 ab pmc (cli90k: lost the box twice, do not run)
 # Writes everything under gpurun_out/<tag>/ (copy what is to be judged into profiles/).
 set -u
 exec < /dev/null
@@ -138,6 +138,18 @@ if has c5warm; then
   grep -c "hipMalloc" "$OUT/c5warm.err"; grep "hipMalloc" "$OUT/c5warm.err" | awk '{mb+=$4; ms+=$6} END {print "fresh device memory:", mb/1024, "GB,", ms/1000, "s inside hipMalloc"}' | tee "$OUT/c5warm_pool.txt"
   grep -n "timed step" "$OUT/c5warm.err" | head; grep "hipMalloc" "$OUT/c5warm.err" | sort -k6 -n -r | head -12 >> "$OUT/c5warm_pool.txt"
   gzip -f "$OUT/c5warm.err"
+fi
+if has c5big; then
+  # configs[4] with a query count that makes the matrix real: 90 000 x 5 Mbp references x C5_QUERIES (default 10 000) queries on one GPU.
+  # The queries' fragment sketches stay resident (1.6 GB per 1000 genomes), the references stream block by block, chunk by chunk.
+  if [ -z "${C5_SKIP_SMALL:-}" ]; then
+  echo "== configs[4]: 90 000 references x 1000 queries (the known-safe size, new query-set path), one cold step"
+  timeout 600 python bench.py --config c5 --genomes 90000 --queries 1000 --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --oracle-pairs 20 2> "$OUT/c5_1000.err" | tee "$OUT/c5_1000.json.log" | cut -c1-1200
+  tail -2 "$OUT/c5_1000.err"; free -g | head -2
+  fi
+  echo "== configs[4]: 90 000 references x ${C5_QUERIES:-10000} queries, one cold step"
+  /usr/bin/time -v -o "$OUT/c5_big.time" timeout 900 python bench.py --config c5 --genomes 90000 --queries ${C5_QUERIES:-10000} --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --oracle-pairs 20 2> "$OUT/c5_big.err" | tee "$OUT/c5_big.json.log" | cut -c1-1500
+  tail -3 "$OUT/c5_big.err"; free -g | head -2; grep -E "Maximum resident|Elapsed" "$OUT/c5_big.time"
 fi
 if has ubench; then
   echo "== random reads / writes" | tee "$OUT/ubench_gather.txt"
