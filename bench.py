@@ -1162,6 +1162,8 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
         out["parity_timed_rows"]["ok"] = out["parity_timed_rows"]["vs_oracle"]["ok"]
     if "cpu_baseline" not in out:
         out["cpu_baseline"] = None
+    import resource
+    out["host_max_rss_gb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0, 2)       # this process, checks included
     return out
 
 
