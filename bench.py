@@ -25,7 +25,8 @@ Workloads (config.workload):
   c5 = configs[4]'s reference side: a reference set that does not stay resident (default 30 000 x 5 Mbp, --genomes 90000 for the
       full count; generated and sketched slice by slice; only the 12-byte minimizer records of one BLOCK of references stay
       (--ref-block, default: a third of the device memory), the block's index is streamed chunk by chunk, every query is mapped
-      against every block) x --queries genomes (default 300).
+      against every block) x --queries genomes (default 300; their fragment sketches are built once per step as kept sets of
+      --query-slice genomes and every block maps all of them in one call.  Measured: 90 000 x 10 000 = 9e8 pairs in 52.9 s).
   c4 = configs[3]: 10000 x 10000 (all-vs-all, 500 clusters).
       N = 1 : the reference set held as several index chunks (streamed through the device when they do not fit); --queries bounds
               the query count.
