@@ -437,21 +437,31 @@ int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuer
   TRY(pinned_buffer(ctx, 1, nPairs * 8 + 8, (void **)&dense));
   HIP_TRY(hipMemcpyAsync(dense, ctx->rows.p, nPairs * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  size_t m = 0;
-  for (size_t p = 0; p < nPairs; p++) m += dense[p] != 0;
-  ani_cgi_t *out = rows->grow(m);
-  if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", m);
+  // rows per query, then every query's rows at their place: both loops on the host pool (round 5: the serial walk over the table was
+  // 1.3 ms per sub-batch of the 1000 x 1000 job — the device idle meanwhile — and seconds of the 9 x 10^8 pairs of 90 000 x 10 000)
+  std::vector<size_t> qOff((size_t)nQuery + 1, 0);
+  parallel_for((size_t)nQuery, (uint64_t)nPairs * 8, [&](size_t qi) {
+    const uint32_t *cnt = dense + qi * (size_t)nCols;
+    size_t c = 0;
+    for (int32_t g = 0; g < nCols; g++) c += cnt[g] != 0;
+    qOff[qi + 1] = c;
+  });
+  for (int32_t qi = 0; qi < nQuery; qi++) qOff[qi + 1] += qOff[qi];
+  const size_t m = qOff[nQuery];
+  ani_cgi_t *out0 = rows->grow(m);
+  if (!out0) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", m);
   rows->n += m;
-  for (int32_t qi = 0; qi < nQuery; qi++) {                         // query ascending, reference ascending
-    const uint32_t *cnt = dense + (size_t)qi * (size_t)nCols, *idb = cnt + nPairs;
+  parallel_for((size_t)nQuery, (uint64_t)nPairs * 8, [&](size_t qi) {                       // query ascending, reference ascending
+    const uint32_t *cnt = dense + qi * (size_t)nCols, *idb = cnt + nPairs;
+    ani_cgi_t *out = out0 + qOff[qi];
     for (int32_t g = 0; g < nCols; g++) {
       if (!cnt[g]) continue;
-      ani_cgi_t r; r.refGenomeId = col0 + g; r.qryGenomeId = firstQueryId + (queryIds ? queryIds[qi] : qi); r.countSeq = (int32_t)cnt[g];
+      ani_cgi_t r; r.refGenomeId = col0 + g; r.qryGenomeId = firstQueryId + (queryIds ? queryIds[qi] : (int32_t)qi); r.countSeq = (int32_t)cnt[g];
       r.totalQueryFragments = fs.genomeFragments[qi];
       memcpy(&r.identity, &idb[g], 4);
       *out++ = r;
     }
-  }
+  });
   ctx->counters.cgiRows += m;
   return ANI_OK;
 }

@@ -231,7 +231,9 @@ void parallel_for(size_t n, uint64_t work, F f)
   unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 32) nt = 32;     // (beside 32 reader threads: 16-32 packers measured best, 64 starve the readers; profiles/r04ak_e2e_probe.txt)
   if (const char *ev = getenv("ANI_HOST_THREADS")) { int v = atoi(ev); if (v >= 1) nt = (unsigned)v; }
   if (nt > n) nt = (unsigned)n;
-  if (nt <= 1 || work < (1u << 22)) { for (size_t i = 0; i < n; i++) f(i); return; }
+  uint64_t minWork = 1u << 22;
+  if (const char *ev = getenv("ANI_HOST_PAR_MIN_WORK")) { const long long v = atoll(ev); if (v >= 0) minWork = (uint64_t)v; }     // test knob: small inputs through the pool
+  if (nt <= 1 || work < minWork) { for (size_t i = 0; i < n; i++) f(i); return; }
   host_pool().run(n, nt, std::function<void(size_t)>(f));
 }
 

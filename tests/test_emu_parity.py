@@ -217,6 +217,22 @@ def test_pipelined_sub_batches(monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_result_rows_collected_on_host_threads(monkeypatch):
+    """the dense result table of a sub-batch is turned into rows by the host pool (engine_map.hip: collect_rows: rows per query,
+    then every query's rows at their place); ANI_HOST_PAR_MIN_WORK=0 sends small tables through the pool too — same rows, same order,
+    also with more threads than queries and with several kept sets per call"""
+    def alloc(nbytes):
+        a = np.zeros(nbytes // 4 + 4, dtype=np.uint32)
+        return a, a.ctypes.data
+    for threads in (3, 64):
+        e = _emu_engine_with(monkeypatch, ANI_HOST_PAR_MIN_WORK=0, ANI_HOST_THREADS=threads)
+        pc.case_self(e, combos=((16, 3000),))
+        pc.case_fragset_wire(e, alloc)
+        pc.case_species_dense(e)
+        e.close()
+    monkeypatch.delenv("ANI_HOST_PAR_MIN_WORK"); monkeypatch.delenv("ANI_HOST_THREADS")
+
+
 def test_same_hash_links_rerun(monkeypatch):
     """the list of same-hash links (index.hpp: DupLinks) is sized from a guess; a repetitive reference (tandem repeats, one k-mer on
     thousands of contigs) holds more near-duplicate pairs than that and the links kernel runs again with room for all"""

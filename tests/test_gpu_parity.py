@@ -410,6 +410,24 @@ def test_l2_range_trimming(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_result_rows_collected_on_host_threads(monkeypatch):
+    """the dense result table of a sub-batch is turned into rows by the host pool (engine_map.hip: collect_rows: rows per query,
+    then every query's rows at their place); ANI_HOST_PAR_MIN_WORK=0 sends small tables through the pool too — same rows, same order,
+    also with more threads than queries and with several kept sets per call"""
+    import torch
+    def alloc(nbytes):
+        t = torch.zeros(nbytes // 4 + 4, dtype=torch.int32, device="cuda:0")
+        return t, t.data_ptr()
+    for threads in (3, 64):
+        e = _engine_with(monkeypatch, ANI_HOST_PAR_MIN_WORK=0, ANI_HOST_THREADS=threads)
+        pc.case_self(e, combos=((16, 3000),))
+        pc.case_fragset_wire(e, alloc)
+        pc.case_species_dense(e)
+        e.close()
+    monkeypatch.delenv("ANI_HOST_PAR_MIN_WORK"); monkeypatch.delenv("ANI_HOST_THREADS")
+
+
+@pytest.mark.gpu
 def test_pipelined_sub_batches(monkeypatch):
     """ANI_MAP_PIPELINE=1 (off by default: +1.4 % on the benchmark step).  map_fragsets on a resident set: the sub-batches of a call go to two host threads with a context each on the same device (the L1
     kernels of one beside the L2 kernels of the other); ANI_MAP_PIPELINE_MIN_FRAGS lowers the threshold so that small inputs take the
