@@ -1087,7 +1087,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
     # + WRITE_SIZE, per launch) — only quoted when it is this default workload
     try:
         if cfg == "many-to-many" and NR == 1000 and L == 5_000_000 and world == 1 and mode == "single":
-            for tag in ("r04", "r03", "r02", "r01p"):
+            for tag in ("r05", "r04", "r03", "r02", "r01p"):
                 fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
                 if not os.path.exists(fn):
                     continue
