@@ -92,6 +92,7 @@ def _bind(lib):
         "ani_sketch_writer_add": (C.c_int, [vp, vp, vp]),
         "ani_sketch_writer_close": (C.c_int, [vp]),
         "ani_device_memory": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "ani_pool_prewarm_index": (C.c_int, [vp, C.c_uint64]),
         "ani_sketch_file_info": (C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
         "ani_sketch_genome_name": (C.c_char_p, [vp, C.c_int32]),
         "ani_sketch_tables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -329,6 +330,10 @@ class Engine:
 
     def device_free(self, ptr):
         self.lib.ani_device_free(self.h, ptr)
+
+    def pool_prewarm_index(self, n_minimizers):
+        """a hint (ani_abi.h): the index arrays for about n_minimizers minimizers allocated and touched now, left in the cache"""
+        self._chk(self.lib.ani_pool_prewarm_index(self.h, int(n_minimizers)))
 
     def device_copy(self, dst, src, nbytes):
         self._chk(self.lib.ani_device_copy(self.h, dst, src, nbytes))

@@ -437,6 +437,35 @@ int exact_unique(ani_sketch *sk)
 
 extern "C" {
 
+// The arrays build_chunk_index asks the pool for, for a chunk of about n minimizers (the probe table is left out: its size follows
+// the number of DISTINCT hashes, which no one knows yet): six of 4 n bytes (mHash, mSeq, mWpos, sHash, mWin, the sort's key buffer),
+// two of 8 n (sSW, the sort's value buffer).
+int ani_pool_prewarm_index(ani_ctx *ctx, uint64_t nMinimizers)
+{
+  if (!ctx) return fail(ANI_ERR_ARG, "bad argument to ani_pool_prewarm_index");
+  if (nMinimizers == 0) return ANI_OK;
+  if (nMinimizers > ctx->maxIndexMinimizers) nMinimizers = ctx->maxIndexMinimizers;        // a larger set is built chunk by chunk
+  HIP_TRY(hipSetDevice(ctx->device));
+  size_t freeB = 0, totalB = 0;
+  HIP_TRY(hipMemGetInfo(&freeB, &totalB));
+  const size_t n4 = (size_t)nMinimizers * 4;
+  if (10 * n4 > freeB / 2) return ANI_OK;                  // not on a device that is short of memory
+  DevicePool &pool = cur_pool(0);
+  std::vector<size_t> sizes;
+  for (int i = 0; i < 8; i++) sizes.push_back(i < 6 ? n4 : 2 * n4);
+  std::sort(sizes.rbegin(), sizes.rend());                 // the large ones first: the sort asks for them first
+  for (size_t b : sizes) pool.promise(b);                  // a request that one of them will fit waits for it from now on
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreate(&s);
+  size_t made = 0;
+  for (; made < sizes.size() && e == hipSuccess; made++) e = pool.prewarm(sizes[made], s);
+  if (made < sizes.size()) pool.drop_promises(std::vector<size_t>(sizes.begin() + made, sizes.end()));
+  if (s) (void)hipStreamDestroy(s);
+  if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return ANI_OK; }      // a hint: nothing to report
+  HIP_TRY(e);
+  return ANI_OK;
+}
+
 int ani_sketch_from_records(ani_ctx *ctx, const ani_params_t *p, const void *devRecords, size_t n, const int32_t *contigLen, int32_t nContigs,
                             const int32_t *genomeContigStart, int32_t nGenomes, ani_sketch **out)
 {

@@ -30,6 +30,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -67,20 +68,16 @@ struct DevicePool {
   size_t cachedBytes = 0;
   hipError_t alloc(void **out, size_t bytes)
   {
-    if (bytes == 0) bytes = 1;
-    // Size classes for large blocks (round 5): a request of >= 64 MiB is rounded up to a multiple of 2^(floor(log2 bytes) - 5), i.e.
+    // Size classes for large blocks (round 5; class_size below): a request of >= 64 MiB is rounded up to a multiple of 2^(floor(log2 bytes) - 5), i.e.
     // 1/32 .. 1/64 of its size (<= 3 % slack).  The index chunks of a streamed reference set are cut at genome borders and differ by
     // a few 10^-4 of their size: without classes a chunk that is a little LARGER than the one just dropped finds no cached block
     // (lower_bound), takes ~36 GB of fresh memory, and the dropped chunk's blocks stay cached until the device is full — the 39 chunk
     // builds of the 90 000-genome run spent as long in first-touch memory and hipFree as in kernels (profiles/r04c5b).
-    static const bool classes = !(getenv("ANI_POOL_CLASSES") && !strcmp(getenv("ANI_POOL_CLASSES"), "0"));
-    if (classes && bytes >= ((size_t)64 << 20)) {
-      int lg = 63; while (!((bytes >> lg) & 1)) lg--;
-      const size_t gran = (size_t)1 << (lg - 5);
-      bytes = (bytes + gran - 1) / gran * gran;
-    }
-    std::lock_guard<std::mutex> g(mu);
+    bytes = class_size(bytes);
+    std::unique_lock<std::mutex> g(mu);
     auto it = cache.lower_bound(bytes);
+    // a block of this size is being made on another thread (prewarm): its tail is shorter than a second fresh allocation beside it
+    while ((it == cache.end() || it->first > bytes + bytes / 16 + (1u << 20)) && promised_fit_locked(bytes)) { cvPromised.wait_for(g, std::chrono::milliseconds(20)); it = cache.lower_bound(bytes); }
     // reuse only a closely fitting block: a looser fit lets a long-lived buffer capture the block a per-sketch array of a
     // different size will ask for again, and that array then needs fresh memory in the middle of a later step
     // ANI_POOL_POISON=<byte> (tests): every block handed out is filled with that byte first, so that a kernel which reads memory
@@ -133,6 +130,44 @@ struct DevicePool {
     auto it = live.find(p);
     if (it == live.end()) { (void)hipFree(p); return; }
     cache.emplace(it->second, p); cachedBytes += it->second; live.erase(it);
+  }
+  // the size a request of `bytes` is served with (alloc's size classes)
+  static size_t class_size(size_t bytes)
+  {
+    if (bytes == 0) bytes = 1;
+    static const bool classes = !(getenv("ANI_POOL_CLASSES") && !strcmp(getenv("ANI_POOL_CLASSES"), "0"));
+    if (classes && bytes >= ((size_t)64 << 20)) {
+      int lg = 63; while (!((bytes >> lg) & 1)) lg--;
+      const size_t gran = (size_t)1 << (lg - 5);
+      bytes = (bytes + gran - 1) / gran * gran;
+    }
+    return bytes;
+  }
+  // Prewarming (ani_pool_prewarm_index): fresh blocks of announced sizes, touched (hipMemset on `s`) and put straight into the cache
+  // for later requests of about those sizes.  The pool is NOT locked while the driver works — other threads keep allocating — and a
+  // request that an announced block will fit waits for it instead of taking fresh memory beside it.
+  std::multiset<size_t> promised; std::condition_variable cvPromised;
+  bool promised_fit_locked(size_t bytes) const { auto it = promised.lower_bound(bytes); return it != promised.end() && *it <= bytes + bytes / 16 + (1u << 20); }
+  void promise(size_t bytes) { std::lock_guard<std::mutex> g(mu); promised.insert(class_size(bytes)); }
+  hipError_t prewarm(size_t bytes, hipStream_t s)           // one promised block
+  {
+    bytes = class_size(bytes);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) { e = hipMemsetAsync(p, 0, bytes, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) { (void)hipFree(p); p = nullptr; } }
+    else (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = promised.find(bytes); if (it != promised.end()) promised.erase(it);
+      if (p) { cache.emplace(bytes, p); cachedBytes += bytes; }
+    }
+    cvPromised.notify_all();
+    return e;
+  }
+  void drop_promises(const std::vector<size_t> &sizes)      // (error path: nothing more will come)
+  {
+    { std::lock_guard<std::mutex> g(mu); for (size_t b : sizes) { auto it = promised.find(class_size(b)); if (it != promised.end()) promised.erase(it); } }
+    cvPromised.notify_all();
   }
   void trim_locked() { for (auto &kv : cache) (void)hipFree(kv.second); cache.clear(); cachedBytes = 0; }
   void trim() { std::lock_guard<std::mutex> g(mu); trim_locked(); }

@@ -463,6 +463,27 @@ int main(int argc, char **argv)
   const int nDev = (int)dev.size();
   if (fpPtr) fpPtr->set_active(1 << 30);
   trace("devices initialised");
+  // Fresh device memory is slow on some hosts (20 - 40 us per MB: the index build of a cold 1000-genome run took 0.6 s instead of
+  // 0.03): the index arrays are allocated and touched NOW, on a side thread, while the readers parse the first files.  The size is
+  // an estimate — plain FASTA holds one base per byte but for line ends and headers, winnowing keeps 2 / (w + 1) of the positions —
+  // and only a hint (ani_abi.h): compressed inputs, several devices, reference sketch files and inputs below 64 MiB go without.
+  // ANI_CLI_PREWARM=0: off; =force: small inputs too.
+  std::thread prewarm;
+  struct PrewarmJoin { std::thread &t; ~PrewarmJoin() { if (t.joinable()) t.join(); } } prewarmJoin{prewarm};
+  if (fpPtr && nDev == 1 && !fromFile && !(getenv("ANI_CLI_PREWARM") && !strcmp(getenv("ANI_CLI_PREWARM"), "0"))) {
+    uint64_t refBytes = 0; bool plain = true;
+    for (size_t i = 0; i < (size_t)nRef && plain; i++) {
+      const std::string &f = o.refs[i];
+      if (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0) { plain = false; break; }
+      struct stat st; if (stat(f.c_str(), &st) == 0) refBytes += (uint64_t)st.st_size;
+    }
+    const bool force = getenv("ANI_CLI_PREWARM") && !strcmp(getenv("ANI_CLI_PREWARM"), "force");       // (tests: small inputs too)
+    if (plain && (refBytes >= (64ull << 20) || force)) {
+      const uint64_t nEst = (uint64_t)((double)refBytes * 2.0 / (ap.windowSize + 1));
+      ani_ctx *pc = dev[0].ctx;
+      prewarm = std::thread([pc, nEst]() { (void)ani_pool_prewarm_index(pc, nEst); });
+    }
+  }
   std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
   std::cerr << "INFO [thread 0], skch::main, Count of threads executing parallel_for : " << (o.sanityCheck ? o.threads : nDev) << std::endl;
 

@@ -123,9 +123,11 @@ def _run_streaming_variants(binary, tmp, full=True):
             # the query slices in waves (fragment sketches of one wave made, mapped against every shard, freed): one slice per wave
             # over two contexts, two slices per wave against a streamed set
             ({"ANI_SLICE_BYTES": "40000", "ANI_CLI_QUERY_WAVE_BYTES": "1"}, ["--devices", "0,0"]),
-            ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000", "ANI_MAX_RESIDENT_CHUNKS": "1", "ANI_CLI_QUERY_WAVE_BYTES": "80000"}, [])]
-    if not full:                    # CPU build: the two streamed variants (one of them chunked over two contexts)
-        envs = [envs[5], envs[6]]
+            ({"ANI_SLICE_BYTES": "40000", "ANI_MAX_INDEX_MINIMIZERS": "7000", "ANI_MAX_RESIDENT_CHUNKS": "1", "ANI_CLI_QUERY_WAVE_BYTES": "80000"}, []),
+            # the index arrays allocated ahead of the build on a side thread (ani_pool_prewarm_index; forced: these inputs are small)
+            ({"ANI_CLI_PREWARM": "force", "ANI_SLICE_BYTES": "40000"}, [])]
+    if not full:                    # CPU build: the two streamed variants (one of them chunked over two contexts) and the prewarmed one
+        envs = [envs[5], envs[6], envs[-1]]
     for env, extra in envs:
         for name, (args, rout) in ref.items():
             out = os.path.join(tmp, "new_%s.out" % name)

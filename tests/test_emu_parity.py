@@ -233,6 +233,21 @@ def test_result_rows_collected_on_host_threads(monkeypatch):
     monkeypatch.delenv("ANI_HOST_PAR_MIN_WORK"); monkeypatch.delenv("ANI_HOST_THREADS")
 
 
+def test_pool_prewarm_is_only_a_hint(emu_engine):
+    """ani_pool_prewarm_index: the index arrays for an estimated minimizer count allocated ahead of the build, on another thread as
+    the command line does it — while this thread sketches and builds, whose requests wait for the promised blocks; estimates that
+    are right, far too small, far too large (refused: more than half the free memory) or zero change nothing but where the memory
+    comes from"""
+    import threading
+    for est in (0, 30, 2400, 40000, 1 << 40):
+        t = threading.Thread(target=emu_engine.pool_prewarm_index, args=(est,))
+        t.start()
+        pc.case_self(emu_engine, combos=((16, 3000),))
+        t.join()
+    emu_engine.pool_prewarm_index(2400)
+    pc.case_synthetic_cluster(emu_engine, 30000)
+
+
 def test_same_hash_links_rerun(monkeypatch):
     """the list of same-hash links (index.hpp: DupLinks) is sized from a guess; a repetitive reference (tandem repeats, one k-mer on
     thousands of contigs) holds more near-duplicate pairs than that and the links kernel runs again with room for all"""
