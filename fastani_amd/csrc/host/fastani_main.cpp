@@ -467,10 +467,12 @@ int main(int argc, char **argv)
   // 0.03): the index arrays are allocated and touched NOW, on a side thread, while the readers parse the first files.  The size is
   // an estimate — plain FASTA holds one base per byte but for line ends and headers, winnowing keeps 2 / (w + 1) of the positions —
   // and only a hint (ani_abi.h): compressed inputs, several devices, reference sketch files and inputs below 64 MiB go without.
-  // ANI_CLI_PREWARM=0: off; =force: small inputs too.
+  // OPT-IN (ANI_CLI_PREWARM=1; =force: small inputs too): on the two boxes it could be measured on, fresh memory was cheap (index
+  // built 41 ms after the last slice either way) and 12 runs each way averaged 0.995 and 0.993 s (profiles/r05ad_e2e_prewarm_*.txt);
+  // the slow-allocation hosts it was written for did not come up again.
   std::thread prewarm;
   struct PrewarmJoin { std::thread &t; ~PrewarmJoin() { if (t.joinable()) t.join(); } } prewarmJoin{prewarm};
-  if (fpPtr && nDev == 1 && !fromFile && !(getenv("ANI_CLI_PREWARM") && !strcmp(getenv("ANI_CLI_PREWARM"), "0"))) {
+  if (fpPtr && nDev == 1 && !fromFile && getenv("ANI_CLI_PREWARM") && strcmp(getenv("ANI_CLI_PREWARM"), "0")) {
     uint64_t refBytes = 0; bool plain = true;
     for (size_t i = 0; i < (size_t)nRef && plain; i++) {
       const std::string &f = o.refs[i];

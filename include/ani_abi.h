@@ -148,7 +148,7 @@ int ani_device_memory(ani_ctx *ctx, size_t *freeBytes, size_t *totalBytes);
 /* A hint, never needed for correctness: allocate and touch NOW the device arrays an index over about `nMinimizers` minimizers will
  * ask for (ani_sketch_from_records / ani_sketch_build), and leave them in the allocator's cache.  Fresh device memory costs
  * 20 - 40 us per MB on some hosts — 0.6 s of a cold 1000-genome run sat in the index build for that reason; the command line
- * calls this on a side thread while its readers parse the first files (estimate: input bytes x 2 / (w + 1)).  An estimate that
+ * can call this on a side thread while its readers parse the first files (ANI_CLI_PREWARM=1; estimate: input bytes x 2 / (w + 1)).  An estimate that
  * is off by more than a few percent only wastes the memory until the cache is trimmed.  No counterpart in the reference. */
 int ani_pool_prewarm_index(ani_ctx *ctx, uint64_t nMinimizers);
 int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void *src, size_t bytes);
