@@ -102,7 +102,9 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
 {
   const size_t n = sk->n;
   const int32_t c0 = sk->c0, nContigs = sk->nContigs;
-  auto bail = [&](int rc) { free_chunk_index(sk); return rc; };
+  // (error paths: kernels of either stream may still be writing the chunk's arrays — a `return bail(...)` frees them before the
+  //  guards below go out of scope — so both streams are drained first)
+  auto bail = [&](int rc) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream); free_chunk_index(sk); return rc; };
 #define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
 #define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const size_t n4 = (n ? n : 1) * 4;
