@@ -62,7 +62,7 @@ if has prof; then
 fi
 if has trace; then
   echo "== kernel timeline of the last index build (rocprofv3 --kernel-trace)"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d "$OUT/trace" -o bench --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify $TRACE_ARGS > "$OUT/trace_bench.log" 2>&1)     # TRACE_ARGS: e.g. "--simulate-world 8"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d "$OUT/trace" -o bench --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify ${TRACE_ARGS:-} > "$OUT/trace_bench.log" 2>&1)     # TRACE_ARGS: e.g. "--simulate-world 8"
   f=$(find "$OUT/trace" -name "*kernel_trace*.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'EOF2' | tee "$OUT/index_timeline.txt"
 import csv, sys
@@ -162,7 +162,7 @@ fi
 if has ab; then
   # A/B/A/B of an environment switch on one box: AB_VAR=<name> AB_VALUES="1 0" [AB_ARGS="--simulate-world 8"]
   for v in ${AB_VALUES:-1 0} ${AB_VALUES:-1 0}; do
-    env ${AB_VAR:-ANI_L2_TRIM}=$v timeout 300 python bench.py $QUICK $AB_ARGS 2>/dev/null | line "${AB_VAR:-ANI_L2_TRIM}=$v" | tee -a "$OUT/ab_${AB_VAR:-ANI_L2_TRIM}.txt"
+    env ${AB_VAR:-ANI_L2_TRIM}=$v timeout 300 python bench.py $QUICK ${AB_ARGS:-} 2>/dev/null | line "${AB_VAR:-ANI_L2_TRIM}=$v" | tee -a "$OUT/ab_${AB_VAR:-ANI_L2_TRIM}.txt"
   done
 fi
 if has pmc; then
