@@ -304,6 +304,12 @@ static __global__ void k_index_contig_first(const int32_t *__restrict__ mSeq, ui
 // Both offsets count entries inside one super-window (<= cmw + 1 < 2^14, checked by the host).  One thread per entry, two binary
 // searches over at most cmw entries; the lanes of a wave search neighbouring ranges with the same step pattern, so the loads
 // coalesce.
+// a global load the optimiser cannot merge with an LDS load of the other branch into one flat load of a selected pointer
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ANI_LOAD_APART(p) __builtin_nontemporal_load(p)
+#else
+#define ANI_LOAD_APART(p) (*(p))
+#endif
 constexpr int kWinHalo = 768;             // positions staged in LDS on either side of a workgroup's entries (~3 typical spans)
 constexpr int kWinBlock = 1024;           // entries per workgroup (four per thread: the halo is read once per 1024 entries, 2.5 x the data instead of 7 x)
 static __global__ __launch_bounds__(256) void k_index_window_links(const int32_t *__restrict__ mSeq, const int32_t *__restrict__ mWpos,
@@ -313,33 +319,39 @@ static __global__ __launch_bounds__(256) void k_index_window_links(const int32_t
   // The searches of neighbouring entries touch the same few hundred positions on either side: staged once (coalesced), searched
   // in LDS — the kernel was nothing but chains of dependent global loads.  A search that leaves the staged range (unusually sparse
   // stretches) reads global memory as before.
+  // (32-bit index arithmetic: a chunk holds < 2^31 entries.  The staged read is an LDS read of a clamped offset, the rare miss a
+  //  separate global load behind a branch: written as one conditional expression the compiler selected between the two POINTERS and
+  //  issued flat loads — 64-bit compares and address selects, ~500 instructions executed per entry (SQ counters in
+  //  profiles/r05af_pmc_SQ_WAVES_summary.txt); 5.09 -> 4.86 ms beside the build's main stream, profiles/r05ag_index_timeline.txt.)
   __shared__ int32_t sw[kWinBlock + 2 * kWinHalo];
-  const int64_t j0 = (int64_t)blockIdx.x * kWinBlock;
-  const int64_t w0 = j0 - kWinHalo > 0 ? j0 - kWinHalo : 0, w1 = j0 + kWinBlock + kWinHalo < (int64_t)n ? j0 + kWinBlock + kWinHalo : (int64_t)n;
-  for (int64_t x = w0 + threadIdx.x; x < w1; x += 256) sw[x - w0] = mWpos[x];
+  const int32_t j0 = (int32_t)(blockIdx.x * (uint32_t)kWinBlock);
+  const int32_t w0 = j0 > kWinHalo ? j0 - kWinHalo : 0;
+  const uint32_t span = (uint32_t)(((uint32_t)j0 + (uint32_t)(kWinBlock + kWinHalo) < n ? (uint32_t)j0 + (uint32_t)(kWinBlock + kWinHalo) : n) - (uint32_t)w0);
+  for (uint32_t x = threadIdx.x; x < span; x += 256) sw[x] = mWpos[(uint32_t)w0 + x];
   block_barrier();
-  auto wpos_at = [&](int32_t x) -> int32_t { return ((int64_t)x >= w0 && (int64_t)x < w1) ? sw[x - w0] : mWpos[x]; };
+  // (a macro, not a lambda: captured by reference the __shared__ array becomes a generic pointer and every read a flat load)
+#define wpos_at(x_) ([&](int32_t xx_, int32_t staged_) -> int32_t { return (uint32_t)(xx_ - w0) < span ? staged_ : ANI_LOAD_APART(mWpos + xx_); }((x_), sw[(uint32_t)((x_) - w0) < span ? (uint32_t)((x_) - w0) : 0u]))
   // Four CONSECUTIVE entries per thread (round 5; it was four entries 256 apart): both answers are non-decreasing in j inside a
   // contig — the thresholds grow with wpos[j] and the range bounds with j — so only the thread's first entry (and the first of a
   // contig) runs the two searches; the next ones advance the previous answers by the one or two entries the window has moved
   // (up to kWinLinear steps, then the search on what is left).  Measured beside the build's main stream: 5.1 ms per 4 x 10^8
   // entries before and after (profiles/r05s, r05t_index_timeline.txt) — there the kernel is paced by what the other queue leaves it, not by its searches.
   constexpr int kPer = kWinBlock / 256, kWinLinear = 6;
-  const int64_t jj0 = j0 + (int64_t)threadIdx.x * kPer;
-  if (jj0 >= (int64_t)n) return;
+  const uint32_t jj0 = (uint32_t)j0 + threadIdx.x * (uint32_t)kPer;
+  if (jj0 >= n) return;
   int32_t sqv[kPer]; uint32_t out[kPer];
-  const bool full = jj0 + kPer <= (int64_t)n, vec = full && (((uintptr_t)mSeq | (uintptr_t)mWin) & 15u) == 0;
+  const bool full = jj0 + kPer <= n, vec = full && (((uintptr_t)mSeq | (uintptr_t)mWin) & 15u) == 0;
   if (vec) { const uint4 v = *(const uint4 *)(mSeq + jj0); sqv[0] = (int32_t)v.x; sqv[1] = (int32_t)v.y; sqv[2] = (int32_t)v.z; sqv[3] = (int32_t)v.w; }
   else {
 #pragma unroll
-    for (int q = 0; q < kPer; q++) sqv[q] = jj0 + q < (int64_t)n ? mSeq[jj0 + q] : -1;
+    for (int q = 0; q < kPer; q++) sqv[q] = jj0 + q < n ? mSeq[jj0 + q] : -1;
   }
   static_assert(kPer == 4, "k_index_window_links: four entries per thread (one 16-byte load / store)");
   int32_t prevSq = -1, prevB = 0, prevA = 0, cLo = 0, cHi = 0;
   bool prevHasA = false;
 #pragma unroll
   for (int q = 0; q < kPer; q++) {
-    if (jj0 + q >= (int64_t)n) break;
+    if (jj0 + q >= n) break;
     const int32_t j = (int32_t)(jj0 + q);
     const int32_t sq = sqv[q], wj = wpos_at(j);
     const bool cont = q > 0 && sq == prevSq;
@@ -389,9 +401,11 @@ static __global__ __launch_bounds__(256) void k_index_window_links(const int32_t
   if (vec) { uint4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3]; *(uint4 *)(mWin + jj0) = v; }
   else {
 #pragma unroll
-    for (int q = 0; q < kPer; q++) if (jj0 + q < (int64_t)n) mWin[jj0 + q] = out[q];
+    for (int q = 0; q < kPer; q++) if (jj0 + q < n) mWin[jj0 + q] = out[q];
   }
 }
+
+#undef wpos_at
 
 // 12-byte records in position order with GLOBAL seqIds: out[c] = first record with seqId >= seqIdBase + c, c = 0..nContigs.
 // Used to cut a record stream into index chunks at genome borders.
