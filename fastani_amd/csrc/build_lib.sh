@@ -1,5 +1,6 @@
 #!/bin/bash
 # Builds libfastani_amd.so for gfx950 from its units (host/engine.hpp lists them), one hipcc per unit, in parallel.
+# (engine_l2 is compiled with its own scheduling strategy, see unit_flags below.)
 #
 # ANI_ASM_PEEPHOLE=1 routes the device code of engine_map.hip (the L2 simulation lives there) through a one-line assembly peephole
 # between hipcc's code generation and the assembler:
@@ -14,13 +15,15 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 LLVM=${LLVM_BIN:-/opt/rocm/lib/llvm/bin}
 OUT=${1:-$HERE/libfastani_amd.so}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC ${ANI_EXTRA_FLAGS:-}"
-UNITS="engine_core engine_ingest engine_sketch engine_index engine_map sort_device"
+UNITS="engine_core engine_ingest engine_sketch engine_index engine_map engine_l2 sort_device"
+# per-unit flags: the L2 codes / simulation kernels with the max-ILP scheduler (engine_l2.hip says why); ANI_L2_UNIT_FLAGS="" builds them like the rest
+unit_flags() { if [ "$1" = "engine_l2" ]; then echo "${ANI_L2_UNIT_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp}"; fi; }
 T=$(mktemp -d)
 trap 'rm -rf "$T"' EXIT
 pids=()
 for u in $UNITS; do
   if [ "${ANI_ASM_PEEPHOLE:-0}" = "1" ] && [ "$u" = "engine_map" ]; then continue; fi
-  ( $HIPCC $FLAGS -c -o "$T/$u.o" "$HERE/$u.hip" 2> "$T/$u.err" || { cat "$T/$u.err" >&2; exit 1; } ) &
+  ( $HIPCC $FLAGS $(unit_flags $u) -c -o "$T/$u.o" "$HERE/$u.hip" 2> "$T/$u.err" || { cat "$T/$u.err" >&2; exit 1; } ) &
   pids+=($!)
 done
 if [ "${ANI_ASM_PEEPHOLE:-0}" = "1" ]; then

@@ -10,6 +10,11 @@
 
 namespace anih {
 using namespace ani;
+
+// engine_l2.hip (a unit with its own compiler flags): the codes and simulation kernels of the L2 stage
+void launch_l2_codes(unsigned grid, hipStream_t s, const L2FastArgs &fa);
+void launch_l2_sim_a(unsigned grid, hipStream_t s, const L2FastArgs &fa, const int32_t *list, const unsigned int *listCount);
+void launch_l2_sim_b(unsigned grid, hipStream_t s, const L2FastArgs &fa, const int32_t *list, const unsigned int *listCount);
 static_assert(kL1FilterMinHits == 300 && kL1HitCapMax == 4096, "defaults of ani_ctx::l1FilterMin / l1LdsMax (host/engine.hpp)");
 
 // L1 + L2 + identity for the fragments of `fs` against ONE index chunk; candidates and their results stay in the context's
@@ -317,7 +322,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Codes, 1);
-          hipLaunchKernelGGL(k_l2_codes, dim3((unsigned)((fa.nFragChunk + 7) / 8 * 8)), dim3(kTPB), 0, ctx->stream, fa);
+          launch_l2_codes((unsigned)((fa.nFragChunk + 7) / 8 * 8), ctx->stream, fa);
         }
         // The simulation (VALU-bound) runs on the side stream so that the next chunk's ranges / codes kernels (memory- and latency-
         // bound) start beside it; ANI_L2_OVERLAP=0 keeps everything on the main stream.  Measured (1000 x 1000; round 3:
@@ -335,8 +340,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1, simStream);
-          hipLaunchKernelGGL((k_l2_sim<L2GeomA>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
-                               (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
+          launch_l2_sim_a(grid_for(n, kL2SimTPB), simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(), (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
         }
         ctx->counters.l2Launches++;
       }
@@ -350,8 +354,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
                            ctx->l2ClassList[p].as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
         L2FastArgs fb = fa;       // class B accumulates its algorithmic-byte counters separately
         fb.g.sumEntries = cnt_ptr(ctx, CNT_ENTRIES_B); fb.g.sumQ = cnt_ptr(ctx, CNT_SUMQ_B); fb.g.sumSteps = cnt_ptr(ctx, CNT_STEPS_B);
-        hipLaunchKernelGGL((k_l2_sim<L2GeomB>), dim3(grid_for(n, kL2SimTPB)), dim3(kL2SimTPB), 0, ctx->stream2, fb, (const int32_t *)ctx->l2ClassList[p].as<int32_t>(),
-                           (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
+        launch_l2_sim_b(grid_for(n, kL2SimTPB), ctx->stream2, fb, (const int32_t *)ctx->l2ClassList[p].as<int32_t>(), (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
       }
       // whatever did not qualify (or overflowed a gap counter) is appended to the sub-batch's list for the general kernel
       hipLaunchKernelGGL(k_l2_collect_slow, dim3(grid_for(n)), dim3(256), 0, ctx->stream2, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag,

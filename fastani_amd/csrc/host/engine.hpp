@@ -5,6 +5,7 @@
 //   engine_sketch.hip  minimizer records and fragment sketches (≙ Sketch::build, Map::doL1Mapping's sketch), kept fragment sets + wire format
 //   engine_index.hip   index chunks (≙ Sketch::index), chunk streaming, sketch file                    (winSketch.hpp:181-193; section 8 f3)
 //   engine_map.hip     L1 + L2 + identity + reducer (≙ Map::mapQuery ... cgi::computeCGI)              (computeMap.hpp:112-545, computeCoreIdentity.hpp:166-298)
+//   engine_l2.hip      the launches of k_l2_codes / k_l2_sim (a unit of its own for its compiler flags: build_lib.sh)
 //   sort_device.hip    the radix sort
 // Kernels live in kernels/*.hpp (internal linkage: a unit compiles the ones it launches).  Nothing here crosses the C-ABI.
 #pragma once
