@@ -3,6 +3,7 @@
 
     python bench.py --gpus 1 --steps K --warmup W [--config many-to-many|one-to-many|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...        (no launcher around it: bench.py starts its N ranks itself, see self_launch)
 
 One step = one pass of the whole hot path over the workload with the packed genomes already resident in HBM:
 reference sketch + index build (skch::Sketch), mapping of every query genome (skch::Map) and the ANI reducer
@@ -964,8 +965,38 @@ def gather_rank_info(R, res, steps, mode):
     return info
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks here — the same
+    `torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` line the driver uses, on a free port, host threads
+    split between the ranks — and leave with its exit code.  Rank 0 of the children prints the ONE JSON line.
+    (The reference's only parallel split, core_genome_identity.cpp:55-121, is what the ranks mirror: bench.py: step_ring.)"""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or args.simulate_world > 1:
+        return
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("ANI_BENCH_THREADS_PER_RANK", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    env.setdefault("OMP_NUM_THREADS", env["ANI_BENCH_THREADS_PER_RANK"])
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("ANI_BENCH_BACKEND", "") != "emu":
+        # fail before the rendezvous when the box has fewer devices than ranks (an 8-rank start on a 1-GPU box would otherwise end
+        # in N - 1 ranks dying inside set_device and the survivor waiting for the store)
+        probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, env=env)
+        have = int((probe.stdout.decode().strip().splitlines() or ["0"])[-1]) if probe.returncode == 0 else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: this box shows %d GPU(s)" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    self_launch(args)
     R = setup_runtime(args)
     import numpy as np
     e, p, cfg = R.e, R.p, args.config

@@ -147,24 +147,27 @@ def test_sharded_sketch_allgather_matches_single_process(tmp_path, emu_engine, w
     assert np.array_equal(single, np.concatenate(exp))
 
 
-@pytest.mark.parametrize("config,scaling", [("many-to-many", "auto"), ("many-to-many", "weak"), ("c4", "auto")])
-def test_bench_orchestration_two_ranks(config, scaling, emu_engine, tmp_path):
+@pytest.mark.parametrize("config,scaling,launcher", [("many-to-many", "auto", True), ("many-to-many", "weak", True), ("c4", "auto", True),
+                                                     ("many-to-many", "auto", False)])
+def test_bench_orchestration_two_ranks(config, scaling, launcher, emu_engine, tmp_path):
     """bench.py's own multi-rank steps launched the way the driver launches it, on the CPU build of the product sources over gloo
     (ANI_BENCH_BACKEND=emu, a test-only switch): 6 genomes of one cluster, every pair related.
       many-to-many (default at N > 1) = STRONG scaling: the fixed 6 x 6 job, reference-sharded, fragment sets ring-passed; the
           weak-scaling leg (query-sharded, reference records all-gathered) is measured beside it
       many-to-many --scaling weak     = the weak leg as the timed region
       c4                              = the reference-sharded ring again (configs[3] shape)
+    launcher = False: plain `python bench.py --gpus 2` with no WORLD_SIZE around it — bench.py starts its own ranks (self_launch).
     The rows every rank dumps must add up to the single-process rows."""
     import json
     import subprocess
     from fastani_amd.api import DeviceGenomes, Sketch
     port = 29300 + (os.getpid() % 300) + (7 if config == "c4" else 0) + (13 if scaling == "weak" else 0)
     dump = os.path.join(str(tmp_path), "rows")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", config, "--scaling", scaling, "--genomes", "6", "--genome-len", "24000",
-                        "--dump-rows", dump],
-                       capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=1200)
+    outer = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] if launcher else [sys.executable]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(outer + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", config, "--scaling", scaling, "--genomes", "6",
+                                "--genome-len", "24000", "--dump-rows", dump],
+                       capture_output=True, env=dict(env, ANI_BENCH_BACKEND="emu"), timeout=1200)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
