@@ -93,6 +93,7 @@ def _bind(lib):
         "ani_sketch_writer_close": (C.c_int, [vp]),
         "ani_device_memory": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "ani_pool_prewarm_index": (C.c_int, [vp, C.c_uint64]),
+        "ani_pool_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "ani_sketch_file_info": (C.c_int, [C.c_char_p, C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
         "ani_sketch_genome_name": (C.c_char_p, [vp, C.c_int32]),
         "ani_sketch_tables": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -328,12 +329,24 @@ class Engine:
         self._chk(self.lib.ani_fragset_build(self.h, C.byref(params), C.byref(b), C.byref(f)))
         return FragmentSet(self, f)
 
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.ani_device_alloc(self.h, int(nbytes), C.byref(p)))
+        return p.value
+
     def device_free(self, ptr):
         self.lib.ani_device_free(self.h, ptr)
 
     def pool_prewarm_index(self, n_minimizers):
-        """a hint (ani_abi.h): the index arrays for about n_minimizers minimizers allocated and touched now, left in the cache"""
+        """a hint (ani_abi.h): the device memory sketching and indexing about n_minimizers minimizers will take, reserved now"""
         self._chk(self.lib.ani_pool_prewarm_index(self.h, int(n_minimizers)))
+
+    def pool_stats(self):
+        """the device allocator (ani_pool_stats): segment / free / live bytes, segments, hipMalloc calls / bytes / microseconds so far"""
+        out = (C.c_uint64 * 8)()
+        self._chk(self.lib.ani_pool_stats(self.h, out))
+        keys = ("segment_bytes", "free_bytes", "live_bytes", "segments", "hipmalloc_calls", "hipmalloc_bytes", "hipmalloc_us", "largest_free_extent")
+        return dict(zip(keys, [int(x) for x in out]))
 
     def device_copy(self, dst, src, nbytes):
         self._chk(self.lib.ani_device_copy(self.h, dst, src, nbytes))

@@ -16,7 +16,7 @@ int fail(int code, const char *fmt, ...)
   return code;
 }
 
-DevicePool g_pools[64][2];
+DevicePool g_pools[64];
 
 int zero_counters(ani_ctx *c)
 {
@@ -190,7 +190,7 @@ void ani_shutdown(ani_ctx *c)
   for (int i = 0; i < 5; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
-  cur_pool(0).trim(); cur_pool(1).trim();
+  cur_pool().trim();
 }
 
 int ani_device_copy(ani_ctx *c, void *dst, const void *src, size_t bytes)

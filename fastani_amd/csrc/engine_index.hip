@@ -335,7 +335,7 @@ int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
     size_t freeB = 0, totB = 0;
     if (hipMemGetInfo(&freeB, &totB) == hipSuccess) {
       uint64_t cached = 0;
-      for (int cls = 0; cls < 2; cls++) { DevicePool &pl = cur_pool(cls); std::lock_guard<std::mutex> g(pl.mu); cached += pl.cachedBytes; }
+      { DevicePool &pl = cur_pool(); std::lock_guard<std::mutex> g(pl.mu); cached += pl.cachedBytes; }
       const uint64_t avail = (uint64_t)freeB + cached, reserve = std::min<uint64_t>((uint64_t)32 << 30, (uint64_t)totB / 8);
       const uint64_t largest = std::min<uint64_t>(total, maxN);
       // (Streamed chunks of a fixed 10^9 minimizers.  Measured: chunks as large as the free memory allows — 4 instead of 5 for
@@ -439,9 +439,13 @@ int exact_unique(ani_sketch *sk)
 
 extern "C" {
 
-// The arrays build_chunk_index asks the pool for, for a chunk of about n minimizers (the probe table is left out: its size follows
-// the number of DISTINCT hashes, which no one knows yet): six of 4 n bytes (mHash, mSeq, mWpos, sHash, mWin, the sort's key buffer),
-// two of 8 n (sSW, the sort's value buffer).
+// Device memory for sketching and indexing a reference set of about n minimizers, taken from the driver NOW, on the calling (side)
+// thread, as free segments of the pool (host/engine.hpp: DevicePool::reserve).  Measured on the 1000 x 5 Mbp command-line run
+// (4.03 x 10^8 minimizers; profiles/r06a_e2e_pool_trace.txt): the slices' records, fragment sets and workspaces take 6.6 GB = 16.4
+// bytes per minimizer, asked for in pieces of < 300 MB while the input is read — reserved as 1 GiB segments, first, so that the
+// first slice waits for one of them only; the index build takes 19.0 GB = 47 bytes per minimizer (six arrays of 4 n, two of 8 n,
+// link candidates, the probe table at ~8 n) within a few milliseconds — reserved as ONE segment, from which the build's requests
+// are cut one after the other and into which its transient arrays go back for the mapping buffers.
 int ani_pool_prewarm_index(ani_ctx *ctx, uint64_t nMinimizers)
 {
   if (!ctx) return fail(ANI_ERR_ARG, "bad argument to ani_pool_prewarm_index");
@@ -450,21 +454,36 @@ int ani_pool_prewarm_index(ani_ctx *ctx, uint64_t nMinimizers)
   HIP_TRY(hipSetDevice(ctx->device));
   size_t freeB = 0, totalB = 0;
   HIP_TRY(hipMemGetInfo(&freeB, &totalB));
-  const size_t n4 = (size_t)nMinimizers * 4;
-  if (10 * n4 > freeB / 2) return ANI_OK;                  // not on a device that is short of memory
-  DevicePool &pool = cur_pool(0);
+  const size_t sketchBytes = (size_t)nMinimizers * 17, indexBytes = (size_t)nMinimizers * 49;
+  if (sketchBytes + indexBytes > freeB / 2) return ANI_OK;                  // not on a device that is short of memory
+  DevicePool &pool = cur_pool();
   std::vector<size_t> sizes;
-  for (int i = 0; i < 8; i++) sizes.push_back(i < 6 ? n4 : 2 * n4);
-  std::sort(sizes.rbegin(), sizes.rend());                 // the large ones first: the sort asks for them first
-  for (size_t b : sizes) pool.promise(b);                  // a request that one of them will fit waits for it from now on
+  const size_t piece = std::min<size_t>((size_t)1 << 30, std::max(sketchBytes, DevicePool::kSmallLimit));
+  for (size_t b = 0; b < sketchBytes; b += piece) sizes.push_back(piece);
+  sizes.push_back(std::max(indexBytes, DevicePool::kSmallLimit));
+  for (size_t b : sizes) pool.promise(b);                  // a request that only one of them can serve waits for it from now on
   hipStream_t s = nullptr;
   hipError_t e = hipStreamCreate(&s);
   size_t made = 0;
-  for (; made < sizes.size() && e == hipSuccess; made++) e = pool.prewarm(sizes[made], s);
+  for (; made < sizes.size() && e == hipSuccess; made++) e = pool.reserve(sizes[made], s);
   if (made < sizes.size()) pool.drop_promises(std::vector<size_t>(sizes.begin() + made, sizes.end()));
   if (s) (void)hipStreamDestroy(s);
   if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return ANI_OK; }      // a hint: nothing to report
   HIP_TRY(e);
+  return ANI_OK;
+}
+
+// what the pool of the context's device holds (see ani_abi.h)
+int ani_pool_stats(ani_ctx *ctx, uint64_t out[8])
+{
+  if (!ctx || !out) return fail(ANI_ERR_ARG, "bad argument to ani_pool_stats");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevicePool &pl = cur_pool();
+  std::lock_guard<std::mutex> g(pl.mu);
+  uint64_t largest = 0;
+  if (!pl.freeBySize[0].empty()) largest = pl.freeBySize[0].rbegin()->first;              // (of the large segments)
+  out[0] = pl.segBytes; out[1] = pl.cachedBytes; out[2] = pl.liveBytes; out[3] = pl.segs.size();
+  out[4] = pl.freshCalls; out[5] = pl.freshBytes; out[6] = (uint64_t)(pl.freshMs * 1e3); out[7] = largest;
   return ANI_OK;
 }
 

@@ -58,81 +58,41 @@ extern thread_local std::string g_err;
 int fail(int code, const char *fmt, ...);
 
 // -----------------------------------------------------------------------------------------------------
-// Caching device allocator: hipMalloc/hipFree of multi-GB arrays cost milliseconds each and a many-to-many run builds and
-// drops the same-sized index arrays over and over; freed blocks are kept and handed out again (best fit within 25 %).
-// On allocation failure the cache is dropped and the request retried.
+// Device allocator (round 6: one arena per device instead of two caches of whole blocks).
+//
+// Why: fresh device memory costs up to 20 - 40 us per MB on some hosts (a 4.5 GB hipMalloc: 135 ms) and hipFree ~40 ms per GB; a
+// many-to-many run builds and drops same-sized index arrays over and over, and a cold command-line run needs ~29 GB once.  The
+// round-2..5 pools kept freed blocks WHOLE and reused one only for a request within 6 % of its size, so the 11.8 GB the index build
+// hands back (sort buffers, link candidates, minimizer records) could not serve the 3.2 GB of mapping buffers asked for a moment
+// later: that was fresh memory again (profiles/r06a_e2e_pool_trace.txt).
+//
+// Now: memory is taken from the driver in SEGMENTS and handed out as EXTENTS of them — best fit, split, coalesced with free
+// neighbours on release — so anything that is free can serve anything that fits.
+//   * large requests (>= 32 MiB): a miss takes a fresh segment of exactly the request's size (size classes as before), so the hole a
+//     dropped index array leaves is the hole the next build's array of that size fits;
+//   * small requests share 256 MiB segments of their own and never chip at a large hole;
+//   * the device is full: wholly free segments go back to the driver one at a time, largest first, until the request fits;
+//   * reserve(): a segment made on ANOTHER thread ahead of need (ani_pool_prewarm_index: the command line reserves what sketching and
+//     indexing its input will take while the readers parse the first files); a request that only a promised segment can serve waits
+//     for it — up to a deadline — instead of taking fresh memory beside it.
+// The lock is not held while the driver works.  ANI_POOL_TRACE=1 prints every segment taken from the driver.
 // -----------------------------------------------------------------------------------------------------
 struct DevicePool {
+  static constexpr size_t kGran = 512, kSmallLimit = (size_t)32 << 20, kSmallSegment = (size_t)256 << 20;
+  struct Ext { size_t size; bool free; char *seg; };
+  struct Seg { size_t size; bool small; };
   std::mutex mu;
-  std::unordered_map<void *, size_t> live;
-  std::multimap<size_t, void *> cache;
-  size_t cachedBytes = 0;
-  hipError_t alloc(void **out, size_t bytes)
-  {
-    // Size classes for large blocks (round 5; class_size below): a request of >= 64 MiB is rounded up to a multiple of 2^(floor(log2 bytes) - 5), i.e.
-    // 1/32 .. 1/64 of its size (<= 3 % slack).  The index chunks of a streamed reference set are cut at genome borders and differ by
-    // a few 10^-4 of their size: without classes a chunk that is a little LARGER than the one just dropped finds no cached block
-    // (lower_bound), takes ~36 GB of fresh memory, and the dropped chunk's blocks stay cached until the device is full — the 39 chunk
-    // builds of the 90 000-genome run spent as long in first-touch memory and hipFree as in kernels (profiles/r04c5b).
-    bytes = class_size(bytes);
-    std::unique_lock<std::mutex> g(mu);
-    auto it = cache.lower_bound(bytes);
-    // a block of this size is being made on another thread (prewarm): its tail is shorter than a second fresh allocation beside it
-    while ((it == cache.end() || it->first > bytes + bytes / 16 + (1u << 20)) && promised_fit_locked(bytes)) { cvPromised.wait_for(g, std::chrono::milliseconds(20)); it = cache.lower_bound(bytes); }
-    // reuse only a closely fitting block: a looser fit lets a long-lived buffer capture the block a per-sketch array of a
-    // different size will ask for again, and that array then needs fresh memory in the middle of a later step
-    // ANI_POOL_POISON=<byte> (tests): every block handed out is filled with that byte first, so that a kernel which reads memory
-    // it (or an earlier kernel) has not written sees the same garbage every time instead of whatever the previous owner left
-    static const int poison = getenv("ANI_POOL_POISON") ? (int)strtol(getenv("ANI_POOL_POISON"), nullptr, 0) : -1;
-    if (it != cache.end() && it->first <= bytes + bytes / 16 + (1u << 20)) {
-      *out = it->second; live[*out] = it->first; cachedBytes -= it->first; cache.erase(it);
-      if (poison >= 0) { (void)hipDeviceSynchronize(); (void)hipMemset(*out, poison, bytes); (void)hipDeviceSynchronize(); }
-      return hipSuccess;
-    }
-    static const bool trace = getenv("ANI_POOL_TRACE") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(out, bytes);
-    size_t freed = 0; bool loose = false;
-    if (e != hipSuccess) {
-      // The device is full while this pool sits on cached blocks.  Dropping the whole cache is what NOT to do: hipFree costs ~40 ms
-      // per GB on this stack (a 125 GB cache: 4.8 s, measured in the warm step of the 10 000 x 10 000 run, profiles/r03l).  First any
-      // cached block that is large enough serves, whatever its slack; else cached blocks go one at a time, largest first, until the
-      // request fits.
-      (void)hipGetLastError();
-      if (it != cache.end()) {
-        *out = it->second; live[*out] = it->first; cachedBytes -= it->first; cache.erase(it);
-        e = hipSuccess; loose = true;
-      } else {
-        while (e != hipSuccess && free_largest_locked(&freed)) { e = hipMalloc(out, bytes); if (e != hipSuccess) (void)hipGetLastError(); }
-        if (e == hipSuccess) live[*out] = bytes;
-      }
-    } else live[*out] = bytes;
-    if (trace) fprintf(stderr, "[ani pool] hipMalloc %.1f MB: %.2f ms%s (cache %.1f MB in %zu blocks%s)\n", bytes / 1048576.0,
-                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), e == hipSuccess ? "" : " FAILED", cachedBytes / 1048576.0, cache.size(),
-                       loose ? "; device full: served by a larger cached block" : freed ? "; device full: cached blocks freed" : "");
-    if (e == hipSuccess && poison >= 0) { (void)hipDeviceSynchronize(); (void)hipMemset(*out, poison, bytes); (void)hipDeviceSynchronize(); }
-    return e;
-  }
-  // frees the largest cached block; false if the cache is empty
-  bool free_largest_locked(size_t *freedBytes)
-  {
-    if (cache.empty()) return false;
-    auto last = std::prev(cache.end());
-    (void)hipFree(last->second);
-    cachedBytes -= last->first; if (freedBytes) *freedBytes += last->first;
-    cache.erase(last);
-    return true;
-  }
-  bool free_largest() { std::lock_guard<std::mutex> g(mu); return free_largest_locked(nullptr); }
-  void release(void *p)
-  {
-    if (!p) return;
-    std::lock_guard<std::mutex> g(mu);
-    auto it = live.find(p);
-    if (it == live.end()) { (void)hipFree(p); return; }
-    cache.emplace(it->second, p); cachedBytes += it->second; live.erase(it);
-  }
-  // the size a request of `bytes` is served with (alloc's size classes)
+  std::map<char *, Ext> ext;                               // every extent of every segment, by address
+  std::multimap<size_t, char *> freeBySize[2];             // free extents: [0] large segments, [1] small segments
+  std::map<char *, Seg> segs;
+  size_t cachedBytes = 0, liveBytes = 0, segBytes = 0;     // cachedBytes = free bytes inside the segments
+  uint64_t freshCalls = 0, freshBytes = 0; double freshMs = 0;   // what the driver was asked for so far (ani_pool_stats)
+  std::multiset<size_t> promised; std::condition_variable cvPromised;
+
+  // the size a request of `bytes` is served with: large blocks in classes of 1/32 .. 1/64 of their size (<= 3 % slack) — the index
+  // chunks of a streamed reference set are cut at genome borders and differ by a few 10^-4 of their size; with classes the hole one
+  // leaves fits the next (profiles/r04c5b: without them the 39 chunk builds of the 90 000-genome run spent as long in fresh memory
+  // and hipFree as in kernels)
   static size_t class_size(size_t bytes)
   {
     if (bytes == 0) bytes = 1;
@@ -142,26 +102,138 @@ struct DevicePool {
       const size_t gran = (size_t)1 << (lg - 5);
       bytes = (bytes + gran - 1) / gran * gran;
     }
-    return bytes;
+    return (bytes + kGran - 1) / kGran * kGran;
   }
-  // Prewarming (ani_pool_prewarm_index): fresh blocks of announced sizes, touched (hipMemset on `s`) and put straight into the cache
-  // for later requests of about those sizes.  The pool is NOT locked while the driver works — other threads keep allocating — and a
-  // request that an announced block will fit waits for it instead of taking fresh memory beside it.
-  std::multiset<size_t> promised; std::condition_variable cvPromised;
-  bool promised_fit_locked(size_t bytes) const { auto it = promised.lower_bound(bytes); return it != promised.end() && *it <= bytes + bytes / 16 + (1u << 20); }
-  void promise(size_t bytes) { std::lock_guard<std::mutex> g(mu); promised.insert(class_size(bytes)); }
-  hipError_t prewarm(size_t bytes, hipStream_t s)           // one promised block
+  void free_insert_locked(char *a, const Ext &e) { freeBySize[segs[e.seg].small ? 1 : 0].emplace(e.size, a); }
+  void free_erase_locked(char *a, const Ext &e)
+  {
+    auto &m = freeBySize[segs[e.seg].small ? 1 : 0];
+    for (auto r = m.equal_range(e.size); r.first != r.second; ++r.first) if (r.first->second == a) { m.erase(r.first); return; }
+  }
+  // hands out the first `bytes` of the free extent at `a`; the rest stays free
+  void *take_locked(char *a, size_t bytes)
+  {
+    auto it = ext.find(a);
+    Ext e = it->second;
+    free_erase_locked(a, e);
+    if (e.size > bytes) {
+      const Ext rest{e.size - bytes, true, e.seg};
+      ext.emplace(a + bytes, rest); free_insert_locked(a + bytes, rest);
+      it->second.size = bytes;
+    }
+    it->second.free = false;
+    cachedBytes -= it->second.size; liveBytes += it->second.size;
+    return a;
+  }
+  void add_segment_locked(char *p, size_t bytes, bool small)
+  {
+    segs[p] = Seg{bytes, small}; segBytes += bytes;
+    const Ext e{bytes, true, p};
+    ext.emplace(p, e); free_insert_locked(p, e); cachedBytes += bytes;
+  }
+  // gives the largest wholly free segment back to the driver; false if there is none
+  bool free_largest_locked(size_t *freedBytes)
+  {
+    char *best = nullptr; size_t bestSize = 0;
+    for (auto &kv : segs) {
+      auto it = ext.find(kv.first);
+      if (it != ext.end() && it->second.free && it->second.size == kv.second.size && kv.second.size > bestSize) { best = kv.first; bestSize = kv.second.size; }
+    }
+    if (!best) return false;
+    free_erase_locked(best, ext[best]); ext.erase(best);
+    segs.erase(best); segBytes -= bestSize; cachedBytes -= bestSize;
+    (void)hipFree(best);
+    if (freedBytes) *freedBytes += bestSize;
+    return true;
+  }
+  bool free_largest() { std::lock_guard<std::mutex> g(mu); return free_largest_locked(nullptr); }
+  bool promised_fit_locked(size_t bytes) const { return !promised.empty() && *promised.rbegin() >= bytes; }
+
+  hipError_t alloc(void **out, size_t bytes)
   {
     bytes = class_size(bytes);
+    const bool small = bytes < kSmallLimit;
+    // ANI_POOL_POISON=<byte> (tests): every block handed out is filled with that byte first, so that a kernel which reads memory
+    // it (or an earlier kernel) has not written sees the same garbage every time instead of whatever the previous owner left
+    static const int poison = getenv("ANI_POOL_POISON") ? (int)strtol(getenv("ANI_POOL_POISON"), nullptr, 0) : -1;
+    static const bool trace = getenv("ANI_POOL_TRACE") != nullptr;
+    auto handout = [&](void *p) {
+      *out = p;
+      if (poison >= 0) { (void)hipDeviceSynchronize(); (void)hipMemset(p, poison, bytes); (void)hipDeviceSynchronize(); }
+      return hipSuccess;
+    };
+    std::unique_lock<std::mutex> g(mu);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+    for (;;) {
+      auto &m = freeBySize[small ? 1 : 0];
+      auto it = m.lower_bound(bytes);
+      if (it != m.end()) { void *p = take_locked(it->second, bytes); g.unlock(); return handout(p); }
+      // a segment that will fit is being made on another thread: its tail is shorter than a second fresh allocation beside it
+      if (!small && promised_fit_locked(bytes) && std::chrono::steady_clock::now() < deadline) { cvPromised.wait_for(g, std::chrono::milliseconds(5)); continue; }
+      break;
+    }
+    const size_t segSize = small ? kSmallSegment : bytes;
+    g.unlock();
+    const auto t0 = std::chrono::steady_clock::now();
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, segSize);
+    size_t freed = 0;
+    g.lock();
+    if (e != hipSuccess) {
+      // the device is full: wholly free segments go back one at a time, largest first (hipFree costs ~40 ms per GB on this stack: a
+      // 125 GB cache dropped at once took 4.8 s in the warm step of the 10 000 x 10 000 run, profiles/r03l) — but first another thread
+      // may have released something that fits in the meantime
+      (void)hipGetLastError();
+      auto &m = freeBySize[small ? 1 : 0];
+      auto it = m.lower_bound(bytes);
+      if (it != m.end()) { void *q = take_locked(it->second, bytes); g.unlock(); return handout(q); }
+      while (e != hipSuccess && free_largest_locked(&freed)) { e = hipMalloc(&p, segSize); if (e != hipSuccess) (void)hipGetLastError(); }
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (trace) fprintf(stderr, "[ani pool] hipMalloc %.1f MB: %.2f ms%s (%.1f MB free in %zu segments of %.1f MB%s)\n", segSize / 1048576.0, ms, e == hipSuccess ? "" : " FAILED",
+                       cachedBytes / 1048576.0, segs.size(), segBytes / 1048576.0, freed ? "; device full: free segments returned" : "");
+    if (e != hipSuccess) return e;
+    freshCalls++; freshBytes += segSize; freshMs += ms;
+    add_segment_locked((char *)p, segSize, small);
+    void *q = take_locked((char *)p, bytes);
+    g.unlock();
+    return handout(q);
+  }
+  // false: not a block of this pool
+  bool release(void *p)
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = ext.find((char *)p);
+    if (it == ext.end() || it->second.free) return false;
+    it->second.free = true;
+    cachedBytes += it->second.size; liveBytes -= it->second.size;
+    auto nx = std::next(it);
+    if (nx != ext.end() && nx->second.free && nx->second.seg == it->second.seg) { free_erase_locked(nx->first, nx->second); it->second.size += nx->second.size; ext.erase(nx); }
+    if (it != ext.begin()) {
+      auto pv = std::prev(it);
+      if (pv->second.free && pv->second.seg == it->second.seg) { free_erase_locked(pv->first, pv->second); pv->second.size += it->second.size; ext.erase(it); it = pv; }
+    }
+    free_insert_locked(it->first, it->second);
+    return true;
+  }
+  // Reserving (ani_pool_prewarm_index): a fresh large segment of an announced size, touched (hipMemset on `s`) and entered as free.
+  void promise(size_t bytes) { std::lock_guard<std::mutex> g(mu); promised.insert(class_size(bytes)); }
+  hipError_t reserve(size_t bytes, hipStream_t s)           // one promised segment
+  {
+    bytes = class_size(bytes);
+    static const bool trace = getenv("ANI_POOL_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e == hipSuccess) { e = hipMemsetAsync(p, 0, bytes, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) { (void)hipFree(p); p = nullptr; } }
     else (void)hipGetLastError();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     {
       std::lock_guard<std::mutex> g(mu);
       auto it = promised.find(bytes); if (it != promised.end()) promised.erase(it);
-      if (p) { cache.emplace(bytes, p); cachedBytes += bytes; }
+      if (p) { add_segment_locked((char *)p, bytes, false); freshCalls++; freshBytes += bytes; freshMs += ms; }
     }
+    if (trace) fprintf(stderr, "[ani pool] reserved %.1f MB ahead of need: %.2f ms%s\n", bytes / 1048576.0, ms, p ? "" : " FAILED");
     cvPromised.notify_all();
     return e;
   }
@@ -170,32 +242,18 @@ struct DevicePool {
     { std::lock_guard<std::mutex> g(mu); for (size_t b : sizes) { auto it = promised.find(class_size(b)); if (it != promised.end()) promised.erase(it); } }
     cvPromised.notify_all();
   }
-  void trim_locked() { for (auto &kv : cache) (void)hipFree(kv.second); cache.clear(); cachedBytes = 0; }
-  void trim() { std::lock_guard<std::mutex> g(mu); trim_locked(); }
+  void trim() { std::lock_guard<std::mutex> g(mu); while (free_largest_locked(nullptr)) {} }
 };
 
-// Two pools per device ordinal (one process normally drives one GPU): class 0 for what lives and dies with a sketch (its arrays
-// and the transient buffers of its build), class 1 for the grow-only buffers of a context.  Kept apart so that a context buffer
-// growing between two sketch builds cannot capture a block the next build will ask for again — fresh device memory in the
-// middle of a steady-state step costs up to ~30 us/MB on this stack (a 4.5 GB hipMalloc: 135 ms).
-extern DevicePool g_pools[64][2];
-inline DevicePool &cur_pool(int cls) { int d = 0; (void)hipGetDevice(&d); return g_pools[(d < 0 || d >= 64) ? 0 : d][cls]; }
-inline hipError_t pool_malloc(void **p, size_t bytes, int cls = 0)
-{
-  hipError_t e = cur_pool(cls).alloc(p, bytes);           // gives up only with its own cache empty
-  while (e != hipSuccess && cur_pool(cls ^ 1).free_largest()) { (void)hipGetLastError(); e = cur_pool(cls).alloc(p, bytes); }   // then the other class's cache, block by block
-  return e;
-}
+// One pool per device ordinal (one process normally drives one GPU).  (`cls` of the earlier two-pool design — 0: what lives and dies
+// with a sketch, 1: the grow-only buffers of a context — is kept in the signatures as documentation of the caller's intent.)
+extern DevicePool g_pools[64];
+inline DevicePool &cur_pool(int /*cls*/ = 0) { int d = 0; (void)hipGetDevice(&d); return g_pools[(d < 0 || d >= 64) ? 0 : d]; }
+inline hipError_t pool_malloc(void **p, size_t bytes, int /*cls*/ = 0) { return cur_pool().alloc(p, bytes); }
 inline void pool_free(void *p)
 {
   if (!p) return;
-  for (int cls = 0; cls < 2; cls++) {
-    DevicePool &pl = cur_pool(cls);
-    { std::lock_guard<std::mutex> g(pl.mu); if (!pl.live.count(p)) continue; }
-    pl.release(p);
-    return;
-  }
-  (void)hipFree(p);
+  if (!cur_pool().release(p)) (void)hipFree(p);
 }
 
 #define HIP_TRY(expr)                                                                                   \

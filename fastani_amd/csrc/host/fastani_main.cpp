@@ -464,26 +464,26 @@ int main(int argc, char **argv)
   if (fpPtr) fpPtr->set_active(1 << 30);
   trace("devices initialised");
   // Fresh device memory is slow on some hosts (20 - 40 us per MB: the index build of a cold 1000-genome run took 0.6 s instead of
-  // 0.03): the index arrays are allocated and touched NOW, on a side thread, while the readers parse the first files.  The size is
-  // an estimate — plain FASTA holds one base per byte but for line ends and headers, winnowing keeps 2 / (w + 1) of the positions —
-  // and only a hint (ani_abi.h): compressed inputs, several devices, reference sketch files and inputs below 64 MiB go without.
-  // OPT-IN (ANI_CLI_PREWARM=1; =force: small inputs too): on the two boxes it could be measured on, fresh memory was cheap (index
-  // built 41 ms after the last slice either way) and 12 runs each way averaged 0.995 and 0.993 s (profiles/r05ad_e2e_prewarm_*.txt);
-  // the slow-allocation hosts it was written for did not come up again.
-  std::thread prewarm;
-  struct PrewarmJoin { std::thread &t; ~PrewarmJoin() { if (t.joinable()) t.join(); } } prewarmJoin{prewarm};
-  if (fpPtr && nDev == 1 && !fromFile && getenv("ANI_CLI_PREWARM") && strcmp(getenv("ANI_CLI_PREWARM"), "0")) {
+  // 0.03, BENCH_r05.json): what sketching and indexing the references will take is reserved NOW, on a side thread per device, while
+  // the readers parse the first files (ani_pool_prewarm_index: 1 GiB segments for the slices first, then one segment for the index
+  // build; the build's transient arrays go back into it and serve the mapping buffers).  The size is an estimate — plain FASTA
+  // holds one base per byte but for line ends and headers, winnowing keeps 2 / (w + 1) of the positions — and only a hint
+  // (ani_abi.h): compressed inputs, reference sketch files and inputs below 64 MiB go without.  ANI_CLI_PREWARM=0 switches it off,
+  // =force reserves for small inputs too (tests).
+  std::vector<std::thread> prewarm;
+  struct PrewarmJoin { std::vector<std::thread> &t; ~PrewarmJoin() { for (auto &x : t) if (x.joinable()) x.join(); } } prewarmJoin{prewarm};
+  const char *pwEnv = getenv("ANI_CLI_PREWARM");
+  if (fpPtr && !fromFile && !(pwEnv && !strcmp(pwEnv, "0"))) {
     uint64_t refBytes = 0; bool plain = true;
     for (size_t i = 0; i < (size_t)nRef && plain; i++) {
       const std::string &f = o.refs[i];
       if (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0) { plain = false; break; }
       struct stat st; if (stat(f.c_str(), &st) == 0) refBytes += (uint64_t)st.st_size;
     }
-    const bool force = getenv("ANI_CLI_PREWARM") && !strcmp(getenv("ANI_CLI_PREWARM"), "force");       // (tests: small inputs too)
+    const bool force = pwEnv && !strcmp(pwEnv, "force");
     if (plain && (refBytes >= (64ull << 20) || force)) {
-      const uint64_t nEst = (uint64_t)((double)refBytes * 2.0 / (ap.windowSize + 1));
-      ani_ctx *pc = dev[0].ctx;
-      prewarm = std::thread([pc, nEst]() { (void)ani_pool_prewarm_index(pc, nEst); });
+      const uint64_t nEst = (uint64_t)((double)refBytes * 2.0 / (ap.windowSize + 1)) / (uint64_t)nDev;
+      for (int d = 0; d < nDev; d++) { ani_ctx *pc = dev[d].ctx; prewarm.emplace_back([pc, nEst]() { (void)ani_pool_prewarm_index(pc, nEst); }); }
     }
   }
   std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
@@ -959,6 +959,7 @@ int main(int argc, char **argv)
     const uint64_t shared = (uint64_t)e.countSeq * (uint64_t)ap.fragLen;
     return shared >= minLen * o.minFraction;                            // uint64 * float, as in :328
   };
+  trace("rows ordered");
   {
     std::ofstream out(o.out);
     std::vector<char> obuf(1 << 20); out.rdbuf()->pubsetbuf(obuf.data(), (std::streamsize)obuf.size());
@@ -1012,6 +1013,16 @@ int main(int argc, char **argv)
   }
   std::cerr << "INFO, skch::main, Time spent writing the output : " << secs_since(tOut) << " sec; total : " << secs_since(tStart) << " sec" << std::endl;
   trace("output written");
+  if (getenv("ANI_CLI_TRACE"))                        // what fresh device memory cost on this box (the allocator's own clock)
+    for (auto &d : dev) {
+      uint64_t ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ani_pool_stats(d.ctx, ps) == 0) {
+        char line[256];
+        snprintf(line, sizeof line, "device %d memory: %.1f MB in %llu segments, %.1f MB handed out; %llu hipMalloc calls took %.1f ms (%.2f us per MB)", d.id, ps[0] / 1048576.0,
+                 (unsigned long long)ps[3], ps[2] / 1048576.0, (unsigned long long)ps[4], ps[6] / 1e3, ps[5] ? (double)ps[6] / (ps[5] / 1048576.0) : 0.0);
+        trace(line);
+      }
+    }
   if (getenv("ANI_CLEAN_EXIT")) {                     // tests / leak checkers: release everything in order
     fpPtr.reset();
     for (auto &d : dev) { ani_shutdown(d.up); ani_shutdown(d.ctx); }

@@ -145,12 +145,18 @@ int ani_device_alloc(ani_ctx *ctx, size_t bytes, void **out);
 /* free / total memory of the context's device in bytes (the command line sizes the blocks of a reference sketch file with it;
  * no counterpart in the reference, which splits its database by hand: scripts/splitDatabase.sh) */
 int ani_device_memory(ani_ctx *ctx, size_t *freeBytes, size_t *totalBytes);
-/* A hint, never needed for correctness: allocate and touch NOW the device arrays an index over about `nMinimizers` minimizers will
- * ask for (ani_sketch_from_records / ani_sketch_build), and leave them in the allocator's cache.  Fresh device memory costs
- * 20 - 40 us per MB on some hosts — 0.6 s of a cold 1000-genome run sat in the index build for that reason; the command line
- * can call this on a side thread while its readers parse the first files (ANI_CLI_PREWARM=1; estimate: input bytes x 2 / (w + 1)).  An estimate that
- * is off by more than a few percent only wastes the memory until the cache is trimmed.  No counterpart in the reference. */
+/* A hint, never needed for correctness: take from the driver NOW, on the calling thread, the device memory that sketching and
+ * indexing a reference set of about `nMinimizers` minimizers will ask for (~66 bytes per minimizer: 1 GiB segments for the slices'
+ * records and fragment sets first, then one segment for the index build), and leave it free in the allocator.  Fresh device memory
+ * costs 20 - 40 us per MB on some hosts — 0.6 s of a cold 1000-genome run sat in the index build for that reason; the command line
+ * calls this on a side thread while its readers parse the first files (estimate: input bytes x 2 / (w + 1); ANI_CLI_PREWARM=0
+ * switches it off).  An estimate that is off only wastes the memory until the allocator is trimmed (ani_shutdown).  No counterpart in
+ * the reference. */
 int ani_pool_prewarm_index(ani_ctx *ctx, uint64_t nMinimizers);
+/* The device allocator of the context's device: out[0] bytes held in segments, [1] of them free, [2] handed out, [3] segments,
+ * [4] hipMalloc calls so far, [5] bytes they took, [6] microseconds they took, [7] the largest free extent of the segments that serve requests >= 32 MiB.  (The end-to-end line of
+ * bench.py and the command line's trace print [5] / [6]: what fresh device memory cost on the box.)  No counterpart in the reference. */
+int ani_pool_stats(ani_ctx *ctx, uint64_t out[8]);
 int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void *src, size_t bytes);
 /* Ingest: classify + 2-bit pack host sequences on host threads into page-locked staging, copy them to the
  * device and keep them there.  The handle can be passed to every entry point that takes a sequence batch (layout

@@ -291,3 +291,52 @@ def test_host_pool_packing(monkeypatch):
             assert np.array_equal(sk.minimizers(), want)
             sk.close()
         e.close()
+
+
+def test_device_arena_allocator(emu_engine):
+    """host/engine.hpp: DevicePool (round 6) through the C-ABI (ani_device_alloc / ani_device_free / ani_pool_stats): extents of segments,
+    best fit, split, coalesced with free neighbours on release.  Random sizes on both sides of the small / large limit; every live block
+    keeps its own pattern (no two overlap); released memory serves later requests (the segments stay within 1.5 x the largest live
+    total); with everything released the extents have coalesced."""
+    import ctypes
+    e = emu_engine
+    rng = np.random.default_rng(5)
+    base = e.pool_stats()
+    live = {}
+    peak_segments = 0
+
+    def check(ptr):
+        n, tag = live[ptr]
+        got = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(n,))
+        assert got[0] == tag and got[n - 1] == tag and got[n // 2] == tag, "a live block was overwritten: extents overlap"
+
+    for it in range(400):
+        if live and (rng.random() < 0.45 or len(live) > 40):
+            ptr = list(live)[int(rng.integers(len(live)))]
+            check(ptr)
+            e.device_free(ptr)
+            del live[ptr]
+        else:
+            n = int(rng.choice([700, 5000, 300_000, 3 << 20, 40 << 20, 70 << 20, 90 << 20])) + int(rng.integers(0, 4096))
+            ptr = e.device_alloc(n)
+            assert ptr % 16 == 0 and ptr not in live          # (the emulator's segments come from malloc: 16-byte aligned; extents are multiples of 512 inside them)
+            tag = int(rng.integers(1, 255))
+            ctypes.memset(ptr, tag, 1); ctypes.memset(ptr + n - 1, tag, 1); ctypes.memset(ptr + n // 2, tag, 1)
+            live[ptr] = (n, tag)
+        st = e.pool_stats()
+        assert st["live_bytes"] - base["live_bytes"] >= sum(n for n, _ in live.values())
+        assert st["segment_bytes"] == st["live_bytes"] + st["free_bytes"]
+        peak_segments = max(peak_segments, st["live_bytes"])
+    for ptr in list(live):
+        check(ptr)
+        e.device_free(ptr)
+    st = e.pool_stats()
+    assert st["live_bytes"] == base["live_bytes"]
+    # fragmentation stays bounded: what was taken from the driver is within 1.5 x the largest live total (+ the small segments)
+    assert st["segment_bytes"] <= peak_segments * 3 // 2 + (512 << 20), (st, peak_segments)
+    # a request as large as the largest free extent is served without new memory: the extents coalesced
+    big = st["largest_free_extent"] * 15 // 16         # (size classes round a request up by < 1/32)
+    assert big >= 32 << 20
+    ptr = e.device_alloc(big)
+    assert e.pool_stats()["hipmalloc_calls"] == st["hipmalloc_calls"]
+    e.device_free(ptr)

@@ -40,8 +40,11 @@ def main():
             t0 = time.time()
             pr = subprocess.Popen([cli, "--ql", lst, "--rl", lst, "-t", threads, "-o", os.path.join(td, "out.txt")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
             marks = []
+            keep = open(os.path.join(os.environ["E2E_STDERR_DIR"], "stderr_%s_rep%d.txt" % (v.replace("=", "-").replace(",", "_"), rep)), "w") if os.environ.get("E2E_STDERR_DIR") else None
             for raw in pr.stderr:
                 ln = raw.decode(errors="replace").rstrip("\n")
+                if keep:
+                    keep.write("%.4f %s\n" % (time.time() - t0, ln))
                 if ln.startswith("[fastANI trace]"):
                     marks.append((time.time() - t0, float(ln.split()[2]), " ".join(ln.split()[4:])))
             pr.wait()
