@@ -355,7 +355,13 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
             t_full = fixed + m_q * n_queries
             tl["pairs_per_s_of_the_sample_itself"] = round(len(q_hi) * n_cpu_refs / t_hi, 1)
             tl["marginal_s_per_query"], tl["fixed_s"] = round(m_q, 4), round(fixed, 2)
+            m_loop = tl["loop_level_s_per_query"]
+            t_full_loop = (t_hi - m_loop * len(q_hi)) + m_loop * n_queries
             out["cpu_baseline"] = {"value": round(n_queries * n_cpu_refs / t_full, 3), "unit": "pairs/s", "cores": threads, "kind": "reference",
+                                   "value_loop_level": round(n_queries * n_cpu_refs / t_full_loop, 3),
+                                   "stated_baseline": "value (per-query cost = median of thread 0's own timers).  value_loop_level takes the per-query cost from the arrival times of "
+                                                      "'Start Map 1' and 'parallel_for execution finished' instead, which also holds the threads' sketch-phase imbalance and is the LOWER "
+                                                      "CPU figure; the higher one is the stated baseline because it is the conservative one for every GPU / CPU ratio",
                                    "cpu_model": hi["cpu_model"], "logical_cpus": hi["logical_cpus"], "physical_cores": hi["physical_cores"],
                                    "fixed_s": round(fixed, 2), "marginal_s_per_query": round(m_q, 3), "extrapolated_full_workload_s": round(t_full, 1),
                                    "measured": tl,
@@ -424,6 +430,21 @@ def cpu_legs(args, engine, params, rows, n_refs, query_ids, L):
         parity["ok"] = all(v.get("ok", True) for v in parity.values() if isinstance(v, dict))
         out["parity_timed_rows"] = parity
     return out
+
+
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) over the library's sources: identifies the code a PMC traffic file was taken on (tools/pmc_traffic.py writes it)"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "fastani_amd", "csrc")
+    names = []
+    for d, _, files in os.walk(base):
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".sh")):
+                names.append(os.path.join(d, f))
+    for fn in sorted(names):
+        h.update(os.path.relpath(fn, base).encode()); h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def int_ops_block(c, steps, fused=False):
@@ -1114,23 +1135,43 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
                           "waves per SIMD, profiles/r02X_pmc_sq_summary.txt); since round 4 the simulation of a chunk runs on a side stream beside the next chunk's "
                           "codes kernel (ANI_L2_OVERLAP=0 serialises them: stage +3.6 ms), so the two kernels' own durations — HIP events here, rocprofv3 in "
                           "profiles/ — are those of kernels that share the machine and add up to more than the stage; the stage figure (achieved / frac) is the one to read")
-    # HBM traffic of the dominant kernel from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction
-    # + WRITE_SIZE, per launch) — only quoted when it is this default workload
+    # what binds, beside the accounting convention (`bound` keeps the contract's vocabulary: hbm | mfma)
+    roof["accounting"] = "hbm"
+    roof["binds"] = {"what": "vector instruction issue", "evidence": "profiles/r02X_pmc_sq_summary.txt (SQ counters: VALU wave-instructions x 4 cycles = 86 % of k_l2_sim's SIMD cycles), "
+                                                                        "tools/ubench/valu.hip (every wave64 instruction ~4 SIMD cycles); exceptions: k_l1_probe (random reads, 0.75 of the "
+                                                                        "measured random-read rate, tools/ubench/gather.hip) and the k_l1 gathers (memory-paced)"}
+    # every stage against SURVEY.md section 8d's own bytes: sketch G/4 + 12 M (+ 4 F s, fused pass), index 24 M, L1 4 F s + 8 H, L2 sum(12 m_c + 4 s), reducer 112 B per mapping
+    st_bytes = {"sketch": c["refBases"] / 4.0 + 12.0 * c["refMinimizers"] + (4.0 * c["querySketchHashes"] if fused else c["queryBases"] / 4.0 + 4.0 * c["querySketchHashes"]),
+                "index": 24.0 * c["refMinimizers"], "L1": 4.0 * c["l1Probes"] + 8.0 * c["seedHits"], "L2": l2_bytes, "reduce": 112.0 * c["l1Candidates"]}
+    st_ms = {"sketch": c["msSketch"] + c["msFragSketch"], "index": c["msIndex"], "L1": c["msL1"], "L2": c["msL2"], "reduce": c["msReduce"]}
+    roof["stages"] = {k: {"algorithmic_bytes_per_step": round(st_bytes[k] / args.steps, 1), "ms_per_step": round(st_ms[k] / args.steps, 3),
+                          "achieved": round(st_bytes[k] / (st_ms[k] / 1e3) / 1e9, 2) if st_ms[k] > 0 else None, "unit": "GB/s",
+                          "frac": round(st_bytes[k] / (st_ms[k] / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if st_ms[k] > 0 else None, "counter_traffic_ratio": None} for k in st_bytes}
+    roof["stages_note"] = ("bytes = SURVEY.md section 8d's per-stage figures from this run's counters (reduce: 112 B x candidates, an upper bound of the mappings); ms = HIP-event time of the stage "
+                           "on its launch stream; counter_traffic_ratio = HBM bytes of the stage's kernels from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes")
+    # HBM traffic from the committed PMC passes of the same workload (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch).  The
+    # passes are separate runs (rocprofv3 --pmc cannot ride in the timed run), so the file carries a hash of the kernel sources it was
+    # taken on: it is quoted only when that is the hash of the sources of THIS run, and only for this default workload.
     try:
         if cfg == "many-to-many" and NR == 1000 and L == 5_000_000 and world == 1 and mode == "single":
-            for tag in ("r05", "r04", "r03", "r02", "r01p"):
-                fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
-                if not os.path.exists(fn):
-                    continue
+            fn = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
+            if os.path.exists(fn):
                 tj = json.load(open(fn))
-                key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
-                hit = [k for k in tj["kernels"] if k.startswith(key)]
-                if hit:
-                    roof["traffic"] = tj["kernels"][hit[0]]["hbm_bytes_per_launch_corrected"]
-                    roof["traffic_source"] = "profiles/%s_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % tag
-                    break
-    except Exception:
-        pass
+                cur = kernel_sources_sha16()
+                if tj.get("kernel_sources_sha16") != cur:
+                    roof["traffic_note"] = "profiles/r06_pmc_traffic.json was taken on kernel sources %s, this run is on %s: not quoted" % (tj.get("kernel_sources_sha16"), cur)
+                else:
+                    key = {"ani::k_l2_sim": "void ani::k_l2_sim<ani::L2Geom<255> >"}.get(dom, dom)
+                    hit = [k for k in tj["kernels"] if k.startswith(key)]
+                    if hit:
+                        roof["traffic"] = tj["kernels"][hit[0]]["hbm_bytes_per_launch_corrected"]
+                        roof["traffic_source"] = ("profiles/r06_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, kernel sources %s = this run's)" % cur)
+                    psteps = max(1, int(tj.get("steps", 1)))
+                    for stg, tot in (tj.get("stage_hbm_bytes_total") or {}).items():
+                        if stg in roof["stages"] and st_bytes[stg] > 0:
+                            roof["stages"][stg]["counter_traffic_ratio"] = round((tot / psteps) / (st_bytes[stg] / args.steps), 2)
+    except Exception as ex:
+        roof["traffic_note"] = "traffic file unreadable: %r" % (ex,)
     if dom in ("ani::k_l2_sim", "ani::k_l2_codes"):          # one launch of each per L2 chunk
         launches = max(1, c["l2Launches"])
         roof.update({"launches": int(launches), "avg_launch_ms": round(ms / launches, 4),
@@ -1194,6 +1235,10 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
         out["parity_timed_rows"]["ok"] = out["parity_timed_rows"]["vs_oracle"]["ok"]
     if "cpu_baseline" not in out:
         out["cpu_baseline"] = None
+    if out.get("end_to_end"):
+        # SURVEY.md section 8d's wall-clock metric beside the contract's device-resident `value`
+        out["value_wall"] = {"value": out["end_to_end"]["pairs_per_s"], "unit": "pairs/s", "seconds": out["end_to_end"]["seconds"],
+                             "what": "the same 1000 x 1000 job through the command line: first FASTA byte read -> output file closed (end_to_end)"}
     import resource
     out["host_max_rss_gb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0, 2)       # this process, checks included
     return out
