@@ -1093,7 +1093,6 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
         "ani::k_l2_sim": (c["msL2Kernel"], l2_bytes - (12.0 * c["l2WindowEntriesB"] + 4.0 * c["l2QueryHashesB"]),
                           "class-A launches (k_l2_sim<L2Geom<255>>): 12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per class-A candidate"),
         "ani::k_l2_codes": (c["msL2Codes"], l2_bytes, "12 B x reference minimizers in the candidate range + 4 B x fragment sketch size, per candidate (the SAME bytes as k_l2_sim: the two kernels share one set of algorithmic bytes, see roofline.stage)"),
-        "ani::k_l2_trim_eval+apply": (c["msL2Trim"], 4.0 * 240.0 * c["l2TrimmedCandidates"], "range trimming: ~240 reference hashes of the probed super-window per trimmed candidate (its time is part of the L2 stage)"),
         "ani::k_l2": (c["msL2Slow"], l2_bytes * (c["l2SlowCandidates"] / max(1, c["l1Candidates"])), "general L2 kernel, share of the L2 bytes by candidate count"),
         "ani::k_l1_probe": (c["msL1Probe"], 4.0 * c["l1Probes"], "4 B x fragment sketch hashes probed (per index chunk)"),
         "ani::k_l1<0,2048>": (c["msL1Main"], 8.0 * c["seedHits"], "8 B x seed hits (all LDS classes; the small class handles nearly all fragments)"),
@@ -1202,8 +1201,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
            "stage_ms_per_step_rank0": stages, "host_timeline_ms_per_step_rank0": host_timeline, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
            "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                           "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
-                                                                          "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments", "l1TinyFragments",
-                                                                          "l2TrimmedEntries", "l2TrimmedCandidates")},
+                                                                          "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "cgiRows", "indexChunkBuilds", "l1Probes", "l1MidFragments", "l1TinyFragments")},
            "roofline": roof}
     if sim:
         out["simulated"] = {"world": R.W, "rank": R.r, "what": "value = %d x %d pairs / the time ONE rank of a %d-GPU strong-scaling job computes (sketch + index of its %d genomes, %d mapping calls: its own set, the others merged); "

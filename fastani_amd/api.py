@@ -47,8 +47,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("refBases", "refMinimizers", "refUniqueHashes", "queryGenomes", "queryFragments",
                                           "queryBases", "querySketchHashes", "seedHits", "l1Candidates", "l2WindowEntries",
                                           "l2Steps", "l2QueryHashes", "l2WindowEntriesB", "l2QueryHashesB", "l2Launches", "l2FastCandidates", "l2SlowCandidates", "l2SlowLimit", "l2SlowDup", "l2SlowOverflow", "mappings", "cgiRows", "indexChunks", "l1Probes", "l2ChunkHalvings", "indexChunkBuilds", "l1BigFragments", "l1MidFragments", "l1TinyFragments")] + \
-               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main", "msL1Big", "msL1Tiny")] + \
-               [("l2TrimmedEntries", C.c_uint64), ("l2TrimmedCandidates", C.c_uint64), ("msL2Trim", C.c_double)]
+               [(n, C.c_double) for n in ("msSketch", "msIndex", "msFragSketch", "msL1", "msL2", "msReduce", "msL2Kernel", "msL2Ranges", "msL2Codes", "msL2Slow", "msL2SimB", "msL1Probe", "msL1Main", "msL1Big", "msL1Tiny")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -91,6 +90,7 @@ def _bind(lib):
         "ani_sketch_writer_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
         "ani_sketch_writer_add": (C.c_int, [vp, vp, vp]),
         "ani_sketch_writer_close": (C.c_int, [vp]),
+        "ani_sketch_writer_abort": (None, [vp]),
         "ani_device_memory": (C.c_int, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "ani_pool_prewarm_index": (C.c_int, [vp, C.c_uint64]),
         "ani_pool_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
@@ -423,6 +423,28 @@ class SketchWriter:
         if self.h:
             h, self.h = self.h, None
             self.e._chk(self.e.lib.ani_sketch_writer_close(h))
+
+    def abort(self):
+        """give the file up (it is removed)"""
+        if self.h:
+            h, self.h = self.h, None
+            self.e.lib.ani_sketch_writer_abort(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+        else:
+            self.abort()
+        return False
+
+    def __del__(self):
+        try:
+            self.abort()             # a writer dropped without close(): no half-written file stays behind
+        except Exception:
+            pass
 
 
 class Sketch:

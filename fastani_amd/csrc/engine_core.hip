@@ -68,7 +68,7 @@ void add_counters(ani_counters_t *d, const ani_counters_t *s)
   ADD(l2SlowLimit); ADD(l2SlowDup); ADD(l2SlowOverflow); ADD(mappings); ADD(cgiRows); ADD(indexChunks); ADD(l1Probes); ADD(l2ChunkHalvings); ADD(indexChunkBuilds);
   ADD(l1BigFragments); ADD(l1MidFragments); ADD(l1TinyFragments);
   ADD(msSketch); ADD(msIndex); ADD(msFragSketch); ADD(msL1); ADD(msL2); ADD(msReduce); ADD(msL2Kernel); ADD(msL2Ranges); ADD(msL2Codes); ADD(msL2Slow); ADD(msL2SimB);
-  ADD(msL1Probe); ADD(msL1Main); ADD(msL1Big); ADD(msL1Tiny); ADD(l2TrimmedEntries); ADD(l2TrimmedCandidates); ADD(msL2Trim);
+  ADD(msL1Probe); ADD(msL1Main); ADD(msL1Big); ADD(msL1Tiny);
 #undef ADD
 }
 
@@ -155,9 +155,6 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_DUP_PAIR_CAP")) { const long long v = atoll(ev); if (v >= 1) c->dupPairCap = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L1_TINY")) c->l1Tiny = strcmp(ev, "0") != 0;
   if (const char *ev = getenv("ANI_L2_OVERLAP")) c->l2Overlap = strcmp(ev, "0") != 0;
-  if (const char *ev = getenv("ANI_L2_TRIM")) c->l2Trim = strcmp(ev, "0") != 0;
-  if (const char *ev = getenv("ANI_MAP_PIPELINE")) c->mapPipeline = strcmp(ev, "0") != 0;
-  if (const char *ev = getenv("ANI_MAP_PIPELINE_MIN_FRAGS")) { const long long v = atoll(ev); if (v >= 1) c->mapPipelineMinFrags = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L1_HIT_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l1HitLimit = std::min<uint64_t>((uint64_t)v, 0x7ffffff0ull); }
   if (const char *ev = getenv("ANI_CAND_POOL_MIN")) { const long long v = atoll(ev); if (v >= 1) c->candPoolMin = (uint64_t)v; }
   if (const char *ev = getenv("ANI_L1_BIG_GROUP_HITS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupHits = (uint64_t)v; }
@@ -174,15 +171,13 @@ int ani_init(int device, ani_ctx **out)
 void ani_shutdown(ani_ctx *c)
 {
   if (!c) return;
-  if (c->helper) { ani_shutdown(c->helper); c->helper = nullptr; }
   (void)hipSetDevice(c->device);
   DevBuf *bufs[] = {&c->dCounters, &c->seqPacked, &c->seqAscii, &c->contigOff, &c->contigLen, &c->contigMode, &c->sortTmp, &c->unitStart, &c->unitAux, &c->tiles, &c->tileInfo, &c->tileMeta, &c->tileCnt,
                     &c->tileDrop, &c->tileOff, &c->poolHash, &c->poolWpos, &c->scanTmpA, &c->scanTmpB, &c->scanTmpC, &c->scanTmpD, &c->frags, &c->fragOff, &c->fragS,
                     &c->fragGenome, &c->fragQSeq, &c->qPool, &c->probeFirst, &c->probeCnt, &c->l1MidList, &c->l1SmallList, &c->l1BigList, &c->l1BigHitsA, &c->l1BigHitsB, &c->l1BigV, &c->l1BigTbl, &c->l1BigHash, &c->candFrag, &c->candSeq, &c->candStart, &c->candEnd, &c->fragCandOff, &c->fragCandCnt,
                     &c->fragCandCntClamped, &c->fragHits, &c->fragOrdOff, &c->fragOrder, &c->fragOrderTmp, &c->ocFrag, &c->ocSeq, &c->ocStart, &c->ocEnd, &c->l2Scratch, &c->l2Ranges[0], &c->l2CodeCount[0], &c->l2CodeOff[0], &c->l2Codes[0], &c->l2SlowFlag[0], &c->l2ClassList[0], &c->l2Order[0], &c->l2LenHist[0],
                     &c->l2Ranges[1], &c->l2CodeCount[1], &c->l2CodeOff[1], &c->l2Codes[1], &c->l2SlowFlag[1], &c->l2ClassList[1], &c->l2Order[1], &c->l2LenHist[1], &c->l2SlowList, &c->l2Best,
-                    &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows,
-                    &c->ocSlot, &c->candProf, &c->l2TrimSel[0], &c->l2TrimSel[1]};
+                    &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); if (c->evIndex[i]) (void)hipEventDestroy(c->evIndex[i]); }

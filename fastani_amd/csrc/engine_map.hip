@@ -67,17 +67,12 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   if (smallBatch) ccap = std::min<uint64_t>(std::max<uint64_t>(ccap, ctx->smallBatchCandCap), kCandLimit);
   TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
   unsigned nMid = 0, nBig = 0; unsigned long long nTiny = 0, nSmall = 0;
-  // L2 range trimming (l2.hpp: k_l2_trim_eval): L1 writes a hit profile per candidate.  Needs the fast path's geometry (14-bit window
-  // links) and a window wider than a profile bin can be.
-  const int32_t cmwAll = L - (w - 1) - (k - 1);
-  const bool trim = ctx->l2Trim && cmwAll >= 1 && cmwAll + 2 <= (int)kWinMask && !(getenv("ANI_L2_PATH") && !strcmp(getenv("ANI_L2_PATH"), "general"));
   std::vector<int32_t> bigFrags, bigInfo;          // fragments beyond the LDS classes and their (sketch size, seed hits)
   unsigned long long hitsTotal = 0;
   uint32_t probeOverflow = 0;                       // fragments k_l1_probe marked with >= 2^31 seed hits: latched after attempt 0 (the probe runs once)
   for (int attempt = 0;; attempt++) {
     ccap = (uint64_t)stripe_cap(ccap) * kPoolStripes;
     TRY(ctx->candFrag.ensure(ccap * 4)); TRY(ctx->candSeq.ensure(ccap * 4)); TRY(ctx->candStart.ensure(ccap * 4)); TRY(ctx->candEnd.ensure(ccap * 4));
-    if (trim) TRY(ctx->candProf.ensure(ccap * (size_t)kProfBins));
     if (attempt == 0) TRY(zero_counters(ctx));
     else TRY(zero_cursors(ctx, POOL_CAND));            // only the candidate pool is redone: k_l1_probe's results (CNT_HITS, CNT_NEG = its overflow marker, the class lists) stay
     L1Args a;
@@ -95,7 +90,6 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     a.midList = ctx->l1MidList.as<int32_t>(); a.midCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTM);
     a.bigList = ctx->l1BigList.as<int32_t>(); a.bigCount = (unsigned int *)cnt_ptr(ctx, CNT_LISTBIG);
     a.overflowCount = (unsigned int *)cnt_ptr(ctx, CNT_NEG); a.hitLimit = ctx->l1HitLimit;
-    a.candProf = trim ? ctx->candProf.as<uint32_t>() : nullptr;
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
       if (attempt == 0) {
@@ -218,16 +212,14 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     TRY(device_scan(ctx, ctx->fragCandCntClamped.as<int32_t>(), ctx->fragOrdOff.as<uint32_t>(), (uint32_t)nF, &nCand));
     if (nCand) {
       TRY(ctx->ocFrag.ensure(nCand * 4)); TRY(ctx->ocSeq.ensure(nCand * 4)); TRY(ctx->ocStart.ensure(nCand * 4)); TRY(ctx->ocEnd.ensure(nCand * 4));
-      if (trim) TRY(ctx->ocSlot.ensure(nCand * 4));
       hipLaunchKernelGGL(k_l1_order, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, ctx->fragCandOff.as<uint32_t>(), ctx->fragCandCntClamped.as<int32_t>(),
                          ctx->fragOrdOff.as<uint32_t>(), fragOrder, (int32_t)nF, ctx->candSeq.as<int32_t>(), ctx->candStart.as<int32_t>(), ctx->candEnd.as<int32_t>(),
-                         ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(), ctx->ocStart.as<int32_t>(), ctx->ocEnd.as<int32_t>(), trim ? ctx->ocSlot.as<uint32_t>() : (uint32_t *)nullptr);
+                         ctx->ocFrag.as<int32_t>(), ctx->ocSeq.as<int32_t>(), ctx->ocStart.as<int32_t>(), ctx->ocEnd.as<int32_t>());
       HIP_TRY(hipGetLastError());
     }
   }
   *nCandOut = (int32_t)nCand;
   ctx->counters.l1Candidates += nCand;
-  if (ctx->l1Done) ctx->l1Done->store(1, std::memory_order_release);      // (pipelined sub-batches, map_fragsets: the other thread's L1 may start beside this sub-batch's L2)
   if (nCand == 0) return ANI_OK;
 
   // ---- L2 ----
@@ -260,7 +252,6 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     for (int p = 0; p < 2; p++) {
       TRY(ctx->l2Ranges[p].ensure(CH * sizeof(L2Range))); TRY(ctx->l2CodeCount[p].ensure(CH * 4)); TRY(ctx->l2CodeOff[p].ensure(CH * 4));
       TRY(ctx->l2SlowFlag[p].ensure(CH * 4)); TRY(ctx->l2ClassList[p].ensure(CH * 4));
-      if (trim) TRY(ctx->l2TrimSel[p].ensure(CH * 8));
       TRY(ctx->l2Order[p].ensure(CH * 4)); TRY(ctx->l2LenHist[p].ensure((kL2LenBuckets + 4) * 4));
     }
     TRY(ctx->l2SlowList.ensure(nCand * 4));
@@ -282,8 +273,6 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       fa.g = a; fa.c0 = (int32_t)c0; fa.c1 = (int32_t)c1;
       fa.ranges = ctx->l2Ranges[p].as<L2Range>(); fa.codeCount = ctx->l2CodeCount[p].as<int32_t>(); fa.codeOff = ctx->l2CodeOff[p].as<uint32_t>();
       fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag[p].as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.fragOrder = fragOrder; fa.nFrag = (int32_t)nF;
-      fa.candProf = trim ? ctx->candProf.as<uint32_t>() : nullptr; fa.candSlot = trim ? ctx->ocSlot.as<uint32_t>() : nullptr; fa.trimSel = trim ? ctx->l2TrimSel[p].as<int32_t>() : nullptr;
-      fa.sumTrimEntries = cnt_ptr(ctx, CNT_TRIM_E); fa.sumTrimCands = cnt_ptr(ctx, CNT_TRIM_C);
       // fragments that own candidates c0 and c1-1 (ordOff is non-decreasing; fragments without candidates repeat a value)
       const int32_t fA = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)c0) - ordOff) - 1;
       const int32_t fB = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)(c1 - 1)) - ordOff) - 1;
@@ -295,12 +284,6 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         hipLaunchKernelGGL(k_l2_ranges, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);
       }
       fa.nFragChunk = fB - fA + 1;
-      if (trim && fa.allowFast) {
-        // the ranges shrink to the placements that can still reach the best one (l2.hpp): before the streams are sized
-        StageTimer tk(ctx, &ctx->counters.msL2Trim, 1);
-        hipLaunchKernelGGL(k_l2_trim_eval, dim3((unsigned)((fa.nFragChunk + 7) / 8 * 8)), dim3(kTPB), 0, ctx->stream, fa);
-        hipLaunchKernelGGL(k_l2_trim_apply, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);
-      }
       uint64_t nCodes = 0;
       {
         const int rc = device_scan(ctx, fa.codeCount, ctx->l2CodeOff[p].as<uint32_t>(), (uint32_t)n, &nCodes, ctx->l2CodeLimit);
@@ -391,7 +374,6 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   ctx->counters.l2WindowEntries += host[CNT_ENTRIES] + host[CNT_ENTRIES_B]; ctx->counters.l2Steps += host[CNT_STEPS] + host[CNT_STEPS_B];
   ctx->counters.l2QueryHashes += host[CNT_SUMQ] + host[CNT_SUMQ_B];
   ctx->counters.l2WindowEntriesB += host[CNT_ENTRIES_B]; ctx->counters.l2QueryHashesB += host[CNT_SUMQ_B];
-  ctx->counters.l2TrimmedEntries += host[CNT_TRIM_E]; ctx->counters.l2TrimmedCandidates += host[CNT_TRIM_C];
   ctx->counters.l2SlowLimit += host[CNT_REASON + 1]; ctx->counters.l2SlowDup += host[CNT_REASON + 2]; ctx->counters.l2SlowOverflow += host[CNT_REASON + 3];
   return ANI_OK;
 }
@@ -491,11 +473,7 @@ int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_frags
 {
   std::vector<SubBatch> sub;
   int maxS = 0;
-  // pipelined sub-batches (below) want at least four of about equal size: a quarter of the call's fragments each, within bounds
-  uint64_t totalFrags = 0;
-  for (const ani_fragset *f : sets) totalFrags += (uint64_t)f->fs.nFrag;
-  const bool pipeline = ctx->mapPipeline && !sk->streaming && totalFrags >= ctx->mapPipelineMinFrags;
-  const uint64_t subFrags = pipeline ? std::min<uint64_t>(ctx->subBatchFragments, std::max<uint64_t>(std::max<uint64_t>(ctx->mapPipelineMinFrags / 4, 1), (totalFrags + 3) / 4 + 8)) : ctx->subBatchFragments;
+  const uint64_t subFrags = ctx->subBatchFragments;
   for (size_t si = 0; si < sets.size(); si++) {
     const ani_fragset *f = sets[si];
     if (f->device != ctx->device) return fail(ANI_ERR_ARG, "fragment set lives on device %d, context on %d", f->device, ctx->device);
@@ -525,53 +503,7 @@ int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_frags
     }
   }
   if (!sk->streaming) {
-    if (!(pipeline && sub.size() >= 2)) {
-      for (const SubBatch &sb : sub) TRY(map_fragset(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, rows, sb.queryIds));
-      return ANI_OK;
-    }
-    // Two host threads, two contexts of this device (own streams, pools, counters): this thread takes the even sub-batches, the
-    // second one the odd ones and starts when the first sub-batch's L1 kernels are through, so that from then on the L1 kernels of
-    // one (memory-paced: the seed probe and the hit gathers wait for random lines) run beside the L2 kernels of the other (vector-
-    // issue-bound).  Measured with two contexts driven from outside the library: 140.5 -> 131.8 ms per 1000 x 1000 mapping
-    // (profiles/r05a_overlap_probe.txt).  A sub-batch's rows are independent of every other's; they are appended in order.
-    if (!ctx->helper) { TRY(ani_init(ctx->device, &ctx->helper)); ctx->helper->mapPipeline = false; }
-    ani_ctx *hx = ctx->helper;
-    TRY(upload_luts(sk, maxS));                      // once, before two threads look at the tables
-    std::vector<RowBuf> part(sub.size());
-    std::atomic<int> l1Done{0}; std::atomic<bool> stop{false};
-    int rcB = ANI_OK; std::string errB;
-    ctx->l1Done = &l1Done;
-    std::thread second([&]() {
-      (void)hipSetDevice(hx->device);
-      while (!l1Done.load(std::memory_order_acquire) && !stop.load()) std::this_thread::yield();
-      for (size_t i = 1; i < sub.size() && !stop.load(); i += 2) {
-        const SubBatch &sb = sub[i];
-        rcB = map_fragset(hx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, &part[i], sb.queryIds);
-        if (rcB != ANI_OK) { errB = ani_last_error(); stop.store(true); break; }
-      }
-    });
-    int rcA = ANI_OK;
-    for (size_t i = 0; i < sub.size() && !stop.load(); i += 2) {
-      const SubBatch &sb = sub[i];
-      rcA = map_fragset(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, &part[i], sb.queryIds);
-      if (rcA != ANI_OK) { stop.store(true); break; }
-    }
-    l1Done.store(1);                                 // (a first sub-batch that failed before its L1 finished must not leave the second thread waiting)
-    second.join();
-    ctx->l1Done = nullptr;
-    flush_timers(hx);
-    add_counters(&ctx->counters, &hx->counters);
-    memset(&hx->counters, 0, sizeof hx->counters);
-    if (rcA != ANI_OK) return rcA;
-    if (rcB != ANI_OK) return fail(rcB, "%s", errB.c_str());
-    for (RowBuf &pb : part) {
-      if (!pb.n) continue;
-      ani_cgi_t *out = rows->grow(pb.n);
-      if (!out) return fail(ANI_ERR_NOMEM, "host allocation of %zu result rows failed", pb.n);
-      memcpy(out, pb.p, pb.n * sizeof(ani_cgi_t));
-      rows->n += pb.n;
-      free(pb.p); pb.p = nullptr; pb.n = pb.cap = 0;
-    }
+    for (const SubBatch &sb : sub) TRY(map_fragset(ctx, sk, sb.v, sb.g1 - sb.g0, sb.firstQueryId, rows, sb.queryIds));
     return ANI_OK;
   }
   TRY(upload_luts(sk, maxS));

@@ -356,15 +356,6 @@ struct ani_ctx {
   uint64_t dupPairCap = 0;                                                           // first guess of the same-hash link list (env ANI_DUP_PAIR_CAP, tests: forces the rerun)
   bool l1Tiny = true;                                                               // env ANI_L1_TINY=0: fragments with <= 64 seed hits take the workgroup path like the others
   bool l2Overlap = true;                                                            // the L2 simulation on the side stream, beside the next chunk's ranges / codes kernels (env ANI_L2_OVERLAP=0 switches it off; see the L2 loop)
-  bool l2Trim = false;                                                              // L2 ranges trimmed by the hit profiles of L1 (l2.hpp: k_l2_trim_eval / _apply; env ANI_L2_TRIM=1).  Exact, removes 42 % of the
-                                                                                    // placements of the benchmark — and costs more than it saves (profiles/r05h_trim_ab_no_overlap.txt): off by default, kept with its tests
-  bool mapPipeline = false;                                                         // sub-batches of a resident set mapped by two host threads on two contexts of this device, so that one's L1 kernels
-                                                                                    // (memory-paced) meet the other's L2 kernels (issue-bound); env ANI_MAP_PIPELINE=1 (map_fragsets).  Measured: the 1000 x 1000
-                                                                                    // step 200.7 -> 197.9 ms (profiles/r05i_map_pipeline_ab.txt) — the kernels slow each other by nearly what they overlap, and the
-                                                                                    // per-stage event timers become sums over overlapping kernels; off by default, kept with its tests
-  uint64_t mapPipelineMinFrags = (uint64_t)1 << 18;                                 // ... for calls with at least this many fragments (env ANI_MAP_PIPELINE_MIN_FRAGS: tests)
-  ani_ctx *helper = nullptr;                                                        // ... the second context (created on first use, shut down with this one)
-  std::atomic<int> *l1Done = nullptr;                                               // ... set by map_stage when a sub-batch's L1 kernels are through (the second thread starts behind the first one's L1)
   uint64_t l1HitLimit = 0x7ffffff0ull;                                              // seed hits per fragment and index chunk (32-bit hit offsets; env ANI_L1_HIT_LIMIT, tests)
   uint64_t candPoolMin = 4096;                                                      // floor of the L1 candidate pool, per stripe (env ANI_CAND_POOL_MIN, tests: forces the retry path)
   uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;              // seed hits / fragments per group of the batched global-memory L1 path (env ANI_L1_BIG_GROUP_HITS / _FRAGS, tests)
@@ -393,9 +384,9 @@ struct ani_ctx {
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
   DevBuf probeFirst, probeCnt, l1MidList, l1SmallList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
-  DevBuf ocFrag, ocSeq, ocStart, ocEnd, ocSlot, candProf;                    // ocSlot / candProf: pool slot of every ordered candidate, hit profiles by pool slot (range trimming)
+  DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
-  DevBuf l2TrimSel[2], l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
+  DevBuf l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
   DevBuf l2SlowList;
   DevBuf bins, queryFragments, rows;
 };
@@ -452,7 +443,7 @@ struct ani_sketch {
 namespace anih {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_ENTRIES_B = 19, CNT_SUMQ_B = 20, CNT_STEPS_B = 21, CNT_TINY = 22, CNT_SMALL = 23, CNT_TRIM_E = 24, CNT_TRIM_C = 25, CNT_N = 26 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_ENTRIES_B = 19, CNT_SUMQ_B = 20, CNT_STEPS_B = 21, CNT_TINY = 22, CNT_SMALL = 23, CNT_N = 24 };
 
 
 inline unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }

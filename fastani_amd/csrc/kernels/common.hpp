@@ -24,7 +24,7 @@ constexpr uint32_t kMurmurSeed = 42;  // commonFunc.hpp:32
 // Statistics counters (sums only, never cursors) are striped over kStatStripes copies of the counter block so that the
 // per-wave atomics of a large grid do not serialise on one address; the host adds the stripes up.
 constexpr int kStatStripes = 32;
-constexpr int kStatStripeWords = 26;   // 64-bit words per stripe (= number of counters)
+constexpr int kStatStripeWords = 24;   // 64-bit words per stripe (= number of counters)
 __device__ __forceinline__ unsigned long long *stat_slot(unsigned long long *base) { return base + (blockIdx.x & (kStatStripes - 1)) * kStatStripeWords; }
 
 // Bump allocation out of a pool, one request per workgroup.  A returning atomicAdd on ONE address costs 12 ns on MI355X however many

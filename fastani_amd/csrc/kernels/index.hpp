@@ -16,14 +16,6 @@ namespace ani {
 constexpr uint32_t kWinMask = 0x3fffu, kWinMoreBit = 1u << 30, kWinDupBit = 1u << 31;
 constexpr int kWinShiftA = 14;
 
-// Hit profile of an L1 candidate (round 5; l1.hpp writes it, l2.hpp: k_l2_trim_eval reads it): kProfBins saturating byte counters,
-// bin b = the fragment's seed hits on the candidate's contig with wpos in [start + b * delta, start + (b + 1) * delta), where
-// [start, end + L) are the positions the candidate's L2 range covers (computeMap.hpp:424-436) and delta = prof_delta(...).  A
-// super-window that starts at position pos holds at most 1 + (hits in [pos, pos + cmw)) of them (the "1": the sticky first entry of
-// MIIteratorL2, the only one that may lie before pos), which bounds sharedSketchElements of that window from above.
-constexpr int kProfBins = 64;
-__host__ __device__ __forceinline__ int32_t prof_delta(int32_t start, int32_t end, int32_t L) { return ((end + L - start) + kProfBins - 1) / kProfBins; }
-
 // (records -> position-ordered SoA arrays: written by the histogram read of the index sort, radix.hpp: k_radix_histogram)
 
 // Same-hash links.  The sliding map of the reference is a SET (slidingMap.hpp:150-154, :178): an entry whose hash already sits in the

@@ -45,11 +45,7 @@ struct L1Args {
   int filterMinHits;                    // kL1FilterMinHits (ANI_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
   int ldsHitCap;                        // fragments with more seed hits take the batched global-memory path (<= kL1HitCapMax; ANI_L1_LDS_MAX)
   int tinyPath;                         // fragments with <= 64 seed hits are finished by one wave (l1_tiny; ANI_L1_TINY=0 switches it off: A/B and tests)
-  uint32_t *candProf;                   // [candidate pool][kProfBins / 4]: hit profile of every candidate (index.hpp: kProfBins), or nullptr (range trimming off)
 };
-constexpr int kL1ProfCands = 96;        // candidates per fragment that get a real profile: V's 8 KiB hold 96 x 64 bytes of profiles and, behind them, 96 x 16 bytes
-                                        // of descriptors (no LDS of their own: 2 KiB more took k_l1<0, 2048> from six workgroups per CU to five); the rest: "unknown" (all 0xff)
-constexpr int kL1ProfCandsTiny = 12;    // ... of the wave kernel (1 KiB of V per wave)
 
 // Counter indices of a hit's two tiles for the noise filter (k_l1): tiles of width 2^shift, the second tiling offset by half a tile.
 // The xor-shift between the two multiplications matters: without it the index is (seqId * K) >> n for hits in tile 0 of consecutive
@@ -86,51 +82,8 @@ __device__ __forceinline__ bool l1_head(const uint64_t *hits, const int *V, int 
 }
 
 // Sorted hits -> candidate regions of one fragment (computeMap.hpp:313-354).  hits/V may live in LDS or in global memory.
-// Hit profiles of a fragment's candidates (index.hpp: kProfBins; round 5).  Two steps around a barrier:
-//   l1_profile_desc  thread g describes candidate g — (seqId, start, stop = end + L, magic multiplier of its bin width) — from the run
-//                    indices of the group's first and last run (jh, jl).  A candidate whose bins would be wider than 255 positions (a
-//                    range of more than ~16 000 positions: merged groups over repeats) gets no profile (magic = 0 -> "unknown").
-//   l1_profile_fill  one thread per HIT: the candidates whose range [start, stop) holds the hit (binary search over the descriptors,
-//                    which are ordered like the hits; neighbouring ranges of one contig may overlap) get one more in the hit's bin — a
-//                    byte of a packed dword, by LDS atomic; a bin cannot overflow, because a contig has at most one minimizer per
-//                    position and a bin is at most 255 positions wide.  EVERY hit of the fragment inside a range counts, member of the
-//                    candidate's runs or not (the noise filter never drops one of them: each lies within < L of a hit of the group).
-// (The first form gave every candidate to one thread that walked its hits: ~17 busy lanes and a chain of ~100 dependent LDS reads per
-// workgroup — k_l1<0, 2048> 33 -> 61 ms per benchmark step, profiles/r05b_trim_first_form_ab.txt.)
-struct L1ProfDesc { uint64_t keyStop; int32_t start; uint32_t magic; };      // keyStop = seqId << 32 | (end + L): ordered like the hits' keys
-static_assert(sizeof(L1ProfDesc) == 16, "descriptor layout");
-__device__ __forceinline__ L1ProfDesc l1_profile_desc(const uint64_t *hits, const int *V, int m, int L, int jh, int jl)
-{
-  const int x0 = V[jh];
-  int32_t start = hit_wpos(hits[x0 + m - 1]) - L + 1; if (start < 0) start = 0;          // = candStart (:335)
-  const int32_t end = hit_wpos(hits[V[jl]]);                                            // = candEnd (:336,:347)
-  const int32_t delta = prof_delta(start, end, L);
-  L1ProfDesc d;
-  d.keyStop = ((uint64_t)(uint32_t)hit_seq(hits[x0]) << 32) | (uint32_t)(end + L);
-  d.start = start;
-  d.magic = delta <= 255 ? (uint32_t)((1ull << 32) / (uint64_t)delta + 1ull) : 0u;       // floor(x * magic / 2^32) = x / delta for x < 64 * delta
-  return d;
-}
-__device__ __forceinline__ void l1_profile_fill(const uint64_t *hits, int n, const L1ProfDesc *desc, int nP, uint32_t *pw, int tid, int nThreads)
-{
-  for (int x = tid; x < n; x += nThreads) {
-    const uint64_t h = hits[x];
-    int lo = 0, hi = nP;                               // first candidate whose range ends behind the hit: keyStop > (seq, wpos)
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (desc[mid].keyStop <= h) lo = mid + 1; else hi = mid; }
-    const int32_t wp = hit_wpos(h);
-    for (int g = lo; g < nP; g++) {
-      const L1ProfDesc d = desc[g];
-      if ((uint32_t)(d.keyStop >> 32) != (uint32_t)(h >> 32) || d.start > wp) break;
-      if (d.magic) {
-        const uint32_t bin = (uint32_t)(((uint64_t)(uint32_t)(wp - d.start) * d.magic) >> 32);
-        atomicAdd(&pw[g * (kProfBins / 4) + (int)(bin >> 2)], 1u << ((bin & 3u) * 8u));
-      }
-    }
-  }
-}
-
 __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, int m /* minimumHits of s, :301 */, const uint64_t *hits, int *V,
-                                          int *ws, unsigned long long *sBasePtr, uint16_t *headRun /* [kL1ProfCands + 2] */)
+                                          int *ws, unsigned long long *sBasePtr)
 {
   const int t = threadIdx.x;
   if (m < 1) m = 1;                                                     // :316
@@ -162,29 +115,8 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
         if (head) {
           int32_t start = hit_wpos(hits[V[j] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
           a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[j]]); a.candStart[slot] = start;
-          if (a.candProf && g - 1 <= kL1ProfCands) headRun[g - 1] = (uint16_t)j;
         }
         if (j == nv - 1 || l1_head(hits, V, j + 1, m, a.L)) a.candEnd[slot] = hit_wpos(hits[V[j]]);   // :336,:347
-      }
-      // ---- hit profiles of the candidates (round 5: the L2 stage trims its ranges with them, l2.hpp: k_l2_trim_eval) ----
-      // thread g takes candidate g: 64 bytes of V each (V is dead once the run indices of the groups' ends are in registers), then
-      // one coalesced copy of the fragment's profiles into its run of the candidate pool
-      if (a.candProf && nG > 0) {
-        const int nP = nG < kL1ProfCands ? nG : kL1ProfCands;
-        if (t == 0 && nG <= kL1ProfCands) headRun[nG] = (uint16_t)nv;
-        block_barrier();
-        L1ProfDesc myDesc; myDesc.keyStop = 0; myDesc.start = 0; myDesc.magic = 0;
-        if (t < nP) myDesc = l1_profile_desc(hits, V, m, a.L, headRun[t], (int)headRun[t + 1] - 1);
-        block_barrier();                                                      // V is dead from here on: profiles in front, descriptors behind them
-        uint32_t *pw = (uint32_t *)V;
-        L1ProfDesc *pDesc = (L1ProfDesc *)((uint8_t *)V + kL1ProfCands * kProfBins);
-        for (int i = t; i < nP * (kProfBins / 4); i += kTPB) pw[i] = 0u;
-        if (t < nP) pDesc[t] = myDesc;
-        block_barrier();
-        l1_profile_fill(hits, H, pDesc, nP, pw, t, kTPB);
-        block_barrier();
-        uint32_t *out = a.candProf + base * (kProfBins / 4);
-        for (int i = t; i < nG * (kProfBins / 4); i += kTPB) { const int g = i / (kProfBins / 4); out[i] = (g < nP && pDesc[g].magic) ? pw[i] : 0xffffffffu; }   // beyond kL1ProfCands / too long a range: unknown
       }
     }
     if (t == 0) a.fragCandOff[f] = (uint32_t)base;
@@ -241,8 +173,6 @@ __device__ inline void l1_emit_candidates_stream(const L1Args &a, int f, int H, 
         }
         gBefore += tot;
       }
-      // (no hit profile on the batched path: "unknown" = all 0xff, which keeps the whole L2 range)
-      if (a.candProf) { uint32_t *out = a.candProf + base0 * (kProfBins / 4); for (int i = t; i < nG * (kProfBins / 4); i += kTPB) out[i] = 0xffffffffu; }
     }
     if (t == 0) a.fragCandOff[f] = (uint32_t)base0;
   } else if (t == 0) a.fragCandOff[f] = 0;
@@ -298,7 +228,8 @@ static __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
       int H = tooMany ? -1 : (int)H64;
       // Fewer seed hits than a candidate region needs (minimumHits, computeMap.hpp:316-336) find nothing: such a fragment — a third
       // of the visits of a fragment set to a foreign reference shard or index chunk, which collect two or three chance hits — counts
-      // as one without hits from here on (the LDS classes only: the batched path sizes its buffers from the probe counts).
+      // as one without hits from here on.  (Any fragment with s <= kL1MaxS, whatever path its hit count would have sent it to: below
+      // minimumHits hits there is no candidate on any path.  sumHits / seedHits still counts the dropped hits: they were probed.)
       if (H > 0 && s[q] <= kL1MaxS) { int m = s[q] <= a.lutMaxS ? a.minHitsLUT[s[q]] : 1; if (H < (m < 1 ? 1 : m)) H = 0; }
       a.fragHits[f] = H;
       if (H64) atomicAdd(stat_slot(a.sumHits), H64);
@@ -340,7 +271,7 @@ template <int KPT> __device__ __forceinline__ void l1_tiny_sort(uint64_t *hits, 
   for (int r = 0; r < KPT; r++) hits[lane * KPT + r] = k[r];
   ANI_WAVE_SYNC();
 }
-__device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, uint64_t *hits, int *V, uint16_t *headRun /* [kL1ProfCandsTiny + 2] of this wave */)
+__device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, uint64_t *hits, int *V)
 {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t off = a.fragOff[f];
@@ -392,48 +323,27 @@ __device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, ui
           if (head) {
             int32_t start = hit_wpos(hits[V[j] + m - 1]) - a.L + 1; if (start < 0) start = 0;   // :335
             a.candFrag[slot] = f; a.candSeq[slot] = hit_seq(hits[V[j]]); a.candStart[slot] = start;
-            if (a.candProf && g - 1 <= kL1ProfCandsTiny) headRun[g - 1] = (uint16_t)j;
           }
           if (j == nv - 1 || l1_head(hits, V, j + 1, m, a.L)) a.candEnd[slot] = hit_wpos(hits[V[j]]);   // :336,:347
         }
         gBefore += __popcll(hm);
-      }
-      // hit profiles (l1_emit_candidates has the workgroup form): lane g takes candidate g, 64 bytes of this wave's V each
-      if (a.candProf && nG > 0) {
-        const int nP = nG < kL1ProfCandsTiny ? nG : kL1ProfCandsTiny;
-        if (lane == 0 && nG <= kL1ProfCandsTiny) headRun[nG] = (uint16_t)nv;
-        ANI_WAVE_SYNC();
-        L1ProfDesc myDesc; myDesc.keyStop = 0; myDesc.start = 0; myDesc.magic = 0;
-        if (lane < nP) myDesc = l1_profile_desc(hits, V, m, a.L, headRun[lane], (int)headRun[lane + 1] - 1);
-        ANI_WAVE_SYNC();
-        uint32_t *pw = (uint32_t *)V;
-        L1ProfDesc *pDesc = (L1ProfDesc *)((uint8_t *)V + kL1ProfCandsTiny * kProfBins);
-        for (int i = lane; i < nP * (kProfBins / 4); i += kWave) pw[i] = 0u;
-        if (lane < nP) pDesc[lane] = myDesc;
-        ANI_WAVE_SYNC();
-        l1_profile_fill(hits, H, pDesc, nP, pw, lane, kWave);
-        ANI_WAVE_SYNC();
-        uint32_t *out = a.candProf + base * (kProfBins / 4);
-        for (int i = lane; i < nG * (kProfBins / 4); i += kWave) { const int g = i / (kProfBins / 4); out[i] = (g < nP && pDesc[g].magic) ? pw[i] : 0xffffffffu; }
       }
     }
     if (lane == 0) a.fragCandOff[f] = (uint32_t)base;
   } else if (lane == 0) a.fragCandOff[f] = 0;
   if (lane == 0) a.fragCandCnt[f] = nG;
 }
-static_assert(kL1HitCapTiny * 4 >= kL1ProfCandsTiny * (kProfBins + 16) && kL1HitCapSmall * 4 >= kL1ProfCands * (kProfBins + 16), "the profiles and descriptors of a fragment's candidates are staged in V");
 static __global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
 {
   __shared__ uint64_t hits[kL1TinyFrags][kL1HitCapTiny];
   __shared__ int V[kL1TinyFrags][kL1HitCapTiny];
-  __shared__ uint16_t headRun[kL1TinyFrags][kL1ProfCandsTiny + 2];
   const int wv = wave_uniform((int32_t)(threadIdx.x >> 6));                  // the wave's fragment, its counts and offsets: scalar registers
   const int i = xcd_item(blockIdx.x, gridDim.x) * kL1TinyFrags + wv;
   if (i >= a.nFrag) return;
   const int f = a.fragOrder ? a.fragOrder[i] : i;
   const int s = a.fragS[f], H = a.fragHits[f];
   if (s <= 0 || s > kL1MaxS || H <= 0 || H > kL1HitCapTiny || H > a.ldsHitCap) return;   // the workgroup classes / the batched path (same class predicate as k_l1_probe: H > ldsHitCap is bigList's) / nothing to do (k_l1<0, 2048> or k_l1_list writes the zero counts)
-  l1_tiny(a, f, s, H, hits[wv], V[wv], headRun[wv]);
+  l1_tiny(a, f, s, H, hits[wv], V[wv]);
 }
 
 // The fragments of class S (256 < H <= 2048) as a list, for batches in which they are the exception: a fragment set that meets a
@@ -481,7 +391,6 @@ static __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__r
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
   __shared__ int sKeep;
-  __shared__ uint16_t headRun[kL1ProfCands + 2];    // first run of every candidate (profile phase of l1_emit_candidates)
   int f;
   if (list) f = list[blockIdx.x];
   else {
@@ -567,7 +476,7 @@ static __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__r
   }
   block_sort<uint64_t>(hits, n);                    // :320 (starts with a barrier: the gather is complete)
 
-  l1_emit_candidates(a, f, s, n, m, hits, V, ws, &sBase, headRun);
+  l1_emit_candidates(a, f, s, n, m, hits, V, ws, &sBase);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -671,7 +580,7 @@ static __global__ void k_l1_order(const uint32_t *__restrict__ fragCandOff, cons
                            const uint32_t *__restrict__ orderedOff, const int32_t *__restrict__ order, int32_t nFrag,
                            const int32_t *__restrict__ inSeq, const int32_t *__restrict__ inStart, const int32_t *__restrict__ inEnd,
                            int32_t *__restrict__ outFrag, int32_t *__restrict__ outSeq, int32_t *__restrict__ outStart,
-                           int32_t *__restrict__ outEnd, uint32_t *__restrict__ outSlot /* pool slot of every ordered candidate (its hit profile lives there), or nullptr */)
+                           int32_t *__restrict__ outEnd)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nFrag) return;
@@ -680,7 +589,6 @@ static __global__ void k_l1_order(const uint32_t *__restrict__ fragCandOff, cons
   const uint32_t src = fragCandOff[f], dst = orderedOff[i];
   for (int j = 0; j < n; j++) {
     outFrag[dst + j] = f; outSeq[dst + j] = inSeq[src + j]; outStart[dst + j] = inStart[src + j]; outEnd[dst + j] = inEnd[src + j];
-    if (outSlot) outSlot[dst + j] = src + (uint32_t)j;
   }
 }
 

@@ -265,11 +265,6 @@ struct L2FastArgs {
   const int32_t *fragOrder;        // processing order (nullptr: fragment ascending)
   int32_t nFrag, fragBase, nFragChunk;   // first fragment of the chunk, fragments that own its candidates
   int32_t allowFast;               // test knob ANI_L2_PATH: 0 = everything to the general kernel, 2 = everything to class B
-  // range trimming (round 5, k_l2_trim_eval / k_l2_trim_apply): hit profiles of the candidates (l1.hpp) through their pool slots
-  const uint32_t *candProf;        // [pool slot][kProfBins / 4], nullptr = trimming off
-  const uint32_t *candSlot;        // [nCand] pool slot of every ordered candidate
-  int32_t *trimSel;                // [c1-c0][2] kept window-start positions [lo, hi] of a candidate, lo < 0 = keep the whole range
-  unsigned long long *sumTrimEntries, *sumTrimCands;    // entries removed from the ranges / candidates trimmed
 };
 
 // lower_bound_wpos over a contig's slice [.., cHi) through the sampled position index: the answer lies inside the target's bin
@@ -326,7 +321,7 @@ constexpr int kL2RankBuckets = 2048;
 // rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
 __device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh; return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
 
-// The fragment sketch and its rank table in LDS (k_l2_codes, k_l2_trim_eval).  st2[b] = #{q : bucket(q) < b} | entries of bucket b
+// The fragment sketch and its rank table in LDS (k_l2_codes).  st2[b] = #{q : bucket(q) < b} | entries of bucket b
 // << 16.  Counted and scanned (one LDS atomic per sketch hash on 16-bit counters packed in pairs, eight buckets per thread, one
 // workgroup scan) — the first form walked, per sketch hash, the buckets up to the next hash: a loop as long as the longest gap among
 // the 64 hashes of a wave.  cnt2: kL2RankBuckets / 2 dwords of scratch (free again when the function returns).  Ends with a barrier.
@@ -551,222 +546,6 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   batch0 = batch1; batch1 = batch0 + kL2CandBatch < cB ? batch0 + kL2CandBatch : cB;
   block_barrier();
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Range trimming (round 5).  The loop of computeMap.hpp:455-476 keeps the best sharedSketchElements over all super-window placements of
-// a candidate and the first / last placement that reaches it.  sharedSketchElements of a placement cannot exceed the number of the
-// fragment's seed hits inside that super-window, and L1 knows where the hits are: it hands over a 64-bin profile of them per candidate
-// (index.hpp: kProfBins; U(pos) = 1 + hits in [pos, pos + cmw) bounds every placement that starts at pos).  So:
-//   k_l2_trim_eval   one wave per candidate: the EXACT sharedSketchElements T of one real placement — the one in the middle of the
-//                    range, where the hits of a true alignment are densest (a histogram of its ~240 entries over the sketch's gaps,
-//                    one wave scan for the pivot; same-hash duplicates are counted as a multiset, which can only lower T) — then
-//                    the first and last 1/64th of the range whose U reaches T.  Every placement outside them has
-//                    sharedSketchElements <= U < T <= best: it can neither raise the best nor tie with it, so neither `best` nor the
-//                    first / last optimal position (:468-476) change when the scan starts and ends there.
-//   k_l2_trim_apply  one lane per candidate: the kept positions back to index entries (three searchIndex calls), the shortened
-//                    range, its event count.
-// The kept run starts at the last entry with wpos <= lo, where the untrimmed scan has a placement with exactly that window (beg =
-// that entry, end = lower_bound(its wpos + cmw)), and from there on the two scans are the same sequence of placements; it ends
-// after the last placement that starts at or before hi.  Exactness rests on U being an upper bound and T a lower one — neither the
-// choice of the probed placement nor the bin width can change a result, only how much is trimmed.
-// ---------------------------------------------------------------------------------------------------------------------------
-constexpr int kL2TrimWords = 320;         // per wave: 160 dwords = 320 16-bit counters of non-sketch hashes per gap, 160 dwords = 320 counters of sketch hashes per rank
-static_assert(kL2FastMaxS + 1 <= 320 && kProfBins == kWave, "five gaps per lane; one profile bin per lane");
-static __global__ __launch_bounds__(kTPB) void k_l2_trim_eval(L2FastArgs a)
-{
-  __shared__ uint32_t qs[kL2FastMaxS + 2];
-  __shared__ __attribute__((aligned(16))) uint32_t st2[kL2RankBuckets];
-  __shared__ __attribute__((aligned(16))) uint32_t scratch[(kTPB / kWave) * kL2TrimWords];    // the rank table's counters, then the waves' histograms
-  __shared__ int cScan[8];
-  static_assert((kTPB / kWave) * kL2TrimWords >= kL2RankBuckets / 2, "the rank table's counters fit the scratch");
-  const int32_t per = (int32_t)(gridDim.x >> 3);
-  const int32_t fl = (int32_t)(blockIdx.x & 7) * per + (int32_t)(blockIdx.x >> 3);      // XCD-aware, like k_l2_codes
-  if (fl >= a.nFragChunk) return;
-  const int32_t fi = a.fragBase + fl;
-  const int32_t f = a.fragOrder ? a.fragOrder[fi] : fi;
-  const int32_t s = a.g.fragS[f];
-  int32_t cA = (int32_t)a.fragCandOff[fi], cB = (fi + 1 < a.nFrag) ? (int32_t)a.fragCandOff[fi + 1] : a.g.nCand;
-  if (cA < a.c0) cA = a.c0;
-  if (cB > a.c1) cB = a.c1;
-  if (cA >= cB) return;
-  if (s < 1 || s > kL2FastMaxS) {                    // not on the fast path: nothing to trim
-    for (int32_t c = cA + (int32_t)threadIdx.x; c < cB; c += kTPB) a.trimSel[2 * (size_t)(c - a.c0)] = -1;
-    return;
-  }
-  const int lane = threadIdx.x & (kWave - 1), wv = wave_uniform((int32_t)(threadIdx.x >> 6));
-  const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
-  const int sh = a.g.rankShift;
-  // A candidate is a chain of dependent round trips to memory (range -> first position of the probed window; range -> its ~240
-  // entries; pool slot -> profile) in front of ~400 instructions.  Taken one at a time a wave spends its life waiting (48 ms per
-  // benchmark step); five at a time out of registers it waits less and fits fewer waves (106 registers, four waves per SIMD: 44 ms;
-  // profiles/r05b_trim_first_form_ab.txt, r05e_trim_groups_of_five_ab.txt).  This form: the scalar chains of ALL the wave's candidates
-  // run side by side, one per lane, before the workgroup builds the sketch's rank table; then the candidates are evaluated one after
-  // the other, the window entries and the profile of the next one in flight while the current one is ranked (as k_l2_codes does).
-  constexpr int kWaves = kTPB / kWave;
-  const int sEff = s;
-  for (int32_t cbase = cA; cbase < cB; cbase += kWave * kWaves) {           // (a fragment has ~17 candidates: one round)
-  const int32_t myC = cbase + wv + lane * kWaves;                           // lane j: candidate j of this wave
-  const bool mine = myC < cB;
-  L2Range mr; mr.beg0 = 0; mr.end0 = 0; mr.last = 1; mr.nEvents = -1;
-  uint32_t mSlot = 0;
-  int32_t mjS = 0, mLimit = 0, mCs = 0, mDelta = 1, mNbw = 0;
-  if (mine) {
-    const int32_t i = myC - a.c0;
-    mr = a.ranges[i];
-    if (a.codeCount[i] == 0) mr.nEvents = -1;
-    mSlot = a.candSlot[myC]; mCs = a.g.candStart[myC];
-    const int32_t ce = a.g.candEnd[myC];
-    if (mr.nEvents > 0) {
-      mjS = mr.beg0 + (((mr.last - mr.beg0) - (mr.end0 - mr.beg0)) >> 1);         // the placement that starts at the middle entry of the range
-      mLimit = a.g.mWpos[mjS] + cmw;                                               // entries with wpos < limit are in its window
-      mDelta = prof_delta(mCs, ce, a.g.L);
-      mNbw = (mDelta + cmw - 2) / mDelta;                                          // a window that starts in bin k ends in bin k + nbw at most (the divisions: all candidates at once)
-    }
-  }
-  const int nMine = (cB - cbase - wv + kWaves - 1) / kWaves < kWave ? (cB - cbase - wv + kWaves - 1) / kWaves : kWave;    // candidates of this wave in this round (may be <= 0)
-  struct Win { uint32_t h[4]; int32_t w[4]; uint32_t prof; int32_t ev, jS, last; };
-  auto load_win = [&](int k, Win &o) {               // candidate k of the wave (k wave-uniform): its first 256 window entries and its profile
-    o.ev = lane_value(mr.nEvents, k); o.jS = lane_value(mjS, k); o.last = lane_value(mr.last, k);
-    const uint32_t slot = (uint32_t)lane_value((int32_t)mSlot, k);
-    o.prof = 0u;
-#pragma unroll
-    for (int e = 0; e < 4; e++) { o.h[e] = 0u; o.w[e] = 0x7fffffff; }
-    if (o.ev > 0) {
-      o.prof = a.candProf[(size_t)slot * (kProfBins / 4) + (uint32_t)(lane >> 2)];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int32_t x = o.jS + lane + e * kWave;
-        if (x < o.last) { o.h[e] = a.g.mHash[x]; o.w[e] = a.g.mWpos[x]; }
-      }
-    }
-  };
-  Win cur, nxt;
-  if (nMine > 0) load_win(0, cur);
-  if (cbase == cA) l2_rank_table(a.g.qPool + a.g.fragOff[f], sEff, sh, qs, st2, scratch, cScan);      // (workgroup-uniform: every wave is in its first round)
-  uint32_t *hw = scratch + wv * kL2TrimWords;        // this wave's counters, 16-bit pairs: [0, 160) non-sketch hashes per gap, [160, 320) sketch hashes per rank - 1
-  const uint16_t *hw16 = (const uint16_t *)hw;
-  for (int k = 0; k < nMine; k++) {
-    if (k + 1 < nMine) load_win(k + 1, nxt);
-    {
-      {
-        const int32_t c = cbase + wv + k * kWaves;
-        int32_t selLo = -1, selHi = -1;
-        if (cur.ev > 0) {
-          const int32_t gLimitG = lane_value(mLimit, k), gCsG = lane_value(mCs, k), gDeltaG = lane_value(mDelta, k), gNbwG = lane_value(mNbw, k);
-          // the candidate's profile, one bin per lane; "unknown" (0xff everywhere) and profiles without room to trim leave early
-          const int bin = (int)((cur.prof >> ((lane & 3) * 8)) & 0xffu);
-          const int pincl = wave_incl_scan_dpp(bin == 255 ? (1 << 20) : bin);
-          const int ptot = lane_value(pincl, kWave - 1);
-          if (ptot >= 3 && ptot < (1 << 20)) {
-            // ---- T: sharedSketchElements of the probed placement ----
-            { uint4 z; z.x = z.y = z.z = z.w = 0u; ((uint4 *)hw)[lane] = z; if (lane < (kL2TrimWords - 4 * kWave) / 4) ((uint4 *)hw)[kWave + lane] = z; }
-            ANI_WAVE_SYNC();
-            int32_t nIn = 0;
-            uint32_t h[4]; bool in[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) { h[e] = cur.h[e]; in[e] = cur.w[e] < gLimitG; }        // (entries beyond the range carry wpos = INT_MAX)
-            for (int32_t base = cur.jS;;) {
-              uint32_t rk[4], deep = 0;
-#pragma unroll
-              for (int e = 0; e < 4; e++) rk[e] = l2_rank_fast(qs, st2, sh, h[e], deep);
-              if (__any(deep != 0)) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) rk[e] = l2_rank_deep(qs, st2, sh, s, h[e], rk[e]);
-              }
-              int got = 0;
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                // one 16-bit counter per gap (non-sketch hash) or per rank (sketch hash: its half of the array starts at 16-bit slot 320)
-                const uint32_t slot16 = (rk[e] >> 1) + ((rk[e] & 1u) ? 320u : 0u);
-                if (in[e]) atomicAdd(&hw[slot16 >> 1], 1u << ((slot16 & 1u) << 4));
-                got += __popcll(__ballot(in[e]));
-              }
-              nIn += got;
-              if (got < 4 * kWave) break;                  // (wave-uniform) the window ends inside this pass
-              base += 4 * kWave;                           // a window of more than 256 entries (dense minimizers): the next 256, fetched now
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const int32_t x = base + lane + e * kWave;
-                const bool valid = x < cur.last;
-                h[e] = valid ? a.g.mHash[x] : 0u;
-                in[e] = valid && a.g.mWpos[valid ? x : cur.last - 1] < gLimitG;
-              }
-            }
-            ANI_WAVE_SYNC();
-            int T = 0;
-            if (cur.jS + nIn < cur.last) {                   // a placement the scan really evaluates (:455: end < last)
-              // pivot: iStar = max{i : i + sum_{g < i} n[g] <= s}; lane l owns gaps 5 l .. 5 l + 4 and the ranks 5 l + 1 .. 5 l + 5.
-              // The qualifying ranks are a prefix (G is strictly increasing): ballots count them, and the present ones among them.
-              int n5[5], sum5 = 0;
-#pragma unroll
-              for (int t5 = 0; t5 < 5; t5++) { n5[t5] = (int)hw16[5 * lane + t5]; sum5 += n5[t5]; }
-              int run = wave_incl_scan_dpp(sum5) - sum5;
-#pragma unroll
-              for (int t5 = 0; t5 < 5; t5++) {
-                const int i = 5 * lane + t5 + 1;
-                run += n5[t5];
-                const bool q = i <= s && i + run <= s;                                  // rank i is among the s smallest of the union
-                T += __popcll(__ballot(q && hw16[320 + 5 * lane + t5] != 0));           // ... and its hash is in the window
-              }
-            }
-            // ---- the first and last profile bin whose bound reaches T ----
-            if (T >= 2) {
-              const int hiBin = lane + gNbwG < kWave - 1 ? lane + gNbwG : kWave - 1;
-              const int pHi = __shfl(pincl, hiBin);
-              const int U = 1 + pHi - pincl + bin;                                      // 1 + the bins lane .. hiBin
-              const unsigned long long keep = __ballot(U >= T);
-              if (keep != 0ull && keep != ~0ull) {
-                const int kLo = __ffsll(keep) - 1, kHi = 63 - __clzll(keep);
-                selLo = gCsG + kLo * gDeltaG; selHi = gCsG + (kHi + 1) * gDeltaG - 1;
-              }
-            }
-          }
-        }
-        if (lane == 0) { a.trimSel[2 * (size_t)(c - a.c0)] = selLo; a.trimSel[2 * (size_t)(c - a.c0) + 1] = selHi; }
-      }
-    }
-    cur = nxt;
-  }
-  }                                                  // next round of 256 candidates
-}
-
-static __global__ __launch_bounds__(kTPB) void k_l2_trim_apply(L2FastArgs a)
-{
-  const int32_t c = a.c0 + blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long rem = 0, cnt = 0;
-  if (c < a.c1) {
-    const int32_t i = c - a.c0;
-    const int32_t lo = a.trimSel[2 * (size_t)i], hi = a.trimSel[2 * (size_t)i + 1];
-    if (lo >= 0 && a.codeCount[i] > 0) {
-      const int32_t seq = a.g.candSeq[c];
-      const int32_t cHi = a.g.contigFirstMin[seq + 1];
-      const int32_t cmw = a.g.L - (a.g.w - 1) - (a.g.k - 1);
-      const uint32_t pb = a.g.posBase[seq]; const int32_t nb = (int32_t)(a.g.posBase[seq + 1] - pb);
-      const L2Range r = a.ranges[i];
-      int32_t b = l2_search_pos(a.g, pb, nb, cHi, lo + 1) - 1;             // the last entry with wpos <= lo ...
-      if (b < r.beg0) b = r.beg0;                                      // ... of the range
-      const int32_t e0 = l2_search_pos(a.g, pb, nb, cHi, a.g.mWpos[b] + cmw);
-      int32_t l = l2_search_pos(a.g, pb, nb, cHi, hi + cmw) + 1;           // every placement that starts at or before hi has end < l
-      if (l > r.last) l = r.last;
-      if (e0 < l && (b > r.beg0 || l < r.last)) {
-        const int32_t lastDel = (l - 1) - (int32_t)(a.g.mWin[l - 1] & kWinMask) - 2;     // as in k_l2_ranges
-        const int32_t nDel = lastDel >= b ? lastDel - b + 1 : 0;
-        const int32_t nEv = (e0 - b) + (l - 1 - e0) + nDel;
-        if (nEv > 0 && nEv < r.nEvents) {
-          L2Range t; t.beg0 = b; t.end0 = e0; t.last = l; t.nEvents = nEv;
-          a.ranges[i] = t;
-          a.codeCount[i] = (nEv + 8) & ~7;
-          rem = (unsigned long long)((r.last - r.beg0) - (l - b)); cnt = 1;
-        }
-      }
-    }
-  }
-  // the entries that leave the ranges stay in the algorithmic-byte figure (SURVEY.md section 8d counts the candidate's whole range:
-  // k_l2_sim adds what it is given, this adds the rest)
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { rem += __shfl_down(rem, d); cnt += __shfl_down(cnt, d); }
-  if ((threadIdx.x & 63) == 0 && cnt) { atomicAdd(stat_slot(a.g.sumEntries), rem); atomicAdd(stat_slot(a.sumTrimEntries), rem); atomicAdd(stat_slot(a.sumTrimCands), cnt); }
 }
 
 // One window event, written without control flow (selects only).  INS: the entry enters the window (slidingMap.hpp:137-161

@@ -125,10 +125,6 @@ typedef struct {
   double msL1Probe, msL1Main; /* ani::k_l1_probe; ani::k_l1<0, 2048> (the small-class gather + filter + sort + candidate kernel) */
   double msL1Big;             /* the batched global-memory L1 path (gather + device sort + candidates) */
   double msL1Tiny;            /* ani::k_l1_tiny */
-  /* round 5 (appended: the fields above keep their offsets) */
-  uint64_t l2TrimmedEntries;  /* reference minimizers removed from candidate ranges by the hit-profile bound (still counted in l2WindowEntries) */
-  uint64_t l2TrimmedCandidates;   /* candidates whose range was shortened */
-  double msL2Trim;            /* ani::k_l2_trim_eval + ani::k_l2_trim_apply */
 } ani_counters_t;
 
 /* ---- life cycle ---- */
@@ -234,6 +230,9 @@ typedef struct ani_sketch_writer ani_sketch_writer;
 int ani_sketch_writer_open(const char *path, ani_sketch_writer **out);
 int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char *const *genomeNames /* [sk's genomes] or NULL */);
 int ani_sketch_writer_close(ani_sketch_writer *w);
+/* gives the writer up: the partial file is removed, the handle released (also the way out after a failed add: a close after a failed
+ * add fails and removes the file as well) */
+void ani_sketch_writer_abort(ani_sketch_writer *w);
 int ani_sketch_file_info(const char *path, ani_params_t *p, int32_t *nContigs, int32_t *nGenomes, uint64_t *nMinimizers);
 const char *ani_sketch_genome_name(const ani_sketch *sk, int32_t genome);
 int ani_sketch_tables(const ani_sketch *sk, const int32_t **contigLen, const int32_t **genomeContigStart);

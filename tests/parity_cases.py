@@ -552,6 +552,33 @@ def case_sketch_file(engine, tmpdir):
         raise AssertionError("a sketch file without a sketch must be refused")
     except AniError as e:
         assert e.code == -1 and not os.path.exists(os.path.join(str(tmpdir), "empty.anisk"))
+    # a refused add (other parameters) leaves the writer failed: close reports it and no file stays behind; so does a writer given up
+    # inside a `with` block or dropped without close (ani_sketch_writer_abort)
+    bad = os.path.join(str(tmpdir), "bad.anisk")
+    w = SketchWriter(engine, bad)
+    w.add(sk, names)
+    other = Sketch(engine, engine.params(15, 3000), genomes[:2])
+    try:
+        w.add(other, names[:2])
+        raise AssertionError("sketches with different parameters must be refused")
+    except AniError as e:
+        assert e.code == -1
+    other.close()
+    try:
+        w.close()
+        raise AssertionError("closing a writer after a failed add must fail")
+    except AniError:
+        assert not os.path.exists(bad)
+    try:
+        with SketchWriter(engine, bad) as w:
+            w.add(sk, names)
+            raise RuntimeError("given up")
+    except RuntimeError:
+        assert not os.path.exists(bad)
+    w = SketchWriter(engine, bad)
+    w.add(sk, names)
+    del w
+    assert not os.path.exists(bad)
     open(path, "r+b").write(b"XXXX")
     try:
         Sketch(engine, p, file=path)

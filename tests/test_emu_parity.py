@@ -179,42 +179,6 @@ def test_sort_is_repeated_once_when_a_look_back_gives_up(monkeypatch):
     e.close()
 
 
-def test_l2_range_trimming(monkeypatch):
-    """ANI_L2_TRIM=1 (off by default: exact, but the bound costs more than the trimmed placements on MI355X):
-    L1 hands a 64-bin hit profile per candidate to the L2 stage, k_l2_trim_eval takes the exact sharedSketchElements T of the
-    placement in the middle of the range, k_l2_trim_apply cuts the range to the bins whose hit count can reach T.  Mapping records,
-    rows and the algorithmic-byte counter must not change; the number of evaluated placements must fall."""
-    steps = []
-    for on in (0, 1):
-        e = _emu_engine_with(monkeypatch, ANI_L2_TRIM=on)
-        pc.case_gap_counter_overflow(e)                # (these reset the counters themselves)
-        pc.case_l1_class_overflow(e)
-        e.reset_counters()
-        pc.case_synthetic_cluster(e, 45000)
-        pc.case_evolved(e)
-        pc.case_tandem_repeats(e)
-        pc.case_low_complexity(e)
-        pc.case_sparse_hits(e)
-        c = e.counters()
-        steps.append((c["l2Steps"], c["l2WindowEntries"], c["l2TrimmedCandidates"]))
-        e.close()
-    assert steps[1][2] > 0 and steps[0][2] == 0 and steps[1][0] < steps[0][0], steps
-
-
-def test_pipelined_sub_batches(monkeypatch):
-    """ANI_MAP_PIPELINE=1 (off by default: +1.4 % on the benchmark step).  map_fragsets on a resident set: the sub-batches of a call go to two host threads with a context each on the same device (the L1
-    kernels of one beside the L2 kernels of the other); ANI_MAP_PIPELINE_MIN_FRAGS lowers the threshold so that small inputs take the
-    path — rows must be those of the serial walk, sub-batch by sub-batch, in order; several kept sets per call; chunked reference sets"""
-    def alloc(nbytes):
-        a = np.zeros(nbytes // 4 + 4, dtype=np.uint32)
-        return a, a.ctypes.data
-    for env in (dict(ANI_MAP_PIPELINE=1, ANI_MAP_PIPELINE_MIN_FRAGS=8), dict(ANI_MAP_PIPELINE=1, ANI_MAP_PIPELINE_MIN_FRAGS=8, ANI_MAX_INDEX_MINIMIZERS=9000), dict(ANI_MAP_PIPELINE=0)):
-        e = _emu_engine_with(monkeypatch, **env)
-        pc.case_self(e, combos=((16, 3000), (16, 1000)))
-        pc.case_fragset_wire(e, alloc)
-        e.close()
-        for k in env:
-            monkeypatch.delenv(k)
 
 
 def test_result_rows_collected_on_host_threads(monkeypatch):

@@ -36,7 +36,7 @@ def main():
                     threads = val
                 else:
                     env[k] = val
-        for rep in range(2):
+        for rep in range(int(os.environ.get("E2E_REPS", "2"))):
             t0 = time.time()
             pr = subprocess.Popen([cli, "--ql", lst, "--rl", lst, "-t", threads, "-o", os.path.join(td, "out.txt")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
             marks = []
