@@ -49,6 +49,29 @@ def main():
     G, L, Q = a.genomes, a.genome_len, min(a.queries, a.genomes)
     out = {"what": "fastANI --ql %d genomes --refSketch <%d x %d bp genomes> %s" % (Q, G, L, "" if a.no_matrix else "--matrix"), "genomes": G, "genome_len": L, "queries": Q}
     skf = os.path.join(a.workdir, "refs_%d_%d.anisk" % (G, L))
+    # free DISK before anything is written: records (12 B x ~2 L / 25 minimizers per genome) + query FASTA + matrix + results, with a tenth
+    # to spare; a work directory on tmpfs is refused outright (its pages count against the container's memory: round 5 lost two boxes)
+    import shutil
+    need = int(G * 12.0 * 2.0 * L / 25.0 * 1.05 + Q * L * 1.02 + (0 if a.no_matrix else G * G * 5.5) + Q * 2000.0)
+    free = shutil.disk_usage(a.workdir).free
+    fstype = ""
+    try:
+        best = ""
+        for ln in open("/proc/mounts"):
+            dev, mnt, typ = ln.split()[:3]
+            if os.path.abspath(a.workdir).startswith(mnt) and len(mnt) >= len(best):
+                best, fstype = mnt, typ
+    except OSError:
+        pass
+    out["disk"] = {"workdir": a.workdir, "filesystem": fstype, "free_GB": round(free / 1e9, 1), "needed_GB": round(need / 1e9, 1)}
+    if fstype in ("tmpfs", "ramfs") and not emu and not os.environ.get("ANI_C5_ALLOW_TMPFS"):
+        out["aborted"] = "work directory is on %s: refused (use a directory on disk)" % fstype
+        print(json.dumps(out), flush=True)
+        raise SystemExit(3)
+    if need * 1.1 > free:
+        out["aborted"] = "not enough free disk: %.1f GB needed (+10 %%), %.1f GB free" % (need / 1e9, free / 1e9)
+        print(json.dumps(out), flush=True)
+        raise SystemExit(3)
 
     # ---- 1. the sketch file ----
     t0 = time.time()
@@ -126,7 +149,8 @@ def main():
     out["cli"] = {"returncode": r.returncode, "wall_s": round(wall, 1), "pairs": Q * G, "pairs_per_s": round(Q * G / wall, 1), "max_rss_GB": round(ru1.ru_maxrss / 1048576.0, 2),
                   "user_s": round(ru1.ru_utime - ru0.ru_utime, 1), "sys_s": round(ru1.ru_stime - ru0.ru_stime, 1),
                   "phases": [ln.replace("[fastANI trace]", "").strip() for ln in err if ln.startswith("[fastANI trace]")],
-                  "info": [ln for ln in err if "index chunks" in ln or "waves" in ln or "Time spent sketching" in ln or "Time spent writing" in ln][:8]}
+                  "info": [ln for ln in err if "index chunks" in ln or "waves" in ln or "blocks of genomes" in ln or "Time spent sketching" in ln or "Time spent writing" in ln][:12],
+                  "env": {k: os.environ[k] for k in ("ANI_CLI_REF_BLOCK_BYTES", "ANI_CLI_QUERY_WAVE_BYTES") if k in os.environ}}
     if r.returncode != 0:
         out["cli"]["stderr_tail"] = err[-12:]
         print(json.dumps(out), flush=True)

@@ -74,6 +74,15 @@ if has c5warm; then
   grep "hipMalloc\|reserved" "$OUT/c5warm.err" | awk '{mb+=$4; ms+=$6} END {print "c5 fresh device memory:", mb/1024, "GB,", ms/1000, "s inside hipMalloc"}' | tee "$OUT/c5warm_pool.txt"
   grep -n "timed step" "$OUT/c5warm.err" | head -3; grep -v "ani pool" "$OUT/c5warm.err" | tail -3; gzip -f "$OUT/c5warm.err"
 fi
+if has cli10k; then
+  # configs[4] through the COMMAND LINE at a size the box's disk holds: 10 000 x 5 Mbp references -> a 48 GB sketch file written in 4 blocks,
+  # read back in >= 4 blocks (ANI_CLI_REF_BLOCK_BYTES), 2000 query genomes in >= 3 waves (ANI_CLI_QUERY_WAVE_BYTES), --matrix
+  { df -h /tmp "$REPO" /dev/shm 2>&1; free -g | head -2; } | tee "$OUT/cli10k_disk.txt"
+  mkdir -p /tmp/ani_c5_cli
+  ANI_CLI_REF_BLOCK_BYTES=12000000000 ANI_CLI_QUERY_WAVE_BYTES=3500000000 timeout 2400 python tests/scale/c5_cli.py --genomes ${CLI_GENOMES:-10000} --queries ${CLI_QUERIES:-2000} --block ${CLI_BLOCK:-2500} \
+      --oracle-pairs 60 --workdir /tmp/ani_c5_cli 2> "$OUT/cli10k.err" | tee "$OUT/cli10k.json.log" | cut -c1-2500
+  tail -5 "$OUT/cli10k.err"; rm -rf /tmp/ani_c5_cli; df -h /tmp | tail -1
+fi
 if has prof; then
   echo "== rocprofv3 kernel stats (same command, no cpu legs)"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench --output-format csv -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/prof_bench.log" 2>&1)
