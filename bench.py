@@ -85,6 +85,11 @@ def parse():
     ap.add_argument("--dump-rows", default="", help="write the rows of the last timed step to <path>[.rank<r>].npy (tests)")
     ap.add_argument("--slice-genomes", type=int, default=1000, help="c5: genomes generated and sketched per slice")
     ap.add_argument("--query-slice", type=int, default=2000, help="c5: query genomes per kept fragment set")
+    ap.add_argument("--query-block", type=int, default=0, help="c5: query genomes whose fragment sets are resident together (0 = all of --queries).  With it the queries, too, are generated "
+                    "slice by slice inside the step and the reference set is streamed once per query block: 90 000 x 90 000 = --queries 90000 --query-block 30000")
+    ap.add_argument("--drop-rows", action="store_true", help="c5: count and checksum the rows of a step block by block and keep only those of --sample-queries query genomes "
+                    "(the 6 x 10^9 rows of 90 000 x 90 000 are 126 GB)")
+    ap.add_argument("--sample-queries", type=int, default=24, help="--drop-rows: query genomes whose rows are kept for the oracle check")
     ap.add_argument("--ref-block", type=int, default=0, help="c5: reference genomes indexed and mapped together (0 = as many as keep the records in a third of the device memory)")
     ap.add_argument("--genomes", type=int, default=0, help="reference genomes (0 = the config's: 1000, c4: 10000, c5: 30000)")
     ap.add_argument("--queries", type=int, default=0, help="query genomes per GPU (0 = the config's)")
@@ -585,9 +590,17 @@ def make_inputs(R):
             R.ref_block = max(R.slice_n, int(total / 3 / per_genome) // R.slice_n * R.slice_n)
         R.ref_block = min(R.ref_block, NR)
         R.ref_buf = torch.empty(R.slice_n * words + 64, dtype=torch.int32, device=R.dev)
-        R.qry_buf = torch.empty(R.nq_local * words + 64, dtype=torch.int32, device=R.dev)
-        e.synth_packed(a.seed, 0, R.nq_local, L, R.qry_buf.data_ptr(), variant=0, cluster_size=a.cluster_size)
-        R.qrys = DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, L)
+        R.query_block = min(a.query_block or R.nq_local, R.nq_local)
+        R.qry_streamed = bool(a.query_block)              # the queries are generated slice by slice inside the step, like the references
+        if R.qry_streamed:
+            R.qry_buf = torch.empty(min(R.query_slice, R.nq_local) * words + 64, dtype=torch.int32, device=R.dev)
+            R.qrys = None
+        else:
+            R.qry_buf = torch.empty(R.nq_local * words + 64, dtype=torch.int32, device=R.dev)
+            e.synth_packed(a.seed, 0, R.nq_local, L, R.qry_buf.data_ptr(), variant=0, cluster_size=a.cluster_size)
+            R.qrys = DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, L)
+        R.drop_rows = bool(a.drop_rows)
+        R.sample_queries = np.sort(np.random.default_rng(a.seed + 11).choice(R.nq_local, size=min(a.sample_queries, R.nq_local), replace=False)).astype(np.int32)
         R.refs = R.my_refs = None
         R.first_query_id = 0
         R.n_queries_total = R.nq_local
@@ -686,48 +699,69 @@ def step_single(R):
         out = []
         R.last_residency = None
         R.blocks_last_step = 0
-        qsets, qfirsts = [], []
-        if c5:
-            # the queries' fragment sketches, once per step, in sets of --query-slice genomes (a set's sketch hashes are a 32-bit
-            # count: 2000 genomes of 5 Mbp hold 8 x 10^8); every reference block maps all of them in ONE call, so a streamed block
-            # builds each of its index chunks once
-            t_q = time.perf_counter()
-            for q0 in range(0, R.nq_local, R.query_slice):
-                q1 = min(R.nq_local, q0 + R.query_slice)
-                qsets.append(e.fragment_set(p, DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, R.L, first=q0, count=q1 - q0)))
-                qfirsts.append(R.first_query_id + q0)
-            T["fragsketch_ms"] += (time.perf_counter() - t_q) * 1e3
-        for b0 in range(0, R.NR, block):
-            b1 = min(R.NR, b0 + block)
-            parts, sets, firsts = [], [], []
-            t_a = time.perf_counter()
-            for s0 in range(b0, b1, step_n):
-                s1 = min(b1, s0 + step_n)
-                if c5:
-                    e.synth_packed(R.args.seed, s0, s1 - s0, R.L, R.ref_buf.data_ptr(), variant=0, cluster_size=R.args.cluster_size)
-                    ptr, n = e.sketch_records(p, DeviceGenomes(R.ref_buf.data_ptr(), s1 - s0, R.L), s0 - b0)
-                else:
-                    ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(R.ref_buf.data_ptr(), R.NR, R.L, first=s0, count=s1 - s0), s0)
-                    sets.append(fr); firsts.append(s0)
-                parts.append((ptr, n, s0 - b0))
-            t_b = time.perf_counter()
-            sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [b1 - b0],
-                                            R.contig_len[:b1 - b0], R.gcs[:b1 - b0 + 1]), adopt=True)
-            t_d = time.perf_counter()
-            rows = sk.map_cgi_fragsets(qsets, qfirsts) if c5 else sk.map_cgi_fragsets(sets, firsts)
-            rows["refGenomeId"] += b0
-            out.append(rows)
-            t_e = time.perf_counter()
-            res = sk.residency()
-            R.last_residency = res if R.last_residency is None else dict(streaming=res["streaming"] or R.last_residency["streaming"],
-                                                                         max_resident=max(res["max_resident"], R.last_residency["max_resident"]), resident_now=res["resident_now"])
-            R.blocks_last_step += 1
-            for fr in sets:
+        R.step_rows, R.step_crc = 0, 0
+        qblocks = [(q0, min(R.nq_local, q0 + R.query_block)) for q0 in range(0, R.nq_local, R.query_block)] if c5 else [(0, 0)]
+        for qb0, qb1 in qblocks:
+            qsets, qfirsts = [], []
+            if c5:
+                # the fragment sketches of one BLOCK of queries (--query-block; default: all of them), in sets of --query-slice genomes (a
+                # set's sketch hashes are a 32-bit count: 2000 genomes of 5 Mbp hold 8 x 10^8); every reference block maps all sets of the
+                # query block in ONE call, so a streamed reference block builds each of its index chunks once per query block
+                t_q = time.perf_counter()
+                for q0 in range(qb0, qb1, R.query_slice):
+                    q1 = min(qb1, q0 + R.query_slice)
+                    if R.qry_streamed:
+                        e.synth_packed(R.args.seed, q0, q1 - q0, R.L, R.qry_buf.data_ptr(), variant=0, cluster_size=R.args.cluster_size)
+                        dg = DeviceGenomes(R.qry_buf.data_ptr(), q1 - q0, R.L)
+                    else:
+                        dg = DeviceGenomes(R.qry_buf.data_ptr(), R.nq_local, R.L, first=q0, count=q1 - q0)
+                    qsets.append(e.fragment_set(p, dg))
+                    qfirsts.append(R.first_query_id + q0)
+                T["fragsketch_ms"] += (time.perf_counter() - t_q) * 1e3
+            for b0 in range(0, R.NR, block):
+                b1 = min(R.NR, b0 + block)
+                parts, sets, firsts = [], [], []
+                t_a = time.perf_counter()
+                for s0 in range(b0, b1, step_n):
+                    s1 = min(b1, s0 + step_n)
+                    if c5:
+                        e.synth_packed(R.args.seed, s0, s1 - s0, R.L, R.ref_buf.data_ptr(), variant=0, cluster_size=R.args.cluster_size)
+                        ptr, n = e.sketch_records(p, DeviceGenomes(R.ref_buf.data_ptr(), s1 - s0, R.L), s0 - b0)
+                    else:
+                        ptr, n, fr = e.sketch_records_self(p, DeviceGenomes(R.ref_buf.data_ptr(), R.NR, R.L, first=s0, count=s1 - s0), s0)
+                        sets.append(fr); firsts.append(s0)
+                    parts.append((ptr, n, s0 - b0))
+                t_b = time.perf_counter()
+                sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [b1 - b0],
+                                                R.contig_len[:b1 - b0], R.gcs[:b1 - b0 + 1]), adopt=True)
+                t_d = time.perf_counter()
+                rows = sk.map_cgi_fragsets(qsets, qfirsts) if c5 else sk.map_cgi_fragsets(sets, firsts)
+                rows["refGenomeId"] += b0
+                if c5 and R.drop_rows:
+                    # the step's rows are counted and checksummed block by block; only the sampled queries' rows stay (oracle check)
+                    # (checksum = sum of the rows' 32-bit words mod 2^64, at memory speed: crc32 runs at ~1 GB/s and the rows of 90 000 x 90 000 are
+                    #  126 GB; sampled queries by binary search: the rows of a call arrive ordered by query)
+                    R.step_rows += len(rows)
+                    R.step_crc = (R.step_crc + int(np.ascontiguousarray(rows).view(np.uint32).sum(dtype=np.uint64))) & 0xffffffffffffffff
+                    qcol = np.ascontiguousarray(rows["qryGenomeId"])
+                    if len(qcol) and bool(np.all(qcol[:-1] <= qcol[1:])):
+                        lo, hi = np.searchsorted(qcol, R.sample_queries, "left"), np.searchsorted(qcol, R.sample_queries, "right")
+                        rows = np.concatenate([rows[a_:b_] for a_, b_ in zip(lo, hi)]) if len(lo) else rows[:0]
+                    else:
+                        rows = rows[np.isin(qcol, R.sample_queries)]
+                    del qcol
+                out.append(rows)
+                t_e = time.perf_counter()
+                res = sk.residency()
+                R.last_residency = res if R.last_residency is None else dict(streaming=res["streaming"] or R.last_residency["streaming"],
+                                                                             max_resident=max(res["max_resident"], R.last_residency["max_resident"]), resident_now=res["resident_now"])
+                R.blocks_last_step += 1
+                for fr in sets:
+                    fr.close()
+                sk.close()
+                T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
+            for fr in qsets:
                 fr.close()
-            sk.close()
-            T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
-        for fr in qsets:
-            fr.close()
         # (several blocks: the rows stay block-major — (query, reference) order inside a block.  Sorting the 7 x 10^8 rows of
         #  90 000 x 10 000 on the host took longer than computing them: 55 of 104 s, profiles/r05c5_bench_c5_90000x10000.json.log)
         return out[0] if len(out) == 1 else np.concatenate(out)
@@ -941,7 +975,7 @@ def timed_loop(R, step, steps, warmup):
     rows = None
     step_ms, crc = [], []
     trace = bool(os.environ.get("ANI_POOL_TRACE"))
-    rows_all = []
+    rows_all, dropped = [], []
     for i in range(steps):
         if trace:
             print("[bench] timed step %d" % i, file=sys.stderr, flush=True)
@@ -949,11 +983,16 @@ def timed_loop(R, step, steps, warmup):
         rows = step(R)                                        # returns with the rows on the host: the step's device work is done
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
         rows_all.append(rows)
+        if getattr(R, "drop_rows", False):
+            dropped.append((R.step_rows, R.step_crc))
     sync(R)
     dt_local = time.perf_counter() - t0
     # outside the timed region: every step must have produced the same rows (run-to-run determinism)
     crc = [zlib.crc32(np.ascontiguousarray(r).view(np.uint8)) & 0xffffffff for r in rows_all]          # (a view: no copy of the rows)
     del rows_all
+    if dropped:                                              # --drop-rows: the steps' own counts and running checksums stand for the rows
+        crc = [c for _, c in dropped]
+        R.rows_last_step = dropped[-1][0]
     dt = dt_local
     if R.dist is not None:
         t = R.torch.tensor([dt], dtype=R.torch.float64, device=R.dev)
@@ -1197,7 +1236,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
                       "name": cfg, "ref_genomes": NR, "query_genomes": n_queries_total, "genome_len": L, "inputs": "2-bit packed, resident in HBM" if cfg != "c5" else "2-bit packed, generated in HBM slice by slice inside the step",
                       "all_vs_all_single_hash_pass": bool(fused), "mode": mode,
                       "index_chunks": int(c["indexChunks"] // max(1, args.steps))},
-           "rows_last_step": int(len(rows)), "rows_identical_across_steps": len(set(res["rows_crc"])) == 1, "step_ms_rank0": res["step_ms"],
+           "rows_last_step": int(getattr(R, "rows_last_step", len(rows))), "rows_identical_across_steps": len(set(res["rows_crc"])) == 1, "step_ms_rank0": res["step_ms"],
            "stage_ms_per_step_rank0": stages, "host_timeline_ms_per_step_rank0": host_timeline, "l1_big_path": {"fragments_per_step": int(c["l1BigFragments"] // args.steps), "ms_per_step": round(c["msL1Big"] / args.steps, 3)},
            "counters_per_step_rank0": {k: int(c[k] // args.steps) for k in ("refMinimizers", "queryFragments", "seedHits", "l1Candidates",
                                                                           "l2WindowEntries", "l2Steps", "l2FastCandidates", "l2SlowCandidates",
@@ -1213,6 +1252,11 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
     if cfg == "c5":
         out["config"]["ref_block"] = {"genomes": R.ref_block, "blocks": getattr(R, "blocks_last_step", 1),
                                       "what": "the reference set is indexed and mapped in blocks of this many genomes (records of one block resident at a time)"}
+        out["config"]["query_block"] = {"genomes": R.query_block, "blocks": -(-R.nq_local // R.query_block), "queries_generated_inside_the_step": bool(R.qry_streamed),
+                                        "what": "the fragment sets of one block of queries are resident together; the reference set is streamed once per query block"}
+        if R.drop_rows:
+            out["rows_kept"] = {"rows": int(len(rows)), "of_queries": [int(q) for q in R.sample_queries],
+                                "what": "--drop-rows: a step's rows are counted and checksummed block by block (rows_last_step, rows_identical_across_steps); only these queries' rows stay for the oracle check"}
     if rank_info:
         out["ranks"] = rank_info
     if weak_leg:
@@ -1220,7 +1264,8 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
     if map_only:
         out["map_only"] = map_only
     if world == 1 and mode == "single" and not R.multi and not (args.no_cpu_baseline and args.no_e2e and args.no_verify):
-        legs = cpu_legs(args, e, p, rows, NR, list(range(R.first_query_id, R.first_query_id + nq_local)), L)
+        qids = [int(q) for q in R.sample_queries] if getattr(R, "drop_rows", False) else list(range(R.first_query_id, R.first_query_id + nq_local))
+        legs = cpu_legs(args, e, p, rows, NR, qids, L)
         out.update(legs)
     elif (mode == "simulate" or R.multi) and world == 1 and not args.no_verify and not R.emu:
         # the rows of a one-rank ring / gather / simulated-rank run against the oracle, pair by pair

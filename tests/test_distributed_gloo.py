@@ -232,14 +232,31 @@ def test_bench_c5_reference_blocks(emu_engine, tmp_path):
     p = emu_engine.params()
     single = Sketch(emu_engine, p, DeviceGenomes(buf.ctypes.data, n, L)).map_cgi_batch(DeviceGenomes(buf.ctypes.data, nq, L), 0)
     assert len(single) >= 2 * nq
-    for block, slc, qslc in ((3, 2, 2), (4, 4, 1), (7, 3, 2000)):        # (--query-slice: the queries as one or several kept fragment sets)
-        dump = os.path.join(str(tmp_path), "rows_%d_%d" % (block, slc))
+    # (--query-slice: the queries as one or several kept fragment sets; --query-block: the queries generated inside the step and taken in
+    #  blocks, the reference set streamed once per query block — how 90 000 x 90 000 runs on one GPU)
+    for block, slc, qslc, qblock in ((3, 2, 2, 0), (4, 4, 1, 0), (7, 3, 2000, 0), (3, 2, 1, 2)):
+        dump = os.path.join(str(tmp_path), "rows_%d_%d_%d" % (block, slc, qblock))
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "c5", "--genomes", str(n), "--queries", str(nq),
-                            "--genome-len", str(L), "--ref-block", str(block), "--slice-genomes", str(slc), "--query-slice", str(qslc), "--dump-rows", dump],
+                            "--genome-len", str(L), "--ref-block", str(block), "--slice-genomes", str(slc), "--query-slice", str(qslc), "--dump-rows", dump]
+                           + (["--query-block", str(qblock)] if qblock else []),
                            capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=1200)
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
-        assert out["config"]["ref_block"]["genomes"] == block and out["config"]["ref_block"]["blocks"] == -(-n // block)
+        nqb = -(-nq // qblock) if qblock else 1
+        assert out["config"]["ref_block"]["genomes"] == block and out["config"]["ref_block"]["blocks"] == -(-n // block) * nqb
+        assert out["config"]["query_block"]["blocks"] == nqb and out["config"]["query_block"]["queries_generated_inside_the_step"] == bool(qblock)
         got = np.load(dump + ".npy")
         got = got[np.lexsort((got["refGenomeId"], got["qryGenomeId"]))]    # (several blocks arrive block-major)
         assert np.array_equal(got, single)
+    # --drop-rows: the rows are counted and checksummed block by block, only the sampled queries' rows stay
+    dump = os.path.join(str(tmp_path), "rows_dropped")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0", "--config", "c5", "--genomes", str(n), "--queries", str(nq),
+                        "--genome-len", str(L), "--ref-block", "3", "--slice-genomes", "2", "--query-slice", "1", "--query-block", "2", "--drop-rows", "--sample-queries", "1",
+                        "--dump-rows", dump], capture_output=True, env=dict(os.environ, ANI_BENCH_BACKEND="emu"), timeout=1200)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert out["rows_last_step"] == len(single) and out["rows_identical_across_steps"]
+    kept_q = out["rows_kept"]["of_queries"]
+    got = np.load(dump + ".npy")
+    got = got[np.lexsort((got["refGenomeId"], got["qryGenomeId"]))]
+    assert len(kept_q) == 1 and np.array_equal(got, single[single["qryGenomeId"] == kept_q[0]])

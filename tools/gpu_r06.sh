@@ -83,6 +83,14 @@ if has cli10k; then
       --oracle-pairs 60 --workdir /tmp/ani_c5_cli 2> "$OUT/cli10k.err" | tee "$OUT/cli10k.json.log" | cut -c1-2500
   tail -5 "$OUT/cli10k.err"; rm -rf /tmp/ani_c5_cli; df -h /tmp | tail -1
 fi
+if has c5full; then
+  # configs[4] as stated: all-vs-all over 90 000 x 5 Mbp genomes = 8.1 x 10^9 pairs on ONE GPU — queries generated inside the step and taken in
+  # blocks of 30 000 (48 GB of fragment sets), the references streamed block by block once per query block; rows counted + checksummed, 24 queries kept
+  echo "== configs[4]: ${C5_GENOMES:-90000} x ${C5_QUERIES:-90000}, one cold step"
+  timeout 2400 python bench.py --config c5 --genomes ${C5_GENOMES:-90000} --queries ${C5_QUERIES:-90000} --query-block ${C5_QBLOCK:-30000} --drop-rows --steps 1 --warmup 0 \
+      --no-cpu-baseline --no-e2e --oracle-pairs 48 2> "$OUT/c5full.err" | tee "$OUT/c5full.json.log" | cut -c1-1800
+  tail -3 "$OUT/c5full.err"; free -g | head -2
+fi
 if has prof; then
   echo "== rocprofv3 kernel stats (same command, no cpu legs)"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench --output-format csv -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/prof_bench.log" 2>&1)
