@@ -17,15 +17,18 @@
 namespace ani {
 
 constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS classes accept
+constexpr int kL1SmallMaxS = 1024;      // ... class S (its 4 KiB of scratch hold the per-hash hit offsets); a fragment with more goes to class M whatever its hit count
 constexpr int kFragHashCapL1 = 4096;    // = kFragHashCap (sketch.hpp): the most sketch hashes a fragment can have
-constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 8 KiB scratch -> 6 workgroups per CU
+constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 4 KiB scratch, <= 72 registers -> 7 workgroups per CU.  The kernel's time follows the number of
+                                        // resident workgroups (a workgroup's life is a chain of latencies — probe results, hit runs, LDS round trips of the sort — and
+                                        // what hides them is other workgroups): 5 per CU 35.8 ms, 6 per CU 30.0 ms per benchmark step (profiles/r06f_l1_occupancy_ab.txt)
 constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgroups per CU
 constexpr int kL1HitCapMax = kL1HitCapMid;   // beyond: the batched global-memory path.  (A class L of 8192 hits — 96 KiB of LDS, one workgroup
                                              // per CU — existed until round 3: 0.43 us per fragment where the batched path takes 0.33, measured at
                                              // 493 k such fragments per step of the cluster-size-100 benchmark.)
 static_assert(kL1HitCapMax <= kBlockSortMax, "block_sort (common.hpp) sorts at most kBlockSortMax keys");
 constexpr int kL1FilterMinHits = 300;   // below this the sort is cheaper than the noise filter
-template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 14 : 15; }   // log2(8 * HCAP) occupancy counters per tiling
+template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 13 : 15; }   // log2 of the occupancy counters per tiling: four bit arrays in the class's scratch (S: 4 x 1 KiB, M: 4 x 4 KiB)
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
@@ -73,7 +76,8 @@ __device__ __forceinline__ bool l1_valid(const uint64_t *hits, int a, int m, int
   return hit_seq(x) == hit_seq(y) && hit_wpos(y) - hit_wpos(x) < L;
 }
 // j-th valid run opens a new candidate (computeMap.hpp:342-350, negated)
-__device__ __forceinline__ bool l1_head(const uint64_t *hits, const int *V, int j, int m, int L)
+template <class VT>
+__device__ __forceinline__ bool l1_head(const uint64_t *hits, const VT *V, int j, int m, int L)
 {
   if (j == 0) return true;
   const uint64_t x = hits[V[j]], px = hits[V[j - 1]];
@@ -82,7 +86,9 @@ __device__ __forceinline__ bool l1_head(const uint64_t *hits, const int *V, int 
 }
 
 // Sorted hits -> candidate regions of one fragment (computeMap.hpp:313-354).  hits/V may live in LDS or in global memory.
-__device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, int m /* minimumHits of s, :301 */, const uint64_t *hits, int *V,
+// VT: type of the run indices in V (uint16_t in class S: its hits number <= 2048)
+template <class VT>
+__device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, int m /* minimumHits of s, :301 */, const uint64_t *hits, VT *V,
                                           int *ws, unsigned long long *sBasePtr)
 {
   const int t = threadIdx.x;
@@ -96,7 +102,7 @@ __device__ inline void l1_emit_candidates(const L1Args &a, int f, int s, int H, 
     int c = 0;
     for (int x = lo; x < hi; x++) c += l1_valid(hits, x, m, a.L);
     int nv; int r = block_excl_scan(c, ws, &nv);
-    for (int x = lo; x < hi; x++) if (l1_valid(hits, x, m, a.L)) V[r++] = x;
+    for (int x = lo; x < hi; x++) if (l1_valid(hits, x, m, a.L)) V[r++] = (VT)x;
     block_barrier_mem();
     // candidate heads
     per = (nv + kTPB - 1) / kTPB;
@@ -237,7 +243,7 @@ static __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
       else if (s[q] > 0) {
         // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
         if (s[q] <= kL1MaxS && H <= a.ldsHitCap) {
-          if (H > kL1HitCapSmall) a.midList[atomicAdd(a.midCount, 1u)] = f;
+          if (H > kL1HitCapSmall || (s[q] > kL1SmallMaxS && !(H <= 4 * kWave && a.tinyPath))) a.midList[atomicAdd(a.midCount, 1u)] = f;     // (a long sketch with a handful of hits: the wave kernel)
           else if (H > 0 && H <= 4 * kWave && a.tinyPath) atomicAdd(stat_slot(a.tinyCount), 1ull);      // (striped statistics counters: the host launches k_l1_tiny if there are any,
           else if (H > 0) atomicAdd(stat_slot(a.smallCount), 1ull);                                 //  and k_l1<0, 2048> over a list instead of over every fragment if there are few)
         } else a.bigList[atomicAdd(a.bigCount, 1u)] = f;         // beyond every LDS class: global-memory path
@@ -361,7 +367,7 @@ static __global__ __launch_bounds__(kTPB) void k_l1_list(L1Args a, int32_t *__re
     f = a.fragOrder ? a.fragOrder[i] : i;
     const int s = a.fragS[f], H = a.fragHits[f];
     if (s <= 0 || H <= 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; }        // (H < 0: overflow marker of k_l1_probe, the host fails the call)
-    else small = s <= kL1MaxS && H <= a.ldsHitCap && H <= kL1HitCapSmall && !(H <= kL1HitCapTiny && a.tinyPath);
+    else small = s <= kL1SmallMaxS && H <= a.ldsHitCap && H <= kL1HitCapSmall && !(H <= kL1HitCapTiny && a.tinyPath);
   }
   const unsigned long long m = __ballot(small);
   if (lane == 0) wcount[wv] = (unsigned int)__popcll(m);
@@ -384,13 +390,27 @@ static __global__ __launch_bounds__(kTPB) void k_l1_list(L1Args a, int32_t *__re
 // look-up per hit — five more barrier-separated phases and 20 more registers (5 instead of 6 workgroups per CU): k_l1<0,2048> went
 // from 30.7 to 41.2 ms per step, bit-exact.)
 template <int HLO, int HCAP>
-static __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__restrict__ list)
+static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a, const int32_t *__restrict__ list)
 {
+  // scratch V: the per-hash hit offsets during the gather (pOff), four bit arrays during the noise filter, the indices of the valid runs
+  // during emission.  Class S: 4 KiB (<= 1024 sketch hashes, 13-bit filter, 16-bit run indices); class M: 16 KiB.
+  using VT = typename std::conditional<HLO == 0, uint16_t, int>::type;
+  constexpr int kMaxS = HLO == 0 ? kL1SmallMaxS : kL1MaxS;
+  constexpr int NBW = (1 << kL1FilterBits<HCAP>()) / 32;          // words per bit array; V holds {seenA, twiceA, seenB, twiceB}
+  constexpr int kVWords = 4 * NBW > kMaxS ? 4 * NBW : kMaxS;
+  static_assert(kVWords * 4 >= HCAP * (int)sizeof(VT) && kVWords >= kMaxS, "the scratch holds the run indices and the hit offsets");
   __shared__ uint64_t hits[HCAP];
-  __shared__ int V[HCAP];
+  __shared__ __attribute__((aligned(16))) uint32_t Vraw[kVWords];
+  VT *V = (VT *)Vraw;
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
   __shared__ int sKeep;
+#ifdef ANI_L1_PAD_WORDS
+  // occupancy experiment (profiles/r06f_l1_occupancy_ab.txt): dead LDS that takes the kernel from six workgroups per CU to five — does its
+  // time follow the number of resident workgroups?
+  __shared__ volatile uint32_t padLds[ANI_L1_PAD_WORDS];
+  if (HLO == 0 && threadIdx.x == 0) padLds[blockIdx.x & (ANI_L1_PAD_WORDS - 1)] = 1u;
+#endif
   int f;
   if (list) f = list[blockIdx.x];
   else {
@@ -406,12 +426,13 @@ static __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__r
     return;
   }
   if (HLO == 0 && (s > kL1MaxS || H > a.ldsHitCap)) return;        // beyond the LDS classes: k_l1_big_* below
-  if (H <= HLO || H > HCAP || s <= 0 || s > kL1MaxS) return;     // another class handles it
   if (HLO == 0 && H <= kL1HitCapTiny && a.tinyPath) return;        // a handful of hits: k_l1_tiny has them (one wave per fragment)
+  if (H > HCAP || s <= 0 || s > kL1MaxS) return;                 // another class handles it ...
+  if (HLO == 0 ? s > kMaxS : (H <= HLO && s <= kL1SmallMaxS)) return;     // ... class S takes sketches of <= 1024 hashes, class M the longer ones as well (k_l1_probe lists them)
   const uint32_t off = a.fragOff[f];
   const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather
-  int *pOff = V;                                    // hit offsets per probe alias V (V is only written after the gather)
-  constexpr int kPerS = kL1MaxS / kTPB;              // sketch hashes per thread at most
+  int *pOff = (int *)Vraw;                          // hit offsets per probe alias V (V is only written after the gather)
+  constexpr int kPerS = kMaxS / kTPB;                // sketch hashes per thread at most
   uint32_t pFirst[kPerS];                           // the runs' starts travel with the counts: one round trip to memory instead of two
 #pragma unroll
   for (int j = 0; j < kPerS; j++) {
@@ -443,31 +464,34 @@ static __global__ __launch_bounds__(kTPB) void k_l1(L1Args a, const int32_t *__r
   // tile in one of them) hashed into 2-bit occupancy counters: a collision only keeps a hit that could have been dropped.
   int n = H;
   if (m >= 2 && H > a.filterMinHits) {
-    constexpr int NBW = HCAP / 4;                    // words per bit array; V holds {seenA, twiceA, seenB, twiceB}
-    uint32_t *bits = (uint32_t *)V;
+    uint32_t *bits = Vraw;
     block_barrier();                                 // the gather is complete
-    for (int i = t; i < HCAP; i += kTPB) bits[i] = 0u;
+    for (int i = t; i < 4 * NBW; i += kTPB) bits[i] = 0u;
     if (t == 0) sKeep = 0;
     block_barrier();
     constexpr int PER = HCAP / kTPB;
-    uint64_t hv[PER]; uint32_t ia[PER], ib[PER];
+    uint64_t hv[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const int x = t + j * kTPB;
       if (x < H) {
         hv[j] = hits[x];
-        l1_filter_tiles<kL1FilterBits<HCAP>()>(hv[j], a.filterShift, ia[j], ib[j]);
-        const uint32_t ba = 1u << (ia[j] & 31), bb = 1u << (ib[j] & 31);
-        if (atomicOr(&bits[ia[j] >> 5], ba) & ba) atomicOr(&bits[NBW + (ia[j] >> 5)], ba);
-        if (atomicOr(&bits[2 * NBW + (ib[j] >> 5)], bb) & bb) atomicOr(&bits[3 * NBW + (ib[j] >> 5)], bb);
+        uint32_t ia, ib;
+        l1_filter_tiles<kL1FilterBits<HCAP>()>(hv[j], a.filterShift, ia, ib);
+        const uint32_t ba = 1u << (ia & 31), bb = 1u << (ib & 31);
+        if (atomicOr(&bits[ia >> 5], ba) & ba) atomicOr(&bits[NBW + (ia >> 5)], ba);
+        if (atomicOr(&bits[2 * NBW + (ib >> 5)], bb) & bb) atomicOr(&bits[3 * NBW + (ib >> 5)], bb);
       }
     }
     block_barrier();
+    // (the counter indices are computed again rather than kept across the barrier: sixteen registers, which decide how many workgroups a CU holds)
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const int x = t + j * kTPB;
       if (x < H) {
-        const bool keep = ((bits[NBW + (ia[j] >> 5)] >> (ia[j] & 31)) | (bits[3 * NBW + (ib[j] >> 5)] >> (ib[j] & 31))) & 1u;
+        uint32_t ia, ib;
+        l1_filter_tiles<kL1FilterBits<HCAP>()>(hv[j], a.filterShift, ia, ib);
+        const bool keep = ((bits[NBW + (ia >> 5)] >> (ia & 31)) | (bits[3 * NBW + (ib >> 5)] >> (ib & 31))) & 1u;
         if (keep) hits[atomicAdd(&sKeep, 1)] = hv[j];      // every lane has read its hits: compaction in place, order irrelevant
       }
     }

@@ -396,6 +396,11 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
   __shared__ L2Range cRange[kL2CandBatch];         // the candidates' descriptors, fetched side by side (nEvents < 0: no stream)
   __shared__ uint64_t cOff[kL2CandBatch];
   __shared__ int cRangeScan[8];                    // scratch of the workgroup scan
+#ifdef ANI_L2C_PAD_WORDS
+  // occupancy experiment (profiles/r06h_l2_codes_occupancy_ab.txt): dead LDS, five workgroups per CU instead of six
+  __shared__ volatile uint32_t padLds[ANI_L2C_PAD_WORDS];
+  if (threadIdx.x == 0) padLds[blockIdx.x & (ANI_L2C_PAD_WORDS - 1)] = 1u;
+#endif
   // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive fragments of a query map to overlapping
   // reference ranges, so XCD x takes a contiguous eighth of the chunk's fragments: neighbours share their reference reads in L2.
   const int32_t per = (int32_t)(gridDim.x >> 3);

@@ -21,6 +21,16 @@ QUICK="--steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-verify"
 if has alloc; then
   { echo "== fresh device memory on this box"; timeout 300 tools/ubench/alloc; } 2>&1 | tee "$OUT/ubench_alloc.txt"
 fi
+if has radixbits; then
+  { echo "== radix bits per pass (rocPRIM onesweep as the yardstick)"; timeout 300 tools/ubench/radix_bits; } 2>&1 | tee "$OUT/ubench_radix_bits.txt"
+fi
+if has libab; then
+  # A/B/A/B of two builds of the library on one box: LIB_VARIANTS="<tag> default"
+  for v in ${LIB_VARIANTS:-default} ${LIB_VARIANTS:-default}; do
+    if [ "$v" = default ]; then vv=""; else vv=$v; fi
+    ANI_LIB_VARIANT=$vv timeout 300 python bench.py $QUICK 2>/dev/null | line "lib=$v" | tee -a "$OUT/libab.txt"
+  done
+fi
 if has e2e; then
   echo "== command line end to end (1000 x 5 Mbp FASTA on local disk)"
   timeout 900 python tools/e2e_probe.py 1000 ${E2E_VARIANTS:-default} 2>&1 | tee "$OUT/e2e_probe.txt"
