@@ -405,12 +405,6 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
   __shared__ int ws[16];
   __shared__ unsigned long long sBase;
   __shared__ int sKeep;
-#ifdef ANI_L1_PAD_WORDS
-  // occupancy experiment (profiles/r06f_l1_occupancy_ab.txt): dead LDS that takes the kernel from six workgroups per CU to five — does its
-  // time follow the number of resident workgroups?
-  __shared__ volatile uint32_t padLds[ANI_L1_PAD_WORDS];
-  if (HLO == 0 && threadIdx.x == 0) padLds[blockIdx.x & (ANI_L1_PAD_WORDS - 1)] = 1u;
-#endif
   int f;
   if (list) f = list[blockIdx.x];
   else {
