@@ -1171,7 +1171,7 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
     roof["bound_note"] = ("'hbm' by the algorithmic-byte accounting of SURVEY.md section 8d (12 B per reference minimizer in a candidate range); what "
                           "limits k_l2_sim and k_l2_codes is vector instruction issue (k_l2_sim: VALU wave-instructions x 4 cycles = 86 % of its SIMD cycles at 2.5 "
                           "waves per SIMD, profiles/r02X_pmc_sq_summary.txt); since round 4 the simulation of a chunk runs on a side stream beside the next chunk's "
-                          "codes kernel (ANI_L2_OVERLAP=0 serialises them: stage +3.6 ms), so the two kernels' own durations — HIP events here, rocprofv3 in "
+                          "codes kernel (ANI_TEST_L2_OVERLAP=0 serialises them: stage +3.6 ms), so the two kernels' own durations — HIP events here, rocprofv3 in "
                           "profiles/ — are those of kernels that share the machine and add up to more than the stage; the stage figure (achieved / frac) is the one to read")
     # what binds, beside the accounting convention (`bound` keeps the contract's vocabulary: hbm | mfma)
     roof["accounting"] = "hbm"

@@ -43,7 +43,8 @@ int read_counters(ani_ctx *c, unsigned long long *host)
   for (int p = 0; p < POOL_N; p++) {
     c->poolUsed[p] = 0; c->poolMaxStripe[p] = 0;
     const unsigned long long *cur = all.data() + (size_t)ani::kStatStripes * CNT_N + (size_t)p * ani::kPoolStripes * ani::kPoolStripeWords;
-    for (int r = 0; r < ani::kPoolStripes; r++) { const unsigned long long v = cur[(size_t)r * ani::kPoolStripeWords]; c->poolUsed[p] += v; c->poolMaxStripe[p] = std::max(c->poolMaxStripe[p], v); }
+    for (int r = 0; r < ani::kPoolStripes; r++) { const unsigned long long v = cur[(size_t)r * ani::kPoolStripeWords]; c->poolUsed[p] += v;
+      c->poolMaxStripe[p] = std::max(c->poolMaxStripe[p], v); }
   }
   return ANI_OK;
 }
@@ -63,11 +64,15 @@ int pinned_buffer(ani_ctx *c, int slot, size_t bytes, void **out)
 void add_counters(ani_counters_t *d, const ani_counters_t *s)
 {
 #define ADD(f) d->f += s->f
-  ADD(refBases); ADD(refMinimizers); ADD(refUniqueHashes); ADD(queryGenomes); ADD(queryFragments); ADD(queryBases); ADD(querySketchHashes); ADD(seedHits); ADD(l1Candidates);
-  ADD(l2WindowEntries); ADD(l2Steps); ADD(l2QueryHashes); ADD(l2WindowEntriesB); ADD(l2QueryHashesB); ADD(l2Launches); ADD(l2FastCandidates); ADD(l2SlowCandidates);
-  ADD(l2SlowLimit); ADD(l2SlowDup); ADD(l2SlowOverflow); ADD(mappings); ADD(cgiRows); ADD(indexChunks); ADD(l1Probes); ADD(l2ChunkHalvings); ADD(indexChunkBuilds);
+  ADD(refBases); ADD(refMinimizers); ADD(refUniqueHashes); ADD(queryGenomes); ADD(queryFragments); ADD(queryBases); ADD(querySketchHashes); ADD(seedHits);
+  ADD(l1Candidates);
+  ADD(l2WindowEntries); ADD(l2Steps); ADD(l2QueryHashes); ADD(l2WindowEntriesB); ADD(l2QueryHashesB); ADD(l2Launches); ADD(l2FastCandidates);
+  ADD(l2SlowCandidates);
+  ADD(l2SlowLimit); ADD(l2SlowDup); ADD(l2SlowOverflow); ADD(mappings); ADD(cgiRows); ADD(indexChunks); ADD(l1Probes); ADD(l2ChunkHalvings);
+  ADD(indexChunkBuilds);
   ADD(l1BigFragments); ADD(l1MidFragments); ADD(l1TinyFragments);
-  ADD(msSketch); ADD(msIndex); ADD(msFragSketch); ADD(msL1); ADD(msL2); ADD(msReduce); ADD(msL2Kernel); ADD(msL2Ranges); ADD(msL2Codes); ADD(msL2Slow); ADD(msL2SimB);
+  ADD(msSketch); ADD(msIndex); ADD(msFragSketch); ADD(msL1); ADD(msL2); ADD(msReduce); ADD(msL2Kernel); ADD(msL2Ranges); ADD(msL2Codes); ADD(msL2Slow);
+  ADD(msL2SimB);
   ADD(msL1Probe); ADD(msL1Main); ADD(msL1Big); ADD(msL1Tiny);
 #undef ADD
 }
@@ -139,29 +144,32 @@ int ani_init(int device, ani_ctx **out)
   memset(&c->counters, 0, sizeof c->counters);
   HIP_TRY(hipStreamCreate(&c->stream));
   {
-    // ANI_SIDE_PRIORITY=low|high: queue priority of the side stream (index side work, the L2 simulation) — an A/B knob
-    const char *ev = getenv("ANI_SIDE_PRIORITY");
+    // ANI_TEST_SIDE_PRIORITY=low|high: queue priority of the side stream (index side work, the L2 simulation) — an A/B knob
+    const char *ev = getenv("ANI_TEST_SIDE_PRIORITY");
     int least = 0, greatest = 0;
     if (ev && (!strcmp(ev, "low") || !strcmp(ev, "high")) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
       HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamDefault, !strcmp(ev, "low") ? least : greatest));
     else HIP_TRY(hipStreamCreate(&c->stream2));
   }
   if (const char *ev = getenv("ANI_SUBBATCH_FRAGS")) { const long long v = atoll(ev); if (v > 0) c->subBatchFragments = (uint64_t)v; }
-  if (const char *ev = getenv("ANI_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
-  if (const char *ev = getenv("ANI_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_TEST_L2_CHUNK")) { const long long v = atoll(ev); if (v >= 1) c->l2ChunkCandidates = (size_t)v; }
+  if (const char *ev = getenv("ANI_TEST_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_INDEX_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->maxIndexMinimizers = (uint64_t)v; }
-  if (const char *ev = getenv("ANI_L1_FILTER_MIN")) c->l1FilterMin = atoi(ev);
-  if (const char *ev = getenv("ANI_L1_LDS_MAX")) c->l1LdsMax = std::max(0, std::min(atoi(ev), 4096 /* ani::kL1HitCapMax */));
-  if (const char *ev = getenv("ANI_DUP_PAIR_CAP")) { const long long v = atoll(ev); if (v >= 1) c->dupPairCap = (uint64_t)v; }
-  if (const char *ev = getenv("ANI_L1_TINY")) c->l1Tiny = strcmp(ev, "0") != 0;
-  if (const char *ev = getenv("ANI_L2_OVERLAP")) c->l2Overlap = strcmp(ev, "0") != 0;
-  if (const char *ev = getenv("ANI_L1_HIT_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l1HitLimit = std::min<uint64_t>((uint64_t)v, 0x7ffffff0ull); }
-  if (const char *ev = getenv("ANI_CAND_POOL_MIN")) { const long long v = atoll(ev); if (v >= 1) c->candPoolMin = (uint64_t)v; }
-  if (const char *ev = getenv("ANI_L1_BIG_GROUP_HITS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupHits = (uint64_t)v; }
-  if (const char *ev = getenv("ANI_L1_BIG_GROUP_FRAGS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupFrags = (uint64_t)v; }
-  if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev); if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
+  if (const char *ev = getenv("ANI_TEST_L1_FILTER_MIN")) c->l1FilterMin = atoi(ev);
+  if (const char *ev = getenv("ANI_TEST_L1_LDS_MAX")) c->l1LdsMax = std::max(0, std::min(atoi(ev), 4096 /* ani::kL1HitCapMax */));
+  if (const char *ev = getenv("ANI_TEST_DUP_PAIR_CAP")) { const long long v = atoll(ev); if (v >= 1) c->dupPairCap = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_TEST_L1_TINY")) c->l1Tiny = strcmp(ev, "0") != 0;
+  if (const char *ev = getenv("ANI_TEST_L2_OVERLAP")) c->l2Overlap = strcmp(ev, "0") != 0;
+  if (const char *ev = getenv("ANI_TEST_L1_HIT_LIMIT")) { const long long v = atoll(ev);
+    if (v >= 1) c->l1HitLimit = std::min<uint64_t>((uint64_t)v, 0x7ffffff0ull); }
+  if (const char *ev = getenv("ANI_TEST_CAND_POOL_MIN")) { const long long v = atoll(ev); if (v >= 1) c->candPoolMin = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_TEST_L1_BIG_GROUP_HITS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupHits = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_TEST_L1_BIG_GROUP_FRAGS")) { const long long v = atoll(ev); if (v >= 1) c->l1BigGroupFrags = (uint64_t)v; }
+  if (const char *ev = getenv("ANI_MAX_RESIDENT_CHUNKS")) { const long long v = atoll(ev);
+    if (v >= 0) c->maxResidentChunks = (int32_t)std::min<long long>(v, 1 << 20); }
   if (const char *ev = getenv("ANI_STREAM_CHUNK_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->streamChunkMinimizers = (uint64_t)v; }
-  for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evIndex[i], hipEventDisableTiming)); }
+  for (int i = 0; i < 2; i++) { HIP_TRY(hipEventCreateWithFlags(&c->evSimA[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evSetDone[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evIndex[i], hipEventDisableTiming)); }
   int rc = c->dCounters.ensure(kCounterWords * 8);
   if (rc != ANI_OK) { delete c; return rc; }
   *out = c;
@@ -180,7 +188,8 @@ void ani_shutdown(ani_ctx *c)
                     &c->l2First, &c->l2Last, &c->refStart, &c->idBits, &c->keepFlags, &c->keepOff, &c->mapOut, &c->bins, &c->queryFragments, &c->rows};
   for (DevBuf *b : bufs) b->release();
   for (hipEvent_t e : c->timerEvents) if (e) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]); if (c->evIndex[i]) (void)hipEventDestroy(c->evIndex[i]); }
+  for (int i = 0; i < 2; i++) { if (c->evSimA[i]) (void)hipEventDestroy(c->evSimA[i]); if (c->evSetDone[i]) (void)hipEventDestroy(c->evSetDone[i]);
+    if (c->evIndex[i]) (void)hipEventDestroy(c->evIndex[i]); }
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   for (int i = 0; i < 5; i++) if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -225,7 +234,8 @@ int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void
   else {
     int can = 0;
     (void)hipDeviceCanAccessPeer(&can, dstCtx->device, srcCtx->device);
-    if (can) { hipError_t e = hipDeviceEnablePeerAccess(srcCtx->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e); (void)hipGetLastError(); }
+    if (can) { hipError_t e = hipDeviceEnablePeerAccess(srcCtx->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+      (void)hipGetLastError(); }
     HIP_TRY(hipMemcpyPeerAsync(dst, dstCtx->device, src, srcCtx->device, bytes, dstCtx->stream));
   }
   HIP_TRY(hipStreamSynchronize(dstCtx->stream));
@@ -275,13 +285,15 @@ int ani_synth_packed(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firs
   return ani_synth_packed_clusters(ctx, seed, variant, firstGenomeId, nGenomes, genomeLen, 20, devOut);
 }
 
-int ani_synth_packed_clusters(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, int32_t clusterSize, void *devOut)
+int ani_synth_packed_clusters(ani_ctx *ctx, uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, int32_t clusterSize,
+    void *devOut)
 {
   if (!ctx || !devOut || nGenomes < 0 || genomeLen <= 0 || firstGenomeId < 0 || clusterSize < 1) return fail(ANI_ERR_ARG, "invalid argument");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t words = (size_t)nGenomes * (((size_t)genomeLen + 15) / 16);
   if (words == 0) return ANI_OK;
-  hipLaunchKernelGGL(ani::k_synth_packed, dim3(grid_for(words, 256, 65535)), dim3(256), 0, ctx->stream, seed, variant, firstGenomeId, nGenomes, genomeLen, clusterSize, (uint32_t *)devOut);
+  hipLaunchKernelGGL(ani::k_synth_packed, dim3(grid_for(words, 256, 65535)), dim3(256), 0, ctx->stream, seed, variant, firstGenomeId, nGenomes, genomeLen,
+      clusterSize, (uint32_t *)devOut);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return ANI_OK;

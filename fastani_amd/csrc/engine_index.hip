@@ -45,9 +45,11 @@ int upload_luts(ani_sketch *sk, int maxS)
   for (auto &l : ctx->lutCache) if (l->k == sk->params.kmerSize && l->identityCutoff == sk->params.percentageIdentity) sk->luts = l.get();
   if (!sk->luts) { ctx->lutCache.emplace_back(new ani::stat::Luts()); sk->luts = ctx->lutCache.back().get(); }
   sk->luts->extend(sk->params.kmerSize, sk->params.percentageIdentity, target);
-  if (sk->dMinHits) { pool_free(sk->dMinHits); pool_free(sk->dMinShared); pool_free(sk->dIdLUT); sk->dMinHits = sk->dMinShared = nullptr; sk->dIdLUT = nullptr; }
+  if (sk->dMinHits) { pool_free(sk->dMinHits); pool_free(sk->dMinShared); pool_free(sk->dIdLUT); sk->dMinHits = sk->dMinShared = nullptr;
+    sk->dIdLUT = nullptr; }
   const size_t n1 = (size_t)target + 1, n2 = ani::stat::Luts::off(target + 1);
-  HIP_TRY(pool_malloc((void **)&sk->dMinHits, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dMinShared, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dIdLUT, n2 * 4 + 4));
+  HIP_TRY(pool_malloc((void **)&sk->dMinHits, n1 * 4)); HIP_TRY(pool_malloc((void **)&sk->dMinShared, n1 * 4));
+  HIP_TRY(pool_malloc((void **)&sk->dIdLUT, n2 * 4 + 4));
   HIP_TRY(hipMemcpy(sk->dMinHits, sk->luts->minHits.data(), n1 * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(sk->dMinShared, sk->luts->minShared.data(), n1 * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(sk->dIdLUT, sk->luts->idBits.data(), n2 * 4, hipMemcpyHostToDevice));
@@ -117,7 +119,8 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
   {
     StageTimer tm(ctx, &ctx->counters.msIndex);
     const int32_t cmw = p->fragLen - (p->windowSize - 1) - (p->kmerSize - 1);
-    const bool winLinks = n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask;        // otherwise the L2 fast path is off (map_stage) and the window links are never read
+    // otherwise the L2 fast path is off (map_stage) and the window links are never read
+    const bool winLinks = n && cmw >= 1 && cmw + 2 <= (int32_t)kWinMask;
     uint32_t *tmpK = nullptr; uint64_t *tmpV = nullptr;
     SK_HIP(pool_malloc((void **)&tmpK, n4));
     { const hipError_t ev = pool_malloc((void **)&tmpV, 2 * n4); if (ev != hipSuccess) { pool_free(tmpK); SK_HIP(ev); } }
@@ -132,23 +135,31 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
       std::vector<const void *> recs; std::vector<size_t> cnts;
       for (const RecordPiece &pc : sk->pieces) if (pc.n) { recs.push_back(pc.rec); cnts.push_back(pc.n); }
       size_t tb = 0;
-      int rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, nullptr, &tb, ctx->stream, nullptr, nullptr);
-      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256); if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, nullptr, nullptr); }
-      if (rc != 0) { pool_free(tmpK); pool_free(tmpV); return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
+      int rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV, sk->sHash, sk->sSW,
+          nullptr, &tb, ctx->stream, nullptr, nullptr);
+      if (rc == 0) { rc = ctx->sortTmp.ensure(tb + 256);
+        if (rc == ANI_OK) rc = ani_sort_index(recs.data(), cnts.data(), (int)recs.size(), (uint32_t)c0, n, sk->mHash, sk->mSeq, sk->mWpos, tmpK, tmpV,
+          sk->sHash, sk->sSW, ctx->sortTmp.p, &tb, ctx->stream, nullptr, nullptr); }
+      if (rc != 0) { pool_free(tmpK); pool_free(tmpV);
+        return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the index failed (%d)", rc)); }
     }
     pool_free(tmpK); pool_free(tmpV);
-    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs, sk->contigFirstMin);
+    hipLaunchKernelGGL(k_index_contig_first, dim3(grid_for((size_t)nContigs + 1, 256, 65535)), dim3(256), 0, ctx->stream, sk->mSeq, (uint32_t)n, nContigs,
+        sk->contigFirstMin);
     SK_HIP(hipEventRecord(ctx->evIndex[0], ctx->stream));
     SK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->evIndex[0], 0));
     if (winLinks)
-      hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + kWinBlock - 1) / kWinBlock)), dim3(256), 0, ctx->stream2, (const int32_t *)sk->mSeq, (const int32_t *)sk->mWpos,
+      hipLaunchKernelGGL(k_index_window_links, dim3((unsigned)((n + kWinBlock - 1) / kWinBlock)), dim3(256), 0, ctx->stream2, (const int32_t *)sk->mSeq,
+          (const int32_t *)sk->mWpos,
                          (const int32_t *)sk->contigFirstMin, (uint32_t)n, cmw - 1, (int32_t)((2 * (int64_t)cmw) / (p->windowSize + 1)), sk->mWin);
-    if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mWpos, sk->contigFirstMin, sk->posBase, nContigs,
+    if (nContigs) hipLaunchKernelGGL(k_index_pos_sample, dim3(grid_for((size_t)sk->totalPosBins + 1, 256, 65535)), dim3(256), 0, ctx->stream2, sk->mWpos,
+        sk->contigFirstMin, sk->posBase, nContigs,
                                     sk->totalPosBins, (uint32_t)n, sk->posSample);
     SK_HIP(hipGetLastError());                                             // (joined at the end: the nearDup flags go into the window links there)
     // same-hash links of near duplicates (index.hpp: DupLinks) and the number of distinct hashes
     uint64_t *dupPairs = nullptr; int dupKeyBits = 0;           // the unsorted half-records while their sort is in flight on the side stream
-    struct PairsGuard { uint64_t *&p; ani_ctx *c; ~PairsGuard() { if (p) { (void)hipStreamSynchronize(c->stream2); pool_free(p); p = nullptr; } } } pairsGuard{dupPairs, ctx};
+    struct PairsGuard { uint64_t *&p; ani_ctx *c; ~PairsGuard() { if (p) { (void)hipStreamSynchronize(c->stream2); pool_free(p); p = nullptr;
+      } } } pairsGuard{dupPairs, ctx};
     unsigned long long host[CNT_N];
     host[CNT_UNIQ] = 0;
     // (the probe table's block totals are queued right behind the links — the kernel takes the number of distinct hashes from the
@@ -160,13 +171,16 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
     int32_t *best = cnt + (nb ? nb : 1);
     if (n) {
       SK_TRY(ctx->scanTmpA.ensure((size_t)nb * 4)); SK_TRY(ctx->scanTmpB.ensure((size_t)nb * 4));
-      uint32_t pairCap = (uint32_t)std::min<uint64_t>(n, ctx->dupPairCap ? ctx->dupPairCap : n / 64 + 4096);     // first guess; a repetitive reference reruns with the exact count
+      // first guess; a repetitive reference reruns with the exact count
+      uint32_t pairCap = (uint32_t)std::min<uint64_t>(n, ctx->dupPairCap ? ctx->dupPairCap : n / 64 + 4096);
       for (int attempt = 0;; attempt++) {
         uint64_t *pairs = nullptr;
         SK_HIP(pool_malloc((void **)&pairs, (size_t)pairCap * 16));
         { const int rz = zero_counters(ctx); if (rz != ANI_OK) { pool_free(pairs); return bail(rz); } }
-        hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n, sk->mWpos, sk->contigFirstMin,
-                           cmw, pairs, pairCap, (unsigned int *)cnt_ptr(ctx, CNT_NEG), sk->dupBits, (uint32_t *)nullptr /* k_index_mark_dups sets the window links' flags */, cnt_ptr(ctx, CNT_UNIQ));
+        hipLaunchKernelGGL(k_index_links, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ctx->stream, sk->sHash, (const uint64_t *)sk->sSW, (uint32_t)n,
+            sk->mWpos, sk->contigFirstMin,
+                           cmw, pairs, pairCap, (unsigned int *)cnt_ptr(ctx,
+                               CNT_NEG), sk->dupBits, (uint32_t *)nullptr /* k_index_mark_dups sets the window links' flags */, cnt_ptr(ctx, CNT_UNIQ));
         if (attempt == 0) {
           hipLaunchKernelGGL(k_table_block_totals, dim3(nb), dim3(kTPB), 0, ctx->stream, (const uint32_t *)sk->sHash, (uint32_t)n, p->windowSize,
                              (const unsigned long long *)cnt_ptr(ctx, CNT_UNIQ), ctx->scanTmpA.as<int32_t>(), ctx->scanTmpB.as<int32_t>());
@@ -237,13 +251,17 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
       // entries with same-hash links go into the finished window links
       if (dupPairs) {
         int rc = ani_sort_check(ctx->sortTmp.p, ctx->stream2);
-        if (rc == 9001) { size_t tb = ctx->sortTmp.cap; rc = ani_sort_keys_u64_range(dupPairs, sk->dupList, sk->nDup, 31, dupKeyBits, ctx->sortTmp.p, &tb, ctx->stream2, 0); }     // a look-back gave up: once more, waiting for it
-        if (rc != 0) return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE, "radix sort of the same-hash links failed (%d)", rc));
+        // a look-back gave up: once more, waiting for it
+        if (rc == 9001) { size_t tb = ctx->sortTmp.cap;
+          rc = ani_sort_keys_u64_range(dupPairs, sk->dupList, sk->nDup, 31, dupKeyBits, ctx->sortTmp.p, &tb, ctx->stream2, 0); }
+        if (rc != 0) return bail(rc < 0 && rc >= ANI_ERR_INTERNAL ? rc : fail(rc > 9000 ? ANI_ERR_INTERNAL : ANI_ERR_DEVICE,
+            "radix sort of the same-hash links failed (%d)", rc));
         pool_free(dupPairs); dupPairs = nullptr;
       }
       SK_HIP(hipEventRecord(ctx->evIndex[1], ctx->stream2));
       SK_HIP(hipStreamWaitEvent(ctx->stream, ctx->evIndex[1], 0));
-      if (winLinks && sk->nDup) hipLaunchKernelGGL(k_index_mark_dups, dim3(grid_for((size_t)sk->nDup)), dim3(256), 0, ctx->stream, (const uint64_t *)sk->dupList, sk->nDup, sk->mWin);
+      if (winLinks && sk->nDup) hipLaunchKernelGGL(k_index_mark_dups, dim3(grid_for((size_t)sk->nDup)), dim3(256), 0, ctx->stream,
+          (const uint64_t *)sk->dupList, sk->nDup, sk->mWin);
       SK_HIP(hipStreamSynchronize(ctx->stream));                             // cnt / best / sentinel are host memory
       sk->tableSlots = nSlots;
     }
@@ -316,7 +334,8 @@ int add_chunks(ani_ctx *ctx, ani_sketch *sk, std::vector<RecordPart> &parts)
     std::vector<uint64_t> first((size_t)nc + 1, 0);
     if (pt.n) {
       TRY(ctx->unitAux.ensure(((size_t)nc + 1) * 8));
-      hipLaunchKernelGGL(k_records_contig_first, dim3(grid_for((size_t)nc + 1, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)pt.rec, (uint64_t)pt.n, c0, nc,
+      hipLaunchKernelGGL(k_records_contig_first, dim3(grid_for((size_t)nc + 1, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)pt.rec,
+          (uint64_t)pt.n, c0, nc,
                          ctx->unitAux.as<uint64_t>());
       HIP_TRY(hipMemcpyAsync(first.data(), ctx->unitAux.p, ((size_t)nc + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -420,7 +439,8 @@ int exact_unique(ani_sketch *sk)
       IndexChunk *E = sk->chunks[x];
       if (!E->n) continue;
       { const int rcE = ensure_chunk(sk, x, (int)c); if (rcE != ANI_OK) { pool_free(seen); return rcE; } }
-      hipLaunchKernelGGL(k_index_mark_shared, dim3(grid_for(C->n, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)C->sHash, C->n, (const TableSlot *)E->table,
+      hipLaunchKernelGGL(k_index_mark_shared, dim3(grid_for(C->n, 256, 65535)), dim3(256), 0, ctx->stream, (const uint32_t *)C->sHash, C->n,
+          (const TableSlot *)E->table,
                          E->tableSlots, sk->params.windowSize, seen);
     }
     int rc = e == hipSuccess ? zero_counters(ctx) : fail(ANI_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(e));
@@ -537,7 +557,8 @@ int sketch_from_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const
                       const int32_t *partGenomeStart, const int32_t *contigLen, int32_t nContigs,
                       const int32_t *genomeContigStart, int32_t nGenomes, bool adopt, ani_sketch **out, bool *consumed)
 {
-  if (!ctx || !out || nParts < 0 || (nParts && (!devRecords || !n || !partGenomeStart)) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen) || !genomeContigStart)
+  if (!ctx || !out || nParts < 0 || (nParts && (!devRecords || !n || !partGenomeStart)) || nContigs < 0 || nGenomes < 0 || (nContigs && !contigLen)
+      || !genomeContigStart)
     return fail(ANI_ERR_ARG, "invalid argument");
   if (genomeContigStart[0] != 0 || genomeContigStart[nGenomes] != nContigs) return fail(ANI_ERR_ARG, "genomeContigStart does not cover the contig table");
   if (nParts && (partGenomeStart[0] != 0 || partGenomeStart[nParts] != nGenomes)) return fail(ANI_ERR_ARG, "partGenomeStart does not cover the genomes");
@@ -547,7 +568,8 @@ int sketch_from_parts(ani_ctx *ctx, const ani_params_t *p, int32_t nParts, const
   std::vector<RecordPart> parts((size_t)nParts);
   for (int32_t i = 0; i < nParts; i++) {
     if (partGenomeStart[i + 1] < partGenomeStart[i] || (n[i] && !devRecords[i])) return fail(ANI_ERR_ARG, "record part %d is malformed", i);
-    parts[i].rec = (uint32_t *)devRecords[i]; parts[i].n = (size_t)n[i]; parts[i].g0 = partGenomeStart[i]; parts[i].g1 = partGenomeStart[i + 1]; parts[i].owned = false;
+    parts[i].rec = (uint32_t *)devRecords[i]; parts[i].n = (size_t)n[i]; parts[i].g0 = partGenomeStart[i]; parts[i].g1 = partGenomeStart[i + 1];
+    parts[i].owned = false;
   }
   // adopted buffers: a streamed set keeps them as they are (no copy of the records: a set near the device's capacity has no room
   // for one), a resident set releases each as soon as the chunks that need it are built; whatever add_chunks did not take goes back here
@@ -624,7 +646,8 @@ int ani_sketch_export(const ani_sketch *sk, ani_minimizer_t **out, size_t *n)
     uint32_t *tmp = nullptr;
     hipError_t e = pool_malloc((void **)&tmp, (size_t)ch->n * 12);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(ch->n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash, ch->mSeq, ch->mWpos, ch->n, (uint32_t)ch->c0, tmp);
+      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(ch->n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash, ch->mSeq, ch->mWpos, ch->n,
+          (uint32_t)ch->c0, tmp);
       e = hipMemcpyAsync(*out + o, tmp, (size_t)ch->n * 12, hipMemcpyDeviceToHost, ctx->stream);
     }
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);
@@ -689,8 +712,10 @@ struct SketchFileHeader {
 };
 constexpr uint64_t kFileAlign = 4096;
 inline uint64_t align_up(uint64_t x) { return (x + kFileAlign - 1) / kFileAlign * kFileAlign; }
-bool write_all(int fd, const void *p, size_t n) { const char *c = (const char *)p; while (n) { const ssize_t w = ::write(fd, c, n); if (w <= 0) return false; c += w; n -= (size_t)w; } return true; }
-bool pad_to(int fd, uint64_t *pos, uint64_t target) { static const char z[4096] = {0}; while (*pos < target) { const size_t n = (size_t)std::min<uint64_t>(4096, target - *pos); if (!write_all(fd, z, n)) return false; *pos += n; } return true; }
+bool write_all(int fd, const void *p, size_t n) { const char *c = (const char *)p; while (n) { const ssize_t w = ::write(fd, c, n); if (w <= 0) return false;
+  c += w; n -= (size_t)w; } return true; }
+bool pad_to(int fd, uint64_t *pos, uint64_t target) { static const char z[4096] = {0};
+  while (*pos < target) { const size_t n = (size_t)std::min<uint64_t>(4096, target - *pos); if (!write_all(fd, z, n)) return false; *pos += n; } return true; }
 }  // namespace
 
 // A sketch file is written through a WRITER, so that a reference set whose records exceed the device memory (90 000 x 5 Mbp genomes:
@@ -711,7 +736,8 @@ int ani_sketch_writer_open(const char *path, ani_sketch_writer **out)
   if (fd < 0) return fail(ANI_ERR_ARG, "cannot create %s", path);
   ani_sketch_writer *w = new ani_sketch_writer();
   w->fd = fd; w->path = path;
-  if (!pad_to(fd, &w->pos, kFileAlign)) { ::close(fd); ::unlink(path); delete w; return fail(ANI_ERR_DEVICE, "writing %s failed", path); }     // the header's place
+  // the header's place
+  if (!pad_to(fd, &w->pos, kFileAlign)) { ::close(fd); ::unlink(path); delete w; return fail(ANI_ERR_DEVICE, "writing %s failed", path); }
   *out = w;
   return ANI_OK;
 }
@@ -729,7 +755,8 @@ int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char
   const std::vector<uint64_t> &genomeRec = sk->genomeRecStart;      // first record of every genome (add_chunks)
   if (genomeRec.size() != (size_t)sk->nGenomes + 1) { w->failed = true; return fail(ANI_ERR_INTERNAL, "sketch without its genome record table"); }
   const int64_t contigBase = (int64_t)w->contigLen.size();
-  if (contigBase + sk->nContigs > 0x7fffffffll || (int64_t)w->gcs.size() - 1 + sk->nGenomes > 0x7fffffffll) { w->failed = true; return fail(ANI_ERR_LIMIT, "more than 2^31 contigs or genomes in one sketch file"); }
+  if (contigBase + sk->nContigs > 0x7fffffffll || (int64_t)w->gcs.size() - 1 + sk->nGenomes > 0x7fffffffll) { w->failed = true;
+    return fail(ANI_ERR_LIMIT, "more than 2^31 contigs or genomes in one sketch file"); }
   // records: joined on the device into 12-byte records with file-global seqIds, through page-locked staging, 64 M records at a time
   const size_t kPiece = (size_t)64 << 20;
   bool ok = true;
@@ -745,7 +772,8 @@ int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char
           if (contigBase) {                  // seqIds move up by the contigs already in the file
             if (pool_malloc((void **)&tmp, m * 12) != hipSuccess) { ok = false; break; }
             e = hipMemcpyAsync(tmp, src, m * 12, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) hipLaunchKernelGGL(ani::k_records_rebase, dim3(grid_for(m, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, tmp, (uint64_t)m, (int32_t)(-contigBase));
+            if (e == hipSuccess) hipLaunchKernelGGL(ani::k_records_rebase, dim3(grid_for(m, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, tmp, (uint64_t)m,
+                (int32_t)(-contigBase));
             src = tmp;
           }
           if (e == hipSuccess) e = hipMemcpyAsync(host, src, m * 12, hipMemcpyDeviceToHost, ctx->stream);
@@ -759,7 +787,8 @@ int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char
       const size_t m = std::min<size_t>(kPiece, ch->n - o);
       uint32_t *tmp = nullptr; void *host = nullptr;
       if (pool_malloc((void **)&tmp, m * 12) != hipSuccess || pinned_buffer(ctx, 0, m * 12, &host) != ANI_OK) { if (tmp) pool_free(tmp); ok = false; break; }
-      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(m, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash + o, ch->mSeq + o, ch->mWpos + o, (uint32_t)m, (uint32_t)(ch->c0 + contigBase), tmp);
+      hipLaunchKernelGGL(ani::k_index_join, dim3(grid_for(m, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, ch->mHash + o, ch->mSeq + o, ch->mWpos + o,
+          (uint32_t)m, (uint32_t)(ch->c0 + contigBase), tmp);
       hipError_t e = hipMemcpyAsync(host, tmp, m * 12, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       pool_free(tmp);
@@ -769,7 +798,8 @@ int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char
   if (!ok) { w->failed = true; return fail(ANI_ERR_DEVICE, "writing %s failed", w->path.c_str()); }
   w->pos += sk->n * 12;
   w->contigLen.insert(w->contigLen.end(), sk->contigLen.begin(), sk->contigLen.begin() + sk->nContigs);
-  for (int32_t g = 1; g <= sk->nGenomes; g++) { w->gcs.push_back((int32_t)(contigBase + sk->genomeContigStart[g])); w->genomeRec.push_back(w->nRecords + genomeRec[g]); }
+  for (int32_t g = 1; g <= sk->nGenomes; g++) { w->gcs.push_back((int32_t)(contigBase + sk->genomeContigStart[g]));
+    w->genomeRec.push_back(w->nRecords + genomeRec[g]); }
   w->nRecords += sk->n;
   for (int32_t g = 0; g < sk->nGenomes; g++) { w->names += genomeNames && genomeNames[g] ? genomeNames[g] : (g < (int32_t)sk->genomeNames.size() ? sk->genomeNames[g].c_str() : ""); w->names.push_back('\0'); }
   return ANI_OK;
@@ -810,7 +840,8 @@ int ani_sketch_writer_close(ani_sketch_writer *w)
   const std::string path = w->path;
   const bool hadSketch = w->haveParams;
   delete w;
-  if (!ok) { ::unlink(path.c_str()); return fail(hadSketch ? ANI_ERR_DEVICE : ANI_ERR_ARG, hadSketch ? "writing %s failed" : "%s: a sketch file needs at least one sketch", path.c_str()); }
+  if (!ok) { ::unlink(path.c_str()); return fail(hadSketch ? ANI_ERR_DEVICE : ANI_ERR_ARG,
+      hadSketch ? "writing %s failed" : "%s: a sketch file needs at least one sketch", path.c_str()); }
   return ANI_OK;
 }
 
@@ -843,7 +874,8 @@ int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_
   // section extents without overflow: a section [off, off + count * size) lies inside the file iff off <= fileBytes and count <= (fileBytes - off) / size
   auto inside = [&](uint64_t off, uint64_t count, uint64_t size) { return off <= fileBytes && count <= (fileBytes - off) / size; };
   if (h.nContigs < 0 || h.nGenomes < 0 || !inside(h.offRecords, h.nRecords, 12) || !inside(h.offNames, h.namesBytes, 1) ||
-      !inside(h.offGenomeRec, (uint64_t)h.nGenomes + 1, 8) || !inside(h.offGcs, (uint64_t)h.nGenomes + 1, 4) || !inside(h.offContigLen, (uint64_t)h.nContigs, 4) ||
+      !inside(h.offGenomeRec, (uint64_t)h.nGenomes + 1, 8) || !inside(h.offGcs, (uint64_t)h.nGenomes + 1, 4) || !inside(h.offContigLen, (uint64_t)h.nContigs,
+          4) ||
       (h.offRecords | h.offGenomeRec | h.offGcs | h.offContigLen) % 4 != 0 || h.offGenomeRec % 8 != 0)
     return fail(ANI_ERR_ARG, "%s is truncated", path);
   {
@@ -866,7 +898,8 @@ int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_
   for (int32_t g = 0; g <= nG; g++) gcs[g] = gcsF[g0 + g] - c0;
   ani_sketch *sk = new_sketch(ctx, &p, clenF + c0, c1 - c0, gcs.data(), nG);
   { const char *nm = (const char *)(base + h.offNames), *end = nm + h.namesBytes;
-    for (int32_t g = 0; g < h.nGenomes && nm < end; g++) { const size_t l = strnlen(nm, (size_t)(end - nm)); if (g >= g0 && g < g1) sk->genomeNames.emplace_back(nm, l); nm += l + 1; } }
+    for (int32_t g = 0; g < h.nGenomes && nm < end; g++) { const size_t l = strnlen(nm, (size_t)(end - nm));
+      if (g >= g0 && g < g1) sk->genomeNames.emplace_back(nm, l); nm += l + 1; } }
   // records to the device in pieces of whole genomes (<= 64 M records), seqIds rebased to the range's first contig
   std::vector<RecordPart> parts;
   auto bail = [&](int rc) { for (auto &q : parts) if (q.rec) pool_free(q.rec); free_sketch_device(sk); delete sk; return rc; };
@@ -880,7 +913,8 @@ int ani_sketch_load(ani_ctx *ctx, const char *path, int32_t g0, int32_t g1, ani_
       if (pool_malloc((void **)&pt.rec, pt.n * 12) != hipSuccess) return bail(fail(ANI_ERR_NOMEM, "device allocation of %zu records failed", pt.n));
       parts.push_back(pt);
       hipError_t e = hipMemcpyAsync(pt.rec, base + h.offRecords + grec[ga] * 12, pt.n * 12, hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess && c0) hipLaunchKernelGGL(ani::k_records_rebase, dim3(grid_for(pt.n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, pt.rec, (uint64_t)pt.n, c0);
+      if (e == hipSuccess && c0) hipLaunchKernelGGL(ani::k_records_rebase, dim3(grid_for(pt.n, 256, 65535u * 8u)), dim3(256), 0, ctx->stream, pt.rec,
+          (uint64_t)pt.n, c0);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "copying records to the device failed: %s", hipGetErrorString(e)));
     } else parts.push_back(pt);
@@ -911,7 +945,8 @@ int ani_sketch_file_info(const char *path, ani_params_t *p, int32_t *nContigs, i
 }
 
 // genome name / contig lengths of a (loaded) sketch: what the command line needs to print results without the FASTA files
-const char *ani_sketch_genome_name(const ani_sketch *sk, int32_t g) { return (sk && g >= 0 && g < (int32_t)sk->genomeNames.size()) ? sk->genomeNames[g].c_str() : ""; }
+const char *ani_sketch_genome_name(const ani_sketch *sk, int32_t g) { return (sk && g >= 0
+    && g < (int32_t)sk->genomeNames.size()) ? sk->genomeNames[g].c_str() : ""; }
 int ani_sketch_tables(const ani_sketch *sk, const int32_t **contigLen, const int32_t **genomeContigStart)
 {
   if (!sk) return fail(ANI_ERR_ARG, "null sketch");

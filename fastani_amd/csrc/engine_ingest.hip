@@ -10,7 +10,8 @@ int check_batch(const ani_seq_batch_t *b)
     return fail(ANI_ERR_ARG, "invalid sequence batch");
   if (b->layout == ANI_SEQ_DEVICE_BATCH) return b->data ? ANI_OK : fail(ANI_ERR_ARG, "sequence batch without its device batch handle");
   if (b->nContigs && !b->data) return fail(ANI_ERR_ARG, "sequence batch without data");
-  if (b->layout != ANI_SEQ_HOST_ASCII && b->layout != ANI_SEQ_DEVICE_PACKED2 && b->layout != ANI_SEQ_HOST_ASCII_PTRS) return fail(ANI_ERR_ARG, "unknown sequence layout %d", b->layout);
+  if (b->layout != ANI_SEQ_HOST_ASCII && b->layout != ANI_SEQ_DEVICE_PACKED2 && b->layout != ANI_SEQ_HOST_ASCII_PTRS) return fail(ANI_ERR_ARG,
+      "unknown sequence layout %d", b->layout);
   if (b->layout != ANI_SEQ_HOST_ASCII_PTRS && b->nContigs && !b->contigOffset) return fail(ANI_ERR_ARG, "sequence batch without contig offsets");
   for (int32_t c = 0; c < b->nContigs; c++) if (b->contigLen[c] < 0) return fail(ANI_ERR_LIMIT, "contig %d has a negative length (>= 2^31 bases?)", c);
   return ANI_OK;

@@ -41,7 +41,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // the fragment id, the candidates of a fragment stay contiguous, and single-genome calls (ani_map_query, whose mappings are
   // returned in callback order) keep the ascending order.
   const int32_t *fragOrder = nullptr;
-  { const char *ev = getenv("ANI_FRAG_ORDER");
+  { const char *ev = getenv("ANI_TEST_FRAG_ORDER");
     if (fs.genomeFragments.size() >= 2 && fs.fragQSeq && !(ev && !strcmp(ev, "plain"))) {
       TRY(ctx->fragOrder.ensure(nF * 4)); TRY(ctx->fragOrderTmp.ensure(nF * 20));
       uint64_t *keyIn = ctx->fragOrderTmp.as<uint64_t>(), *keyOut = keyIn + nF; uint32_t *idxIn = (uint32_t *)(keyOut + nF);
@@ -50,7 +50,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       int keyBits = 1;                              // keys are running fragment ids inside a genome: 11 bits for 5 Mbp genomes, two 8-bit passes
       { int32_t mx = 0; for (int32_t v : fs.genomeFragments) mx = std::max(mx, v); while (keyBits < 32 && (1ll << keyBits) <= (long long)mx) keyBits++; }
       int rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, keyBits, nullptr, &tb, ctx->stream);
-      if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 256)); rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, keyBits, ctx->sortTmp.p, &tb, ctx->stream); }
+      if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 256));
+        rc = ani_sort_pairs_u64_u32(keyIn, keyOut, idxIn, ctx->fragOrder.as<uint32_t>(), nF, keyBits, ctx->sortTmp.p, &tb, ctx->stream); }
       if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of the fragment order failed (%d)", rc);
       fragOrder = ctx->fragOrder.as<int32_t>();
     } }
@@ -62,7 +63,9 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // First guess of the candidate pool from the context's running estimate, never beyond what 32-bit candidate ids allow (the limit
   // is an error only when the batch really needs more: the retry below).
   const uint64_t kCandLimit = 0x7fffff00ull;      // whole stripes below 2^31
-  uint64_t ccap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)nF * ctx->candPerFrag) + ctx->candPoolMin, ctx->candPoolMin * kPoolStripes), kCandLimit);   // at least 4096 per stripe (4 MB): a few heavy fragments fit without a retry
+  // at least 4096 per stripe (4 MB): a few heavy fragments fit without a retry
+  uint64_t ccap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)nF * ctx->candPerFrag) + ctx->candPoolMin, ctx->candPoolMin * kPoolStripes),
+      kCandLimit);
   const bool smallBatch = nF < 16 * (size_t)kPoolStripes;
   if (smallBatch) ccap = std::min<uint64_t>(std::max<uint64_t>(ccap, ctx->smallBatchCandCap), kCandLimit);
   TRY(ctx->l1MidList.ensure(nF * 4)); TRY(ctx->l1BigList.ensure(nF * 4));
@@ -74,12 +77,14 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     ccap = (uint64_t)stripe_cap(ccap) * kPoolStripes;
     TRY(ctx->candFrag.ensure(ccap * 4)); TRY(ctx->candSeq.ensure(ccap * 4)); TRY(ctx->candStart.ensure(ccap * 4)); TRY(ctx->candEnd.ensure(ccap * 4));
     if (attempt == 0) TRY(zero_counters(ctx));
-    else TRY(zero_cursors(ctx, POOL_CAND));            // only the candidate pool is redone: k_l1_probe's results (CNT_HITS, CNT_NEG = its overflow marker, the class lists) stay
+    // only the candidate pool is redone: k_l1_probe's results (CNT_HITS, CNT_NEG = its overflow marker, the class lists) stay
+    else TRY(zero_cursors(ctx, POOL_CAND));
     L1Args a;
     a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS; a.nFrag = (int32_t)nF;
     a.table = sk->table; a.tableSlots = sk->tableSlots; a.sSW = sk->sSW; a.bucketW = w; a.nIndex = sk->n;
     a.minHitsLUT = set->dMinHits; a.lutMaxS = set->dLutMaxS; a.L = L;
-    a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>(); a.candEnd = ctx->candEnd.as<int32_t>();
+    a.candFrag = ctx->candFrag.as<int32_t>(); a.candSeq = ctx->candSeq.as<int32_t>(); a.candStart = ctx->candStart.as<int32_t>();
+    a.candEnd = ctx->candEnd.as<int32_t>();
     a.candCap = stripe_cap(ccap); a.candCount = cur_ptr(ctx, POOL_CAND);
     a.fragCandOff = ctx->fragCandOff.as<uint32_t>(); a.fragCandCnt = ctx->fragCandCnt.as<int32_t>(); a.fragHits = ctx->fragHits.as<int32_t>();
     a.sumHits = cnt_ptr(ctx, CNT_HITS); a.tinyCount = cnt_ptr(ctx, CNT_TINY); a.smallCount = cnt_ptr(ctx, CNT_SMALL);
@@ -93,23 +98,28 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     {
       StageTimer tm(ctx, &ctx->counters.msL1);
       if (attempt == 0) {
-        { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1); hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
+        { StageTimer tk(ctx, &ctx->counters.msL1Probe, 1);
+          hipLaunchKernelGGL(k_l1_probe, dim3(pad8((nF + kL1ProbeFrags - 1) / kL1ProbeFrags)), dim3(kTPB), 0, ctx->stream, a); }
         // the probe routed the fragments to their classes: how many of each decides what is launched
         unsigned long long cls[CNT_N];
         TRY(read_counters(ctx, cls));
         nMid = (unsigned)cls[CNT_LISTM]; nBig = (unsigned)cls[CNT_LISTBIG]; nTiny = cls[CNT_TINY]; nSmall = cls[CNT_SMALL];
         ctx->counters.l1TinyFragments += nTiny;
       }
-      if (nTiny && ctx->l1Tiny) { StageTimer tk(ctx, &ctx->counters.msL1Tiny, 1); hipLaunchKernelGGL(k_l1_tiny, dim3(pad8((nF + kL1TinyFrags - 1) / kL1TinyFrags)), dim3(kTPB), 0, ctx->stream, a); }
+      if (nTiny && ctx->l1Tiny) { StageTimer tk(ctx, &ctx->counters.msL1Tiny, 1);
+        hipLaunchKernelGGL(k_l1_tiny, dim3(pad8((nF + kL1TinyFrags - 1) / kL1TinyFrags)), dim3(kTPB), 0, ctx->stream, a); }
       {
         StageTimer tk(ctx, &ctx->counters.msL1Main, 1);
-        if (2 * nSmall >= nF || getenv("ANI_L1_DENSE"))                  // the usual case: (nearly) every fragment is of class S, one workgroup per fragment
+        // the usual case: (nearly) every fragment is of class S, one workgroup per fragment
+        if (2 * nSmall >= nF || getenv("ANI_TEST_L1_DENSE"))
           hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3(pad8(nF)), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)nullptr);
         else {                                                            // a fragment set against a foreign shard / chunk: class S is the exception, listed
           TRY(ctx->l1SmallList.ensure((nSmall + 1) * 4));
           HIP_TRY(hipMemsetAsync(cnt_ptr(ctx, CNT_LISTL), 0, 8, ctx->stream));
-          hipLaunchKernelGGL(k_l1_list, dim3(grid_for(nF, kTPB)), dim3(kTPB), 0, ctx->stream, a, ctx->l1SmallList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_LISTL));
-          if (nSmall) hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nSmall), dim3(kTPB), 0, ctx->stream, a, (const int32_t *)ctx->l1SmallList.as<int32_t>());
+          hipLaunchKernelGGL(k_l1_list, dim3(grid_for(nF, kTPB)), dim3(kTPB), 0, ctx->stream, a, ctx->l1SmallList.as<int32_t>(), (unsigned int *)cnt_ptr(ctx,
+              CNT_LISTL));
+          if (nSmall) hipLaunchKernelGGL((k_l1<0, kL1HitCapSmall>), dim3((unsigned)nSmall), dim3(kTPB), 0, ctx->stream, a,
+              (const int32_t *)ctx->l1SmallList.as<int32_t>());
         }
       }
       if (attempt == 0) {
@@ -145,11 +155,13 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
             b1++;
           }
           const size_t n = b1 - b0;
-          if (tiles > 0x7ffffff0ull || hashes > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "group of oversized fragments with %llu seed hits", (unsigned long long)hits);
+          if (tiles > 0x7ffffff0ull || hashes > 0xfffffff0ull) return fail(ANI_ERR_LIMIT, "group of oversized fragments with %llu seed hits",
+              (unsigned long long)hits);
           // group tables: [frag n][sOff n+1][tileFirst n+1] as 32-bit words, then hitOff (64-bit) — one upload
           const size_t w32 = n + 2 * (n + 1), tblBytes = ((w32 * 4 + 7) / 8) * 8 + (n + 1) * 8;
           TRY(ctx->l1BigTbl.ensure(tblBytes)); TRY(ctx->l1BigHash.ensure((hashes ? hashes : 1) * 4));
-          TRY(ctx->l1BigHitsA.ensure((hits ? hits : 1) * 8)); TRY(ctx->l1BigHitsB.ensure((hits ? hits : 1) * 8)); TRY(ctx->l1BigV.ensure((hits ? hits : 1) * 4 + (size_t)nBig * 8));
+          TRY(ctx->l1BigHitsA.ensure((hits ? hits : 1) * 8)); TRY(ctx->l1BigHitsB.ensure((hits ? hits : 1) * 8));
+          TRY(ctx->l1BigV.ensure((hits ? hits : 1) * 4 + (size_t)nBig * 8));
           uint8_t *hostTbl = nullptr;
           TRY(pinned_buffer(ctx, 2, tblBytes, (void **)&hostTbl));
           uint32_t *h32 = (uint32_t *)hostTbl;
@@ -166,10 +178,14 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
             hipLaunchKernelGGL(k_l1_big_gather, dim3((unsigned)tiles), dim3(kTPB), 0, ctx->stream, a, g);
             int rankBits = 1; while (rankBits < 64 - shiftRank && (1ull << rankBits) < n) rankBits++;
             size_t tbytes = 0;
-            int rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, nullptr, &tbytes, ctx->stream);
-            if (rc == 0) { TRY(ctx->sortTmp.ensure(tbytes + 256)); rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, ctx->sortTmp.p, &tbytes, ctx->stream); }
+            int rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, nullptr,
+                &tbytes, ctx->stream);
+            if (rc == 0) { TRY(ctx->sortTmp.ensure(tbytes + 256));
+              rc = ani_sort_keys_u64_bits(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), (size_t)hits, shiftRank + rankBits, ctx->sortTmp.p,
+                &tbytes, ctx->stream); }
             if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of seed hits failed (%d)", rc);
-            hipLaunchKernelGGL(k_l1_big_unpack, dim3(grid_for((size_t)hits, 256, 65535)), dim3(256), 0, ctx->stream, ctx->l1BigHitsB.as<uint64_t>(), (uint64_t)hits, shiftSeq, shiftRank);
+            hipLaunchKernelGGL(k_l1_big_unpack, dim3(grid_for((size_t)hits, 256, 65535)), dim3(256), 0, ctx->stream, ctx->l1BigHitsB.as<uint64_t>(),
+                (uint64_t)hits, shiftSeq, shiftRank);
           }
           g.keys = ctx->l1BigHitsB.as<uint64_t>();
           hipLaunchKernelGGL(k_l1_big_candidates, dim3((unsigned)n), dim3(kTPB), 0, ctx->stream, a, g, ctx->l1BigV.as<int>() + 2 * (size_t)nBig);
@@ -194,14 +210,15 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
   // Size the pool right next time (by the fullest stripe).  Only a batch that fills the stripes evenly says anything about the next
   // one: a handful of fragments sit in a handful of stripes, and "fullest stripe x 64 / fragments" of a one-fragment batch with
   // 1000 candidates would ask for 80 000 candidates per fragment of the next, million-fragment batch (a bogus 2^31 limit error
-  // after 34 GB of pool; seen in the parity suite under ANI_POOL_POISON).  The estimate follows the batches down as well as up.
+  // after 34 GB of pool; seen in the parity suite under ANI_TEST_POOL_POISON).  The estimate follows the batches down as well as up.
   if (!smallBatch) {                             // (a one-to-many query of 1666 fragments counts: without its update every call ran the L1 kernels twice)
     const double seen = 1.25 * (double)ctx->poolMaxStripe[POOL_CAND] * kPoolStripes / (double)nF;
     ctx->candSeen[ctx->candSeenAt++ & 31] = seen;
     double mx = 12.0;
     for (double v : ctx->candSeen) mx = std::max(mx, v);
     ctx->candPerFrag = mx;
-  } else ctx->smallBatchCandCap = std::min<uint64_t>(grown_cap(ctx->poolMaxStripe[POOL_CAND]), (uint64_t)1 << 26);   // the next small batch starts from what this one needed (bounded: 1 GB of pool)
+  // the next small batch starts from what this one needed (bounded: 1 GB of pool)
+  } else ctx->smallBatchCandCap = std::min<uint64_t>(grown_cap(ctx->poolMaxStripe[POOL_CAND]), (uint64_t)1 << 26);
   if (probeOverflow != 0)                      // k_l1_probe: hit counts and offsets are 32-bit per fragment
     return fail(ANI_ERR_LIMIT, "%u query fragment(s) have 2^31 or more seed hits in one index chunk (a hash with ~10^9 occurrences: low-complexity / "
                                "repetitive references); use the reference's -s sanity check or a smaller ANI_MAX_INDEX_MINIMIZERS", probeOverflow);
@@ -229,9 +246,11 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
     StageTimer tm(ctx, &ctx->counters.msL2);
     TRY(zero_counters(ctx));
     L2Args a;
-    a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>(); a.candEnd = ctx->ocEnd.as<int32_t>();
+    a.candFrag = ctx->ocFrag.as<int32_t>(); a.candSeq = ctx->ocSeq.as<int32_t>(); a.candStart = ctx->ocStart.as<int32_t>();
+    a.candEnd = ctx->ocEnd.as<int32_t>();
     a.nCand = (int32_t)nCand; a.qPool = fs.qPool; a.fragOff = fs.fragOff; a.fragS = fs.fragS;
-    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.dup = DupLinks{sk->dupList, sk->nDup, sk->dupBits}; a.mWin = sk->mWin; a.posBase = sk->posBase; a.posSample = sk->posSample;
+    a.mHash = sk->mHash; a.mWpos = sk->mWpos; a.dup = DupLinks{sk->dupList, sk->nDup, sk->dupBits}; a.mWin = sk->mWin; a.posBase = sk->posBase;
+    a.posSample = sk->posSample;
     a.contigFirstMin = sk->contigFirstMin;
     { int lg = 0; while ((2 << lg) <= w) lg++; a.rankShift = 21 - std::max(0, lg - 1); }   // w = 24: 2048 buckets over [0, 2^29)
     a.L = L; a.w = w; a.k = k; a.scratch = nullptr; a.laneStride = 0;
@@ -272,13 +291,15 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       L2FastArgs fa;
       fa.g = a; fa.c0 = (int32_t)c0; fa.c1 = (int32_t)c1;
       fa.ranges = ctx->l2Ranges[p].as<L2Range>(); fa.codeCount = ctx->l2CodeCount[p].as<int32_t>(); fa.codeOff = ctx->l2CodeOff[p].as<uint32_t>();
-      fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag[p].as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.fragOrder = fragOrder; fa.nFrag = (int32_t)nF;
+      fa.codes = nullptr; fa.slowFlag = ctx->l2SlowFlag[p].as<int32_t>(); fa.fragCandOff = ctx->fragOrdOff.as<uint32_t>(); fa.fragOrder = fragOrder;
+      fa.nFrag = (int32_t)nF;
       // fragments that own candidates c0 and c1-1 (ordOff is non-decreasing; fragments without candidates repeat a value)
       const int32_t fA = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)c0) - ordOff) - 1;
       const int32_t fB = (int32_t)(std::upper_bound(ordOff, ordOff + nF, (uint32_t)(c1 - 1)) - ordOff) - 1;
       fa.fragBase = fA;
-      { const char *ev = getenv("ANI_L2_PATH"); fa.allowFast = (ev && !strcmp(ev, "general")) ? 0 : (ev && !strcmp(ev, "classB")) ? 2 : 1; }
-      if (L - (w - 1) - (k - 1) + 2 > (int)kWinMask || L - (w - 1) - (k - 1) < 1) fa.allowFast = 0;      // the 14-bit window links need cmw + 2 < 2^14 (and a window at all)
+      { const char *ev = getenv("ANI_TEST_L2_PATH"); fa.allowFast = (ev && !strcmp(ev, "general")) ? 0 : (ev && !strcmp(ev, "classB")) ? 2 : 1; }
+      // the 14-bit window links need cmw + 2 < 2^14 (and a window at all)
+      if (L - (w - 1) - (k - 1) + 2 > (int)kWinMask || L - (w - 1) - (k - 1) < 1) fa.allowFast = 0;
       {
         StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
         hipLaunchKernelGGL(k_l2_ranges, dim3(grid_for(n)), dim3(kTPB), 0, ctx->stream, fa);
@@ -287,7 +308,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       uint64_t nCodes = 0;
       {
         const int rc = device_scan(ctx, fa.codeCount, ctx->l2CodeOff[p].as<uint32_t>(), (uint32_t)n, &nCodes, ctx->l2CodeLimit);
-        if (rc == ANI_ERR_LIMIT && n > 1) { chunk = (n + 1) / 2; ctx->counters.l2ChunkHalvings++; continue; }     // very long candidate ranges: smaller chunk, same candidates again
+        // very long candidate ranges: smaller chunk, same candidates again
+        if (rc == ANI_ERR_LIMIT && n > 1) { chunk = (n + 1) / 2; ctx->counters.l2ChunkHalvings++; continue; }
         TRY(rc);
       }
       TRY(ctx->l2Codes[p].ensure((nCodes + 64) * 2));
@@ -297,8 +319,10 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
           // order the chunk's candidates by code-stream length (longest first) for the simulation
           StageTimer tk(ctx, &ctx->counters.msL2Ranges, 1);
           HIP_TRY(hipMemsetAsync(ctx->l2LenHist[p].p, 0, kL2LenBuckets * 4, ctx->stream));
-          HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets), (int)n, 1, ctx->stream));   // list length for the simulation launch
-          hipLaunchKernelGGL(k_l2_len_hist, dim3(grid_for(n, kTPB, 2048)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)n, ctx->l2LenHist[p].as<unsigned int>());
+          // list length for the simulation launch
+          HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets), (int)n, 1, ctx->stream));
+          hipLaunchKernelGGL(k_l2_len_hist, dim3(grid_for(n, kTPB, 2048)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)n,
+              ctx->l2LenHist[p].as<unsigned int>());
           hipLaunchKernelGGL(k_l2_len_scan, dim3(1), dim3(kTPB), 0, ctx->stream, ctx->l2LenHist[p].as<unsigned int>());
           hipLaunchKernelGGL(k_l2_len_scatter, dim3(grid_for(n, kTPB)), dim3(kTPB), 0, ctx->stream, (const int32_t *)fa.codeCount, (int32_t)c0, (int32_t)n,
                              ctx->l2LenHist[p].as<unsigned int>(), ctx->l2Order[p].as<int32_t>());
@@ -308,7 +332,7 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
           launch_l2_codes((unsigned)((fa.nFragChunk + 7) / 8 * 8), ctx->stream, fa);
         }
         // The simulation (VALU-bound) runs on the side stream so that the next chunk's ranges / codes kernels (memory- and latency-
-        // bound) start beside it; ANI_L2_OVERLAP=0 keeps everything on the main stream.  Measured (1000 x 1000; round 3:
+        // bound) start beside it; ANI_TEST_L2_OVERLAP=0 keeps everything on the main stream.  Measured (1000 x 1000; round 3:
         // profiles/r03f_bench_overlap.json.log, round 4 A/B/A/B on one box: profiles/r04p_overlap_ab.txt): the L2 stage 91.4 -> 87.8 ms,
         // the step 211.5 -> 207.9 ms — all of it from the tails: a codes workgroup (25 KiB of LDS) does not fit the 16 KiB slot a
         // retiring simulation workgroup frees.  Default since round 4.  With it the per-kernel times (bench line, rocprofv3) are those
@@ -323,7 +347,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
         }
         {
           StageTimer tk(ctx, &ctx->counters.msL2Kernel, 1, simStream);
-          launch_l2_sim_a(grid_for(n, kL2SimTPB), simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(), (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
+          launch_l2_sim_a(grid_for(n, kL2SimTPB), simStream, fa, (const int32_t *)ctx->l2Order[p].as<int32_t>(),
+              (const unsigned int *)ctx->l2LenHist[p].as<unsigned int>() + kL2LenBuckets);
         }
         ctx->counters.l2Launches++;
       }
@@ -337,7 +362,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
                            ctx->l2ClassList[p].as<int32_t>(), (unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
         L2FastArgs fb = fa;       // class B accumulates its algorithmic-byte counters separately
         fb.g.sumEntries = cnt_ptr(ctx, CNT_ENTRIES_B); fb.g.sumQ = cnt_ptr(ctx, CNT_SUMQ_B); fb.g.sumSteps = cnt_ptr(ctx, CNT_STEPS_B);
-        launch_l2_sim_b(grid_for(n, kL2SimTPB), ctx->stream2, fb, (const int32_t *)ctx->l2ClassList[p].as<int32_t>(), (const unsigned int *)cnt_ptr(ctx, CNT_CLASSB));
+        launch_l2_sim_b(grid_for(n, kL2SimTPB), ctx->stream2, fb, (const int32_t *)ctx->l2ClassList[p].as<int32_t>(), (const unsigned int *)cnt_ptr(ctx,
+            CNT_CLASSB));
       }
       // whatever did not qualify (or overflowed a gap counter) is appended to the sub-batch's list for the general kernel
       hipLaunchKernelGGL(k_l2_collect_slow, dim3(grid_for(n)), dim3(256), 0, ctx->stream2, (int32_t)c0, (int32_t)n, (const int32_t *)fa.slowFlag,
@@ -359,7 +385,8 @@ int map_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &fs, 
       L2Args sa = a; sa.scratch = ctx->l2Scratch.as<uint32_t>(); sa.laneStride = lanes;
       StageTimer tk(ctx, &ctx->counters.msL2Slow, 1);
       for (size_t base = 0; base < nSlowTotal; base += lanes)
-        hipLaunchKernelGGL(k_l2, dim3((unsigned)(lanes / kTPB)), dim3(kTPB), 0, ctx->stream, sa, (const int32_t *)ctx->l2SlowList.as<int32_t>(), (int32_t)nSlowTotal, (int32_t)base);
+        hipLaunchKernelGGL(k_l2, dim3((unsigned)(lanes / kTPB)), dim3(kTPB), 0, ctx->stream, sa, (const int32_t *)ctx->l2SlowList.as<int32_t>(),
+            (int32_t)nSlowTotal, (int32_t)base);
       HIP_TRY(hipGetLastError());
     }
     ctx->counters.l2SlowCandidates += nSlowTotal; ctx->counters.l2FastCandidates += nCand - nSlowTotal;
@@ -413,7 +440,8 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &f
 
 // the dense table of a sub-batch (all chunks reduced) -> rows in (query, reference genome) order, appended to `rows`
 // (`block`: the table is the compact one of that chunk — reference genome = block->g0 + column)
-int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows, const IndexChunk *block = nullptr, const int32_t *queryIds = nullptr)
+int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows, const IndexChunk *block = nullptr,
+    const int32_t *queryIds = nullptr)
 {
   const int32_t nCols = block ? block->nGenomes : set->nGenomes, col0 = block ? block->g0 : 0;
   const size_t nPairs = (size_t)nQuery * (size_t)nCols;
@@ -468,7 +496,8 @@ int map_fragset(ani_ctx *ctx, ani_sketch *sk, const FragSet &fs, int32_t nQuery,
 // map every sub-batch of every set against it, drop it — so that each chunk is built once per call however many query genomes
 // there are (the reference's own loop has the same shape: per reference split, all queries; core_genome_identity.cpp:55-106);
 // the rows of a sub-batch then come chunk by chunk and are put back into (query, reference) order at the end.
-struct SubBatch { const ani_fragset *set; int32_t g0, g1, firstQueryId; FragSet v; const int32_t *queryIds; };   // queryIds: per genome, relative to firstQueryId (merged sets), else consecutive
+// queryIds: per genome, relative to firstQueryId (merged sets), else consecutive
+struct SubBatch { const ani_fragset *set; int32_t g0, g1, firstQueryId; FragSet v; const int32_t *queryIds; };
 int map_fragsets(ani_ctx *ctx, ani_sketch *sk, const std::vector<const ani_fragset *> &sets, const std::vector<int32_t> &firstQueryIds, RowBuf *rows)
 {
   std::vector<SubBatch> sub;
@@ -548,7 +577,8 @@ int ani_map_cgi_fragset(ani_ctx *ctx, const ani_sketch *skc, const ani_fragset *
   return ani_map_cgi_fragsets(ctx, skc, 1, &f, &firstQueryId, out, m);
 }
 
-int ani_map_cgi_fragsets(ani_ctx *ctx, const ani_sketch *skc, int32_t nSets, const ani_fragset *const *frags, const int32_t *firstQueryIds, ani_cgi_t **out, size_t *m)
+int ani_map_cgi_fragsets(ani_ctx *ctx, const ani_sketch *skc, int32_t nSets, const ani_fragset *const *frags, const int32_t *firstQueryIds, ani_cgi_t **out,
+    size_t *m)
 {
   if (!ctx || !skc || nSets < 0 || (nSets && (!frags || !firstQueryIds)) || !out || !m) return fail(ANI_ERR_ARG, "null argument");
   for (int32_t i = 0; i < nSets; i++) if (!frags[i]) return fail(ANI_ERR_ARG, "null fragment set %d", i);
@@ -634,7 +664,8 @@ int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *skc, const ani_mapping_t *ma
     if (a.refStartPos < 0 || a.refStartPos > sk->contigLen[a.refSeqId]) return fail(ANI_ERR_ARG, "mapping %zu has refStartPos outside its contig", i);
     if (a.nucIdentity <= 0.0f) return fail(ANI_ERR_ARG, "mapping %zu has non-positive identity", i);
     if (a.querySeqId < 0) return fail(ANI_ERR_ARG, "mapping %zu has a negative querySeqId", i);
-    if (i && (mappings[i - 1].querySeqId > a.querySeqId || (mappings[i - 1].querySeqId == a.querySeqId && mappings[i - 1].refSeqId > a.refSeqId))) ordered = false;
+    if (i && (mappings[i - 1].querySeqId > a.querySeqId || (mappings[i - 1].querySeqId == a.querySeqId
+        && mappings[i - 1].refSeqId > a.refSeqId))) ordered = false;
   }
   std::vector<uint32_t> ord;
   if (!ordered) {
@@ -645,8 +676,11 @@ int ani_compute_cgi(ani_ctx *ctx, const ani_sketch *skc, const ani_mapping_t *ma
     HIP_TRY(hipMemcpyAsync(ctx->l1BigHitsA.p, keys.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->keepFlags.p, ord.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
     size_t tb = 0;
-    int rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, 64, nullptr, &tb, ctx->stream);
-    if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 256)); rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(), n, 64, ctx->sortTmp.p, &tb, ctx->stream); }
+    int rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(),
+        ctx->keepOff.as<uint32_t>(), n, 64, nullptr, &tb, ctx->stream);
+    if (rc == 0) { TRY(ctx->sortTmp.ensure(tb + 256));
+      rc = ani_sort_pairs_u64_u32(ctx->l1BigHitsA.as<uint64_t>(), ctx->l1BigHitsB.as<uint64_t>(), ctx->keepFlags.as<uint32_t>(), ctx->keepOff.as<uint32_t>(),
+        n, 64, ctx->sortTmp.p, &tb, ctx->stream); }
     if (rc != 0) return fail(ANI_ERR_DEVICE, "radix sort of mappings failed (%d)", rc);
     HIP_TRY(hipMemcpyAsync(ord.data(), ctx->keepOff.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -11,7 +11,8 @@ int check_params(const ani_params_t *p)
 {
   if (!p) return fail(ANI_ERR_ARG, "null parameters");
   if (p->kmerSize < 1 || p->kmerSize > 16) return fail(ANI_ERR_ARG, "kmerSize must be in 1..16 (hash_t is 32 bit, parseCmdArgs.hpp:142)");
-  if (p->windowSize < 1 || p->windowSize > ani::kTile - ani::kTPB) return fail(ANI_ERR_LIMIT, "windowSize %d outside 1..%d", p->windowSize, ani::kTile - ani::kTPB);
+  if (p->windowSize < 1 || p->windowSize > ani::kTile - ani::kTPB) return fail(ANI_ERR_LIMIT, "windowSize %d outside 1..%d", p->windowSize,
+      ani::kTile - ani::kTPB);
   if (p->fragLen < 1 || p->fragLen <= 20) return fail(ANI_ERR_ARG, "fragLen must exceed 20 (bin width is fragLen-20, computeCoreIdentity.hpp:194)");
   return ANI_OK;
 }
@@ -59,7 +60,8 @@ int frag_tables(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, Frag
   HIP_TRY(hipMemcpyAsync(ctx->unitStart.p, fragStart.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->unitAux.p, cGenome.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->unitAux.as<int32_t>() + nc1, cQBase.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_expand_frags, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), (const int32_t *)ctx->unitAux.as<int32_t>(),
+  hipLaunchKernelGGL(k_expand_frags, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(),
+      (const int32_t *)ctx->unitAux.as<int32_t>(),
                      (const int32_t *)(ctx->unitAux.as<int32_t>() + nc1), db.nContigs, (uint32_t)nF, L, ctx->frags.as<FragDesc>(), arr.fragGenome, arr.fragQSeq);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   qr->fragOff = arr.fragOff; qr->fragS = arr.fragS; qr->fragGenome = arr.fragGenome; qr->fragQSeq = arr.fragQSeq; qr->genomeBase = 0;
@@ -70,18 +72,22 @@ inline bool fusable(const ani_params_t *p) { return p->fragLen + p->windowSize -
 
 // The fragment sketches of a batch as they come out of the sketch kernels lie in 64 partly filled stripes of the pool (pool_take).
 // A set that is kept is packed: sketches back to back in fragment order, exactly nHashes entries, fragOff rewritten in place.
-int compact_fragment_pool(ani_ctx *ctx, const uint32_t *pool, uint32_t *fragOff /* in: striped offsets, out: packed offsets */, const int32_t *fragS, size_t nF, uint64_t nHashes, uint32_t **out)
+int compact_fragment_pool(ani_ctx *ctx, const uint32_t *pool, uint32_t *fragOff /* in: striped offsets, out: packed offsets */, const int32_t *fragS,
+    size_t nF, uint64_t nHashes, uint32_t **out)
 {
   *out = nullptr;
   HIP_TRY(pool_malloc((void **)out, (nHashes ? nHashes : 1) * 4));
   if (nF == 0) return ANI_OK;
   TRY(ctx->scanTmpC.ensure(nF * 4)); TRY(ctx->scanTmpD.ensure(nF * 4));
-  hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, fragS, (const int32_t *)nullptr, ctx->scanTmpC.as<int32_t>());   // s = -1 marks an overflowed fragment
+  // s = -1 marks an overflowed fragment
+  hipLaunchKernelGGL(k_clamp_counts, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (int32_t)nF, fragS, (const int32_t *)nullptr, ctx->scanTmpC.as<int32_t>());
   uint64_t total = 0;
   int rc = device_scan(ctx, ctx->scanTmpC.as<int32_t>(), ctx->scanTmpD.as<uint32_t>(), (uint32_t)nF, &total);
-  if (rc == ANI_OK && total != nHashes) rc = fail(ANI_ERR_INTERNAL, "fragment sketch pool: %llu hashes counted, %llu in the sketches", (unsigned long long)nHashes, (unsigned long long)total);
+  if (rc == ANI_OK && total != nHashes) rc = fail(ANI_ERR_INTERNAL, "fragment sketch pool: %llu hashes counted, %llu in the sketches",
+      (unsigned long long)nHashes, (unsigned long long)total);
   if (rc != ANI_OK) { pool_free(*out); *out = nullptr; return rc; }
-  hipLaunchKernelGGL(k_pack_fragment_pool, dim3(grid_for(nF * 64)), dim3(256), 0, ctx->stream, pool, fragOff, (const int32_t *)ctx->scanTmpC.as<int32_t>(), (const uint32_t *)ctx->scanTmpD.as<uint32_t>(), (uint32_t)nF, *out);
+  hipLaunchKernelGGL(k_pack_fragment_pool, dim3(grid_for(nF * 64)), dim3(256), 0, ctx->stream, pool, fragOff, (const int32_t *)ctx->scanTmpC.as<int32_t>(),
+      (const uint32_t *)ctx->scanTmpD.as<uint32_t>(), (uint32_t)nF, *out);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { pool_free(*out); *out = nullptr; HIP_TRY(e); }
@@ -131,12 +137,14 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
   TRY(ctx->unitStart.ensure(tileStart.size() * 4));
   HIP_TRY(hipMemcpyAsync(ctx->unitStart.p, tileStart.data(), tileStart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   if (!fused)
-    hipLaunchKernelGGL(k_expand_tiles, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), db.nContigs, (uint32_t)nT, stride,
+    hipLaunchKernelGGL(k_expand_tiles, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), db.nContigs,
+        (uint32_t)nT, stride,
                        ctx->tiles.as<TileDesc>());
   else {
     TRY(ctx->tileInfo.ensure(nT * sizeof(FusedInfo))); TRY(ctx->unitAux.ensure(fragStart.size() * 4));
     HIP_TRY(hipMemcpyAsync(ctx->unitAux.p, fragStart.data(), fragStart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_expand_fused, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(), (const uint32_t *)ctx->unitAux.as<uint32_t>(), db.nContigs,
+    hipLaunchKernelGGL(k_expand_fused, dim3(grid_for(nT)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(),
+        (const uint32_t *)ctx->unitAux.as<uint32_t>(), db.nContigs,
                        (uint32_t)nT, L, w, stride, ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>());
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -164,7 +172,8 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
       else
         hipLaunchKernelGGL(k_sketch_fused, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigLen, db.dContigMode,
                            ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>(), k, w, L, ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(), stripe_cap(cap),
-                           cur_ptr(ctx, POOL_REF), ctx->tileMeta.as<TileMeta>(), *fused->qPool, stripe_cap(qcap), cur_ptr(ctx, POOL_Q), fused->arr->fragOff, fused->arr->fragS,
+                           cur_ptr(ctx, POOL_REF), ctx->tileMeta.as<TileMeta>(), *fused->qPool, stripe_cap(qcap), cur_ptr(ctx,
+                               POOL_Q), fused->arr->fragOff, fused->arr->fragS,
                            (int *)cnt_ptr(ctx, CNT_MAXS));
     }
     HIP_TRY(hipGetLastError());
@@ -216,9 +225,11 @@ int fragment_stage(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, F
   {
     uint64_t nF = 0;
     for (int32_t c = 0; c < db.nContigs; c++) { const int32_t len = db.contigLen[c]; if (!(len < w || len < k || len < L)) nF += (uint64_t)(len / L); }
-    TRY(ctx->fragOff.ensure((nF + 1) * 4)); TRY(ctx->fragS.ensure((nF + 1) * 4)); TRY(ctx->fragGenome.ensure((nF + 1) * 4)); TRY(ctx->fragQSeq.ensure((nF + 1) * 4));
+    TRY(ctx->fragOff.ensure((nF + 1) * 4)); TRY(ctx->fragS.ensure((nF + 1) * 4)); TRY(ctx->fragGenome.ensure((nF + 1) * 4));
+    TRY(ctx->fragQSeq.ensure((nF + 1) * 4));
   }
-  FragArrays fa; fa.fragOff = ctx->fragOff.as<uint32_t>(); fa.fragS = ctx->fragS.as<int32_t>(); fa.fragGenome = ctx->fragGenome.as<int32_t>(); fa.fragQSeq = ctx->fragQSeq.as<int32_t>();
+  FragArrays fa; fa.fragOff = ctx->fragOff.as<uint32_t>(); fa.fragS = ctx->fragS.as<int32_t>(); fa.fragGenome = ctx->fragGenome.as<int32_t>();
+  fa.fragQSeq = ctx->fragQSeq.as<int32_t>();
   std::vector<uint32_t> fragStart;
   TRY(frag_tables(ctx, p, db, qr, &fragStart, fa, false, nullptr));
   const size_t nF = (size_t)qr->nFrag;
@@ -331,7 +342,8 @@ int records_of_batch(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t 
       o += parts[i].n;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { if (all) pool_free(all); cleanup(); return fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "gathering %zu records failed: %s", total, hipGetErrorString(e)); }
+    if (e != hipSuccess) { if (all) pool_free(all); cleanup();
+      return fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "gathering %zu records failed: %s", total, hipGetErrorString(e)); }
   }
   cleanup();
   if (ctx->timerPending.size() > 1024) flush_timers(ctx);
@@ -351,7 +363,8 @@ int ani_sketch_records(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_
   return records_of_batch(ctx, p, refs, seqIdBase, devRecords, n, nullptr);
 }
 
-int ani_sketch_records_self(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *genomes, int32_t seqIdBase, void **devRecords, size_t *n, ani_fragset **frags)
+int ani_sketch_records_self(ani_ctx *ctx, const ani_params_t *p, const ani_seq_batch_t *genomes, int32_t seqIdBase, void **devRecords, size_t *n,
+    ani_fragset **frags)
 {
   if (!ctx || !devRecords || !n || !frags) return fail(ANI_ERR_ARG, "null argument");
   TRY(check_params(p)); TRY(check_batch(genomes));
@@ -427,7 +440,8 @@ const char *validate_wire_header(const FragWireHeader &h, uint64_t bytesAvailabl
   if (h.nFrag < 0 || h.nGenomes < 0 || h.maxS < 0 || h.poolSize > 0xfffffff0ull || h.nHashes > h.poolSize) return "inconsistent counts";
   ani_fragset tmp; tmp.fs.nFrag = h.nFrag; tmp.fs.poolSize = h.poolSize; tmp.fs.genomeFragments.assign((size_t)h.nGenomes, 0);
   const FragWireHeader want = wire_header(&tmp);       // the layout follows from the counts: the offsets in the buffer must be these
-  if (want.offGenomeFragments != h.offGenomeFragments || want.offFragOff != h.offFragOff || want.offFragS != h.offFragS || want.offFragGenome != h.offFragGenome ||
+  if (want.offGenomeFragments != h.offGenomeFragments || want.offFragOff != h.offFragOff || want.offFragS != h.offFragS
+      || want.offFragGenome != h.offFragGenome ||
       want.offFragQSeq != h.offFragQSeq || want.offPool != h.offPool || want.totalBytes != h.totalBytes || h.totalBytes > bytesAvailable)
     return "truncated or malformed";
   return nullptr;
@@ -473,7 +487,8 @@ int ani_fragset_unpack(ani_ctx *ctx, const void *devBuf, size_t bytes, ani_frags
   FragWireHeader h;
   HIP_TRY(hipMemcpy(&h, devBuf, sizeof h, hipMemcpyDeviceToHost));
   if (const char *why = validate_wire_header(h, bytes)) return fail(ANI_ERR_ARG, "packed fragment set: %s", why);
-  ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen; tmp.params.percentageIdentity = h.percentageIdentity;
+  ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen;
+  tmp.params.percentageIdentity = h.percentageIdentity;
   TRY(check_params(&tmp.params));
   tmp.fs.nFrag = h.nFrag; tmp.fs.maxS = h.maxS; tmp.fs.nHashes = h.nHashes; tmp.fs.poolSize = h.poolSize; tmp.fs.genomeFragments.assign((size_t)h.nGenomes, 0);
   ani_fragset *f = new ani_fragset();
@@ -490,7 +505,8 @@ int ani_fragset_unpack(ani_ctx *ctx, const void *devBuf, size_t bytes, ani_frags
   f->arr.fragOff = (uint32_t *)(b + h.offFragOff); f->arr.fragS = (int32_t *)(b + h.offFragS);
   f->arr.fragGenome = (int32_t *)(b + h.offFragGenome); f->arr.fragQSeq = (int32_t *)(b + h.offFragQSeq);
   f->qPool = (uint32_t *)(b + h.offPool);
-  f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq; f->fs.qPool = f->qPool; f->fs.genomeBase = 0;
+  f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq; f->fs.qPool = f->qPool;
+  f->fs.genomeBase = 0;
   fragset_finish(f);
   *out = f;
   return ANI_OK;
@@ -509,7 +525,8 @@ int ani_fragset_unpack_merged(ani_ctx *ctx, const void *devBuf, size_t slotBytes
   HIP_TRY(hipSetDevice(ctx->device));
   const uint8_t *base = (const uint8_t *)devBuf;
   std::vector<FragWireHeader> hs((size_t)nSlots);
-  for (int32_t i = 0; i < nSlots; i++) if (slotQueryBase[i] >= 0) HIP_TRY(hipMemcpyAsync(&hs[i], base + (size_t)i * slotBytes, sizeof(FragWireHeader), hipMemcpyDeviceToHost, ctx->stream));
+  for (int32_t i = 0; i < nSlots; i++) if (slotQueryBase[i] >= 0) HIP_TRY(hipMemcpyAsync(&hs[i], base + (size_t)i * slotBytes, sizeof(FragWireHeader),
+      hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ani_fragset *f = new ani_fragset();
   f->ctx = ctx; f->device = ctx->device; f->borrowed = true; f->ownTables = true;
@@ -518,25 +535,31 @@ int ani_fragset_unpack_merged(ani_ctx *ctx, const void *devBuf, size_t slotBytes
   for (int32_t i = 0; i < nSlots; i++) {
     if (slotQueryBase[i] < 0) continue;
     const FragWireHeader &h = hs[i];
-    if (const char *why = validate_wire_header(h, slotBytes)) return bail(fail(ANI_ERR_ARG, "slot %d: %s (a peer that packed nothing, or a stale buffer?)", i, why));
+    if (const char *why = validate_wire_header(h, slotBytes)) return bail(fail(ANI_ERR_ARG, "slot %d: %s (a peer that packed nothing, or a stale buffer?)", i,
+        why));
     // the streamed re-order of map_fragsets finds a query's set by a lower bound over the genomes' query ids: the used slots must
     // come in ascending, non-overlapping query-id order (ranks own contiguous genome ranges in rank order)
-    if ((int64_t)slotQueryBase[i] < nextQueryId) return bail(fail(ANI_ERR_ARG, "slot %d: query ids must ascend over the used slots (slot starts at %d, the slots before it end at %lld)", i, slotQueryBase[i], (long long)nextQueryId));
+    if ((int64_t)slotQueryBase[i] < nextQueryId) return bail(fail(ANI_ERR_ARG,
+        "slot %d: query ids must ascend over the used slots (slot starts at %d, the slots before it end at %lld)", i, slotQueryBase[i], (long long)nextQueryId));
     nextQueryId = (int64_t)slotQueryBase[i] + h.nGenomes;
-    ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen; tmp.params.percentageIdentity = h.percentageIdentity;
+    ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen;
+    tmp.params.percentageIdentity = h.percentageIdentity;
     if (first) { f->params = tmp.params; const int rc = check_params(&f->params); if (rc != ANI_OK) return bail(rc); first = false; }
-    else if (f->params.kmerSize != h.kmerSize || f->params.windowSize != h.windowSize || f->params.fragLen != h.fragLen || f->params.percentageIdentity != h.percentageIdentity)
+    else if (f->params.kmerSize != h.kmerSize || f->params.windowSize != h.windowSize || f->params.fragLen != h.fragLen
+        || f->params.percentageIdentity != h.percentageIdentity)
       return bail(fail(ANI_ERR_ARG, "slot %d was sketched with other parameters", i));
     nF += (uint64_t)h.nFrag; nG += h.nGenomes;
     if (nF > 0x3fffffffull) return bail(fail(ANI_ERR_LIMIT, "too many fragments in the merged set"));
   }
-  if (first) { f->params.kmerSize = 16; f->params.windowSize = 1; f->params.fragLen = 3000; f->params.percentageIdentity = 80.0f; }      // nothing to merge: an empty set
+  // nothing to merge: an empty set
+  if (first) { f->params.kmerSize = 16; f->params.windowSize = 1; f->params.fragLen = 3000; f->params.percentageIdentity = 80.0f; }
   f->fs.nFrag = (int32_t)nF; f->fs.poolSize = (uint64_t)slotBytes * (uint64_t)nSlots / 4; f->fs.genomeBase = 0;
   f->qPool = (uint32_t *)const_cast<void *>(devBuf); f->fs.qPool = f->qPool;
   if (nF) {
     hipError_t e = pool_malloc((void **)&f->arr.fragOff, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragS, nF * 4);
     if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragGenome, nF * 4); if (e == hipSuccess) e = pool_malloc((void **)&f->arr.fragQSeq, nF * 4);
-    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "tables of the merged fragment set: %s", hipGetErrorString(e)));
+    if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "tables of the merged fragment set: %s",
+        hipGetErrorString(e)));
   }
   uint64_t fAt = 0; int32_t gAt = 0;
   std::vector<int32_t> gf;
@@ -545,21 +568,24 @@ int ani_fragset_unpack_merged(ani_ctx *ctx, const void *devBuf, size_t slotBytes
     const FragWireHeader &h = hs[i];
     const uint8_t *b = base + (size_t)i * slotBytes;
     gf.assign((size_t)h.nGenomes, 0);
-    if (h.nGenomes) { const hipError_t e = hipMemcpy(gf.data(), b + h.offGenomeFragments, (size_t)h.nGenomes * 4, hipMemcpyDeviceToHost); if (e != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "reading slot %d: %s", i, hipGetErrorString(e))); }
+    if (h.nGenomes) { const hipError_t e = hipMemcpy(gf.data(), b + h.offGenomeFragments, (size_t)h.nGenomes * 4, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "reading slot %d: %s", i, hipGetErrorString(e))); }
     int64_t sum = 0;
     for (int32_t v : gf) { if (v < 0) { sum = -1; break; } sum += v; }
     if (sum != (int64_t)h.nFrag) return bail(fail(ANI_ERR_ARG, "slot %d: genome table does not add up to the fragment count", i));
     for (int32_t g = 0; g < h.nGenomes; g++) { f->fs.genomeFragments.push_back(gf[g]); f->genomeQueryId.push_back(slotQueryBase[i] + g); }
     if (h.nFrag) {
       const uint32_t addOff = (uint32_t)(((size_t)i * slotBytes + h.offPool) / 4);
-      hipLaunchKernelGGL(k_fragset_rebase, dim3(std::min<unsigned>(grid_for((size_t)h.nFrag), 65535u)), dim3(256), 0, ctx->stream, (uint32_t)h.nFrag, (const uint32_t *)(b + h.offFragOff), (const int32_t *)(b + h.offFragS),
+      hipLaunchKernelGGL(k_fragset_rebase, dim3(std::min<unsigned>(grid_for((size_t)h.nFrag), 65535u)), dim3(256), 0, ctx->stream, (uint32_t)h.nFrag,
+          (const uint32_t *)(b + h.offFragOff), (const int32_t *)(b + h.offFragS),
                          (const int32_t *)(b + h.offFragGenome), (const int32_t *)(b + h.offFragQSeq), addOff, gAt,
                          f->arr.fragOff + fAt, f->arr.fragS + fAt, f->arr.fragGenome + fAt, f->arr.fragQSeq + fAt);
     }
     f->fs.maxS = std::max(f->fs.maxS, h.maxS); f->fs.nHashes += h.nHashes;
     fAt += (uint64_t)h.nFrag; gAt += h.nGenomes;
   }
-  { const hipError_t e = hipGetLastError(); const hipError_t e2 = hipStreamSynchronize(ctx->stream); if (e != hipSuccess || e2 != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "merging fragment sets failed")); }
+  { const hipError_t e = hipGetLastError(); const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || e2 != hipSuccess) return bail(fail(ANI_ERR_DEVICE, "merging fragment sets failed")); }
   f->fs.fragOff = f->arr.fragOff; f->fs.fragS = f->arr.fragS; f->fs.fragGenome = f->arr.fragGenome; f->fs.fragQSeq = f->arr.fragQSeq;
   fragset_finish(f);
   *out = f;

@@ -4,7 +4,7 @@
 //   engine_ingest.hip  sequence batches: classify, 2-bit pack, upload                                  
 //   engine_sketch.hip  minimizer records and fragment sketches (≙ Sketch::build, Map::doL1Mapping's sketch), kept fragment sets + wire format
 //   engine_index.hip   index chunks (≙ Sketch::index), chunk streaming, sketch file                    (winSketch.hpp:181-193; section 8 f3)
-//   engine_map.hip     L1 + L2 + identity + reducer (≙ Map::mapQuery ... cgi::computeCGI)              (computeMap.hpp:112-545, computeCoreIdentity.hpp:166-298)
+// engine_map.hip     L1 + L2 + identity + reducer (≙ Map::mapQuery ... cgi::computeCGI)              (computeMap.hpp:112-545, computeCoreIdentity.hpp:166-298)
 //   engine_l2.hip      the launches of k_l2_codes / k_l2_sim (a unit of its own for its compiler flags: build_lib.sh)
 //   sort_device.hip    the radix sort
 // Kernels live in kernels/*.hpp (internal linkage: a unit compiles the ones it launches).  Nothing here crosses the C-ABI.
@@ -42,7 +42,8 @@
 
 // kernels/radix.hpp through sort_device.hip (hand-written LSD radix sort; two-phase calls: tmp == nullptr returns the workspace size)
 extern "C" int ani_sort_keys_u64_bits(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream);
-extern "C" int ani_sort_keys_u64_range(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream, int async);
+extern "C" int ani_sort_keys_u64_range(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes,
+    hipStream_t stream, int async);
 extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
                                       size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream);
 extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN, int nPieces, uint32_t seqBase, size_t n,
@@ -96,7 +97,7 @@ struct DevicePool {
   static size_t class_size(size_t bytes)
   {
     if (bytes == 0) bytes = 1;
-    static const bool classes = !(getenv("ANI_POOL_CLASSES") && !strcmp(getenv("ANI_POOL_CLASSES"), "0"));
+    static const bool classes = !(getenv("ANI_TEST_POOL_CLASSES") && !strcmp(getenv("ANI_TEST_POOL_CLASSES"), "0"));
     if (classes && bytes >= ((size_t)64 << 20)) {
       int lg = 63; while (!((bytes >> lg) & 1)) lg--;
       const size_t gran = (size_t)1 << (lg - 5);
@@ -153,9 +154,9 @@ struct DevicePool {
   {
     bytes = class_size(bytes);
     const bool small = bytes < kSmallLimit;
-    // ANI_POOL_POISON=<byte> (tests): every block handed out is filled with that byte first, so that a kernel which reads memory
+    // ANI_TEST_POOL_POISON=<byte> (tests): every block handed out is filled with that byte first, so that a kernel which reads memory
     // it (or an earlier kernel) has not written sees the same garbage every time instead of whatever the previous owner left
-    static const int poison = getenv("ANI_POOL_POISON") ? (int)strtol(getenv("ANI_POOL_POISON"), nullptr, 0) : -1;
+    static const int poison = getenv("ANI_TEST_POOL_POISON") ? (int)strtol(getenv("ANI_TEST_POOL_POISON"), nullptr, 0) : -1;
     static const bool trace = getenv("ANI_POOL_TRACE") != nullptr;
     auto handout = [&](void *p) {
       *out = p;
@@ -169,7 +170,8 @@ struct DevicePool {
       auto it = m.lower_bound(bytes);
       if (it != m.end()) { void *p = take_locked(it->second, bytes); g.unlock(); return handout(p); }
       // a segment that will fit is being made on another thread: its tail is shorter than a second fresh allocation beside it
-      if (!small && promised_fit_locked(bytes) && std::chrono::steady_clock::now() < deadline) { cvPromised.wait_for(g, std::chrono::milliseconds(5)); continue; }
+      if (!small && promised_fit_locked(bytes) && std::chrono::steady_clock::now() < deadline) { cvPromised.wait_for(g, std::chrono::milliseconds(5));
+        continue; }
       break;
     }
     const size_t segSize = small ? kSmallSegment : bytes;
@@ -190,7 +192,8 @@ struct DevicePool {
       while (e != hipSuccess && free_largest_locked(&freed)) { e = hipMalloc(&p, segSize); if (e != hipSuccess) (void)hipGetLastError(); }
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (trace) fprintf(stderr, "[ani pool] hipMalloc %.1f MB: %.2f ms%s (%.1f MB free in %zu segments of %.1f MB%s)\n", segSize / 1048576.0, ms, e == hipSuccess ? "" : " FAILED",
+    if (trace) fprintf(stderr, "[ani pool] hipMalloc %.1f MB: %.2f ms%s (%.1f MB free in %zu segments of %.1f MB%s)\n", segSize / 1048576.0, ms,
+        e == hipSuccess ? "" : " FAILED",
                        cachedBytes / 1048576.0, segs.size(), segBytes / 1048576.0, freed ? "; device full: free segments returned" : "");
     if (e != hipSuccess) return e;
     freshCalls++; freshBytes += segSize; freshMs += ms;
@@ -208,10 +211,12 @@ struct DevicePool {
     it->second.free = true;
     cachedBytes += it->second.size; liveBytes -= it->second.size;
     auto nx = std::next(it);
-    if (nx != ext.end() && nx->second.free && nx->second.seg == it->second.seg) { free_erase_locked(nx->first, nx->second); it->second.size += nx->second.size; ext.erase(nx); }
+    if (nx != ext.end() && nx->second.free && nx->second.seg == it->second.seg) { free_erase_locked(nx->first, nx->second);
+      it->second.size += nx->second.size; ext.erase(nx); }
     if (it != ext.begin()) {
       auto pv = std::prev(it);
-      if (pv->second.free && pv->second.seg == it->second.seg) { free_erase_locked(pv->first, pv->second); pv->second.size += it->second.size; ext.erase(it); it = pv; }
+      if (pv->second.free && pv->second.seg == it->second.seg) { free_erase_locked(pv->first, pv->second); pv->second.size += it->second.size; ext.erase(it);
+        it = pv; }
     }
     free_insert_locked(it->first, it->second);
     return true;
@@ -225,7 +230,8 @@ struct DevicePool {
     const auto t0 = std::chrono::steady_clock::now();
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipSuccess) { e = hipMemsetAsync(p, 0, bytes, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) { (void)hipFree(p); p = nullptr; } }
+    if (e == hipSuccess) { e = hipMemsetAsync(p, 0, bytes, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) { (void)hipFree(p);
+      p = nullptr; } }
     else (void)hipGetLastError();
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     {
@@ -322,11 +328,13 @@ inline HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; }
 template <class F>
 void parallel_for(size_t n, uint64_t work, F f)
 {
-  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 32) nt = 32;     // (beside 32 reader threads: 16-32 packers measured best, 64 starve the readers; profiles/r04ak_e2e_probe.txt)
+  // (beside 32 reader threads: 16-32 packers measured best, 64 starve the readers; profiles/r04ak_e2e_probe.txt)
+  unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 1; if (nt > 32) nt = 32;
   if (const char *ev = getenv("ANI_HOST_THREADS")) { int v = atoi(ev); if (v >= 1) nt = (unsigned)v; }
   if (nt > n) nt = (unsigned)n;
   uint64_t minWork = 1u << 22;
-  if (const char *ev = getenv("ANI_HOST_PAR_MIN_WORK")) { const long long v = atoll(ev); if (v >= 0) minWork = (uint64_t)v; }     // test knob: small inputs through the pool
+  // test knob: small inputs through the pool
+  if (const char *ev = getenv("ANI_TEST_HOST_PAR_MIN_WORK")) { const long long v = atoll(ev); if (v >= 0) minWork = (uint64_t)v; }
   if (nt <= 1 || work < minWork) { for (size_t i = 0; i < n; i++) f(i); return; }
   host_pool().run(n, nt, std::function<void(size_t)>(f));
 }
@@ -349,22 +357,36 @@ struct ani_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   uint64_t subBatchFragments = 1u << 20, subBatchBinBytes = (uint64_t)8 << 30;   // sub-batch bounds of ani_map_cgi_batch (env ANI_SUBBATCH_FRAGS)
-  size_t l2ChunkCandidates = (size_t)1 << 21;                                      // L2 chunk size (env ANI_L2_CHUNK, tests)
-  uint64_t l2CodeLimit = 0xfffffff0ull;                                             // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_L2_CODE_LIMIT, tests)
-  uint64_t maxIndexMinimizers = 1700000000ull;                                      // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
-  int l1FilterMin = 300 /* ani::kL1FilterMinHits */, l1LdsMax = 4096 /* ani::kL1HitCapMax */;   // (engine_map.hip checks them against kernels/l1.hpp)           // env ANI_L1_FILTER_MIN / ANI_L1_LDS_MAX, read by ani_init (tests: per engine, not per process)
-  uint64_t dupPairCap = 0;                                                           // first guess of the same-hash link list (env ANI_DUP_PAIR_CAP, tests: forces the rerun)
-  bool l1Tiny = true;                                                               // env ANI_L1_TINY=0: fragments with <= 64 seed hits take the workgroup path like the others
-  bool l2Overlap = true;                                                            // the L2 simulation on the side stream, beside the next chunk's ranges / codes kernels (env ANI_L2_OVERLAP=0 switches it off; see the L2 loop)
-  uint64_t l1HitLimit = 0x7ffffff0ull;                                              // seed hits per fragment and index chunk (32-bit hit offsets; env ANI_L1_HIT_LIMIT, tests)
-  uint64_t candPoolMin = 4096;                                                      // floor of the L1 candidate pool, per stripe (env ANI_CAND_POOL_MIN, tests: forces the retry path)
-  uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;              // seed hits / fragments per group of the batched global-memory L1 path (env ANI_L1_BIG_GROUP_HITS / _FRAGS, tests)
-  int32_t maxResidentChunks = 0;                                                    // index chunks of one reference set kept on the device (env ANI_MAX_RESIDENT_CHUNKS; 0 = decide from the free memory)
-  uint64_t streamChunkMinimizers = 1000000000ull;                                   // chunk size once a set is streamed (env ANI_STREAM_CHUNK_MINIMIZERS): the build's transient arrays must fit beside the records
+  size_t l2ChunkCandidates = (size_t)1 << 21;                                      // L2 chunk size (env ANI_TEST_L2_CHUNK, tests)
+  // 16-bit code entries per L2 chunk (32-bit offsets; env ANI_TEST_L2_CODE_LIMIT, tests)
+  uint64_t l2CodeLimit = 0xfffffff0ull;
+  // minimizers per index chunk (env ANI_MAX_INDEX_MINIMIZERS); indices are 32 bit
+  uint64_t maxIndexMinimizers = 1700000000ull;
+  // (engine_map.hip checks them against kernels/l1.hpp)           // env ANI_TEST_L1_FILTER_MIN / ANI_TEST_L1_LDS_MAX, read by ani_init (tests: per engine, not
+  // per process)
+  int l1FilterMin = 300 /* ani::kL1FilterMinHits */, l1LdsMax = 4096 /* ani::kL1HitCapMax */;
+  // first guess of the same-hash link list (env ANI_TEST_DUP_PAIR_CAP, tests: forces the rerun)
+  uint64_t dupPairCap = 0;
+  // env ANI_TEST_L1_TINY=0: fragments with <= 64 seed hits take the workgroup path like the others
+  bool l1Tiny = true;
+  // the L2 simulation on the side stream, beside the next chunk's ranges / codes kernels (env ANI_TEST_L2_OVERLAP=0 switches it off; see the L2 loop)
+  bool l2Overlap = true;
+  // seed hits per fragment and index chunk (32-bit hit offsets; env ANI_TEST_L1_HIT_LIMIT, tests)
+  uint64_t l1HitLimit = 0x7ffffff0ull;
+  // floor of the L1 candidate pool, per stripe (env ANI_TEST_CAND_POOL_MIN, tests: forces the retry path)
+  uint64_t candPoolMin = 4096;
+  // seed hits / fragments per group of the batched global-memory L1 path (env ANI_TEST_L1_BIG_GROUP_HITS / _FRAGS, tests)
+  uint64_t l1BigGroupHits = 1ull << 27, l1BigGroupFrags = 1ull << 20;
+  // index chunks of one reference set kept on the device (env ANI_MAX_RESIDENT_CHUNKS; 0 = decide from the free memory)
+  int32_t maxResidentChunks = 0;
+  // chunk size once a set is streamed (env ANI_STREAM_CHUNK_MINIMIZERS): the build's transient arrays must fit beside the records
+  uint64_t streamChunkMinimizers = 1000000000ull;
   std::vector<std::unique_ptr<ani::stat::Luts>> lutCache;
-  void *pinned[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t pinnedCap[5] = {0, 0, 0, 0, 0};   // page-locked staging: 0/1 result reads, 2 prefix-sum block totals, 3/4 ingest (packed / raw bytes)
+  // page-locked staging: 0/1 result reads, 2 prefix-sum block totals, 3/4 ingest (packed / raw bytes)
+  void *pinned[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t pinnedCap[5] = {0, 0, 0, 0, 0};
   hipStream_t stream2 = nullptr;          // side stream: latency-bound launches that can run under the main simulation kernel
-  hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr}, evIndex[2] = {nullptr, nullptr};   // evIndex: build_chunk_index's own (sort -> side work -> join)
+  // evIndex: build_chunk_index's own (sort -> side work -> join)
+  hipEvent_t evSimA[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr}, evIndex[2] = {nullptr, nullptr};
   // stage timers: event pairs are recorded as the launches go out and read back lazily (flush_timers), never by blocking the host
   std::vector<hipEvent_t> timerEvents; size_t timerUsed = 0;
   struct PendingTimer { size_t a, b; double *acc; };
@@ -373,9 +395,11 @@ struct ani_ctx {
   std::vector<unsigned long long> hostCounters;                 // read_counters: the raw block
   unsigned long long poolUsed[3] = {0, 0, 0}, poolMaxStripe[3] = {0, 0, 0};
   double candPerFrag = 12.0;      // estimate that sizes the L1 candidate pool: the LARGEST need of the last 32 batches that fill the pool stripes evenly
-  double candSeen[32] = {0}; int candSeenAt = 0;   // (a ring of fragment sets alternates between sets with ~16 candidates per fragment — the rank's own genomes — and sets
+  // (a ring of fragment sets alternates between sets with ~16 candidates per fragment — the rank's own genomes — and sets
+  double candSeen[32] = {0}; int candSeenAt = 0;
                                                     //  with < 1: an estimate that follows the batches down runs the L1 kernels twice for every dense one)
-  uint64_t smallBatchCandCap = 0; // ... and what the last batch too small for that estimate needed (a few hundred fragments against a species-dense index, call after call)
+  // ... and what the last batch too small for that estimate needed (a few hundred fragments against a species-dense index, call after call)
+  uint64_t smallBatchCandCap = 0;
   // scalar device counters (array of 16 x u64)
   DevBuf dCounters;
   // workspaces reused across calls
@@ -455,7 +479,8 @@ static_assert(CNT_N == ani::kStatStripeWords, "counter block size");
 enum { POOL_REF = 0, POOL_Q = 1, POOL_CAND = 2, POOL_N = 3 };
 constexpr size_t kCursorWords = (size_t)POOL_N * ani::kPoolStripes * ani::kPoolStripeWords;
 constexpr size_t kCounterWords = (size_t)ani::kStatStripes * CNT_N + kCursorWords;
-inline unsigned long long *cur_ptr(ani_ctx *c, int pool) { return c->dCounters.as<unsigned long long>() + (size_t)ani::kStatStripes * CNT_N + (size_t)pool * ani::kPoolStripes * ani::kPoolStripeWords; }
+inline unsigned long long *cur_ptr(ani_ctx *c,
+    int pool) { return c->dCounters.as<unsigned long long>() + (size_t)ani::kStatStripes * CNT_N + (size_t)pool * ani::kPoolStripes * ani::kPoolStripeWords; }
 int zero_counters(ani_ctx *c);
 int zero_cursors(ani_ctx *c, int pool);
 // host[]: the summed statistics (CNT_MAXS: the maximum over the stripes); c->poolUsed / c->poolMaxStripe: per pool, the entries

@@ -143,7 +143,8 @@ Options parse(int argc, char **argv)
     else if (a == "--saveSketch") o.saveSketch = need(i);
     else if (a == "--refSketch") o.refSketch = need(i);
     else if (a == "--gpus") { const int n = atoi(need(i)); o.devices.clear(); for (int d = 0; d < std::max(1, n); d++) o.devices.push_back(d); }
-    else if (a == "--devices") { o.devices.clear(); std::stringstream ss(need(i)); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (o.devices.empty()) o.devices.push_back(0); }
+    else if (a == "--devices") { o.devices.clear(); std::stringstream ss(need(i)); std::string t;
+      while (std::getline(ss, t, ',')) if (!t.empty()) o.devices.push_back(atoi(t.c_str())); if (o.devices.empty()) o.devices.push_back(0); }
     else usage(argv[0], 1);
   }
   if (help) usage(argv[0], 0);
@@ -153,7 +154,8 @@ Options parse(int argc, char **argv)
   if (!o.refSketch.empty()) {
     // reference names come from the sketch file; its genome count is needed before the sketch is loaded
     int32_t ng = 0;
-    if (ani_sketch_file_info(o.refSketch.c_str(), nullptr, nullptr, &ng, nullptr)) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << o.refSketch << std::endl; exit(1); }
+    if (ani_sketch_file_info(o.refSketch.c_str(), nullptr, nullptr, &ng,
+        nullptr)) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << o.refSketch << std::endl; exit(1); }
     o.refs.assign((size_t)ng, std::string());
   } else if (!refName.empty()) o.refs.push_back(refName); else parseFileList(refList, o.refs);
   if (!qryName.empty()) o.queries.push_back(qryName); else parseFileList(qryList, o.queries);
@@ -247,7 +249,8 @@ bool readFile(const std::string &path, FileData &fd)
       if (c == '\n') continue;
       fd.data.push_back((uint8_t)c);
       rd.rest_of_line(&fd.data, nullptr);
-      if (rd.gotAny && fd.data.size() - start > 1 && fd.data.back() == '\r') fd.data.pop_back();    // KS_SEP_LINE: a trailing '\r' goes once the sequence so far has more than one byte (kseq.h:141) — unless this byte was the very last of the input (:138)
+      // KS_SEP_LINE: a trailing '\r' goes once the sequence so far has more than one byte (kseq.h:141) — unless this byte was the very last of the input (:138)
+      if (rd.gotAny && fd.data.size() - start > 1 && fd.data.back() == '\r') fd.data.pop_back();
     }
     const size_t len = fd.data.size() - start;
     bool ok = true;
@@ -256,7 +259,8 @@ bool readFile(const std::string &path, FileData &fd)
     if (c == '+') {                                                   // FASTQ: skip the quality block (kseq.h:204-213)
       rd.rest_of_line((std::vector<uint8_t> *)nullptr, nullptr);
       size_t q = 0;
-      while (q < len) {                                              // quality lines are appended like sequence lines, '\r' stripped the same way (kseq.h:213, :141)
+      // quality lines are appended like sequence lines, '\r' stripped the same way (kseq.h:213, :141)
+      while (q < len) {
         size_t line = 0; int lastB = -1;
         const bool more = rd.rest_of_line((std::vector<uint8_t> *)nullptr, &line, &lastB);
         q += line;
@@ -267,7 +271,8 @@ bool readFile(const std::string &path, FileData &fd)
       ok = (q == len);                                                // kseq_read < 0: truncated quality string ends the file
     }
     if (!ok) { fd.data.resize(start); break; }
-    if (len >= 0x7fffffffull) { std::cerr << "ERROR, contig of " << len << " bases in " << path << " exceeds the 2^31 limit of offset_t" << std::endl; return false; }
+    if (len >= 0x7fffffffull) { std::cerr << "ERROR, contig of " << len << " bases in " << path << " exceeds the 2^31 limit of offset_t" << std::endl;
+      return false; }
     fd.off.push_back(start); fd.g.names.push_back(name); fd.g.lens.push_back((int32_t)len);
     if (c < 0 && last == 0) break;
   }
@@ -284,9 +289,11 @@ struct FilePipeline {
   std::mutex mu; std::condition_variable cv;
   size_t next = 0; uint64_t releasedBytes = 0, window; bool failed = false;
   std::vector<std::vector<uint8_t>> spare;      // sequence buffers of released files, reused by the readers
-  int active = getenv("ANI_CLI_INIT_READERS") ? atoi(getenv("ANI_CLI_INIT_READERS")) : 8;      // readers allowed to work: a few until the devices are initialised (set_active), then all
+  // readers allowed to work: a few until the devices are initialised (set_active), then all
+  int active = getenv("ANI_CLI_INIT_READERS") ? atoi(getenv("ANI_CLI_INIT_READERS")) : 8;
   std::vector<std::thread> th;
-  FilePipeline(const std::vector<std::string> &p, int threads, uint64_t windowBytes) : paths(p), slot(p.size()), ready(p.size(), 0), sizeEst(p.size()), sizePrefix(p.size() + 1, 0), window(windowBytes)
+  FilePipeline(const std::vector<std::string> &p, int threads, uint64_t windowBytes) : paths(p), slot(p.size()), ready(p.size(),
+      0), sizeEst(p.size()), sizePrefix(p.size() + 1, 0), window(windowBytes)
   {
     for (size_t i = 0; i < p.size(); i++) {
       struct stat st; uint64_t sz = (stat(p[i].c_str(), &st) == 0) ? (uint64_t)st.st_size : 0;
@@ -360,7 +367,8 @@ struct SliceBatch {
 
 // ANI_CLI_TRACE=1: wall-clock marks of the phases on stderr (where does an end-to-end run spend its time?)
 Clock::time_point g_t0;
-void trace(const char *what) { static const bool on = getenv("ANI_CLI_TRACE") != nullptr; if (on) fprintf(stderr, "[fastANI trace] %8.3f s  %s\n", secs_since(g_t0), what); }
+void trace(const char *what) { static const bool on = getenv("ANI_CLI_TRACE") != nullptr;
+  if (on) fprintf(stderr, "[fastANI trace] %8.3f s  %s\n", secs_since(g_t0), what); }
 
 void die(const char *what) { std::cerr << "ERROR, " << what << ": " << ani_last_error() << std::endl; exit(1); }
 
@@ -404,9 +412,12 @@ int main(int argc, char **argv)
   std::cerr << "Sanity Check  = " << o.sanityCheck << std::endl;
   std::cerr << ">>>>>>>>>>>>>>>>>>" << std::endl;
   // validateInputFiles, parseCmdArgs.hpp:59-88
-  if (o.queries.empty() || o.refs.empty()) { std::cerr << "ERROR, skch::validateInputFiles, Count of query and ref genomes should be non-zero" << std::endl; exit(1); }
-  for (auto &e : o.queries) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
-  if (o.refSketch.empty()) for (auto &e : o.refs) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
+  if (o.queries.empty() || o.refs.empty()) { std::cerr << "ERROR, skch::validateInputFiles, Count of query and ref genomes should be non-zero" << std::endl;
+    exit(1); }
+  for (auto &e : o.queries) { std::ifstream in(e); if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl;
+    exit(1); } }
+  if (o.refSketch.empty()) for (auto &e : o.refs) { std::ifstream in(e);
+    if (in.fail()) { std::cerr << "ERROR, skch::validateInputFiles, Could not open " << e << std::endl; exit(1); } }
   if (!o.refSketch.empty()) {
     ani_params_t fp_;
     if (ani_sketch_file_info(o.refSketch.c_str(), &fp_, nullptr, nullptr, nullptr)) die("reference sketch file");
@@ -423,10 +434,13 @@ int main(int argc, char **argv)
   const int nRef = (int)o.refs.size(), nQry = (int)o.queries.size();
   const bool fromFile = !o.refSketch.empty();
   if (fromFile && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --refSketch cannot be combined with --visualize or -s" << std::endl; exit(1); }
-  if (!o.saveSketch.empty() && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --saveSketch cannot be combined with --visualize or -s (those modes sketch per reference split)" << std::endl; exit(1); }
+  if (!o.saveSketch.empty() && (o.visualize
+      || o.sanityCheck)) { std::cerr << "ERROR, --saveSketch cannot be combined with --visualize or -s (those modes sketch per reference split)" << std::endl; exit(1); }
   const bool allVsAll = !fromFile && (o.queries == o.refs) && !o.visualize && !o.sanityCheck;
   if (o.visualize || o.sanityCheck) o.devices.resize(1);            // the per-split / per-mapping paths are single-device
-  if (!o.saveSketch.empty() && o.devices.size() > 1) { std::cerr << "ERROR, --saveSketch writes the sketch of one device: run it with --gpus 1" << std::endl; exit(1); }   // before anything is read or sketched
+  // before anything is read or sketched
+  if (!o.saveSketch.empty() && o.devices.size() > 1) { std::cerr << "ERROR, --saveSketch writes the sketch of one device: run it with --gpus 1" << std::endl;
+    exit(1); }
 
   std::unordered_map<std::string, uint64_t> genomeLengths;          // computeCoreIdentity.hpp:48-92, filled while the files pass through
   std::mutex lenMu;
@@ -435,7 +449,8 @@ int main(int argc, char **argv)
     for (int32_t l : g.lens) if (l >= ap.fragLen) s += (uint64_t)(l / ap.fragLen) * (uint64_t)ap.fragLen;
     return s;
   };
-  auto noteLength = [&](const std::string &path, const Genome &g) { const uint64_t l = lengthOf(g); std::lock_guard<std::mutex> lk(lenMu); genomeLengths.emplace(path, l); };
+  auto noteLength = [&](const std::string &path, const Genome &g) { const uint64_t l = lengthOf(g); std::lock_guard<std::mutex> lk(lenMu);
+    genomeLengths.emplace(path, l); };
 
   std::vector<ani_cgi_t> finalResults;
   std::vector<VisRow> vis;
@@ -459,7 +474,8 @@ int main(int argc, char **argv)
   trace("options parsed, readers started");
   // ---- devices ----
   std::vector<Device> dev(o.devices.size());
-  for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx) || ani_init(dev[d].id, &dev[d].up)) die("ani_init"); }
+  for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d];
+    if (ani_init(dev[d].id, &dev[d].ctx) || ani_init(dev[d].id, &dev[d].up)) die("ani_init"); }
   const int nDev = (int)dev.size();
   if (fpPtr) fpPtr->set_active(1 << 30);
   trace("devices initialised");
@@ -530,10 +546,12 @@ int main(int argc, char **argv)
     struct Uploaded { ani_dev_batch *b = nullptr; std::vector<int32_t> len, gcs; int32_t seqBase = 0; bool ready = false; };
     auto run_two_stage = [&](const std::vector<std::pair<size_t, size_t>> &slices, const char *what, const std::function<int(size_t)> &ownerOf,
                              const std::function<bool(int, size_t, SliceBatch &, Uploaded &)> &enter,          // bookkeeping before the upload (upload thread)
-                             const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute) {     // device work on the uploaded slice (compute thread)
+                             // device work on the uploaded slice (compute thread)
+                             const std::function<bool(int, size_t, Uploaded &, std::string &)> &compute) {
       std::vector<Uploaded> ups(slices.size());
       std::vector<std::string> errs((size_t)nDev);
-      double stageSecs[7] = {0, 0, 0, 0, 0, 0, 0};                 // ANI_CLI_TRACE: upload threads waiting for the readers / packing + copying, compute threads waiting / working
+      // ANI_CLI_TRACE: upload threads waiting for the readers / packing + copying, compute threads waiting / working
+      double stageSecs[7] = {0, 0, 0, 0, 0, 0, 0};
       std::mutex mu; std::condition_variable cv;
       std::vector<size_t> done((size_t)nDev, 0);          // slices the compute thread of device d has finished (bounds the upload thread's lead)
       std::vector<std::vector<size_t>> mineOf((size_t)nDev);
@@ -559,8 +577,10 @@ int main(int argc, char **argv)
             const auto tr = Clock::now();
             std::string msg = ok ? "" : ani_last_error();
             fp.release(a, b);                               // the host copy is no longer needed
-            { std::lock_guard<std::mutex> lk(mu); stageSecs[0] += std::chrono::duration<double>(tu - tw).count(); stageSecs[1] += std::chrono::duration<double>(tr - tp).count();
-              stageSecs[4] += std::chrono::duration<double>(tw - tl).count(); stageSecs[5] += std::chrono::duration<double>(tp - tu).count(); stageSecs[6] += secs_since(tr); }
+            { std::lock_guard<std::mutex> lk(mu); stageSecs[0] += std::chrono::duration<double>(tu - tw).count();
+              stageSecs[1] += std::chrono::duration<double>(tr - tp).count();
+              stageSecs[4] += std::chrono::duration<double>(tw - tl).count(); stageSecs[5] += std::chrono::duration<double>(tp - tu).count();
+              stageSecs[6] += secs_since(tr); }
             u.len = std::move(sb.len); u.gcs = std::move(sb.gcs);
             { std::lock_guard<std::mutex> lk(mu); if (!ok) errs[d] = msg.empty() ? "upload" : msg; u.ready = true; }
             cv.notify_all();
@@ -583,7 +603,8 @@ int main(int argc, char **argv)
         });
       }
       for (auto &t : th) t.join();        // no thread waits for another device's: a failing device cannot stall the others
-      { char line[400]; snprintf(line, sizeof line, "%s: %zu slices; upload threads waited %.3f s for the readers, %.3f s for the compute threads, entered the slices %.3f s, packed + copied %.3f s, released the host copies %.3f s; compute threads waited %.3f s, worked %.3f s",
+      { char line[400]; snprintf(line, sizeof line,
+          "%s: %zu slices; upload threads waited %.3f s for the readers, %.3f s for the compute threads, entered the slices %.3f s, packed + copied %.3f s, released the host copies %.3f s; compute threads waited %.3f s, worked %.3f s",
                                  what, slices.size(), stageSecs[0], stageSecs[4], stageSecs[5], stageSecs[1], stageSecs[6], stageSecs[2], stageSecs[3]); trace(line); }
       for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, " << what << ": " << e << std::endl; exit(1); }
     };
@@ -655,8 +676,10 @@ int main(int argc, char **argv)
           Shard &sh = shard[(size_t)d];
           sh.nGenomes = (int32_t)sh.gcs.size() - 1;
           std::vector<const void *> recs(sh.parts.size()); std::vector<uint64_t> ns(sh.parts.size()); std::vector<int32_t> pgs(sh.parts.size() + 1, 0);
-          for (size_t k = 0; k < sh.parts.size(); k++) { recs[k] = sh.parts[k].rec; ns[k] = sh.parts[k].n; pgs[k] = sh.parts[k].g0; pgs[k + 1] = sh.parts[k].g1; }
-          if (ani_sketch_from_record_parts(dev[d].ctx, &ap, (int32_t)sh.parts.size(), recs.data(), ns.data(), pgs.data(), sh.contigLen.data(), (int32_t)sh.contigLen.size(),
+          for (size_t k = 0; k < sh.parts.size(); k++) { recs[k] = sh.parts[k].rec; ns[k] = sh.parts[k].n; pgs[k] = sh.parts[k].g0;
+            pgs[k + 1] = sh.parts[k].g1; }
+          if (ani_sketch_from_record_parts(dev[d].ctx, &ap, (int32_t)sh.parts.size(), recs.data(), ns.data(), pgs.data(), sh.contigLen.data(),
+              (int32_t)sh.contigLen.size(),
                                            sh.gcs.data(), sh.nGenomes, &sh.sk)) { errs[d] = ani_last_error(); return; }
           for (auto &pt : sh.parts) if (pt.rec) { ani_device_free(dev[d].ctx, pt.rec); pt.rec = nullptr; }
         });
@@ -687,7 +710,8 @@ int main(int argc, char **argv)
       occAll += occ; chunksAll += nChunks;
       if (blk == 0) {
         std::cerr << "INFO [thread 0], skch::Sketch::build, minimizers picked from reference = " << (nBlocks > 1 ? fileMinimizers : occ) << std::endl;
-        if (nChunks <= 1 && nBlocks == 1) { ani_sketch_stats(shard[0].sk, nullptr, &uniq, nullptr, nullptr, nullptr); std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl; }
+        if (nChunks <= 1 && nBlocks == 1) { ani_sketch_stats(shard[0].sk, nullptr, &uniq, nullptr, nullptr, nullptr);
+          std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl; }
         else if (nBlocks == 1) std::cerr << "INFO [thread 0], skch::Sketch::index, reference set held as " << nChunks << " index chunks on " << nDev << " device(s)" << (streamed ? ", streamed" : "") << std::endl;
         std::cerr << "INFO [thread 0], skch::main, Time spent sketching the reference : " << secs_since(t0) << " sec" << std::endl;
       }
@@ -770,7 +794,8 @@ int main(int argc, char **argv)
       if (nDev > 1)
         for (auto &q : qsets) {
           if (!q.f) continue;
-          if (ani_fragset_pack_bytes(q.f, &q.bytes) || ani_device_alloc(dev[q.dev].ctx, q.bytes, &q.packed) || ani_fragset_pack(dev[q.dev].ctx, q.f, q.packed, q.bytes, nullptr)) die("fragment set");
+          if (ani_fragset_pack_bytes(q.f, &q.bytes) || ani_device_alloc(dev[q.dev].ctx, q.bytes, &q.packed) || ani_fragset_pack(dev[q.dev].ctx, q.f, q.packed,
+              q.bytes, nullptr)) die("fragment set");
           ani_fragset_free(q.f); q.f = nullptr;           // the packed form serves the home device as well
         }
       trace("query fragment sketches ready");
@@ -796,7 +821,8 @@ int main(int argc, char **argv)
             const void *buf = q.packed;
             if (src != d) {
               void *p = nullptr;
-              if (ani_device_alloc(dev[d].ctx, q.bytes, &p) || ani_device_copy_peer(dev[d].ctx, p, dev[src].ctx, q.packed, q.bytes)) { errs[d] = ani_last_error(); cleanup(); return; }
+              if (ani_device_alloc(dev[d].ctx, q.bytes, &p) || ani_device_copy_peer(dev[d].ctx, p, dev[src].ctx, q.packed,
+                  q.bytes)) { errs[d] = ani_last_error(); cleanup(); return; }
               pulled.push_back(p); buf = p;
             }
             ani_fragset *v = nullptr;
@@ -808,7 +834,8 @@ int main(int argc, char **argv)
           ani_counters_t c0, c1;
           ani_get_counters(dev[d].ctx, &c0);
           ani_cgi_t *rows = nullptr; size_t m = 0;
-          if (ani_map_cgi_fragsets(dev[d].ctx, shard[d].sk, (int32_t)sets.size(), sets.data(), firsts.data(), &rows, &m)) { errs[d] = ani_last_error(); cleanup(); return; }
+          if (ani_map_cgi_fragsets(dev[d].ctx, shard[d].sk, (int32_t)sets.size(), sets.data(), firsts.data(), &rows, &m)) { errs[d] = ani_last_error();
+            cleanup(); return; }
           for (size_t i = 0; i < m; i++) rows[i].refGenomeId += shard[d].g0;      // shard-local -> reference file index
           devRows[d].insert(devRows[d].end(), rows, rows + m);
           ani_free(rows);
@@ -827,7 +854,8 @@ int main(int argc, char **argv)
     trace("queries mapped");
     for (auto &v : sliceRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }
     for (auto &v : devRows) { finalResults.insert(finalResults.end(), v.begin(), v.end()); std::vector<ani_cgi_t>().swap(v); }
-    for (int d = 0; d < nDev; d++) { if (shard[d].sk) ani_sketch_destroy(shard[d].sk); std::cerr << "INFO [thread " << d << "], skch::main, ready to exit the loop" << std::endl; }
+    for (int d = 0; d < nDev; d++) { if (shard[d].sk) ani_sketch_destroy(shard[d].sk);
+      std::cerr << "INFO [thread " << d << "], skch::main, ready to exit the loop" << std::endl; }
   } else {
     // =================================================================================================================
     // -s (per-split sanity check, winSketch.hpp:298-318) and --visualize (mappings back on the host): whole sets in memory,
@@ -914,7 +942,8 @@ int main(int argc, char **argv)
           std::sort(v.begin(), v.end(), [](const M &x, const M &y) {
             return std::tie(x.genome, x.qSeq, x.id, x.refSeq, x.refStart) < std::tie(y.genome, y.qSeq, y.id, y.refSeq, y.refStart); });
           std::vector<M> one_way;
-          for (auto &e : v) { if (!one_way.empty() && one_way.back().genome == e.genome && one_way.back().qSeq == e.qSeq) one_way.back() = e; else one_way.push_back(e); }
+          for (auto &e : v) { if (!one_way.empty() && one_way.back().genome == e.genome && one_way.back().qSeq == e.qSeq) one_way.back() = e;
+            else one_way.push_back(e); }
           // Which of several equal-identity mappings of one reference bin survives is decided by the order std::sort leaves equal
           // elements in (computeCoreIdentity.hpp:240: cmp_refbin_bucket compares (contig, bin, identity) only).  That order is a
           // deterministic function of the input sequence and the comparator, so the same call on the same sequence — the 1-way list,
@@ -922,7 +951,8 @@ int main(int argc, char **argv)
           std::sort(one_way.begin(), one_way.end(), [](const M &x, const M &y) { return std::tie(x.refSeq, x.bin, x.id) < std::tie(y.refSeq, y.bin, y.id); });
           visWritten = true;                                                // outputVisualizationFile opens (creates) the file per query
           std::vector<M> two_way;
-          for (auto &e : one_way) { if (!two_way.empty() && two_way.back().refSeq == e.refSeq && two_way.back().bin == e.bin) two_way.back() = e; else two_way.push_back(e); }
+          for (auto &e : one_way) { if (!two_way.empty() && two_way.back().refSeq == e.refSeq && two_way.back().bin == e.bin) two_way.back() = e;
+            else two_way.push_back(e); }
           for (auto &e : two_way)
             vis.push_back(VisRow{o.queries[qi], o.refs[refIdx[e.genome]], e.id, 0 + qOff[e.qSeq], 0 + ap.fragLen - 1 + qOff[e.qSeq],
                                  e.refStart + refOff[e.refSeq], e.refStart + ap.fragLen - 1 + refOff[e.refSeq]});
@@ -1036,7 +1066,8 @@ int main(int argc, char **argv)
       uint64_t ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (ani_pool_stats(d.ctx, ps) == 0) {
         char line[256];
-        snprintf(line, sizeof line, "device %d memory: %.1f MB in %llu segments, %.1f MB handed out; %llu hipMalloc calls took %.1f ms (%.2f us per MB)", d.id, ps[0] / 1048576.0,
+        snprintf(line, sizeof line, "device %d memory: %.1f MB in %llu segments, %.1f MB handed out; %llu hipMalloc calls took %.1f ms (%.2f us per MB)",
+            d.id, ps[0] / 1048576.0,
                  (unsigned long long)ps[3], ps[2] / 1048576.0, (unsigned long long)ps[4], ps[6] / 1e3, ps[5] ? (double)ps[6] / (ps[5] / 1048576.0) : 0.0);
         trace(line);
       }

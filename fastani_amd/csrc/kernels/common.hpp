@@ -359,10 +359,12 @@ template <int M> __device__ __forceinline__ uint32_t lane_xor(uint32_t x)
     return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xf, 0xA, false);                      // row_shr:4 into lanes 4-7, 12-15
   }
   else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xf, 0xf, true);   // row_ror:8
-  else if constexpr (M == 16) {                                                                           // v_permlane16_swap (gfx950): odd rows of one <-> even rows of the other
+  // v_permlane16_swap (gfx950): odd rows of one <-> even rows of the other
+  else if constexpr (M == 16) {
     const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
     return (threadIdx.x & 16) ? r[0] : r[1];
-  } else {                                                                                                // v_permlane32_swap: upper half of one <-> lower half of the other
+  // v_permlane32_swap: upper half of one <-> lower half of the other
+  } else {
     const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return (threadIdx.x & 32) ? r[0] : r[1];
   }
@@ -482,7 +484,8 @@ constexpr int kBlockSortMax = 4096;
 // Frames itself with workgroup barriers: the keys are complete before, the sorted sequence is visible after.
 __host__ __device__ __forceinline__ int next_pow2_dev(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 template <class K>
-__device__ __forceinline__ void block_sort(K *a, int n)      // (inlined: an out-of-line copy would see `a` as a generic pointer and use flat instead of ds instructions)
+// (inlined: an out-of-line copy would see `a` as a generic pointer and use flat instead of ds instructions)
+__device__ __forceinline__ void block_sort(K *a, int n)
 {
   int n2 = next_pow2_dev(n); n2 = n2 < kWave ? kWave : n2;
   for (int i = n + (int)threadIdx.x; i < n2; i += kTPB) a[i] = (K)~(K)0;

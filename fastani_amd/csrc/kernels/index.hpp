@@ -44,7 +44,8 @@ __host__ __device__ __forceinline__ int32_t dup_prev(const DupLinks &d, uint32_t
 __host__ __device__ __forceinline__ int32_t dup_next(const DupLinks &d, uint32_t j)
 {
   uint32_t x = dup_lower_bound(d, j);
-  for (int k = 0; k < 2 && x < d.n; k++, x++) { const uint64_t v = d.list[x]; if ((uint32_t)(v >> 32) != j) break; if ((v >> 31) & 1ull) return (int32_t)(v & 0x7fffffffull); }
+  for (int k = 0; k < 2 && x < d.n; k++, x++) { const uint64_t v = d.list[x]; if ((uint32_t)(v >> 32) != j) break;
+    if ((v >> 31) & 1ull) return (int32_t)(v & 0x7fffffffull); }
   return -1;
 }
 
@@ -65,7 +66,8 @@ static __global__ void k_index_join(const uint32_t *__restrict__ mHash, const in
 // Entries without a link behave as plain set members in L2 (links of non-near pairs would only ever be compared against the bounds of
 // one window).  `nPairs` counts every pair; a pair beyond `pairCap` is not stored (the host reruns the kernel with room for all).
 // one same-hash pair (r - 1, r) of the sorted index: the link records if the two are near duplicates
-__device__ __forceinline__ void index_link_pair(uint32_t r, const uint64_t *__restrict__ sSW, const int32_t *__restrict__ mWpos, const int32_t *__restrict__ contigFirstMin,
+__device__ __forceinline__ void index_link_pair(uint32_t r, const uint64_t *__restrict__ sSW, const int32_t *__restrict__ mWpos,
+    const int32_t *__restrict__ contigFirstMin,
                                                 int32_t cmw, uint64_t *__restrict__ pairs, uint32_t pairCap, unsigned int *__restrict__ nPairs,
                                                 uint32_t *__restrict__ dupBits, uint32_t *__restrict__ mWin)
 {
@@ -203,7 +205,8 @@ __host__ __device__ __forceinline__ uint32_t table_slots(unsigned long long nUni
   const unsigned long long v = nUnique * 2ull;
   return (uint32_t)(v < 1024ull ? 1024ull : v > 0x7ffffff0ull ? 0x7ffffff0ull : v);
 }
-static __global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__restrict__ sHash, uint32_t n, int w, const unsigned long long *__restrict__ nUnique,
+static __global__ __launch_bounds__(kTPB) void k_table_block_totals(const uint32_t *__restrict__ sHash, uint32_t n, int w,
+    const unsigned long long *__restrict__ nUnique,
                                                              int32_t *__restrict__ blockCnt, int32_t *__restrict__ blockBest)
 {
   __shared__ int ws[16];

@@ -5,7 +5,8 @@
 // slide a run of `minimumHits` consecutive hits, keep runs that stay on one contig and span < fragLen, merge
 // overlapping candidates).  Stateless form, SURVEY.md App. A.3.
 //
-// Two passes.  k_l1_probe: one lane per sketch hash, the index chunk's probe table (index.hpp), no LDS.  k_l1<HLO,HCAP>: one workgroup per fragment with HLO < H <= HCAP seed hits,
+// Two passes.  k_l1_probe: one lane per sketch hash, the index chunk's probe table (index.hpp), no LDS.  k_l1<HLO,HCAP>: one workgroup per fragment with HLO <
+// H <= HCAP seed hits,
 // gather the hit runs into LDS as 64-bit (seqId<<32 | wpos) keys, bitonic sort in registers (common.hpp: block_sort), flag valid runs, compact, flag
 // group heads by neighbour comparison (run starts/ends are non-decreasing, so "overlaps the previous candidate" only needs
 // the previous valid run), scan, emit.  Two LDS classes (<= 2048 hits: 6 workgroups per CU; <= 4096: 3), the larger driven by a fragment list.  Fragments
@@ -17,37 +18,43 @@
 namespace ani {
 
 constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS classes accept
-constexpr int kL1SmallMaxS = 1024;      // ... class S (its 4 KiB of scratch hold the per-hash hit offsets); a fragment with more goes to class M whatever its hit count
+// ... class S (its 4 KiB of scratch hold the per-hash hit offsets); a fragment with more goes to class M whatever its hit count
+constexpr int kL1SmallMaxS = 1024;
 constexpr int kFragHashCapL1 = 4096;    // = kFragHashCap (sketch.hpp): the most sketch hashes a fragment can have
-constexpr int kL1HitCapSmall = 2048;    // class S: 16 KiB hits + 4 KiB scratch, <= 72 registers -> 7 workgroups per CU.  The kernel's time follows the number of
-                                        // resident workgroups (a workgroup's life is a chain of latencies — probe results, hit runs, LDS round trips of the sort — and
-                                        // what hides them is other workgroups): 5 per CU 35.8 ms, 6 per CU 30.0 ms per benchmark step (profiles/r06f_l1_occupancy_ab.txt)
+// class S: 16 KiB hits + 4 KiB scratch, <= 72 registers -> 7 workgroups per CU.  The kernel's time follows the number of
+constexpr int kL1HitCapSmall = 2048;
+                                        // resident workgroups (a workgroup's life is a chain of latencies — probe results, hit runs, LDS round trips of the
+                                        // sort — and
+                                        // what hides them is other workgroups): 5 per CU 35.8 ms, 6 per CU 30.0 ms per benchmark step
+                                        // (profiles/r06f_l1_occupancy_ab.txt)
 constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgroups per CU
 constexpr int kL1HitCapMax = kL1HitCapMid;   // beyond: the batched global-memory path.  (A class L of 8192 hits — 96 KiB of LDS, one workgroup
                                              // per CU — existed until round 3: 0.43 us per fragment where the batched path takes 0.33, measured at
                                              // 493 k such fragments per step of the cluster-size-100 benchmark.)
 static_assert(kL1HitCapMax <= kBlockSortMax, "block_sort (common.hpp) sorts at most kBlockSortMax keys");
 constexpr int kL1FilterMinHits = 300;   // below this the sort is cheaper than the noise filter
-template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 13 : 15; }   // log2 of the occupancy counters per tiling: four bit arrays in the class's scratch (S: 4 x 1 KiB, M: 4 x 4 KiB)
+// log2 of the occupancy counters per tiling: four bit arrays in the class's scratch (S: 4 x 1 KiB, M: 4 x 4 KiB)
+template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 13 : 15; }
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
   const TableSlot *table; uint32_t tableSlots; const uint64_t *sSW; int bucketW; uint32_t nIndex;
   const int32_t *minHitsLUT; int32_t lutMaxS;
   int L;
-  int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;   // striped pool (common.hpp: pool_take): capacity per stripe, cursors
+  // striped pool (common.hpp: pool_take): capacity per stripe, cursors
+  int32_t *candFrag, *candSeq, *candStart, *candEnd; uint32_t candCap; unsigned long long *candCount;
   uint32_t *fragCandOff; int32_t *fragCandCnt; int32_t *fragHits;
   uint32_t *probeFirst, *probeCnt;      // per sketch hash (aligned with qPool): occurrence run in the hash-sorted index
   int32_t *midList; unsigned int *midCount;       // fragments with kL1HitCapSmall < H <= kL1HitCapMid
   int32_t *bigList; unsigned int *bigCount;       // fragments beyond the LDS classes (s > kL1MaxS or H > kL1HitCapMax)
   unsigned int *overflowCount;                    // fragments with >= 2^31 seed hits (fragHits = -1): the call fails
-  unsigned long long hitLimit;                    // ... 2^31 - 16 (lowered by tests: ANI_L1_HIT_LIMIT)
+  unsigned long long hitLimit;                    // ... 2^31 - 16 (lowered by tests: ANI_TEST_L1_HIT_LIMIT)
   unsigned long long *sumHits, *tinyCount, *smallCount;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
-  int filterMinHits;                    // kL1FilterMinHits (ANI_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
-  int ldsHitCap;                        // fragments with more seed hits take the batched global-memory path (<= kL1HitCapMax; ANI_L1_LDS_MAX)
-  int tinyPath;                         // fragments with <= 64 seed hits are finished by one wave (l1_tiny; ANI_L1_TINY=0 switches it off: A/B and tests)
+  int filterMinHits;                    // kL1FilterMinHits (ANI_TEST_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
+  int ldsHitCap;                        // fragments with more seed hits take the batched global-memory path (<= kL1HitCapMax; ANI_TEST_L1_LDS_MAX)
+  int tinyPath;                         // fragments with <= 64 seed hits are finished by one wave (l1_tiny; ANI_TEST_L1_TINY=0 switches it off: A/B and tests)
 };
 
 // Counter indices of a hit's two tiles for the noise filter (k_l1): tiles of width 2^shift, the second tiling offset by half a tile.
@@ -64,7 +71,8 @@ __device__ __forceinline__ void l1_filter_tiles(uint64_t hv, int shift, uint32_t
 }
 
 // occurrences of hash h in the hash-ordered payload array: [first, first+cnt)
-__device__ __forceinline__ void l1_probe(const L1Args &a, uint32_t h, uint32_t &first, uint32_t &cnt) { table_probe(a.table, a.bucketW, a.tableSlots, h, first, cnt); }
+__device__ __forceinline__ void l1_probe(const L1Args &a, uint32_t h, uint32_t &first, uint32_t &cnt) { table_probe(a.table, a.bucketW, a.tableSlots, h,
+    first, cnt); }
 
 __device__ __forceinline__ int32_t hit_seq(uint64_t h) { return (int32_t)(h >> 32); }
 __device__ __forceinline__ int32_t hit_wpos(uint64_t h) { return (int32_t)(uint32_t)h; }
@@ -243,9 +251,12 @@ static __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
       else if (s[q] > 0) {
         // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
         if (s[q] <= kL1MaxS && H <= a.ldsHitCap) {
-          if (H > kL1HitCapSmall || (s[q] > kL1SmallMaxS && !(H <= 4 * kWave && a.tinyPath))) a.midList[atomicAdd(a.midCount, 1u)] = f;     // (a long sketch with a handful of hits: the wave kernel)
-          else if (H > 0 && H <= 4 * kWave && a.tinyPath) atomicAdd(stat_slot(a.tinyCount), 1ull);      // (striped statistics counters: the host launches k_l1_tiny if there are any,
-          else if (H > 0) atomicAdd(stat_slot(a.smallCount), 1ull);                                 //  and k_l1<0, 2048> over a list instead of over every fragment if there are few)
+          // (a long sketch with a handful of hits: the wave kernel)
+          if (H > kL1HitCapSmall || (s[q] > kL1SmallMaxS && !(H <= 4 * kWave && a.tinyPath))) a.midList[atomicAdd(a.midCount, 1u)] = f;
+          // (striped statistics counters: the host launches k_l1_tiny if there are any,
+          else if (H > 0 && H <= 4 * kWave && a.tinyPath) atomicAdd(stat_slot(a.tinyCount), 1ull);
+          // and k_l1<0, 2048> over a list instead of over every fragment if there are few)
+          else if (H > 0) atomicAdd(stat_slot(a.smallCount), 1ull);
         } else a.bigList[atomicAdd(a.bigCount, 1u)] = f;         // beyond every LDS class: global-memory path
       }
     }
@@ -270,7 +281,8 @@ template <int KPT> __device__ __forceinline__ void l1_tiny_sort(uint64_t *hits, 
   const int lane = threadIdx.x & (kWave - 1);
   uint64_t k[KPT];
 #pragma unroll
-  for (int r = 0; r < KPT; r++) { const int x = r * kWave + lane; k[r] = x < H ? hits[x] : ~0ull; }     // any assignment of the unordered keys will do: the conflict-free one
+  // any assignment of the unordered keys will do: the conflict-free one
+  for (int r = 0; r < KPT; r++) { const int x = r * kWave + lane; k[r] = x < H ? hits[x] : ~0ull; }
   ANI_WAVE_SYNC();
   wave_sort_regs<uint64_t, KPT>(k);                  // :320
 #pragma unroll
@@ -348,7 +360,9 @@ static __global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
   if (i >= a.nFrag) return;
   const int f = a.fragOrder ? a.fragOrder[i] : i;
   const int s = a.fragS[f], H = a.fragHits[f];
-  if (s <= 0 || s > kL1MaxS || H <= 0 || H > kL1HitCapTiny || H > a.ldsHitCap) return;   // the workgroup classes / the batched path (same class predicate as k_l1_probe: H > ldsHitCap is bigList's) / nothing to do (k_l1<0, 2048> or k_l1_list writes the zero counts)
+  // the workgroup classes / the batched path (same class predicate as k_l1_probe: H > ldsHitCap is bigList's) / nothing to do (k_l1<0, 2048> or k_l1_list
+  // writes the zero counts)
+  if (s <= 0 || s > kL1MaxS || H <= 0 || H > kL1HitCapTiny || H > a.ldsHitCap) return;
   l1_tiny(a, f, s, H, hits[wv], V[wv]);
 }
 
@@ -422,7 +436,8 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
   if (HLO == 0 && (s > kL1MaxS || H > a.ldsHitCap)) return;        // beyond the LDS classes: k_l1_big_* below
   if (HLO == 0 && H <= kL1HitCapTiny && a.tinyPath) return;        // a handful of hits: k_l1_tiny has them (one wave per fragment)
   if (H > HCAP || s <= 0 || s > kL1MaxS) return;                 // another class handles it ...
-  if (HLO == 0 ? s > kMaxS : (H <= HLO && s <= kL1SmallMaxS)) return;     // ... class S takes sketches of <= 1024 hashes, class M the longer ones as well (k_l1_probe lists them)
+  // ... class S takes sketches of <= 1024 hashes, class M the longer ones as well (k_l1_probe lists them)
+  if (HLO == 0 ? s > kMaxS : (H <= HLO && s <= kL1SmallMaxS)) return;
   const uint32_t off = a.fragOff[f];
   const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather
   int *pOff = (int *)Vraw;                          // hit offsets per probe alias V (V is only written after the gather)
@@ -520,7 +535,8 @@ struct L1BigArgs {
   int n; int shiftSeq, shiftRank;       // key = rank << shiftRank | seqId << shiftSeq | wpos
 };
 
-static __global__ void k_l1_big_info(const int32_t *__restrict__ list, uint32_t n, const int32_t *__restrict__ fragS, const int32_t *__restrict__ fragHits, int32_t *__restrict__ out)
+static __global__ void k_l1_big_info(const int32_t *__restrict__ list, uint32_t n, const int32_t *__restrict__ fragS, const int32_t *__restrict__ fragHits,
+    int32_t *__restrict__ out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const int f = list[i]; out[2 * i] = fragS[f]; out[2 * i + 1] = fragHits[f]; }

@@ -226,7 +226,8 @@ static __global__ __launch_bounds__(kTPB) void k_l2(L2Args a, const int32_t *__r
   // counters for the algorithmic-byte figure: one atomic per wave
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { e += __shfl_down(e, d); st += __shfl_down(st, d); sq += __shfl_down(sq, d); }
-  if ((threadIdx.x & 63) == 0 && (e | st | sq)) { atomicAdd(stat_slot(a.sumEntries), e); atomicAdd(stat_slot(a.sumSteps), st); atomicAdd(stat_slot(a.sumQ), sq); }
+  if ((threadIdx.x & 63) == 0 && (e | st | sq)) { atomicAdd(stat_slot(a.sumEntries), e); atomicAdd(stat_slot(a.sumSteps), st);
+    atomicAdd(stat_slot(a.sumQ), sq); }
 }
 
 // ---------------------------------------------------------------- fast path
@@ -264,7 +265,7 @@ struct L2FastArgs {
   const uint32_t *fragCandOff;     // ordered candidate offset per position in the fragments' processing order [nFrag]
   const int32_t *fragOrder;        // processing order (nullptr: fragment ascending)
   int32_t nFrag, fragBase, nFragChunk;   // first fragment of the chunk, fragments that own its candidates
-  int32_t allowFast;               // test knob ANI_L2_PATH: 0 = everything to the general kernel, 2 = everything to class B
+  int32_t allowFast;               // test knob ANI_TEST_L2_PATH: 0 = everything to the general kernel, 2 = everything to class B
 };
 
 // lower_bound_wpos over a contig's slice [.., cHi) through the sampled position index: the answer lies inside the target's bin
@@ -319,7 +320,8 @@ constexpr int kL2DeltaShift = 13;         // bits 13..15: the event's signed cha
 static_assert((kWinDupBit >> 21) == kL2DupBit && (kWinMoreBit >> 18) == kL2NoEvalBit, "flag bits of the window links shift into the event code");
 constexpr int kL2RankBuckets = 2048;
 // rank-table bucket of a hash: linear buckets over the low end of the range, where minimizer hashes live (see L2Args::rankShift)
-__device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh; return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
+__device__ __forceinline__ int l2_rank_bucket(uint32_t h, int sh) { const uint32_t b = h >> sh;
+  return (int)(b < (uint32_t)(kL2RankBuckets - 1) ? b : (uint32_t)(kL2RankBuckets - 1)); }
 
 // The fragment sketch and its rank table in LDS (k_l2_codes).  st2[b] = #{q : bucket(q) < b} | entries of bucket b
 // << 16.  Counted and scanned (one LDS atomic per sketch hash on 16-bit counters packed in pairs, eight buckets per thread, one
@@ -515,7 +517,8 @@ static __global__ __launch_bounds__(kTPB) void k_l2_codes(L2FastArgs a)
         // window's)
         const uint32_t ib = x + ((wl[e] >> kWinShiftA) & kWinMask);
         pd[e] = x < cur.nDel ? x + (ib < cur.nInit ? cur.nInit : ib) : dumpSlot;
-        cdl[e] = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));   // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+        // kWinMoreBit (bit 30) -> kL2NoEvalBit (bit 12)
+        cdl[e] = (uint16_t)(cd | ((wl[e] >> 18) & kL2NoEvalBit) | (6u << kL2DeltaShift) | (mq & (1u << kL2DeltaShift)));
       }
       if (cur.staged) {                                                                   // wave-uniform choice
   #pragma unroll
@@ -590,7 +593,8 @@ __device__ __forceinline__ void l2_apply(uint8_t *F, L2Regs &r, uint32_t code, b
   // delete: q_{iStar+1} joins them iff iStar < s and iStar + cStar + 1 + n[iStar] <= s.  One comparison against s serves both.
   const int reach = INS ? r.tot : r.tot + c1;
   const bool over = reach > r.s;
-  const bool room = (INS ? idx : r.iStar) < (INS ? r.iStar : r.s);   // insert: lt; delete: iStar < s (two selects and one comparison: cheaper than selecting between two flags)
+  // insert: lt; delete: iStar < s (two selects and one comparison: cheaper than selecting between two flags)
+  const bool room = (INS ? idx : r.iStar) < (INS ? r.iStar : r.s);
   const bool mv = on && !isQ && room && (over == INS);
   const int mvm = -(int)mv;                                          // all ones if the pivot moves (masks, not selects: no branch around the rest)
   const int mone = sg & mvm;                                         // insert: -1 on everything, delete: +1
@@ -671,7 +675,8 @@ static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const
           if (on && (code & kL2DupBit)) {
             const int insCount = ev - delCount;                       // entries [delCount, insCount) are in the window
             if (INS) eff = dup_prev(a.g.dup, (uint32_t)(r.beg0 + insCount)) < r.beg0 + delCount;            // new iff no same-hash entry in [beg, end)
-            else { const int32_t nx = dup_next(a.g.dup, (uint32_t)(r.beg0 + delCount)); eff = !(nx >= 0 && nx < r.beg0 + insCount); }   // stays iff a later same-hash entry is in the window
+            // stays iff a later same-hash entry is in the window
+            else { const int32_t nx = dup_next(a.g.dup, (uint32_t)(r.beg0 + delCount)); eff = !(nx >= 0 && nx < r.beg0 + insCount); }
           }
         }
       }
@@ -756,7 +761,8 @@ static __global__ __launch_bounds__(kL2SimTPB) void k_l2_sim(L2FastArgs a, const
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { cntE += __shfl_down(cntE, d); cntS += __shfl_down(cntS, d); cntQ += __shfl_down(cntQ, d); }
-  if (lane == 0 && (cntE | cntS | cntQ)) { atomicAdd(stat_slot(a.g.sumEntries), cntE); atomicAdd(stat_slot(a.g.sumSteps), cntS); atomicAdd(stat_slot(a.g.sumQ), cntQ); }
+  if (lane == 0 && (cntE | cntS | cntQ)) { atomicAdd(stat_slot(a.g.sumEntries), cntE); atomicAdd(stat_slot(a.g.sumSteps), cntS);
+    atomicAdd(stat_slot(a.g.sumQ), cntQ); }
 }
 
 // (Rounds 4 - 5 kept a second simulation kernel here, k_l2_sim_pair: two candidates per lane with the state in packed 16-bit halves —

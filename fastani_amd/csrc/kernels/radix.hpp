@@ -111,7 +111,8 @@ __device__ __forceinline__ void radix_status_store(unsigned long long *p, unsign
 // Digit histograms of every pass in ONE read of the keys: hist[pass * 256 + digit] (64-bit, zeroed by the host).  The index build
 // passes `soa` = true: the same read writes the position-ordered SoA arrays of the chunk (mHash / mSeq / mWpos at `soaBase + i`).
 template <class KeyT, class Src>
-static __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64_t n, int beginBit, int endBit, int nPasses, unsigned long long *__restrict__ hist,
+static __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64_t n, int beginBit, int endBit, int nPasses,
+    unsigned long long *__restrict__ hist,
                                                           uint32_t *__restrict__ mHash, int32_t *__restrict__ mSeq, int32_t *__restrict__ mWpos)
 {
   // one copy of the counters per wave: the top digit of minimizer hashes takes a few dozen values, and 64 lanes adding to a handful of
@@ -129,7 +130,8 @@ static __global__ __launch_bounds__(kTPB) void k_radix_histogram(Src src, uint64
         mHash[i] = (uint32_t)k; mSeq[i] = (int32_t)(v >> 32); mWpos[i] = (int32_t)(uint32_t)v;
       }
     }
-    for (int p = 0; p < nPasses; p++) atomicAdd(&mine[p * kRadixDigits + (int)radix_digit(k, beginBit + p * kRadixBits, endBit)], 1u);   // pass p sorts the bits from beginBit + 8 p
+    // pass p sorts the bits from beginBit + 8 p
+    for (int p = 0; p < nPasses; p++) atomicAdd(&mine[p * kRadixDigits + (int)radix_digit(k, beginBit + p * kRadixBits, endBit)], 1u);
   }
   block_barrier();
   for (int i = threadIdx.x; i < nPasses * kRadixDigits; i += kTPB) {
@@ -165,10 +167,12 @@ static __global__ __launch_bounds__(kTPB) void k_radix_scan(unsigned long long *
 // 512 threads x 12 keys: the tile's life is a string of latencies (key loads, one LDS round trip per ranked key, the look-back's
 // round trips past the L2, value loads) and what hides them is waves — 8 per workgroup; LDS per workgroup = the staging tile (6144 x max(key, value)
 // bytes: 48 KiB for the index's u32 / u64 pass, 24 KiB for u32-only) + 8 KiB of per-wave digit counters + 1 KiB of run bases ≈ 57 KiB for
-// the index pass, i.e. 2 workgroups = 16 waves per CU of 160 KiB — not instruction-level tricks: 256 x 16 (the same tile, 105 VGPRs, 16 waves per CU) measured 4.7 ms per pass of 4 x 10^8
+// the index pass, i.e. 2 workgroups = 16 waves per CU of 160 KiB — not instruction-level tricks: 256 x 16 (the same tile, 105 VGPRs, 16 waves per CU) measured
+// 4.7 ms per pass of 4 x 10^8
 // records against 2.7 ms for rocPRIM's onesweep (profiles/r04c_radix_kernel_stats.csv).
 template <class KeyT, class ValT, class Src>
-static __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restrict__ keysOut, ValT *__restrict__ valsOut, uint64_t n, int shift, int endBit,
+static __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *__restrict__ keysOut, ValT *__restrict__ valsOut, uint64_t n, int shift,
+    int endBit,
                                                           const unsigned long long *__restrict__ digitBase, unsigned long long *__restrict__ status,
                                                           unsigned int *__restrict__ tileCounter, uint32_t tileBase, unsigned int *__restrict__ errFlag)
 {
@@ -178,7 +182,8 @@ static __global__ __launch_bounds__(kRadixTPB) void k_radix_pass(Src src, KeyT *
   constexpr int kWaves = kRadixTPB / kWave;
   __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
   __shared__ unsigned int wc[kWaves * kRadixDigits];                // per-wave digit counters, then each wave's base inside the tile
-  __shared__ uint32_t gbase[kRadixDigits];                          // global position of local position 0 of each digit's run, minus that local position (mod 2^32: n < 2^32)
+  // global position of local position 0 of each digit's run, minus that local position (mod 2^32: n < 2^32)
+  __shared__ uint32_t gbase[kRadixDigits];
   __shared__ int ws[32];
   __shared__ unsigned int sTile, sErr;
   const int t = threadIdx.x, lane = t & (kWave - 1), wv = t >> 6;

@@ -443,7 +443,8 @@ __device__ __forceinline__ void fragment_sketch_body(const void *__restrict__ se
     *sBasePtr = pool_take(poolCount, poolCap, (unsigned long long)s);
     fragOff[blockIdx.x] = (uint32_t)*sBasePtr;
     fragS[blockIdx.x] = overflow ? -1 : s;
-    atomicMax((int *)stat_slot((unsigned long long *)maxS), overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+    // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+    atomicMax((int *)stat_slot((unsigned long long *)maxS), overflow ? 0x7fffffff : s);
   }
   block_barrier();
   const unsigned long long base = *sBasePtr & ~kPoolOverflowBit;
@@ -521,7 +522,8 @@ __device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool over
     *sBasePtr = pool_take(poolCount, poolCap, (unsigned long long)s);
     fragOff[frag] = (uint32_t)*sBasePtr;
     fragS[frag] = overflow ? -1 : s;
-    atomicMax((int *)stat_slot((unsigned long long *)maxS), overflow ? 0x7fffffff : s);   // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+    // 0x7fffffff: a fragment exceeded kFragHashCap minimizers (host reports a limit error)
+    atomicMax((int *)stat_slot((unsigned long long *)maxS), overflow ? 0x7fffffff : s);
   }
   block_barrier();
   const unsigned long long base = *sBasePtr & ~kPoolOverflowBit;
@@ -531,10 +533,12 @@ __device__ __forceinline__ void fragment_finish(uint32_t *hbuf, int n, bool over
 }
 
 // one wave per fragment: its sketch from the striped pool to its place in the packed pool; fragOff is rewritten
-static __global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, uint32_t *__restrict__ fragOff, const int32_t *__restrict__ s, const uint32_t *__restrict__ newOff,
+static __global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, uint32_t *__restrict__ fragOff, const int32_t *__restrict__ s,
+    const uint32_t *__restrict__ newOff,
                                      uint32_t nFrag, uint32_t *__restrict__ out)
 {
-  const uint32_t f = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;      // (64-bit: 64 threads per fragment pass 2^32 at 2^26 fragments)
+  // (64-bit: 64 threads per fragment pass 2^32 at 2^26 fragments)
+  const uint32_t f = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if (f >= nFrag) return;
   const uint32_t src = fragOff[f], dst = newOff[f];
   const int n = s[f];
@@ -545,7 +549,8 @@ static __global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, u
 
 // the per-fragment tables of one packed fragment set (ani_fragset_pack) into their place in the tables of a merged set: sketch
 // offsets rebased to the merged pool, genome numbers to the merged genome list
-static __global__ void k_fragset_rebase(uint32_t n, const uint32_t *__restrict__ srcOff, const int32_t *__restrict__ srcS, const int32_t *__restrict__ srcGenome,
+static __global__ void k_fragset_rebase(uint32_t n, const uint32_t *__restrict__ srcOff, const int32_t *__restrict__ srcS,
+    const int32_t *__restrict__ srcGenome,
                                         const int32_t *__restrict__ srcQSeq, uint32_t addOff, int32_t addGenome,
                                         uint32_t *__restrict__ dstOff, int32_t *__restrict__ dstS, int32_t *__restrict__ dstGenome, int32_t *__restrict__ dstQSeq)
 {
@@ -555,7 +560,8 @@ static __global__ void k_fragset_rebase(uint32_t n, const uint32_t *__restrict__
 }
 
 template <bool PACKED>
-__device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, int64_t off, int32_t len, const TileDesc td, const FusedInfo fi, int k, int w, int fragLen,
+__device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, int64_t off, int32_t len, const TileDesc td, const FusedInfo fi, int k, int w,
+    int fragLen,
                                                 uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
                                                 TileMeta *__restrict__ meta,
                                                 uint32_t *__restrict__ qPool, uint32_t qCap, unsigned long long *__restrict__ qCount,
@@ -638,9 +644,11 @@ static __global__ __launch_bounds__(kTPB, 3) void k_sketch_fused(const uint32_t 
   const int64_t off = contigOff[td.contig];
   const int32_t len = contigLen[td.contig];
   if (contigMode[td.contig])
-    fused_tile_body<true>(packed, off, len, td, fi, k, w, fragLen, poolHash, poolWpos, poolCap, poolCount, meta, qPool, qCap, qCount, fragOff, fragS, maxS, keys, ws, &sBase);
+    fused_tile_body<true>(packed, off, len, td, fi, k, w, fragLen, poolHash, poolWpos, poolCap, poolCount, meta, qPool, qCap, qCount, fragOff, fragS, maxS,
+        keys, ws, &sBase);
   else
-    fused_tile_body<false>(ascii, off, len, td, fi, k, w, fragLen, poolHash, poolWpos, poolCap, poolCount, meta, qPool, qCap, qCount, fragOff, fragS, maxS, keys, ws, &sBase);
+    fused_tile_body<false>(ascii, off, len, td, fi, k, w, fragLen, poolHash, poolWpos, poolCap, poolCount, meta, qPool, qCap, qCount, fragOff, fragS, maxS,
+        keys, ws, &sBase);
 }
 
 }  // namespace ani

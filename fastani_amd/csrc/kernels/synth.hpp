@@ -39,7 +39,8 @@ __host__ __device__ __forceinline__ uint32_t synth_base(uint64_t keyAnc, uint64_
 // members are identical copies
 __host__ __device__ __forceinline__ int synth_rate_index(int m) { return m < 20 ? m : 1 + (m - 20) % 19; }
 
-static __global__ void k_synth_packed(uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, int32_t clusterSize, uint32_t *__restrict__ out)
+static __global__ void k_synth_packed(uint64_t seed, uint64_t variant, int32_t firstGenomeId, int32_t nGenomes, int32_t genomeLen, int32_t clusterSize,
+    uint32_t *__restrict__ out)
 {
   const int32_t wordsPerGenome = (genomeLen + 15) >> 4;
   const long long total = (long long)nGenomes * wordsPerGenome;

@@ -29,7 +29,8 @@ struct Workspace {
   size_t statusBytes;
 };
 // `tiles`: look-back tiles of one pass (partial tiles at buffer ends included); `pongBytes`: ping-pong storage
-size_t workspace_bytes(uint64_t tiles, size_t pongBytes) { return align256(kHistBytes) + align256(kCtrBytes) + align256(tiles * kRadixDigits * 8) + align256(pongBytes) + 256; }
+size_t workspace_bytes(uint64_t tiles,
+    size_t pongBytes) { return align256(kHistBytes) + align256(kCtrBytes) + align256(tiles * kRadixDigits * 8) + align256(pongBytes) + 256; }
 Workspace carve(void *tmp, uint64_t tiles)
 {
   Workspace w;
@@ -47,9 +48,9 @@ int finish(const Workspace &w, hipStream_t stream)
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  // test knob: ANI_SORT_FAIL_EVERY=<k> makes every k-th completed sort of the process report a given-up look-back (k = 2: every
+  // test knob: ANI_TEST_SORT_FAIL_EVERY=<k> makes every k-th completed sort of the process report a given-up look-back (k = 2: every
   // sort fails once and succeeds when it is repeated)
-  if (const char *ev = getenv("ANI_SORT_FAIL_EVERY")) {
+  if (const char *ev = getenv("ANI_TEST_SORT_FAIL_EVERY")) {
     static std::atomic<unsigned> done{0};
     const int k = atoi(ev);
     if (k > 0 && (done.fetch_add(1) + 1) % (unsigned)k == 0) return 9001;
@@ -65,7 +66,8 @@ constexpr int kSortAttempts = 2;
 // `async`: the call returns with the passes in flight (no retry); the caller completes it with ani_sort_check on the same stream
 // and must leave `tmp` alone until then.
 template <class KeyT, class ValT>
-int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *valsOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream, bool async = false)
+int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *valsOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes,
+    hipStream_t stream, bool async = false)
 {
   constexpr bool kHasVal = !std::is_same<ValT, RadixNoVal>::value;
   if (endBit > (int)sizeof(KeyT) * 8) endBit = (int)sizeof(KeyT) * 8;
@@ -88,7 +90,8 @@ int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *val
     if (e != hipSuccess) return (int)e;
     const unsigned hg = (unsigned)std::min<uint64_t>((n + kTPB * 8 - 1) / (kTPB * 8), 4096);
     ArraySrc<KeyT, ValT> in{keysIn, valsIn};
-    hipLaunchKernelGGL((k_radix_histogram<KeyT, ArraySrc<KeyT, ValT>>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, in, (uint64_t)n, beginBit, endBit, P, w.hist, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL((k_radix_histogram<KeyT, ArraySrc<KeyT, ValT>>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, in, (uint64_t)n, beginBit, endBit, P,
+        w.hist, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kTPB), 0, stream, w.hist, P);
     for (int p = 0; p < P; p++) {
       const bool toOut = ((P - 1 - p) & 1) == 0;
@@ -96,7 +99,8 @@ int sort_arrays(const KeyT *keysIn, KeyT *keysOut, const ValT *valsIn, ValT *val
       KeyT *dk = toOut ? keysOut : pongK; ValT *dv = toOut ? valsOut : pongV;
       e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
       if (e != hipSuccess) return (int)e;
-      hipLaunchKernelGGL((k_radix_pass<KeyT, ValT, ArraySrc<KeyT, ValT>>), dim3((unsigned)tiles), dim3(kRadixTPB), 0, stream, src, dk, dv, (uint64_t)n, beginBit + p * kRadixBits, endBit,
+      hipLaunchKernelGGL((k_radix_pass<KeyT, ValT, ArraySrc<KeyT, ValT>>), dim3((unsigned)tiles), dim3(kRadixTPB), 0, stream, src, dk, dv, (uint64_t)n,
+          beginBit + p * kRadixBits, endBit,
                          (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + p, 0u, w.err);
     }
     if (async) return 0;
@@ -119,15 +123,18 @@ extern "C" int ani_sort_pairs_u64_u32(const uint64_t *keysIn, uint64_t *keysOut,
 // chunk needs)
 extern "C" int ani_sort_keys_u64_bits(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream)
 {
-  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, 0, endBit, tmp, tmpBytes, stream);
+  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, 0, endBit, tmp, tmpBytes,
+      stream);
 }
 
 // 64-bit keys ordered by their bits [beginBit, endBit) only; `async` != 0: the passes stay in flight, ani_sort_check(tmp, stream)
 // completes the call.  (The same-hash half-records of the index: entry << 32 | kind << 31 | other are unique in (entry, kind), so the
 // 31 low bits need no pass — four passes instead of eight, on the side stream.)
-extern "C" int ani_sort_keys_u64_range(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes, hipStream_t stream, int async)
+extern "C" int ani_sort_keys_u64_range(const uint64_t *keysIn, uint64_t *keysOut, size_t n, int beginBit, int endBit, void *tmp, size_t *tmpBytes,
+    hipStream_t stream, int async)
 {
-  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, beginBit, endBit, tmp, tmpBytes, stream, async != 0);
+  return sort_arrays<uint64_t, ani::RadixNoVal>(keysIn, keysOut, (const ani::RadixNoVal *)nullptr, (ani::RadixNoVal *)nullptr, n, beginBit, endBit, tmp,
+      tmpBytes, stream, async != 0);
 }
 
 // The index sort (Sketch::index, winSketch.hpp:181-193).  Input: the chunk's minimizer records as `nPieces` device buffers of
@@ -151,7 +158,8 @@ extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN,
   Workspace w = carve(tmp, tiles);
   const bool async = soaReady && sideStream;
   int rc = 0;
-  for (int attempt = 0; attempt < (async ? 1 : kSortAttempts); attempt++) {       // (a caller with a side stream repeats the call without one when ani_sort_check reports 9001)
+  // (a caller with a side stream repeats the call without one when ani_sort_check reports 9001)
+  for (int attempt = 0; attempt < (async ? 1 : kSortAttempts); attempt++) {
   hipError_t e = hipMemsetAsync(w.hist, 0, align256(kHistBytes) + align256(kCtrBytes), stream);
   if (e != hipSuccess) return (int)e;
   size_t o = 0;
@@ -159,7 +167,8 @@ extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN,
     if (!pieceN[i]) continue;
     const unsigned hg = (unsigned)std::min<uint64_t>((pieceN[i] + kTPB * 8 - 1) / (kTPB * 8), 4096);
     RecordSrc src{(const uint32_t *)pieceRec[i], seqBase};
-    hipLaunchKernelGGL((k_radix_histogram<uint32_t, RecordSrc>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, src, (uint64_t)pieceN[i], 0, 32, P, w.hist, mHash + o, mSeq + o, mWpos + o);
+    hipLaunchKernelGGL((k_radix_histogram<uint32_t, RecordSrc>), dim3(hg ? hg : 1), dim3(kTPB), 0, stream, src, (uint64_t)pieceN[i], 0, 32, P, w.hist,
+        mHash + o, mSeq + o, mWpos + o);
     o += pieceN[i];
   }
   // the SoA arrays are complete: work that only needs positions may start on the caller's side stream, underneath the passes
@@ -185,7 +194,8 @@ extern "C" int ani_sort_index(const void *const *pieceRec, const size_t *pieceN,
     ArraySrc<uint32_t, uint64_t> src = toOut ? ArraySrc<uint32_t, uint64_t>{tmpK, tmpV} : ArraySrc<uint32_t, uint64_t>{sHash, sSW};
     e = hipMemsetAsync(w.status, 0, w.statusBytes, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_radix_pass<uint32_t, uint64_t, ArraySrc<uint32_t, uint64_t>>), dim3((unsigned)tiles_of(n)), dim3(kRadixTPB), 0, stream, src, toOut ? sHash : tmpK, toOut ? sSW : tmpV,
+    hipLaunchKernelGGL((k_radix_pass<uint32_t, uint64_t, ArraySrc<uint32_t, uint64_t>>), dim3((unsigned)tiles_of(n)), dim3(kRadixTPB), 0, stream, src,
+        toOut ? sHash : tmpK, toOut ? sSW : tmpV,
                        (uint64_t)n, p * kRadixBits, 32, (const unsigned long long *)(w.hist + p * kRadixDigits), w.status, w.counters + launch, 0u, w.err);
     launch++;
   }

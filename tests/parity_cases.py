@@ -637,9 +637,9 @@ def case_limits(engine):
 
 
 def case_cand_pool_retry(engine_plain, engine_limited):
-    """the L1 candidate pool starts too small (ANI_CAND_POOL_MIN=1: one candidate per stripe) and the L1 kernels are repeated with the
+    """the L1 candidate pool starts too small (ANI_TEST_CAND_POOL_MIN=1: one candidate per stripe) and the L1 kernels are repeated with the
     size the first attempt asked for — same rows as the oracle; and when the batch ALSO holds a fragment beyond the seed-hit limit
-    (ANI_L1_HIT_LIMIT lowered: k_l1_probe marks it, and k_l1_probe runs on the first attempt only) the call must still fail with
+    (ANI_TEST_L1_HIT_LIMIT lowered: k_l1_probe marks it, and k_l1_probe runs on the first attempt only) the call must still fail with
     ANI_ERR_LIMIT after the retry instead of silently dropping the fragment's mappings (the retry used to erase the marker)"""
     from fastani_amd.api import AniError
     base = rng_genome(191, 9000)

@@ -34,7 +34,7 @@ def test_small_batches_and_chunks(monkeypatch):
     import os
     from fastani_amd.api import Engine
     monkeypatch.setenv("ANI_SUBBATCH_FRAGS", "7")
-    monkeypatch.setenv("ANI_L2_CHUNK", "13")
+    monkeypatch.setenv("ANI_TEST_L2_CHUNK", "13")
     e = Engine(ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libfastani_emu.so")), 0)
     pc.case_synthetic_cluster(e, 30000)
     pc.case_messy(e)
@@ -60,7 +60,7 @@ def test_chunked_reference_set(monkeypatch):
 
 def test_chunked_with_small_batches(monkeypatch):
     """index chunks x query sub-batches x L2 chunks, all tiny"""
-    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_L2_CHUNK=11)
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_TEST_L2_CHUNK=11)
     pc.case_synthetic_cluster(e, 30000)
     pc.case_sparse_hits(e)
     pc.case_self(e, combos=((16, 3000), (16, 3050)))
@@ -72,7 +72,7 @@ def test_streamed_reference_set(monkeypatch, tmp_path):
     e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=1)
     pc.case_streamed(e, tmp_path, n=18000)
     e.close()
-    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=2, ANI_SUBBATCH_FRAGS=11, ANI_L2_CHUNK=17)
+    e = _emu_engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=4000, ANI_MAX_RESIDENT_CHUNKS=2, ANI_SUBBATCH_FRAGS=11, ANI_TEST_L2_CHUNK=17)
     pc.case_streamed(e, n=12000, light=True)
     e.close()
 
@@ -96,12 +96,12 @@ def test_sketch_file_chunked(monkeypatch, tmp_path):
 
 def test_big_l1_groups(monkeypatch):
     """the batched global-memory L1 path cut into many small groups (few fragments, few hits per group)"""
-    e = _emu_engine_with(monkeypatch, ANI_L1_BIG_GROUP_HITS=30000, ANI_L1_BIG_GROUP_FRAGS=3)
+    e = _emu_engine_with(monkeypatch, ANI_TEST_L1_BIG_GROUP_HITS=30000, ANI_TEST_L1_BIG_GROUP_FRAGS=3)
     pc.case_species_dense(e, copies=52, n=9000)
     pc.case_low_complexity_big(e)
     e.close()
-    # ANI_L1_LDS_MAX=0: EVERY fragment takes the batched path (the LDS classes are an optimisation of it, not a different algorithm)
-    e = _emu_engine_with(monkeypatch, ANI_L1_LDS_MAX=0, ANI_L1_BIG_GROUP_HITS=200000)
+    # ANI_TEST_L1_LDS_MAX=0: EVERY fragment takes the batched path (the LDS classes are an optimisation of it, not a different algorithm)
+    e = _emu_engine_with(monkeypatch, ANI_TEST_L1_LDS_MAX=0, ANI_TEST_L1_BIG_GROUP_HITS=200000)
     e.reset_counters()
     pc.case_synthetic_cluster(e, 24000)
     pc.case_tandem_repeats(e)
@@ -116,7 +116,7 @@ def test_limits(emu_engine):
 def test_l2_code_overflow_halves_the_chunk(monkeypatch):
     """a chunk whose 16-bit code stream would pass the offset limit is cut in half and redone (engine_map.hip, L2 chunk loop);
     the limit is lowered through a test knob so that small inputs reach the branch"""
-    e = _emu_engine_with(monkeypatch, ANI_L2_CODE_LIMIT=6000, ANI_L2_CHUNK=64)
+    e = _emu_engine_with(monkeypatch, ANI_TEST_L2_CODE_LIMIT=6000, ANI_TEST_L2_CHUNK=64)
     e.reset_counters()
     pc.case_synthetic_cluster(e, 30000)
     assert e.counters()["l2ChunkHalvings"] > 0
@@ -125,16 +125,16 @@ def test_l2_code_overflow_halves_the_chunk(monkeypatch):
 
 def test_candidate_pool_retry_keeps_the_overflow_marker(monkeypatch):
     """a batch that both overflows the L1 candidate pool and holds a fragment beyond the seed-hit limit"""
-    e1 = _emu_engine_with(monkeypatch, ANI_CAND_POOL_MIN=1)
-    e2 = _emu_engine_with(monkeypatch, ANI_CAND_POOL_MIN=1, ANI_L1_HIT_LIMIT=600)
+    e1 = _emu_engine_with(monkeypatch, ANI_TEST_CAND_POOL_MIN=1)
+    e2 = _emu_engine_with(monkeypatch, ANI_TEST_CAND_POOL_MIN=1, ANI_TEST_L1_HIT_LIMIT=600)
     pc.case_cand_pool_retry(e1, e2)
     e1.close(); e2.close()
 
 
 def test_l1_tiny_path_off(monkeypatch):
     """fragments with <= 64 seed hits are finished by one wave (l1.hpp: l1_tiny) — nearly every fragment of the small cases; with
-    ANI_L1_TINY=0 they take the workgroup path like the others: same candidates, same rows"""
-    e = _emu_engine_with(monkeypatch, ANI_L1_TINY=0)
+    ANI_TEST_L1_TINY=0 they take the workgroup path like the others: same candidates, same rows"""
+    e = _emu_engine_with(monkeypatch, ANI_TEST_L1_TINY=0)
     pc.case_synthetic_cluster(e, 30000)
     pc.case_sparse_hits(e)
     pc.case_tandem_repeats(e)
@@ -143,10 +143,10 @@ def test_l1_tiny_path_off(monkeypatch):
 
 
 def test_l1_lds_cap_below_the_wave_class(monkeypatch):
-    """with ANI_L1_LDS_MAX between 1 and 255 a fragment with ldsHitCap < H <= 256 seed hits belongs to the batched path
+    """with ANI_TEST_L1_LDS_MAX between 1 and 255 a fragment with ldsHitCap < H <= 256 seed hits belongs to the batched path
     alone — k_l1_tiny must use k_l1_probe's class predicate, or the fragment's candidates enter the pool twice"""
     cands = []
-    for env in ({}, dict(ANI_L1_LDS_MAX=100, ANI_L1_BIG_GROUP_HITS=200000)):
+    for env in ({}, dict(ANI_TEST_L1_LDS_MAX=100, ANI_TEST_L1_BIG_GROUP_HITS=200000)):
         e = _emu_engine_with(monkeypatch, **env)
         e.reset_counters()
         pc.case_synthetic_cluster(e, 30000)
@@ -166,13 +166,13 @@ def test_l1_lds_cap_below_the_wave_class(monkeypatch):
 
 def test_sort_is_repeated_once_when_a_look_back_gives_up(monkeypatch):
     """a look-back that gives up (spin bound; a scheduling surprise, not a property of the data) repeats the sort once
-    before the call fails — with ANI_SORT_FAIL_EVERY=2 every sort of the process reports that once and passes when repeated (the
+    before the call fails — with ANI_TEST_SORT_FAIL_EVERY=2 every sort of the process reports that once and passes when repeated (the
     index build's side-stream form, the fragment order, the batched L1 path's hit sort, the same-hash links)"""
-    e = _emu_engine_with(monkeypatch, ANI_SORT_FAIL_EVERY=2, ANI_L1_LDS_MAX=0)
+    e = _emu_engine_with(monkeypatch, ANI_TEST_SORT_FAIL_EVERY=2, ANI_TEST_L1_LDS_MAX=0)
     pc.case_synthetic_cluster(e, 24000)
     pc.case_tandem_repeats(e)
     e.close()
-    e = _emu_engine_with(monkeypatch, ANI_SORT_FAIL_EVERY=1)          # never passes: the error surfaces
+    e = _emu_engine_with(monkeypatch, ANI_TEST_SORT_FAIL_EVERY=1)          # never passes: the error surfaces
     from fastani_amd.api import AniError
     with pytest.raises(AniError):
         pc.case_synthetic_cluster(e, 24000)
@@ -183,18 +183,18 @@ def test_sort_is_repeated_once_when_a_look_back_gives_up(monkeypatch):
 
 def test_result_rows_collected_on_host_threads(monkeypatch):
     """the dense result table of a sub-batch is turned into rows by the host pool (engine_map.hip: collect_rows: rows per query,
-    then every query's rows at their place); ANI_HOST_PAR_MIN_WORK=0 sends small tables through the pool too — same rows, same order,
+    then every query's rows at their place); ANI_TEST_HOST_PAR_MIN_WORK=0 sends small tables through the pool too — same rows, same order,
     also with more threads than queries and with several kept sets per call"""
     def alloc(nbytes):
         a = np.zeros(nbytes // 4 + 4, dtype=np.uint32)
         return a, a.ctypes.data
     for threads in (3, 64):
-        e = _emu_engine_with(monkeypatch, ANI_HOST_PAR_MIN_WORK=0, ANI_HOST_THREADS=threads)
+        e = _emu_engine_with(monkeypatch, ANI_TEST_HOST_PAR_MIN_WORK=0, ANI_HOST_THREADS=threads)
         pc.case_self(e, combos=((16, 3000),))
         pc.case_fragset_wire(e, alloc)
         pc.case_species_dense(e)
         e.close()
-    monkeypatch.delenv("ANI_HOST_PAR_MIN_WORK"); monkeypatch.delenv("ANI_HOST_THREADS")
+    monkeypatch.delenv("ANI_TEST_HOST_PAR_MIN_WORK"); monkeypatch.delenv("ANI_HOST_THREADS")
 
 
 def test_pool_prewarm_is_only_a_hint(emu_engine):
@@ -215,7 +215,7 @@ def test_pool_prewarm_is_only_a_hint(emu_engine):
 def test_same_hash_links_rerun(monkeypatch):
     """the list of same-hash links (index.hpp: DupLinks) is sized from a guess; a repetitive reference (tandem repeats, one k-mer on
     thousands of contigs) holds more near-duplicate pairs than that and the links kernel runs again with room for all"""
-    e = _emu_engine_with(monkeypatch, ANI_DUP_PAIR_CAP=3)
+    e = _emu_engine_with(monkeypatch, ANI_TEST_DUP_PAIR_CAP=3)
     pc.case_tandem_repeats(e)
     pc.case_low_complexity(e)
     pc.case_gap_counter_overflow(e)

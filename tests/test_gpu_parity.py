@@ -24,7 +24,7 @@ def test_device_synth(gpu_engine):
 @pytest.mark.parametrize("path", ["general", "classB"])
 def test_l2_alternative_paths(gpu_engine, path, monkeypatch):
     """the general on-the-fly L2 kernel and the wide LDS class must agree with the default class-A path (and the oracle)"""
-    monkeypatch.setenv("ANI_L2_PATH", path)
+    monkeypatch.setenv("ANI_TEST_L2_PATH", path)
     gpu_engine.reset_counters()
     pc.case_synthetic_cluster(gpu_engine, 60000)
     pc.case_tandem_repeats(gpu_engine)
@@ -113,7 +113,7 @@ def test_small_batches_and_chunks(monkeypatch):
     sets, the side stream) must give the same mappings and rows as one big batch"""
     import fastani_amd
     monkeypatch.setenv("ANI_SUBBATCH_FRAGS", "7")
-    monkeypatch.setenv("ANI_L2_CHUNK", "13")
+    monkeypatch.setenv("ANI_TEST_L2_CHUNK", "13")
     e = fastani_amd.api.Engine(fastani_amd._lib.load(), 0)
     pc.case_synthetic_cluster(e, 60000)
     pc.case_messy(e)
@@ -177,7 +177,7 @@ def test_chunked_reference_set(monkeypatch):
 
 
 def test_chunked_with_small_batches(monkeypatch):
-    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_L2_CHUNK=11)
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=5000, ANI_SUBBATCH_FRAGS=9, ANI_TEST_L2_CHUNK=11)
     pc.case_synthetic_cluster(e, 60000)
     pc.case_sparse_hits(e)
     pc.case_self(e)
@@ -233,7 +233,7 @@ def test_repeated_runs_are_identical(monkeypatch):
     wait at the back edge of the sort's pass loop (a mis-sorted fragment in about 10^6, 2-5 % of such runs differed)."""
     import torch
     from fastani_amd.api import DeviceGenomes, Sketch
-    e = _engine_with(monkeypatch, ANI_L1_FILTER_MIN=0)
+    e = _engine_with(monkeypatch, ANI_TEST_L1_FILTER_MIN=0)
     n, L = 24, 5_000_000
     words = (L + 15) // 16
     buf = torch.zeros(n * words + 64, dtype=torch.int32, device="cuda:0")
@@ -260,7 +260,7 @@ def test_streamed_reference_set(monkeypatch, tmp_path):
     pc.case_streamed(e, tmp_path)
     assert pc.fuzz(e, seed=31, iterations=20) == 20
     e.close()
-    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=7000, ANI_MAX_RESIDENT_CHUNKS=2, ANI_SUBBATCH_FRAGS=11, ANI_L2_CHUNK=17)
+    e = _engine_with(monkeypatch, ANI_MAX_INDEX_MINIMIZERS=7000, ANI_MAX_RESIDENT_CHUNKS=2, ANI_SUBBATCH_FRAGS=11, ANI_TEST_L2_CHUNK=17)
     pc.case_streamed(e)
     e.close()
 
@@ -313,12 +313,12 @@ def test_sketch_file_chunked(monkeypatch, tmp_path):
 
 def test_big_l1_groups(monkeypatch):
     """the batched global-memory L1 path cut into many small groups (few fragments, few hits per group)"""
-    e = _engine_with(monkeypatch, ANI_L1_BIG_GROUP_HITS=30000, ANI_L1_BIG_GROUP_FRAGS=3)
+    e = _engine_with(monkeypatch, ANI_TEST_L1_BIG_GROUP_HITS=30000, ANI_TEST_L1_BIG_GROUP_FRAGS=3)
     pc.case_species_dense(e, copies=52, n=9000)
     pc.case_low_complexity_big(e)
     e.close()
-    # ANI_L1_LDS_MAX=0: EVERY fragment takes the batched path (the LDS classes are an optimisation of it, not a different algorithm)
-    e = _engine_with(monkeypatch, ANI_L1_LDS_MAX=0, ANI_L1_BIG_GROUP_HITS=200000)
+    # ANI_TEST_L1_LDS_MAX=0: EVERY fragment takes the batched path (the LDS classes are an optimisation of it, not a different algorithm)
+    e = _engine_with(monkeypatch, ANI_TEST_L1_LDS_MAX=0, ANI_TEST_L1_BIG_GROUP_HITS=200000)
     e.reset_counters()
     pc.case_synthetic_cluster(e)
     pc.case_messy(e)
@@ -335,7 +335,7 @@ def test_limits(gpu_engine):
 
 
 def test_l2_code_overflow_halves_the_chunk(monkeypatch):
-    e = _engine_with(monkeypatch, ANI_L2_CODE_LIMIT=6000, ANI_L2_CHUNK=64)
+    e = _engine_with(monkeypatch, ANI_TEST_L2_CODE_LIMIT=6000, ANI_TEST_L2_CHUNK=64)
     e.reset_counters()
     pc.case_synthetic_cluster(e, 60000)
     assert e.counters()["l2ChunkHalvings"] > 0
@@ -345,8 +345,8 @@ def test_l2_code_overflow_halves_the_chunk(monkeypatch):
 @pytest.mark.gpu
 def test_candidate_pool_retry_keeps_the_overflow_marker(monkeypatch):
     """a batch that both overflows the L1 candidate pool and holds a fragment beyond the seed-hit limit"""
-    e1 = _engine_with(monkeypatch, ANI_CAND_POOL_MIN=1)
-    e2 = _engine_with(monkeypatch, ANI_CAND_POOL_MIN=1, ANI_L1_HIT_LIMIT=600)
+    e1 = _engine_with(monkeypatch, ANI_TEST_CAND_POOL_MIN=1)
+    e2 = _engine_with(monkeypatch, ANI_TEST_CAND_POOL_MIN=1, ANI_TEST_L1_HIT_LIMIT=600)
     pc.case_cand_pool_retry(e1, e2)
     e1.close(); e2.close()
 
@@ -354,8 +354,8 @@ def test_candidate_pool_retry_keeps_the_overflow_marker(monkeypatch):
 @pytest.mark.gpu
 def test_l1_tiny_path_off(monkeypatch):
     """fragments with <= 64 seed hits are finished by one wave (l1.hpp: l1_tiny) — nearly every fragment of the small cases; with
-    ANI_L1_TINY=0 they take the workgroup path like the others: same candidates, same rows"""
-    e = _engine_with(monkeypatch, ANI_L1_TINY=0)
+    ANI_TEST_L1_TINY=0 they take the workgroup path like the others: same candidates, same rows"""
+    e = _engine_with(monkeypatch, ANI_TEST_L1_TINY=0)
     pc.case_synthetic_cluster(e, 30000)
     pc.case_sparse_hits(e)
     pc.case_tandem_repeats(e)
@@ -365,10 +365,10 @@ def test_l1_tiny_path_off(monkeypatch):
 
 @pytest.mark.gpu
 def test_l1_lds_cap_below_the_wave_class(monkeypatch):
-    """with ANI_L1_LDS_MAX between 1 and 255 a fragment with ldsHitCap < H <= 256 seed hits belongs to the batched path
+    """with ANI_TEST_L1_LDS_MAX between 1 and 255 a fragment with ldsHitCap < H <= 256 seed hits belongs to the batched path
     alone — k_l1_tiny must use k_l1_probe's class predicate, or the fragment's candidates enter the pool twice"""
     cands = []
-    for env in ({}, dict(ANI_L1_LDS_MAX=100, ANI_L1_BIG_GROUP_HITS=200000)):
+    for env in ({}, dict(ANI_TEST_L1_LDS_MAX=100, ANI_TEST_L1_BIG_GROUP_HITS=200000)):
         e = _engine_with(monkeypatch, **env)
         e.reset_counters()
         pc.case_synthetic_cluster(e, 30000)
@@ -390,19 +390,19 @@ def test_l1_lds_cap_below_the_wave_class(monkeypatch):
 @pytest.mark.gpu
 def test_result_rows_collected_on_host_threads(monkeypatch):
     """the dense result table of a sub-batch is turned into rows by the host pool (engine_map.hip: collect_rows: rows per query,
-    then every query's rows at their place); ANI_HOST_PAR_MIN_WORK=0 sends small tables through the pool too — same rows, same order,
+    then every query's rows at their place); ANI_TEST_HOST_PAR_MIN_WORK=0 sends small tables through the pool too — same rows, same order,
     also with more threads than queries and with several kept sets per call"""
     import torch
     def alloc(nbytes):
         t = torch.zeros(nbytes // 4 + 4, dtype=torch.int32, device="cuda:0")
         return t, t.data_ptr()
     for threads in (3, 64):
-        e = _engine_with(monkeypatch, ANI_HOST_PAR_MIN_WORK=0, ANI_HOST_THREADS=threads)
+        e = _engine_with(monkeypatch, ANI_TEST_HOST_PAR_MIN_WORK=0, ANI_HOST_THREADS=threads)
         pc.case_self(e, combos=((16, 3000),))
         pc.case_fragset_wire(e, alloc)
         pc.case_species_dense(e)
         e.close()
-    monkeypatch.delenv("ANI_HOST_PAR_MIN_WORK"); monkeypatch.delenv("ANI_HOST_THREADS")
+    monkeypatch.delenv("ANI_TEST_HOST_PAR_MIN_WORK"); monkeypatch.delenv("ANI_HOST_THREADS")
 
 
 
@@ -410,7 +410,7 @@ def test_result_rows_collected_on_host_threads(monkeypatch):
 def test_same_hash_links_rerun(monkeypatch):
     """the list of same-hash links (index.hpp: DupLinks) is sized from a guess; a repetitive reference (tandem repeats, one k-mer on
     thousands of contigs) holds more near-duplicate pairs than that and the links kernel runs again with room for all"""
-    e = _engine_with(monkeypatch, ANI_DUP_PAIR_CAP=3)
+    e = _engine_with(monkeypatch, ANI_TEST_DUP_PAIR_CAP=3)
     pc.case_tandem_repeats(e)
     pc.case_low_complexity(e)
     pc.case_gap_counter_overflow(e)
@@ -419,10 +419,10 @@ def test_same_hash_links_rerun(monkeypatch):
 
 @pytest.mark.gpu
 def test_l2_without_the_side_stream(monkeypatch):
-    """since round 4 the L2 simulation of a chunk runs on the side stream beside the next chunk's ranges / codes kernels; ANI_L2_OVERLAP=0
+    """since round 4 the L2 simulation of a chunk runs on the side stream beside the next chunk's ranges / codes kernels; ANI_TEST_L2_OVERLAP=0
     is the serial order of rounds 1-3: same results (tiny L2 chunks: many hand-overs between the two streams)"""
     for ov in ("0", "1"):
-        e = _engine_with(monkeypatch, ANI_L2_OVERLAP=ov, ANI_L2_CHUNK=97)
+        e = _engine_with(monkeypatch, ANI_TEST_L2_OVERLAP=ov, ANI_TEST_L2_CHUNK=97)
         pc.case_synthetic_cluster(e, 60000)
         pc.case_tandem_repeats(e)
         e.close()

@@ -101,6 +101,12 @@ if has c5full; then
       --no-cpu-baseline --no-e2e --oracle-pairs 48 2> "$OUT/c5full.err" | tee "$OUT/c5full.json.log" | cut -c1-1800
   tail -3 "$OUT/c5full.err"; free -g | head -2
 fi
+if has sim; then
+  for w in 8 4 2; do
+    echo "== simulate-world $w, 1000 genomes"
+    timeout 900 python bench.py --simulate-world $w --steps 5 --warmup 2 --no-verify 2> "$OUT/sim${w}_1000.err" | tee "$OUT/sim${w}_1000.json.log" | line "sim$w/1000"
+  done
+fi
 if has prof; then
   echo "== rocprofv3 kernel stats (same command, no cpu legs)"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench --output-format csv -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/prof_bench.log" 2>&1)

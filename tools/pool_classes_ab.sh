@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r05k
 for v in 0 1; do
-  ANI_POOL_CLASSES=$v ANI_POOL_TRACE=1 timeout 600 python bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-verify 2> gpurun_out/r05k/c4_classes$v.err > gpurun_out/r05k/c4_classes$v.json.log
+  ANI_TEST_POOL_CLASSES=$v ANI_POOL_TRACE=1 timeout 600 python bench.py --config c4 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-verify 2> gpurun_out/r05k/c4_classes$v.err > gpurun_out/r05k/c4_classes$v.json.log
   python - gpurun_out/r05k/c4_classes$v.json.log <<'PY'
 import sys, json
 d=json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')][-1])
