@@ -156,7 +156,7 @@ int ani_init(int device, ani_ctx **out)
   if (const char *ev = getenv("ANI_TEST_L2_CODE_LIMIT")) { const long long v = atoll(ev); if (v >= 1) c->l2CodeLimit = (uint64_t)v; }
   if (const char *ev = getenv("ANI_MAX_INDEX_MINIMIZERS")) { const long long v = atoll(ev); if (v >= 1) c->maxIndexMinimizers = (uint64_t)v; }
   if (const char *ev = getenv("ANI_TEST_L1_FILTER_MIN")) c->l1FilterMin = atoi(ev);
-  if (const char *ev = getenv("ANI_TEST_L1_LDS_MAX")) c->l1LdsMax = std::max(0, std::min(atoi(ev), 4096 /* ani::kL1HitCapMax */));
+  if (const char *ev = getenv("ANI_TEST_L1_LDS_MAX")) c->l1LdsMax = std::max(0, std::min(atoi(ev), 4080 /* ani::kL1HitCapMax */));
   if (const char *ev = getenv("ANI_TEST_DUP_PAIR_CAP")) { const long long v = atoll(ev); if (v >= 1) c->dupPairCap = (uint64_t)v; }
   if (const char *ev = getenv("ANI_TEST_L1_TINY")) c->l1Tiny = strcmp(ev, "0") != 0;
   if (const char *ev = getenv("ANI_TEST_L2_OVERLAP")) c->l2Overlap = strcmp(ev, "0") != 0;

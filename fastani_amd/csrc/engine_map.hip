@@ -15,7 +15,7 @@ using namespace ani;
 void launch_l2_codes(unsigned grid, hipStream_t s, const L2FastArgs &fa);
 void launch_l2_sim_a(unsigned grid, hipStream_t s, const L2FastArgs &fa, const int32_t *list, const unsigned int *listCount);
 void launch_l2_sim_b(unsigned grid, hipStream_t s, const L2FastArgs &fa, const int32_t *list, const unsigned int *listCount);
-static_assert(kL1FilterMinHits == 300 && kL1HitCapMax == 4096, "defaults of ani_ctx::l1FilterMin / l1LdsMax (host/engine.hpp)");
+static_assert(kL1FilterMinHits == 300 && kL1HitCapMax == 4080, "defaults of ani_ctx::l1FilterMin / l1LdsMax (host/engine.hpp)");
 
 // L1 + L2 + identity for the fragments of `fs` against ONE index chunk; candidates and their results stay in the context's
 // buffers (ocFrag/ocSeq [chunk-local seqIds]/refStart/idBits/l2Best) for the reducer or the mapping export.

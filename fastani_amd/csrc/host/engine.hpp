@@ -364,7 +364,7 @@ struct ani_ctx {
   uint64_t maxIndexMinimizers = 1700000000ull;
   // (engine_map.hip checks them against kernels/l1.hpp)           // env ANI_TEST_L1_FILTER_MIN / ANI_TEST_L1_LDS_MAX, read by ani_init (tests: per engine, not
   // per process)
-  int l1FilterMin = 300 /* ani::kL1FilterMinHits */, l1LdsMax = 4096 /* ani::kL1HitCapMax */;
+  int l1FilterMin = 300 /* ani::kL1FilterMinHits */, l1LdsMax = 4080 /* ani::kL1HitCapMax */;
   // first guess of the same-hash link list (env ANI_TEST_DUP_PAIR_CAP, tests: forces the rerun)
   uint64_t dupPairCap = 0;
   // env ANI_TEST_L1_TINY=0: fragments with <= 64 seed hits take the workgroup path like the others

@@ -21,20 +21,23 @@ constexpr int kL1MaxS = 2048;           // sketch hashes per fragment the LDS cl
 // ... class S (its 4 KiB of scratch hold the per-hash hit offsets); a fragment with more goes to class M whatever its hit count
 constexpr int kL1SmallMaxS = 1024;
 constexpr int kFragHashCapL1 = 4096;    // = kFragHashCap (sketch.hpp): the most sketch hashes a fragment can have
-// class S: 16 KiB hits + 4 KiB scratch, <= 72 registers -> 7 workgroups per CU.  The kernel's time follows the number of
-constexpr int kL1HitCapSmall = 2048;
-                                        // resident workgroups (a workgroup's life is a chain of latencies — probe results, hit runs, LDS round trips of the
-                                        // sort — and
-                                        // what hides them is other workgroups): 5 per CU 35.8 ms, 6 per CU 30.0 ms per benchmark step
-                                        // (profiles/r06f_l1_occupancy_ab.txt)
-constexpr int kL1HitCapMid = 4096;      // class M: 32 KiB + 16 KiB -> 3 workgroups per CU
+// The LDS classes.  A class's hit array is a power of two long (block_sort pads to one); its last kL1LdsSpare entries are never hits —
+// the class accepts 16 hits fewer — and hold the workgroup's scan scratch and two scalars: with them inside the array a class-S workgroup
+// is 16 + 4 KiB and a class-M workgroup 32 + 8 KiB of LDS EXACTLY, i.e. 160 KiB / 40 KiB = four class-M workgroups per CU instead of
+// three.  (The sort overwrites the spare entries with its padding when it runs on the full array; none of them is live across it.)
+constexpr int kL1LdsSpare = 16;
+constexpr int kL1HitCapSmall = 2048 - kL1LdsSpare;
+// class S: 16 KiB hits + 4 KiB scratch, <= 72 registers -> 7 workgroups per CU.  The kernel's time follows the number of resident
+// workgroups (a workgroup's life is a chain of latencies — probe results, hit runs, LDS round trips of the sort — and what hides them
+// is other workgroups): 5 per CU 35.8 ms, 6 per CU 30.0 ms, 7 per CU 27.1 ms per benchmark step (profiles/r06f_l1_occupancy_ab.txt)
+constexpr int kL1HitCapMid = 4096 - kL1LdsSpare;      // class M: 32 KiB + 8 KiB -> 4 workgroups per CU
 constexpr int kL1HitCapMax = kL1HitCapMid;   // beyond: the batched global-memory path.  (A class L of 8192 hits — 96 KiB of LDS, one workgroup
                                              // per CU — existed until round 3: 0.43 us per fragment where the batched path takes 0.33, measured at
                                              // 493 k such fragments per step of the cluster-size-100 benchmark.)
 static_assert(kL1HitCapMax <= kBlockSortMax, "block_sort (common.hpp) sorts at most kBlockSortMax keys");
 constexpr int kL1FilterMinHits = 300;   // below this the sort is cheaper than the noise filter
-// log2 of the occupancy counters per tiling: four bit arrays in the class's scratch (S: 4 x 1 KiB, M: 4 x 4 KiB)
-template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == 2048 ? 13 : 15; }
+// log2 of the occupancy counters per tiling: four bit arrays in the class's scratch (S: 4 x 1 KiB, M: 4 x 2 KiB)
+template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == kL1HitCapSmall ? 13 : 14; }
 
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
@@ -407,18 +410,19 @@ template <int HLO, int HCAP>
 static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a, const int32_t *__restrict__ list)
 {
   // scratch V: the per-hash hit offsets during the gather (pOff), four bit arrays during the noise filter, the indices of the valid runs
-  // during emission.  Class S: 4 KiB (<= 1024 sketch hashes, 13-bit filter, 16-bit run indices); class M: 16 KiB.
-  using VT = typename std::conditional<HLO == 0, uint16_t, int>::type;
+  // (16 bit) during emission.  Class S: 4 KiB (<= 1024 sketch hashes, 13-bit filter); class M: 8 KiB (<= 2048 sketch hashes, 14-bit filter).
+  using VT = uint16_t;
+  constexpr int kArr = HCAP + kL1LdsSpare;             // 2048 / 4096
   constexpr int kMaxS = HLO == 0 ? kL1SmallMaxS : kL1MaxS;
   constexpr int NBW = (1 << kL1FilterBits<HCAP>()) / 32;          // words per bit array; V holds {seenA, twiceA, seenB, twiceB}
   constexpr int kVWords = 4 * NBW > kMaxS ? 4 * NBW : kMaxS;
-  static_assert(kVWords * 4 >= HCAP * (int)sizeof(VT) && kVWords >= kMaxS, "the scratch holds the run indices and the hit offsets");
-  __shared__ uint64_t hits[HCAP];
+  static_assert((kArr & (kArr - 1)) == 0 && kVWords * 4 >= kArr * (int)sizeof(VT) && kVWords >= kMaxS, "the scratch holds the run indices and the hit offsets");
+  __shared__ uint64_t hits[kArr];
   __shared__ __attribute__((aligned(16))) uint32_t Vraw[kVWords];
   VT *V = (VT *)Vraw;
-  __shared__ int ws[16];
-  __shared__ unsigned long long sBase;
-  __shared__ int sKeep;
+  int *ws = (int *)&hits[HCAP];                                   // 16 ints of scan scratch ...
+  unsigned long long &sBase = *(unsigned long long *)&hits[HCAP + 8];     // ... and two scalars in the spare entries of the hit array
+  int &sKeep = *(int *)&hits[HCAP + 9];
   int f;
   if (list) f = list[blockIdx.x];
   else {
@@ -478,7 +482,7 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
     for (int i = t; i < 4 * NBW; i += kTPB) bits[i] = 0u;
     if (t == 0) sKeep = 0;
     block_barrier();
-    constexpr int PER = HCAP / kTPB;
+    constexpr int PER = kArr / kTPB;
     uint64_t hv[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) {
@@ -506,6 +510,7 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
     }
     block_barrier();
     n = wave_uniform(sKeep);
+    block_barrier();                                 // sKeep lives in the hit array's spare entries, which the sort's padding overwrites: every thread has read it
   }
   block_sort<uint64_t>(hits, n);                    // :320 (starts with a barrier: the gather is complete)
 
