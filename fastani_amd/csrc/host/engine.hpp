@@ -407,6 +407,7 @@ struct ani_ctx {
   DevBuf sortTmp, unitStart, unitAux, tiles, tileInfo, tileMeta, tileCnt, tileDrop, tileOff, poolHash, poolWpos;
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
+  DevBuf l1FragDesc;                      // per fragment, in processing order: what the L1 gather kernels need of it (kernels/l1.hpp: L1FragDesc)
   DevBuf probeFirst, probeCnt, l1MidList, l1SmallList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;

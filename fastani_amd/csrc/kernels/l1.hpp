@@ -39,6 +39,17 @@ constexpr int kL1FilterMinHits = 300;   // below this the sort is cheaper than t
 // log2 of the occupancy counters per tiling: four bit arrays in the class's scratch (S: 4 x 1 KiB, M: 4 x 2 KiB)
 template <int HCAP> __host__ __device__ constexpr int kL1FilterBits() { return HCAP == kL1HitCapSmall ? 13 : 14; }
 
+// What the gather kernels need to know about a fragment, in ONE 16-byte load at the fragment's place in the processing order (written by
+// k_l1_probe): the workgroup kernels are bound by the latencies of their short lives (kL1HitCapSmall above), and order -> fragment ->
+// (sketch size, hits) -> (pool offset, minimumHits) were three dependent round trips to memory in front of the first probe result.
+struct __attribute__((aligned(16))) L1FragDesc { int32_t f; uint32_t sm; int32_t H; uint32_t off; };      // sm = sketch size | minimumHits << 16
+__device__ __forceinline__ L1FragDesc l1_frag_desc(const L1FragDesc *p)
+{
+  const uint4 v = *(const uint4 *)p;
+  L1FragDesc d; d.f = (int32_t)v.x; d.sm = v.y; d.H = (int32_t)v.z; d.off = v.w;
+  return d;
+}
+
 struct L1Args {
   const uint32_t *qPool; const uint32_t *fragOff; const int32_t *fragS; int32_t nFrag;
   const TableSlot *table; uint32_t tableSlots; const uint64_t *sSW; int bucketW; uint32_t nIndex;
@@ -55,6 +66,7 @@ struct L1Args {
   unsigned long long *sumHits, *tinyCount, *smallCount;
   int filterShift;                      // log2 of the tile width of the noise filter: smallest power of two >= 2 * L
   const int32_t *fragOrder;             // processing order of the fragments (nullptr: ascending), see map_stage
+  L1FragDesc *fragDesc;                 // [nFrag] by position in the processing order (k_l1_probe writes, the gather kernels read)
   int filterMinHits;                    // kL1FilterMinHits (ANI_TEST_L1_FILTER_MIN: test knob; 0 = always filter, large = never)
   int ldsHitCap;                        // fragments with more seed hits take the batched global-memory path (<= kL1HitCapMax; ANI_TEST_L1_LDS_MAX)
   int tinyPath;                         // fragments with <= 64 seed hits are finished by one wave (l1_tiny; ANI_TEST_L1_TINY=0 switches it off: A/B and tests)
@@ -247,15 +259,17 @@ static __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
       // of the visits of a fragment set to a foreign reference shard or index chunk, which collect two or three chance hits — counts
       // as one without hits from here on.  (Any fragment with s <= kL1MaxS, whatever path its hit count would have sent it to: below
       // minimumHits hits there is no candidate on any path.  sumHits / seedHits still counts the dropped hits: they were probed.)
-      if (H > 0 && s[q] <= kL1MaxS) { int m = s[q] <= a.lutMaxS ? a.minHitsLUT[s[q]] : 1; if (H < (m < 1 ? 1 : m)) H = 0; }
+      int m = (s[q] > 0 && s[q] <= a.lutMaxS) ? a.minHitsLUT[s[q]] : 1;
+      if (H > 0 && s[q] <= kL1MaxS && H < (m < 1 ? 1 : m)) H = 0;
       a.fragHits[f] = H;
+      { L1FragDesc d; d.f = f; d.sm = (uint32_t)s[q] | ((uint32_t)(m < 0 ? 0 : (m > 0xffff ? 0xffff : m)) << 16); d.H = H; d.off = off[q]; a.fragDesc[i0 + q] = d; }
       if (H64) atomicAdd(stat_slot(a.sumHits), H64);
       if (tooMany) atomicAdd(a.overflowCount, 1u);
       else if (s[q] > 0) {
         // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
         if (s[q] <= kL1MaxS && H <= a.ldsHitCap) {
           // (a long sketch with a handful of hits: the wave kernel)
-          if (H > kL1HitCapSmall || (s[q] > kL1SmallMaxS && !(H <= 4 * kWave && a.tinyPath))) a.midList[atomicAdd(a.midCount, 1u)] = f;
+          if (H > kL1HitCapSmall || (s[q] > kL1SmallMaxS && !(H <= 4 * kWave && a.tinyPath))) a.midList[atomicAdd(a.midCount, 1u)] = i0 + q;      // (positions in the processing order: fragDesc)
           // (striped statistics counters: the host launches k_l1_tiny if there are any,
           else if (H > 0 && H <= 4 * kWave && a.tinyPath) atomicAdd(stat_slot(a.tinyCount), 1ull);
           // and k_l1<0, 2048> over a list instead of over every fragment if there are few)
@@ -292,11 +306,9 @@ template <int KPT> __device__ __forceinline__ void l1_tiny_sort(uint64_t *hits, 
   for (int r = 0; r < KPT; r++) hits[lane * KPT + r] = k[r];
   ANI_WAVE_SYNC();
 }
-__device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, uint64_t *hits, int *V)
+__device__ __forceinline__ void l1_tiny(const L1Args &a, int f, int s, int H, uint32_t off, int m, uint64_t *hits, int *V)
 {
   const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t off = a.fragOff[f];
-  int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;
   if (m < 1) m = 1;                                  // :316
   int mine = 0;
   for (int i = lane; i < s; i += kWave) mine += (int)a.probeCnt[off + i];
@@ -361,12 +373,12 @@ static __global__ __launch_bounds__(kTPB) void k_l1_tiny(L1Args a)
   const int wv = wave_uniform((int32_t)(threadIdx.x >> 6));                  // the wave's fragment, its counts and offsets: scalar registers
   const int i = xcd_item(blockIdx.x, gridDim.x) * kL1TinyFrags + wv;
   if (i >= a.nFrag) return;
-  const int f = a.fragOrder ? a.fragOrder[i] : i;
-  const int s = a.fragS[f], H = a.fragHits[f];
+  const L1FragDesc d = l1_frag_desc(a.fragDesc + i);
+  const int f = wave_uniform(d.f), s = wave_uniform((int32_t)(d.sm & 0xffffu)), H = wave_uniform(d.H);
   // the workgroup classes / the batched path (same class predicate as k_l1_probe: H > ldsHitCap is bigList's) / nothing to do (k_l1<0, 2048> or k_l1_list
   // writes the zero counts)
   if (s <= 0 || s > kL1MaxS || H <= 0 || H > kL1HitCapTiny || H > a.ldsHitCap) return;
-  l1_tiny(a, f, s, H, hits[wv], V[wv]);
+  l1_tiny(a, f, s, H, wave_uniform(d.off), wave_uniform((int32_t)(d.sm >> 16)), hits[wv], V[wv]);
 }
 
 // The fragments of class S (256 < H <= 2048) as a list, for batches in which they are the exception: a fragment set that meets a
@@ -395,7 +407,7 @@ static __global__ __launch_bounds__(kTPB) void k_l1_list(L1Args a, int32_t *__re
     sBase = tot ? atomicAdd(cursor, tot) : 0u;
   }
   block_barrier();
-  if (small) list[sBase + wcount[wv] + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = f;
+  if (small) list[sBase + wcount[wv] + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = i;      // (position in the processing order: fragDesc)
 }
 
 // Pass 2: gather + sort + candidate regions for the fragments whose hit count is in (HLO, HCAP]; everything in LDS.
@@ -423,16 +435,15 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
   int *ws = (int *)&hits[HCAP];                                   // 16 ints of scan scratch ...
   unsigned long long &sBase = *(unsigned long long *)&hits[HCAP + 8];     // ... and two scalars in the spare entries of the hit array
   int &sKeep = *(int *)&hits[HCAP + 9];
-  int f;
-  if (list) f = list[blockIdx.x];
+  int pos;                                           // the fragment's position in the processing order
+  if (list) pos = list[blockIdx.x];
   else {
-    const int i = xcd_item(blockIdx.x, gridDim.x);
-    if (i >= a.nFrag) return;
-    f = a.fragOrder ? a.fragOrder[i] : i;
+    pos = xcd_item(blockIdx.x, gridDim.x);
+    if (pos >= a.nFrag) return;
   }
   const int t = threadIdx.x;
-  const int s = a.fragS[f];
-  const int H = a.fragHits[f];
+  const L1FragDesc d = l1_frag_desc(a.fragDesc + pos);                // fragment, sketch size | minimumHits, seed hits, pool offset: one load
+  const int f = d.f, s = (int)(d.sm & 0xffffu), H = d.H;
   if (HLO == 0 && (s <= 0 || H <= 0)) {              // (H < 0: overflow marker of k_l1_probe, the host fails the call)
     if (t == 0) { a.fragCandCnt[f] = 0; a.fragCandOff[f] = 0; }
     return;
@@ -442,8 +453,8 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
   if (H > HCAP || s <= 0 || s > kL1MaxS) return;                 // another class handles it ...
   // ... class S takes sketches of <= 1024 hashes, class M the longer ones as well (k_l1_probe lists them)
   if (HLO == 0 ? s > kMaxS : (H <= HLO && s <= kL1SmallMaxS)) return;
-  const uint32_t off = a.fragOff[f];
-  const int m = s <= a.lutMaxS ? a.minHitsLUT[s] : 1;                 // fetched here, beside the other loads: it is needed right after the gather
+  const uint32_t off = d.off;
+  const int m = (int)(d.sm >> 16);                  // minimumHits of s (computeMap.hpp:301)
   int *pOff = (int *)Vraw;                          // hit offsets per probe alias V (V is only written after the gather)
   constexpr int kPerS = kMaxS / kTPB;                // sketch hashes per thread at most
   uint32_t pFirst[kPerS];                           // the runs' starts travel with the counts: one round trip to memory instead of two
