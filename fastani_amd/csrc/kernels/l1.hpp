@@ -466,7 +466,9 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
   block_barrier();
   block_array_excl_scan(pOff, s, ws);
   // gather (computeMap.hpp:283-299).  (Tried and measured equal: four loads in flight per lane; one lane per hit instead of per
-  // sketch hash.)  Measured by compiling the later phases out (1000 x 1000 x 5 Mbp, ms per step of this kernel): gather 13.4,
+  // sketch hash — again in round 6, with the bisection over the offsets in LDS and a lane's eight loads independent of each other:
+  // 27.1 ms against 26.8, although the walk below is 43 % of a workgroup's life by the kernel's own clock, profiles/r06o_l1_phase_clock.txt:
+  // the lines arrive at the memory system's pace for random 128-byte lines, however the requests are issued.)  Measured by compiling the later phases out (1000 x 1000 x 5 Mbp, ms per step of this kernel): gather 13.4,
   // noise filter +2.2, sort +10.3 (in registers; the LDS network it replaced: +14.8), candidate emission +4.0.  The gather reads one
   // short run (~5 entries = 40 bytes) per sketch hash from a random place of the hash-ordered payload: ~45 KB of 128-byte lines per
   // fragment for 10 KB of hits, 77 GB per step by the FETCH_SIZE counter — it runs at the memory system's pace for such lines.
