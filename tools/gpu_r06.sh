@@ -115,5 +115,13 @@ if has prof; then
   rm -rf "$OUT/prof"
 fi
 if has pmc; then
-  echo "(pmc: use tools/pmc_run.sh and tools/pmc_traffic.py directly)"
+  # HBM traffic of the step's kernels: FETCH_SIZE and WRITE_SIZE in SEPARATE passes, counters + kernel trace only (the guide's recipe);
+  # 3 profiled steps (--steps 2 --warmup 1); merged into the file bench.py quotes (it carries the hash of the kernel sources it was taken on)
+  for set in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 900 rocprofv3 --pmc $set --kernel-trace -d "$OUT/pmc_$set" -o pmc --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-verify > "$OUT/pmc_$set.log" 2>&1)
+    f=$(find "$OUT/pmc_$set" -name "*counter_collection*.csv" | head -1)
+    [ -n "$f" ] && python "$REPO/tools/pmc_summary.py" "$f" > "$OUT/pmc_${set}_summary.txt" 2>&1
+    rm -rf "$OUT/pmc_$set"
+  done
+  python tools/pmc_traffic.py "$OUT/pmc_FETCH_SIZE_summary.txt" "$OUT/pmc_WRITE_SIZE_summary.txt" "$OUT/r06_pmc_traffic.json" 3 2>&1 | tail -2
 fi
