@@ -57,6 +57,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  RCCL brings streams of its own, and with
+# them in the process the library's main and side stream landed on ONE queue: the L2 simulation no longer ran beside the next chunk's
+# codes kernel (L2 stage 86.4 instead of 80.0 ms per 1000 x 1000 step, measured with one rank over RCCL; profiles/r06r_dist_ab.txt).
+# Eight queues restore it.  Must be in the environment before the runtime starts, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # VALU integer ceiling for the MurmurHash3 kernels, from the instruction costs measured on MI355X (tools/ubench/valu.hip,
