@@ -465,11 +465,13 @@ extern "C" {
 
 // Device memory for sketching and indexing a reference set of about n minimizers, taken from the driver NOW, on the calling (side)
 // thread, as free segments of the pool (host/engine.hpp: DevicePool::reserve).  Measured on the 1000 x 5 Mbp command-line run
-// (4.03 x 10^8 minimizers; profiles/r06a_e2e_pool_trace.txt): the slices' records, fragment sets and workspaces take 6.6 GB = 16.4
-// bytes per minimizer, asked for in pieces of < 300 MB while the input is read — reserved as 1 GiB segments, first, so that the
-// first slice waits for one of them only; the index build takes 19.0 GB = 47 bytes per minimizer (six arrays of 4 n, two of 8 n,
-// link candidates, the probe table at ~8 n) within a few milliseconds — reserved as ONE segment, from which the build's requests
-// are cut one after the other and into which its transient arrays go back for the mapping buffers.
+// (4.03 x 10^8 minimizers; profiles/r06a_e2e_pool_trace.txt, r06s_e2e_slow_box.txt): the slices' records and fragment sets take 16 bytes
+// per minimizer and the contexts' workspaces 2 GB, asked for in pieces of < 300 MB while the input is read — reserved as 1 GiB segments,
+// first, 22 bytes per minimizer in all, so that the first slice waits for one of them only (with 17 the eighth GiB was missing and the
+// compute threads waited 0.67 s for the index segment behind it on a 30 us/MB box); the index build takes 41 bytes per minimizer at its peak
+// (28 n of arrays that stay, then 12 n of sort buffers or — in the same place, the sort buffers are free by then — link candidates and the
+// probe table) within a few milliseconds — reserved as ONE segment, from which the build's requests are cut one after the other and
+// into which its transient arrays go back for the mapping buffers.
 int ani_pool_prewarm_index(ani_ctx *ctx, uint64_t nMinimizers)
 {
   if (!ctx) return fail(ANI_ERR_ARG, "bad argument to ani_pool_prewarm_index");
@@ -478,7 +480,7 @@ int ani_pool_prewarm_index(ani_ctx *ctx, uint64_t nMinimizers)
   HIP_TRY(hipSetDevice(ctx->device));
   size_t freeB = 0, totalB = 0;
   HIP_TRY(hipMemGetInfo(&freeB, &totalB));
-  const size_t sketchBytes = (size_t)nMinimizers * 17, indexBytes = (size_t)nMinimizers * 49;
+  const size_t sketchBytes = (size_t)nMinimizers * 22, indexBytes = (size_t)nMinimizers * 43;
   if (sketchBytes + indexBytes > freeB / 2) return ANI_OK;                  // not on a device that is short of memory
   DevicePool &pool = cur_pool();
   std::vector<size_t> sizes;

@@ -474,11 +474,8 @@ int main(int argc, char **argv)
   trace("options parsed, readers started");
   // ---- devices ----
   std::vector<Device> dev(o.devices.size());
-  for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d];
-    if (ani_init(dev[d].id, &dev[d].ctx) || ani_init(dev[d].id, &dev[d].up)) die("ani_init"); }
+  for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx)) die("ani_init"); }
   const int nDev = (int)dev.size();
-  if (fpPtr) fpPtr->set_active(1 << 30);
-  trace("devices initialised");
   // Fresh device memory is slow on some hosts (20 - 40 us per MB: the index build of a cold 1000-genome run took 0.6 s instead of
   // 0.03, BENCH_r05.json): what sketching and indexing the references will take is reserved NOW, on a side thread per device, while
   // the readers parse the first files (ani_pool_prewarm_index: 1 GiB segments for the slices first, then one segment for the index
@@ -502,6 +499,10 @@ int main(int argc, char **argv)
       for (int d = 0; d < nDev; d++) { ani_ctx *pc = dev[d].ctx; prewarm.emplace_back([pc, nEst]() { (void)ani_pool_prewarm_index(pc, nEst); }); }
     }
   }
+  // (the reservation runs from the moment the compute contexts exist: the upload contexts — streams, page-locked staging — come up beside it)
+  for (size_t d = 0; d < dev.size(); d++) if (ani_init(dev[d].id, &dev[d].up)) die("ani_init");
+  if (fpPtr) fpPtr->set_active(1 << 30);
+  trace("devices initialised");
   std::cerr << "INFO [thread 0], skch::Sketch::build, window size for minimizer sampling  = " << ap.windowSize << std::endl;
   std::cerr << "INFO [thread 0], skch::main, Count of threads executing parallel_for : " << (o.sanityCheck ? o.threads : nDev) << std::endl;
 

@@ -142,7 +142,7 @@ int ani_device_alloc(ani_ctx *ctx, size_t bytes, void **out);
  * no counterpart in the reference, which splits its database by hand: scripts/splitDatabase.sh) */
 int ani_device_memory(ani_ctx *ctx, size_t *freeBytes, size_t *totalBytes);
 /* A hint, never needed for correctness: take from the driver NOW, on the calling thread, the device memory that sketching and
- * indexing a reference set of about `nMinimizers` minimizers will ask for (~66 bytes per minimizer: 1 GiB segments for the slices'
+ * indexing a reference set of about `nMinimizers` minimizers will ask for (~65 bytes per minimizer: 1 GiB segments for the slices'
  * records and fragment sets first, then one segment for the index build), and leave it free in the allocator.  Fresh device memory
  * costs 20 - 40 us per MB on some hosts — 0.6 s of a cold 1000-genome run sat in the index build for that reason; the command line
  * calls this on a side thread while its readers parse the first files (estimate: input bytes x 2 / (w + 1); ANI_CLI_PREWARM=0
