@@ -9,10 +9,7 @@ echo "== tiny big-L1 groups, noise filter always on, tiny sub-batches"; ANI_TEST
 echo "== host pool for every host loop (ANI_TEST_HOST_PAR_MIN_WORK=0, 5 threads)"; ANI_TEST_HOST_PAR_MIN_WORK=0 ANI_HOST_THREADS=5 timeout 300 python tools/fuzz_gpu.py 67 60 2>&1 | tail -2
 [ -n "${FUZZ_LITE:-}" ] && { echo "== parity suite with poisoned pool memory (0xff)"; ANI_TEST_POOL_POISON=255 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3; echo "== lite round done"; exit 0; }
 echo "== L2 overlap off"; ANI_TEST_L2_OVERLAP=0 timeout 300 python tools/fuzz_gpu.py 47 60 2>&1 | tail -2
-echo "== L2 range trimming on (round 5; off by default)"; ANI_L2_TRIM=1 timeout 300 python tools/fuzz_gpu.py 59 150 2>&1 | tail -2
-echo "== L2 range trimming on, tiny L2 chunks and sub-batches, streamed set"; ANI_L2_TRIM=1 ANI_SUBBATCH_FRAGS=7 ANI_TEST_L2_CHUNK=11 ANI_MAX_INDEX_MINIMIZERS=6000 ANI_MAX_RESIDENT_CHUNKS=1 timeout 300 python tools/fuzz_gpu.py 61 60 2>&1 | tail -2
-echo "== parity suite with L2 range trimming on"; ANI_L2_TRIM=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
-echo "== parity suite with pipelined sub-batches on (threshold lowered)"; ANI_MAP_PIPELINE=1 ANI_MAP_PIPELINE_MIN_FRAGS=8 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+echo "== small L1 classes off the table: hit cap 700 (class M from 701 hits on is skipped: everything beyond goes the batched path), wave kernel off"; ANI_TEST_L1_LDS_MAX=700 ANI_TEST_L1_TINY=0 timeout 300 python tools/fuzz_gpu.py 71 60 2>&1 | tail -2
 echo "== parity suite with poisoned pool memory (0xff)"; ANI_TEST_POOL_POISON=255 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
 echo "== parity suite with poisoned pool memory (0x5a)"; ANI_TEST_POOL_POISON=90 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
 } | tee $OUT/fuzz.log
