@@ -705,6 +705,33 @@ def step_single(R):
         R.last_residency = None
         R.blocks_last_step = 0
         R.step_rows, R.step_crc = 0, 0
+        worker = None
+        if c5 and R.drop_rows:
+            import queue
+            import threading
+            R.row_jobs = queue.Queue(maxsize=2)          # (two blocks' rows in flight at most: 8 GB each at 90 000 x 30 000)
+
+            def bookkeeping():
+                # checksum = sum of the rows' 32-bit words mod 2^64, at memory speed (crc32 runs at ~1 GB/s and the rows of 90 000 x 90 000 are
+                # 126 GB); sampled queries by binary search: the rows of a call arrive ordered by query
+                while True:
+                    job = R.row_jobs.get()
+                    if job is None:
+                        return
+                    rws, b0_ = job
+                    R.step_rows += len(rws)
+                    R.step_crc = (R.step_crc + int(np.ascontiguousarray(rws).view(np.uint32).sum(dtype=np.uint64)) + b0_ * len(rws)) & 0xffffffffffffffff
+                    qcol = np.ascontiguousarray(rws["qryGenomeId"])
+                    if len(qcol) and bool(np.all(qcol[:-1] <= qcol[1:])):
+                        lo, hi = np.searchsorted(qcol, R.sample_queries, "left"), np.searchsorted(qcol, R.sample_queries, "right")
+                        keep = np.concatenate([rws[a_:b_] for a_, b_ in zip(lo, hi)]) if len(lo) else rws[:0].copy()
+                    else:
+                        keep = rws[np.isin(qcol, R.sample_queries)]
+                    keep["refGenomeId"] += b0_
+                    out.append(keep)
+                    del qcol, rws, job
+            worker = threading.Thread(target=bookkeeping, daemon=True)
+            worker.start()
         qblocks = [(q0, min(R.nq_local, q0 + R.query_block)) for q0 in range(0, R.nq_local, R.query_block)] if c5 else [(0, 0)]
         for qb0, qb1 in qblocks:
             qsets, qfirsts = [], []
@@ -741,21 +768,17 @@ def step_single(R):
                                                 R.contig_len[:b1 - b0], R.gcs[:b1 - b0 + 1]), adopt=True)
                 t_d = time.perf_counter()
                 rows = sk.map_cgi_fragsets(qsets, qfirsts) if c5 else sk.map_cgi_fragsets(sets, firsts)
-                rows["refGenomeId"] += b0
                 if c5 and R.drop_rows:
-                    # the step's rows are counted and checksummed block by block; only the sampled queries' rows stay (oracle check)
-                    # (checksum = sum of the rows' 32-bit words mod 2^64, at memory speed: crc32 runs at ~1 GB/s and the rows of 90 000 x 90 000 are
-                    #  126 GB; sampled queries by binary search: the rows of a call arrive ordered by query)
-                    R.step_rows += len(rows)
-                    R.step_crc = (R.step_crc + int(np.ascontiguousarray(rows).view(np.uint32).sum(dtype=np.uint64))) & 0xffffffffffffffff
-                    qcol = np.ascontiguousarray(rows["qryGenomeId"])
-                    if len(qcol) and bool(np.all(qcol[:-1] <= qcol[1:])):
-                        lo, hi = np.searchsorted(qcol, R.sample_queries, "left"), np.searchsorted(qcol, R.sample_queries, "right")
-                        rows = np.concatenate([rows[a_:b_] for a_, b_ in zip(lo, hi)]) if len(lo) else rows[:0]
-                    else:
-                        rows = rows[np.isin(qcol, R.sample_queries)]
-                    del qcol
-                out.append(rows)
+                    # the step's rows are counted and checksummed block by block and only the sampled queries' rows stay (oracle check) —
+                    # the bench's own bookkeeping, done by a worker thread beside the next block's GPU work (numpy releases the interpreter
+                    # lock inside its loops): the rows are on the host when the mapping call returns, which is where a step's work ends.
+                    # (First form, inline: 95 of the 353 s of the 90 000 x 90 000 step, profiles/r06e_bench_c5_90000x90000_one_gpu.json.log.)
+                    R.row_jobs.put((rows, b0))
+                    rows = None
+                else:
+                    rows["refGenomeId"] += b0
+                if rows is not None:
+                    out.append(rows)
                 t_e = time.perf_counter()
                 res = sk.residency()
                 R.last_residency = res if R.last_residency is None else dict(streaming=res["streaming"] or R.last_residency["streaming"],
@@ -767,6 +790,9 @@ def step_single(R):
                 T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["map_ms"] += (t_e - t_d) * 1e3
             for fr in qsets:
                 fr.close()
+        if worker is not None:
+            R.row_jobs.put(None)
+            worker.join()                                 # the step ends when its last rows are counted
         # (several blocks: the rows stay block-major — (query, reference) order inside a block.  Sorting the 7 x 10^8 rows of
         #  90 000 x 10 000 on the host took longer than computing them: 55 of 104 s, profiles/r05c5_bench_c5_90000x10000.json.log)
         return out[0] if len(out) == 1 else np.concatenate(out)
