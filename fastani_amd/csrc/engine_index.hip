@@ -684,6 +684,13 @@ int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGeno
   return ANI_OK;
 }
 
+int ani_sketch_set_ref_id_base(ani_sketch *sk, int32_t base)
+{
+  if (!sk) return fail(ANI_ERR_ARG, "null sketch");
+  sk->refIdBase = base;
+  return ANI_OK;
+}
+
 int ani_sketch_residency(const ani_sketch *sk, int32_t *streaming, int32_t *maxResident, int32_t *residentNow)
 {
   if (!sk) return fail(ANI_ERR_ARG, "null sketch");

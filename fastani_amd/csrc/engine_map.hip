@@ -443,7 +443,7 @@ int reduce_stage(ani_ctx *ctx, ani_sketch *set, IndexChunk *sk, const FragSet &f
 int collect_rows(ani_ctx *ctx, ani_sketch *set, const FragSet &fs, int32_t nQuery, int32_t firstQueryId, RowBuf *rows, const IndexChunk *block = nullptr,
     const int32_t *queryIds = nullptr)
 {
-  const int32_t nCols = block ? block->nGenomes : set->nGenomes, col0 = block ? block->g0 : 0;
+  const int32_t nCols = block ? block->nGenomes : set->nGenomes, col0 = (block ? block->g0 : 0) + set->refIdBase;
   const size_t nPairs = (size_t)nQuery * (size_t)nCols;
   if (nPairs == 0) return ANI_OK;
   uint32_t *dense = nullptr;

@@ -449,6 +449,7 @@ struct ani_sketch {
   uint64_t n = 0;                          // minimizers over all chunks
   int32_t nContigs = 0, nGenomes = 0;
   uint64_t totalLen = 0;
+  int32_t refIdBase = 0;                   // added to refGenomeId in the CGI rows of the batch entry points (ani_sketch_set_ref_id_base: a shard or block of a larger set)
   uint64_t nUnique = 0; bool uniqueExact = false;   // distinct hashes over all chunks (computed on demand when there are several)
   std::vector<int32_t> contigLen, genomeContigStart;
   std::vector<std::string> genomeNames;    // optional (ani_sketch_save / _load carry them)

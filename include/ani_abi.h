@@ -190,6 +190,10 @@ int ani_sketch_chunks(const ani_sketch *sk, int32_t *nChunks, int32_t *firstGeno
  * the 12-byte minimizer records and at most `maxResident` chunks' index arrays; the mapping entry points then walk the set chunk by
  * chunk (build, map every query sub-batch, drop).  Results are identical.  Reports the mode. */
 int ani_sketch_residency(const ani_sketch *sk, int32_t *streaming, int32_t *maxResident, int32_t *residentNow);
+/* A sketch that holds a shard or a block of a larger reference set: `base` = global id of its first genome, added to refGenomeId in the
+ * CGI rows of ani_map_cgi_batch / ani_map_cgi_fragset(s) (mapping records and ani_compute_cgi keep sketch-local ids).  The reference does this
+ * per thread after the fact (cgi::correctRefGenomeIds, computeCoreIdentity.hpp:480-487, for its split of :457-474). */
+int ani_sketch_set_ref_id_base(ani_sketch *sk, int32_t base);
 
 /* Multi-GPU staging: rank r sketches its share of the reference genomes into device-resident
  * 12-byte records with GLOBAL seqIds (seqIdBase = contigs before this shard), the caller all-gathers the

@@ -658,7 +658,32 @@ def case_cand_pool_retry(engine_plain, engine_limited):
     sk2.close()
 
 
-ALL_CASES = [case_goldens, case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
+def case_ref_id_base(engine):
+    """ani_sketch_set_ref_id_base: a sketch that holds a shard / block of a larger set reports refGenomeId + base in the CGI rows of the
+    batch entry points (≙ cgi::correctRefGenomeIds, computeCoreIdentity.hpp:480-487, done where the rows are made); mapping records and
+    ani_compute_cgi keep the sketch's own ids"""
+    genomes = [[orc.synth_genome(21, g, 60000)] for g in (0, 1, 3, 7, 20)]
+    p = engine.params()
+    sk = Sketch(engine, p, genomes)
+    rows0 = sk.map_cgi_batch(genomes, 5)
+    maps0, tot0 = sk.map_query(genomes[1])
+    sk.set_ref_id_base(1000)
+    rows1 = sk.map_cgi_batch(genomes, 5)
+    fr = engine.fragment_set(p, genomes)
+    rows2 = sk.map_cgi_fragset(fr, 5)
+    fr.close()
+    maps1, tot1 = sk.map_query(genomes[1])
+    exp = rows0.copy()
+    exp["refGenomeId"] += 1000
+    assert len(rows0) >= 5 and np.array_equal(rows1, exp) and np.array_equal(rows2, exp)
+    assert tot0 == tot1 and np.array_equal(maps0, maps1)
+    assert np.array_equal(sk.compute_cgi(maps1, tot1, 6), sk.compute_cgi(maps0, tot0, 6))
+    sk.set_ref_id_base(0)
+    assert np.array_equal(sk.map_cgi_batch(genomes, 5), rows0)
+    sk.close()
+
+
+ALL_CASES = [case_ref_id_base, case_goldens, case_synthetic_cluster, case_messy, case_kmer12, case_fraglen1000, case_tandem_repeats, case_low_complexity,
              case_low_complexity_big, case_gap_counter_overflow, case_l1_mid_noise, case_sparse_hits, case_l1_class_overflow, case_species_dense, case_evolved, case_empty_and_short, case_uploaded, case_self, case_window_sizes]
 
 
