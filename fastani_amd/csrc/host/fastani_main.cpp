@@ -476,6 +476,7 @@ int main(int argc, char **argv)
   std::vector<Device> dev(o.devices.size());
   for (size_t d = 0; d < dev.size(); d++) { dev[d].id = o.devices[d]; if (ani_init(dev[d].id, &dev[d].ctx)) die("ani_init"); }
   const int nDev = (int)dev.size();
+  trace("compute contexts up");
   // Fresh device memory is slow on some hosts (20 - 40 us per MB: the index build of a cold 1000-genome run took 0.6 s instead of
   // 0.03, BENCH_r05.json): what sketching and indexing the references will take is reserved NOW, on a side thread per device, while
   // the readers parse the first files (ani_pool_prewarm_index: 1 GiB segments for the slices first, then one segment for the index
