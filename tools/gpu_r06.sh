@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit of round 6.  usage: tools/gpu_r06.sh <tag> [stage ...]
-#   stages: alloc e2e e2etrace tests quick bench3 prof pmc dist1
+#   stages: alloc radixbits libab e2e e2etrace tests quick dist1 bench3 c4one c4sim8 c5warm cli10k c5full sim prof pmc
 # Writes everything under gpurun_out/<tag>/ (copy what is to be judged into profiles/).
 set -u
 exec < /dev/null
