@@ -24,6 +24,7 @@ ANI_SEQ_HOST_ASCII = 0
 ANI_SEQ_DEVICE_PACKED2 = 1
 ANI_SEQ_HOST_ASCII_PTRS = 2
 ANI_SEQ_DEVICE_BATCH = 3
+ANI_SEQ_HOST_MIXED_PTRS = 4
 
 
 class AniError(RuntimeError):
@@ -64,6 +65,7 @@ def _bind(lib):
         "ani_device_copy": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "ani_device_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "ani_device_copy_peer": (C.c_int, [vp, vp, vp, vp, C.c_size_t]),
+        "ani_pack_acgt": (C.c_int, [vp, C.c_int32, vp]),
         "ani_batch_upload": (C.c_int, [vp, C.POINTER(SeqBatch), C.POINTER(vp)]),
         "ani_batch_free": (None, [vp]),
         "ani_get_counters": (C.c_int, [vp, C.POINTER(Counters)]),
@@ -191,15 +193,29 @@ class DeviceGenomes:
 class UploadedGenomes:
     """Host genomes packed and copied to the device once (ani_batch_upload); usable as references and as queries."""
 
-    def __init__(self, engine, genomes, ptrs=False):
+    def __init__(self, engine, genomes, ptrs=False, mixed=False):
         self.e = engine
         self.host = genomes if isinstance(genomes, HostGenomes) else HostGenomes(genomes)
         b = self.host.batch()
-        if ptrs:                                   # per-contig pointer layout (ANI_SEQ_HOST_ASCII_PTRS)
+        if ptrs or mixed:                          # per-contig pointer layout (ANI_SEQ_HOST_ASCII_PTRS)
             self._ptrs = (self.host.data.ctypes.data + self.host.off[:max(self.host.n_contigs, 1)]).astype(np.uint64)
             b.layout = ANI_SEQ_HOST_ASCII_PTRS
             b.data = self._ptrs.ctypes.data
             b.contigOffset = None
+        if mixed:                                  # ANI_SEQ_HOST_MIXED_PTRS: every contig that ani_pack_acgt accepts goes over as 2-bit codes
+            nc = self.host.n_contigs
+            self._kind = np.zeros(max(nc, 1), dtype=np.int64)
+            self._packed = []
+            for c in range(nc):
+                ln = int(self.host.len[c])
+                out = np.zeros((ln + 15) // 16 + 2, dtype=np.uint32)
+                if engine.lib.ani_pack_acgt(C.c_void_p(int(self._ptrs[c])), ln, out.ctypes.data_as(C.c_void_p)) == 1:
+                    self._kind[c] = 1
+                    self._packed.append(out)
+                    self._ptrs[c] = out.ctypes.data
+            b.layout = ANI_SEQ_HOST_MIXED_PTRS
+            b.contigOffset = self._kind.ctypes.data
+            self.packed_contigs = int(self._kind[:nc].sum())
         h = C.c_void_p()
         engine._chk(engine.lib.ani_batch_upload(engine.h, C.byref(b), C.byref(h)))
         self.h = h

@@ -10,9 +10,12 @@ int check_batch(const ani_seq_batch_t *b)
     return fail(ANI_ERR_ARG, "invalid sequence batch");
   if (b->layout == ANI_SEQ_DEVICE_BATCH) return b->data ? ANI_OK : fail(ANI_ERR_ARG, "sequence batch without its device batch handle");
   if (b->nContigs && !b->data) return fail(ANI_ERR_ARG, "sequence batch without data");
-  if (b->layout != ANI_SEQ_HOST_ASCII && b->layout != ANI_SEQ_DEVICE_PACKED2 && b->layout != ANI_SEQ_HOST_ASCII_PTRS) return fail(ANI_ERR_ARG,
-      "unknown sequence layout %d", b->layout);
+  if (b->layout != ANI_SEQ_HOST_ASCII && b->layout != ANI_SEQ_DEVICE_PACKED2 && b->layout != ANI_SEQ_HOST_ASCII_PTRS && b->layout != ANI_SEQ_HOST_MIXED_PTRS)
+    return fail(ANI_ERR_ARG, "unknown sequence layout %d", b->layout);
   if (b->layout != ANI_SEQ_HOST_ASCII_PTRS && b->nContigs && !b->contigOffset) return fail(ANI_ERR_ARG, "sequence batch without contig offsets");
+  if (b->layout == ANI_SEQ_HOST_MIXED_PTRS)
+    for (int32_t c = 0; c < b->nContigs; c++) if (b->contigOffset[c] != 0 && b->contigOffset[c] != 1) return fail(ANI_ERR_ARG, "contig %d: unknown kind %lld", c,
+        (long long)b->contigOffset[c]);
   for (int32_t c = 0; c < b->nContigs; c++) if (b->contigLen[c] < 0) return fail(ANI_ERR_LIMIT, "contig %d has a negative length (>= 2^31 bases?)", c);
   return ANI_OK;
 }
@@ -32,6 +35,33 @@ inline uint32_t pack8(uint64_t x, bool *pure)
   c = (c | (c >> 12)) & 0x000000FF000000FFull;
   c = (c | (c >> 24)) & 0xFFFFull;
   return (uint32_t)c;
+}
+
+// bases [lo, hi) of a contig (lo a multiple of 16) -> words dst[lo / 16 ..]; `whole`: hi is the contig's end (two zero words follow).
+// Returns false if a byte other than A C G T a c g t occurred (the words are then meaningless).
+inline bool pack_range(const uint8_t *sp, int32_t lo, int32_t hi, uint32_t *dst, bool whole)
+{
+  bool allPure = true;
+  int32_t x = lo;
+  for (; x + 16 <= hi; x += 16) {
+    uint64_t a, bb; memcpy(&a, sp + x, 8); memcpy(&bb, sp + x + 8, 8);
+    bool p1, p2;
+    const uint32_t wd = pack8(a, &p1) | (pack8(bb, &p2) << 16);
+    allPure &= p1 & p2;
+    dst[x >> 4] = wd;
+  }
+  if (x < hi) {                                       // last, partial word of the contig
+    uint8_t tail[16]; memset(tail, 'A', 16); memcpy(tail, sp + x, (size_t)(hi - x));
+    uint64_t a, bb; memcpy(&a, tail, 8); memcpy(&bb, tail + 8, 8);
+    bool p1, p2;
+    uint32_t wd = pack8(a, &p1) | (pack8(bb, &p2) << 16);
+    allPure &= p1 & p2;
+    const int nb = hi - x;
+    if (nb < 16) wd &= (1u << (2 * nb)) - 1u;
+    dst[x >> 4] = wd;
+  }
+  if (whole) { const size_t e = ((size_t)hi + 15) / 16; dst[e] = 0; dst[e + 1] = 0; }
+  return allPure;
 }
 
 int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1, DeviceBatch *out, ani_dev_batch *keep)
@@ -71,7 +101,10 @@ int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1,
     // into page-locked staging (contigs are split into segments of 4 Mbases so that one long chromosome still spreads over the
     // threads).  Segments are packed optimistically; a contig with any other byte is copied raw in a second, rare, pass.
     const uint8_t *flat = b->layout == ANI_SEQ_HOST_ASCII ? (const uint8_t *)b->data : nullptr;
-    const uint8_t *const *ptrs = b->layout == ANI_SEQ_HOST_ASCII_PTRS ? (const uint8_t *const *)b->data : nullptr;
+    const uint8_t *const *ptrs = b->layout != ANI_SEQ_HOST_ASCII ? (const uint8_t *const *)b->data : nullptr;
+    // ANI_SEQ_HOST_MIXED_PTRS: contigs the reader packed already (ani_pack_acgt) are copied, the others go through the same loop as ever
+    const bool mixed = b->layout == ANI_SEQ_HOST_MIXED_PTRS;
+    auto prepacked = [&](int32_t c) -> bool { return mixed && b->contigOffset[c0 + c] == 1; };
     auto contig_ptr = [&](int32_t c) -> const uint8_t * { return flat ? flat + b->contigOffset[c0 + c] : ptrs[c0 + c]; };
     const int32_t nC = out->nContigs;
     struct Seg { int32_t c; int32_t lo, hi; };
@@ -89,29 +122,15 @@ int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1,
     std::vector<uint8_t> segImpure(segs.size(), 0);
     parallel_for(segs.size(), out->totalBases, [&](size_t i) {
       const Seg &sg = segs[i];
-      const uint8_t *sp = contig_ptr(sg.c);
       uint32_t *dst = hPacked + wordOff[sg.c];
-      bool allPure = true;
-      int32_t x = sg.lo;
-      for (; x + 16 <= sg.hi; x += 16) {
-        uint64_t a, bb; memcpy(&a, sp + x, 8); memcpy(&bb, sp + x + 8, 8);
-        bool p1, p2;
-        const uint32_t wd = pack8(a, &p1) | (pack8(bb, &p2) << 16);
-        allPure &= p1 & p2;
-        dst[x >> 4] = wd;
+      const bool whole = sg.hi == out->contigLen[sg.c];
+      if (prepacked(sg.c)) {                            // words [lo / 16, ceil(hi / 16)) of the reader's copy (+ the two closing words)
+        const uint32_t *src = (const uint32_t *)(const void *)contig_ptr(sg.c);
+        const size_t w0 = (size_t)sg.lo >> 4, w1 = ((size_t)sg.hi + 15) / 16 + (whole ? 2 : 0);
+        memcpy(dst + w0, src + w0, (w1 - w0) * 4);
+        return;
       }
-      if (x < sg.hi) {                                  // last, partial word of the contig
-        uint8_t tail[16]; memset(tail, 'A', 16); memcpy(tail, sp + x, (size_t)(sg.hi - x));
-        uint64_t a, bb; memcpy(&a, tail, 8); memcpy(&bb, tail + 8, 8);
-        bool p1, p2;
-        uint32_t wd = pack8(a, &p1) | (pack8(bb, &p2) << 16);
-        allPure &= p1 & p2;
-        const int nb = sg.hi - x;
-        if (nb < 16) wd &= (1u << (2 * nb)) - 1u;
-        dst[x >> 4] = wd;
-      }
-      if (sg.hi == out->contigLen[sg.c]) { const size_t e = ((size_t)sg.hi + 15) / 16; dst[e] = 0; dst[e + 1] = 0; }
-      segImpure[i] = !allPure;
+      segImpure[i] = !pack_range(contig_ptr(sg.c), sg.lo, sg.hi, dst, whole);
     });
     for (int32_t c = 0; c < nC; c++) if (out->contigLen[c] == 0) { hPacked[wordOff[c]] = 0; hPacked[wordOff[c] + 1] = 0; }
     std::vector<uint8_t> impure(nC, 0);
@@ -160,6 +179,13 @@ int upload_batch(ani_ctx *ctx, const ani_seq_batch_t *b, int32_t g0, int32_t g1,
 }  // namespace anih
 
 extern "C" {
+
+int ani_pack_acgt(const uint8_t *seq, int32_t len, uint32_t *out)
+{
+  if (len < 0 || !out || (len && !seq)) return 0;
+  if (len == 0) { out[0] = 0; out[1] = 0; return 1; }
+  return pack_range(seq, 0, len, out, true) ? 1 : 0;
+}
 
 int ani_batch_upload(ani_ctx *ctx, const ani_seq_batch_t *genomes, ani_dev_batch **out)
 {

@@ -217,10 +217,26 @@ struct BlockReader {
 struct Genome { std::vector<std::string> names; std::vector<int32_t> lens; };
 
 struct FileData {
-  std::vector<uint8_t> data;            // all contigs of the file back to back
+  std::vector<uint8_t> data;            // all contigs of the file back to back (released by the reader itself if every contig could be packed)
   std::vector<size_t> off;              // start of every contig in `data`
+  // pure-ACGT contigs as 2-bit codes (ani_pack_acgt), made by the reader right behind the parse, while the bytes are in its cache:
+  // kind[c] = 1 -> words packed[poff[c] ..], 0 -> raw bytes data[off[c] ..]   (ANI_SEQ_HOST_MIXED_PTRS)
+  std::vector<uint32_t> packed; std::vector<size_t> poff; std::vector<int64_t> kind;
   Genome g;
-  void clear() { std::vector<uint8_t>().swap(data); std::vector<size_t>().swap(off); }
+  void clear() { std::vector<uint8_t>().swap(data); std::vector<size_t>().swap(off); std::vector<uint32_t>().swap(packed); std::vector<size_t>().swap(poff);
+                 std::vector<int64_t>().swap(kind); }
+  // returns true if no contig needs its raw bytes any more
+  bool pack()
+  {
+    const size_t nc = off.size();
+    size_t words = 0;
+    poff.resize(nc); kind.assign(nc, 0);
+    for (size_t c = 0; c < nc; c++) { poff[c] = words; words += ((size_t)g.lens[c] + 15) / 16 + 2; }
+    packed.resize(words);
+    bool all = true;
+    for (size_t c = 0; c < nc; c++) { kind[c] = ani_pack_acgt(data.data() + off[c], g.lens[c], packed.data() + poff[c]); all = all && kind[c] == 1; }
+    return all;
+  }
 };
 
 // one file -> contigs; returns false at a contig of >= 2^31 bases
@@ -289,6 +305,7 @@ struct FilePipeline {
   std::mutex mu; std::condition_variable cv;
   size_t next = 0; uint64_t releasedBytes = 0, window; bool failed = false;
   std::vector<std::vector<uint8_t>> spare;      // sequence buffers of released files, reused by the readers
+  std::vector<std::vector<uint32_t>> sparePacked;   // ... and their packed copies
   // readers allowed to work: a few until the devices are initialised (set_active), then all
   int active = getenv("ANI_CLI_INIT_READERS") ? atoi(getenv("ANI_CLI_INIT_READERS")) : 8;
   std::vector<std::thread> th;
@@ -319,9 +336,15 @@ struct FilePipeline {
         i = next++;
       }
       FileData fd;
-      { std::lock_guard<std::mutex> g(mu); if (!spare.empty()) { fd.data = std::move(spare.back()); spare.pop_back(); fd.data.clear(); } }
+      { std::lock_guard<std::mutex> g(mu);
+        if (!spare.empty()) { fd.data = std::move(spare.back()); spare.pop_back(); fd.data.clear(); }
+        if (!sparePacked.empty()) { fd.packed = std::move(sparePacked.back()); sparePacked.pop_back(); fd.packed.clear(); } }
       const bool ok = readFile(paths[i], fd);
-      { std::lock_guard<std::mutex> g(mu); slot[i] = std::move(fd); ready[i] = 1; if (!ok) failed = true; }
+      // 2 bits per base, here, on the reader's thread (round 6): the upload thread then only copies.  A file without a single byte
+      // beyond ACGT — nearly every finished genome — hands its byte buffer straight to the next file.
+      std::vector<uint8_t> done;
+      if (ok && fd.pack()) done = std::move(fd.data);
+      { std::lock_guard<std::mutex> g(mu); slot[i] = std::move(fd); ready[i] = 1; if (!ok) failed = true; if (done.capacity()) spare.push_back(std::move(done)); }
       cv.notify_all();
     }
   }
@@ -339,27 +362,37 @@ struct FilePipeline {
   // the pipeline.)
   void release(size_t a, size_t b)
   {
-    std::vector<std::vector<uint8_t>> keep;
-    for (size_t i = a; i < b; i++) { if (slot[i].data.capacity()) keep.push_back(std::move(slot[i].data)); slot[i].clear(); }
-    { std::lock_guard<std::mutex> g(mu); for (auto &v : keep) spare.push_back(std::move(v)); releasedBytes = std::max(releasedBytes, sizePrefix[b]); }
+    std::vector<std::vector<uint8_t>> keep; std::vector<std::vector<uint32_t>> keepP;
+    for (size_t i = a; i < b; i++) {
+      if (slot[i].data.capacity()) keep.push_back(std::move(slot[i].data));
+      if (slot[i].packed.capacity()) keepP.push_back(std::move(slot[i].packed));
+      slot[i].clear();
+    }
+    { std::lock_guard<std::mutex> g(mu); for (auto &v : keep) spare.push_back(std::move(v)); for (auto &v : keepP) sparePacked.push_back(std::move(v));
+      releasedBytes = std::max(releasedBytes, sizePrefix[b]); }
     cv.notify_all();
   }
 };
 
 // a slice of files as one sequence batch (per-contig pointers: no concatenation)
 struct SliceBatch {
-  std::vector<const uint8_t *> ptr; std::vector<int32_t> len, gcs{0};
+  std::vector<const uint8_t *> ptr; std::vector<int32_t> len, gcs{0}; std::vector<int64_t> kind;      // kind: 1 = packed by the reader, 0 = raw bytes
   void add(const FileData &fd)
   {
-    for (size_t c = 0; c < fd.off.size(); c++) { ptr.push_back(fd.data.data() + fd.off[c]); len.push_back(fd.g.lens[c]); }
+    for (size_t c = 0; c < fd.off.size(); c++) {
+      const bool pk = c < fd.kind.size() && fd.kind[c] == 1;
+      ptr.push_back(pk ? (const uint8_t *)(const void *)(fd.packed.data() + fd.poff[c]) : fd.data.data() + fd.off[c]);
+      kind.push_back(pk ? 1 : 0); len.push_back(fd.g.lens[c]);
+    }
     gcs.push_back((int32_t)len.size());
   }
   ani_seq_batch_t batch() const
   {
     static const uint8_t *dummyPtr = nullptr; static const int32_t dummyLen = 0;
     ani_seq_batch_t b;
-    b.layout = ANI_SEQ_HOST_ASCII_PTRS; b.nGenomes = (int32_t)gcs.size() - 1; b.nContigs = (int32_t)len.size();
-    b.genomeContigStart = gcs.data(); b.contigOffset = nullptr; b.contigLen = len.empty() ? &dummyLen : len.data();
+    static const int64_t dummyKind = 0;
+    b.layout = ANI_SEQ_HOST_MIXED_PTRS; b.nGenomes = (int32_t)gcs.size() - 1; b.nContigs = (int32_t)len.size();
+    b.genomeContigStart = gcs.data(); b.contigOffset = kind.empty() ? &dummyKind : kind.data(); b.contigLen = len.empty() ? &dummyLen : len.data();
     b.data = ptr.empty() ? (const void *)&dummyPtr : (const void *)ptr.data();
     return b;
   }

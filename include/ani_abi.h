@@ -77,8 +77,13 @@ typedef struct {
  *   layout ANI_SEQ_DEVICE_BATCH   : `data` is an ani_dev_batch* returned by ani_batch_upload (genomes already packed and
  *                                 resident on the device); the table fields must describe that batch (nGenomes, nContigs,
  *                                 genomeContigStart, contigLen), contigOffset is ignored.
+ *   layout ANI_SEQ_HOST_MIXED_PTRS: `data` is an array of nContigs host pointers; contigOffset[c] says what pointer c is:
+ *                                 0 = raw sequence bytes (as HOST_ASCII_PTRS), 1 = 2-bit codes made by ani_pack_acgt from a
+ *                                 pure-ACGT contig ((len + 15) / 16 + 2 words).  A reader packs every contig it can on its own
+ *                                 thread, while the bytes are in its cache, and the upload only copies (round 6: the packing
+ *                                 of a slice by the upload thread's pool was the longest stage of the command line's ingest).
  */
-typedef enum { ANI_SEQ_HOST_ASCII = 0, ANI_SEQ_DEVICE_PACKED2 = 1, ANI_SEQ_HOST_ASCII_PTRS = 2, ANI_SEQ_DEVICE_BATCH = 3 } ani_seq_layout;
+typedef enum { ANI_SEQ_HOST_ASCII = 0, ANI_SEQ_DEVICE_PACKED2 = 1, ANI_SEQ_HOST_ASCII_PTRS = 2, ANI_SEQ_DEVICE_BATCH = 3, ANI_SEQ_HOST_MIXED_PTRS = 4 } ani_seq_layout;
 typedef struct {
   int32_t layout;
   int32_t nGenomes;
@@ -158,6 +163,11 @@ int ani_device_copy_peer(ani_ctx *dstCtx, void *dst, ani_ctx *srcCtx, const void
  * device and keep them there.  The handle can be passed to every entry point that takes a sequence batch (layout
  * ANI_SEQ_DEVICE_BATCH), any number of times: an all-vs-all run sketches and maps the same upload. */
 int ani_batch_upload(ani_ctx *ctx, const ani_seq_batch_t *genomes, ani_dev_batch **out);
+/* Host-side helper of the ingest path (no device, no context): packs `len` sequence bytes to 2 bits per base (A0 C1 G2 T3, either
+ * case: commonFunc.hpp:56-66 folds a-z) into out[(len + 15) / 16 + 2] if every byte is one of A C G T a c g t and returns 1;
+ * returns 0 (out undefined) if any other byte occurs — such a contig stays raw bytes (the reference hashes raw upper-cased ASCII,
+ * commonFunc.hpp:71-81).  For ANI_SEQ_HOST_MIXED_PTRS. */
+int ani_pack_acgt(const uint8_t *seq, int32_t len, uint32_t *out);
 void ani_batch_free(ani_dev_batch *b);
 int ani_get_counters(ani_ctx *ctx, ani_counters_t *out);
 int ani_reset_counters(ani_ctx *ctx);

@@ -452,8 +452,12 @@ def case_uploaded(engine):
     p = engine.params()
     sk0 = Sketch(engine, p, genomes)
     rows0 = sk0.map_cgi_batch(genomes, 0)
-    for ptrs in (False, True):
-        up = UploadedGenomes(engine, genomes, ptrs=ptrs)
+    # (third layout: ANI_SEQ_HOST_MIXED_PTRS — the contigs ani_pack_acgt accepts arrive as 2-bit codes made by the caller, the others raw;
+    #  lower case packs, anything else does not: the messy genome's contigs with N / IUPAC stay raw bytes)
+    for ptrs, mixed in ((False, False), (True, False), (False, True)):
+        up = UploadedGenomes(engine, genomes, ptrs=ptrs, mixed=mixed)
+        if mixed:
+            assert 0 < up.packed_contigs < up.n_contigs
         sk = Sketch(engine, p, up)
         assert np.array_equal(sk.minimizers(), sk0.minimizers())
         assert np.array_equal(sk.map_cgi_batch(up, 0), rows0)
