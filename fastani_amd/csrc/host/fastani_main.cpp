@@ -1116,5 +1116,15 @@ int main(int argc, char **argv)
   // every output file is closed: returning tens of gigabytes of device memory block by block and unloading the runtime would only
   // delay the caller (0.3 s at 1000 genomes)
   fflush(stdout); fflush(stderr);
+  // What is left is the kernel's work: unmapping 25 GB of device memory and unpinning the staging costs 0.14 - 0.18 s, and a caller in
+  // wait() sits through it when the last thread of the process does it on its way out.  Measured (tools/ubench/exit_threads.cpp — no GPU
+  // needed — and tools/ubench/exit_probe.hip; profiles/r08a_exit_probe.txt, r08a_e2e_exit_ab.txt): when about half a dozen or more
+  // threads are still parked at exit_group(), the caller's wait() returns within a millisecond and the address space is torn down behind
+  // it (memory comes back over the next 0.15 s).  The pools' threads are joined by now, so a few are parked here for that purpose:
+  // 0.80 -> 0.62 s for the 1000-genome run as its caller sees it.  ANI_CLI_EXIT_THREADS=0 turns it off.
+  {
+    const char *v = getenv("ANI_CLI_EXIT_THREADS");
+    for (int i = 0, n = v ? atoi(v) : 16; i < n && i < 256; i++) std::thread([]() { for (;;) pause(); }).detach();
+  }
   _exit(0);
 }

@@ -198,6 +198,16 @@ def test_bench_orchestration_two_ranks(config, scaling, launcher, emu_engine, tm
     single = Sketch(emu_engine, p, dg).map_cgi_batch(dg, 0)
     if strong:
         assert np.array_equal(got, single)
+        # the line's own row check for multi-rank runs: count and multiset hash over all ranks = those of the single-process rows
+        sys.path.insert(0, ROOT)
+        import bench
+        ms = out["rows_multiset"]
+        assert ms["ranks"] == 2 and ms["rows"] == len(single) and ms["hash"] == "%016x" % bench.rows_multiset_hash(single), ms
+        assert ms["expected"] is None and ms["ok"] is None          # no stored expectation for a 6-genome set
+        half = len(single) // 2                                    # the hash adds up over any partition, in any order
+        assert (bench.rows_multiset_hash(single[:half]) + bench.rows_multiset_hash(single[half:][::-1])) % (1 << 64) == bench.rows_multiset_hash(single)
+        other = single.copy(); other["countSeq"][0] += 1
+        assert bench.rows_multiset_hash(other) != bench.rows_multiset_hash(single)
     else:
         # rank 0 maps variant 0 (= the references themselves), rank 1 variant 1 with query ids 6..11
         assert np.array_equal(got[got["qryGenomeId"] < 6], single) and len(got) == 72

@@ -1,7 +1,7 @@
 """stamp -> process gone for tools/ubench/exit_probe under several loads (device GB, pinned MB, parked threads)"""
 import subprocess, sys, time, os
 exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "exit_probe")
-for gb, pin, th in ((0, 0, 0), (0, 0, 96), (0, 600, 0), (26, 0, 0), (26, 600, 96)):
+for gb, pin, th in ((0, 0, 0), (0, 0, 96), (0, 600, 0), (26, 0, 0), (26, 600, 0), (26, 600, 1), (26, 600, 4), (26, 600, 16), (26, 600, 96)):
     ts = []
     for rep in range(3):
         t0 = time.time()
