@@ -22,6 +22,7 @@
 // round-robin splits.
 #include <zlib.h>
 #include <fcntl.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
@@ -426,6 +427,34 @@ struct Device { int id = 0; ani_ctx *ctx = nullptr, *up = nullptr; };    // comp
 struct RefPart { void *rec = nullptr; uint64_t n = 0; int dev = 0; int32_t g0 = 0, g1 = 0; };
 
 }  // namespace
+
+// The end of the process.  What is left after the output is closed is the kernel's work — unmapping 25 GB of device memory and
+// unpinning the staging cost 0.14 - 0.18 s — and a caller in wait() sits through it, because the last thread of a process tears the
+// address space down on its way out.  Linux >= 6.16 keeps a per-process futex hash that grows with the thread count (kernel/futex/core.c:
+// futex_hash_allocate_default, 4 slots per thread); the switch to a larger one holds a reference to the address space across two RCU
+// grace periods and drops it with mmput_async().  A process that ends inside that window leaves the tear-down to a kernel worker: its
+// caller's wait() returns within a millisecond and the memory comes back over the next 0.15 s (tools/ubench/exit_threads.cpp shows it
+// without a GPU, tools/ubench/exit_probe.hip with one; profiles/r08*_exit_*.txt).  So: as many parked threads as make the hash grow,
+// then _exit.  On other kernels prctl() fails and nothing is done; ANI_CLI_EXIT_THREADS=0 turns it off, =N parks exactly N.
+static void exit_behind_the_caller()
+{
+  auto park = [](int n) { for (int i = 0; i < n; i++) std::thread([]() { for (;;) pause(); }).detach(); };
+  if (const char *v = getenv("ANI_CLI_EXIT_THREADS")) { park(std::max(0, std::min(atoi(v), 4096))); return; }
+  if (prctl(78 /* PR_FUTEX_HASH */, 2 /* PR_FUTEX_HASH_GET_SLOTS */, 0, 0, 0) <= 0) return;      // no private futex hash on this kernel
+  park(1);                                                       // (a larger hash that was still waiting for its turn is in place after this clone())
+  const int slots = prctl(78, 2, 0, 0, 0);
+  const long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+  if (slots <= 0 || (long)slots / 4 + 1 > cpus) return;           // the hash is as large as it gets (the thread count it follows is capped by the CPUs)
+  int alive = 1;
+  if (FILE *f = fopen("/proc/self/status", "r")) {
+    char ln[256];
+    while (fgets(ln, sizeof ln, f)) if (!strncmp(ln, "Threads:", 8)) { alive = atoi(ln + 8); break; }
+    fclose(f);
+  }
+  const int n = std::max(1, std::min(slots / 4 + 4 - alive, 4096));
+  if (getenv("ANI_CLI_TRACE")) fprintf(stderr, "[fastANI exit] futex hash %d slots, %d threads alive, %d parked\n", slots, alive, n);
+  park(n);                                                       // the clone() that finds more than slots / 4 threads makes the hash grow
+}
 
 int main(int argc, char **argv)
 {
@@ -1116,15 +1145,6 @@ int main(int argc, char **argv)
   // every output file is closed: returning tens of gigabytes of device memory block by block and unloading the runtime would only
   // delay the caller (0.3 s at 1000 genomes)
   fflush(stdout); fflush(stderr);
-  // What is left is the kernel's work: unmapping 25 GB of device memory and unpinning the staging costs 0.14 - 0.18 s, and a caller in
-  // wait() sits through it when the last thread of the process does it on its way out.  Measured (tools/ubench/exit_threads.cpp — no GPU
-  // needed — and tools/ubench/exit_probe.hip; profiles/r08a_exit_probe.txt, r08a_e2e_exit_ab.txt): when about half a dozen or more
-  // threads are still parked at exit_group(), the caller's wait() returns within a millisecond and the address space is torn down behind
-  // it (memory comes back over the next 0.15 s).  The pools' threads are joined by now, so a few are parked here for that purpose:
-  // 0.80 -> 0.62 s for the 1000-genome run as its caller sees it.  ANI_CLI_EXIT_THREADS=0 turns it off.
-  {
-    const char *v = getenv("ANI_CLI_EXIT_THREADS");
-    for (int i = 0, n = v ? atoi(v) : 16; i < n && i < 256; i++) std::thread([]() { for (;;) pause(); }).detach();
-  }
+  exit_behind_the_caller();
   _exit(0);
 }

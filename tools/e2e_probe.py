@@ -37,9 +37,13 @@ def main():
                 else:
                     env[k] = val
         for rep in range(int(os.environ.get("E2E_REPS", "2"))):
+            # a run that starts right behind another device process pays for that one's release (the runtime's start takes 0.16 - 0.23 s
+            # instead of 0.05, tools/ubench/init_probe.hip): E2E_PAUSE seconds between runs measure a user's single run
+            time.sleep(float(os.environ.get("E2E_PAUSE", "0")))
             t0 = time.time()
             pr = subprocess.Popen([cli, "--ql", lst, "--rl", lst, "-t", threads, "-o", os.path.join(td, "out.txt")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
             marks = []
+            exit_note = ""
             keep = open(os.path.join(os.environ["E2E_STDERR_DIR"], "stderr_%s_rep%d.txt" % (v.replace("=", "-").replace(",", "_"), rep)), "w") if os.environ.get("E2E_STDERR_DIR") else None
             for raw in pr.stderr:
                 ln = raw.decode(errors="replace").rstrip("\n")
@@ -47,10 +51,12 @@ def main():
                     keep.write("%.4f %s\n" % (time.time() - t0, ln))
                 if ln.startswith("[fastANI trace]"):
                     marks.append((time.time() - t0, float(ln.split()[2]), " ".join(ln.split()[4:])))
+                if ln.startswith("[fastANI exit]"):
+                    exit_note = ln
             pr.wait()
             wall = time.time() - t0
-            print("%-40s rep %d  wall %.3f s  before main %.3f  after last mark %.3f | %s" % (
-                v, rep, wall, marks[0][0] - marks[0][1] if marks else -1, wall - marks[-1][0] if marks else -1,
+            print("%-40s rep %d  wall %.3f s  before main %.3f  after last mark %.3f %s | %s" % (
+                v, rep, wall, marks[0][0] - marks[0][1] if marks else -1, wall - marks[-1][0] if marks else -1, exit_note,
                 "; ".join("%.3f %s" % (m[1], m[2]) for m in marks)), flush=True)
     subprocess.call(["rm", "-rf", td])
 

@@ -44,3 +44,29 @@ if has bench1; then
   ms bench < "$OUT/bench.json.log"; tail -3 "$OUT/bench.err"
   rm -rf /tmp/ani_bench_wd
 fi
+if has initprobe; then
+  { echo "== start of the HIP runtime, call by call (tools/ubench/init_probe): idle device (2 s pause before each run)"
+    for i in 1 2 3; do sleep 2; echo "run $i"; timeout 60 tools/ubench/init_probe; done
+    echo "== back to back (no pause)"
+    for i in 1 2 3; do echo "run $i"; timeout 60 tools/ubench/init_probe; done
+    echo "== the library's own start: dlopen of libfastani_amd.so, ani_init"
+    python - <<'PYEOF'
+import time, ctypes, os
+t0 = time.time(); lib = ctypes.CDLL(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "fastani_amd/csrc/libfastani_amd.so")); print("  dlopen libfastani_amd.so %.1f ms" % ((time.time() - t0) * 1e3))
+ctx = ctypes.c_void_p(); t0 = time.time(); rc = lib.ani_init(0, ctypes.byref(ctx)); print("  ani_init(0) rc %d  %.1f ms" % (rc, (time.time() - t0) * 1e3))
+t0 = time.time(); rc = lib.ani_init(0, ctypes.byref(ctx)); print("  second ani_init(0) rc %d  %.1f ms" % (rc, (time.time() - t0) * 1e3))
+os._exit(0)
+PYEOF
+  } 2>&1 | tee "$OUT/init_probe.txt"
+fi
+if has exitcli; then
+  echo "== command line end to end: parked threads at the end (default 16) against none"
+  E2E_REPS=${E2E_REPS:-4} timeout 1200 python tools/e2e_probe.py 1000 default ANI_CLI_EXIT_THREADS=0 default ANI_CLI_EXIT_THREADS=0 2>&1 | cut -c1-420 | tee "$OUT/e2e_exit_default_ab.txt"
+  timeout 300 python tools/exit_probe.py 2>&1 | tee "$OUT/exit_probe.txt"
+  timeout 300 python tools/ubench/exit_threads.py 2>&1 | tee "$OUT/exit_threads.txt"
+  uname -a | tee "$OUT/uname.txt"
+fi
+if has e2eiso; then
+  echo "== command line end to end, runs 2 s apart (a user's single run): default against ANI_CLI_EXIT_THREADS=0"
+  E2E_PAUSE=2 E2E_REPS=${E2E_REPS:-5} timeout 1200 python tools/e2e_probe.py 1000 default ANI_CLI_EXIT_THREADS=0 default ANI_CLI_EXIT_THREADS=0 2>&1 | cut -c1-700 | tee "$OUT/e2e_isolated_ab.txt"
+fi
