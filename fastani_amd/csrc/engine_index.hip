@@ -10,7 +10,8 @@ using namespace ani;
 // the index arrays of a chunk (not its reducer tables): dropped when the chunk is evicted in streaming mode
 void free_chunk_index(IndexChunk *ch)
 {
-  void **ptrs[] = {(void **)&ch->mWin, (void **)&ch->sSW, (void **)&ch->dupBits, (void **)&ch->dupList, (void **)&ch->mHash, (void **)&ch->mSeq, (void **)&ch->mWpos,
+  void **ptrs[] = {(void **)&ch->mWin, (void **)&ch->sSW, (void **)&ch->dupBits, (void **)&ch->dupList, (void **)&ch->mHash, (void **)&ch->mSeq,
+      (void **)&ch->mWpos,
                    (void **)&ch->sHash, (void **)&ch->table, (void **)&ch->contigFirstMin, (void **)&ch->posSample};
   for (void **q : ptrs) if (*q) { pool_free(*q); *q = nullptr; }
   ch->resident = false; ch->nDup = 0;
@@ -71,7 +72,8 @@ int new_chunk(ani_ctx *ctx, const ani_params_t *p, size_t n, const int32_t *cont
   const int32_t *contigLen = contigLenAll + c0;
   sk->n = (uint32_t)n; sk->c0 = c0; sk->nContigs = nContigs; sk->g0 = g0; sk->nGenomes = nGenomes;
   auto bail = [&](int rc) { free_chunk(sk); return rc; };
-#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, \
+    "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   // contig -> genome, bins (computeCoreIdentity.hpp:31-42, :194); all chunk-local
   std::vector<int32_t> cg((size_t)nContigs + 1, nGenomes);
   std::vector<uint32_t> binBase((size_t)nContigs + 1), gBin((size_t)nGenomes + 1), posBase((size_t)nContigs + 1);
@@ -108,7 +110,8 @@ int build_chunk_index(ani_ctx *ctx, const ani_params_t *p, IndexChunk *sk)
   //  guards below go out of scope — so both streams are drained first)
   auto bail = [&](int rc) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamSynchronize(ctx->stream); free_chunk_index(sk); return rc; };
 #define SK_TRY(expr) do { int rc_ = (expr); if (rc_ != ANI_OK) return bail(rc_); } while (0)
-#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+#define SK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fail(e_ == hipErrorOutOfMemory ? ANI_ERR_NOMEM : ANI_ERR_DEVICE, \
+    "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
   const size_t n4 = (n ? n : 1) * 4;
   const size_t bitWords = (n + 31) / 32 + 1;
   SK_HIP(pool_malloc((void **)&sk->mHash, n4)); SK_HIP(pool_malloc((void **)&sk->mSeq, n4)); SK_HIP(pool_malloc((void **)&sk->mWpos, n4));
@@ -760,7 +763,8 @@ int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char
   // (an add that is refused leaves the writer FAILED: a later close must not publish a file that silently lacks this sketch)
   if (!w->haveParams) { w->params = sk->params; w->haveParams = true; }
   else if (w->params.kmerSize != sk->params.kmerSize || w->params.windowSize != sk->params.windowSize || w->params.fragLen != sk->params.fragLen ||
-           w->params.percentageIdentity != sk->params.percentageIdentity) { w->failed = true; return fail(ANI_ERR_ARG, "sketches of one file must share their parameters"); }
+           w->params.percentageIdentity != sk->params.percentageIdentity) { w->failed = true; return fail(ANI_ERR_ARG,
+               "sketches of one file must share their parameters"); }
   const std::vector<uint64_t> &genomeRec = sk->genomeRecStart;      // first record of every genome (add_chunks)
   if (genomeRec.size() != (size_t)sk->nGenomes + 1) { w->failed = true; return fail(ANI_ERR_INTERNAL, "sketch without its genome record table"); }
   const int64_t contigBase = (int64_t)w->contigLen.size();
@@ -810,7 +814,8 @@ int ani_sketch_writer_add(ani_sketch_writer *w, const ani_sketch *sk, const char
   for (int32_t g = 1; g <= sk->nGenomes; g++) { w->gcs.push_back((int32_t)(contigBase + sk->genomeContigStart[g]));
     w->genomeRec.push_back(w->nRecords + genomeRec[g]); }
   w->nRecords += sk->n;
-  for (int32_t g = 0; g < sk->nGenomes; g++) { w->names += genomeNames && genomeNames[g] ? genomeNames[g] : (g < (int32_t)sk->genomeNames.size() ? sk->genomeNames[g].c_str() : ""); w->names.push_back('\0'); }
+  for (int32_t g = 0; g < sk->nGenomes; g++) { w->names += genomeNames && genomeNames[g] ? genomeNames[g] : (g < (int32_t)sk->genomeNames.size()
+      ? sk->genomeNames[g].c_str() : ""); w->names.push_back('\0'); }
   return ANI_OK;
 }
 

@@ -14,7 +14,8 @@ int check_batch(const ani_seq_batch_t *b)
     return fail(ANI_ERR_ARG, "unknown sequence layout %d", b->layout);
   if (b->layout != ANI_SEQ_HOST_ASCII_PTRS && b->nContigs && !b->contigOffset) return fail(ANI_ERR_ARG, "sequence batch without contig offsets");
   if (b->layout == ANI_SEQ_HOST_MIXED_PTRS)
-    for (int32_t c = 0; c < b->nContigs; c++) if (b->contigOffset[c] != 0 && b->contigOffset[c] != 1) return fail(ANI_ERR_ARG, "contig %d: unknown kind %lld", c,
+    for (int32_t c = 0; c < b->nContigs; c++) if (b->contigOffset[c] != 0 && b->contigOffset[c] != 1) return fail(ANI_ERR_ARG,
+        "contig %d: unknown kind %lld", c,
         (long long)b->contigOffset[c]);
   for (int32_t c = 0; c < b->nContigs; c++) if (b->contigLen[c] < 0) return fail(ANI_ERR_LIMIT, "contig %d has a negative length (>= 2^31 bases?)", c);
   return ANI_OK;

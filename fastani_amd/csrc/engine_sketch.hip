@@ -62,7 +62,8 @@ int frag_tables(ani_ctx *ctx, const ani_params_t &p, const DeviceBatch &db, Frag
   HIP_TRY(hipMemcpyAsync(ctx->unitAux.as<int32_t>() + nc1, cQBase.data(), nc1 * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_expand_frags, dim3(grid_for(nF)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->unitStart.as<uint32_t>(),
       (const int32_t *)ctx->unitAux.as<int32_t>(),
-                     (const int32_t *)(ctx->unitAux.as<int32_t>() + nc1), db.nContigs, (uint32_t)nF, L, ctx->frags.as<FragDesc>(), arr.fragGenome, arr.fragQSeq);
+                     (const int32_t *)(ctx->unitAux.as<int32_t>() + nc1), db.nContigs, (uint32_t)nF, L, ctx->frags.as<FragDesc>(), arr.fragGenome,
+                         arr.fragQSeq);
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   qr->fragOff = arr.fragOff; qr->fragS = arr.fragS; qr->fragGenome = arr.fragGenome; qr->fragQSeq = arr.fragQSeq; qr->genomeBase = 0;
   return ANI_OK;
@@ -171,7 +172,8 @@ int sketch_records(ani_ctx *ctx, const ani_params_t *p, const DeviceBatch &db, i
                            ctx->poolWpos.as<int32_t>(), stripe_cap(cap), cur_ptr(ctx, POOL_REF), ctx->tileMeta.as<TileMeta>());
       else
         hipLaunchKernelGGL(k_sketch_fused, dim3((unsigned)nT), dim3(kTPB), 0, ctx->stream, db.dPacked, db.dAscii, db.dContigOff, db.dContigLen, db.dContigMode,
-                           ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>(), k, w, L, ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(), stripe_cap(cap),
+                           ctx->tiles.as<TileDesc>(), ctx->tileInfo.as<FusedInfo>(), k, w, L, ctx->poolHash.as<uint32_t>(), ctx->poolWpos.as<int32_t>(),
+                               stripe_cap(cap),
                            cur_ptr(ctx, POOL_REF), ctx->tileMeta.as<TileMeta>(), *fused->qPool, stripe_cap(qcap), cur_ptr(ctx,
                                POOL_Q), fused->arr->fragOff, fused->arr->fragS,
                            (int *)cnt_ptr(ctx, CNT_MAXS));
@@ -540,7 +542,8 @@ int ani_fragset_unpack_merged(ani_ctx *ctx, const void *devBuf, size_t slotBytes
     // the streamed re-order of map_fragsets finds a query's set by a lower bound over the genomes' query ids: the used slots must
     // come in ascending, non-overlapping query-id order (ranks own contiguous genome ranges in rank order)
     if ((int64_t)slotQueryBase[i] < nextQueryId) return bail(fail(ANI_ERR_ARG,
-        "slot %d: query ids must ascend over the used slots (slot starts at %d, the slots before it end at %lld)", i, slotQueryBase[i], (long long)nextQueryId));
+        "slot %d: query ids must ascend over the used slots (slot starts at %d, the slots before it end at %lld)", i, slotQueryBase[i],
+            (long long)nextQueryId));
     nextQueryId = (int64_t)slotQueryBase[i] + h.nGenomes;
     ani_fragset tmp; tmp.params.kmerSize = h.kmerSize; tmp.params.windowSize = h.windowSize; tmp.params.fragLen = h.fragLen;
     tmp.params.percentageIdentity = h.percentageIdentity;

@@ -408,7 +408,8 @@ struct ani_ctx {
   DevBuf scanTmpA, scanTmpB, scanTmpC, scanTmpD;
   DevBuf frags, fragOff, fragS, fragGenome, fragQSeq, qPool;
   DevBuf l1FragDesc;                      // per fragment, in processing order: what the L1 gather kernels need of it (kernels/l1.hpp: L1FragDesc)
-  DevBuf probeFirst, probeCnt, l1MidList, l1SmallList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd, fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
+  DevBuf probeFirst, probeCnt, l1MidList, l1SmallList, l1BigList, l1BigHitsA, l1BigHitsB, l1BigV, l1BigTbl, l1BigHash, candFrag, candSeq, candStart, candEnd,
+      fragCandOff, fragCandCnt, fragCandCntClamped, fragHits, fragOrdOff, fragOrder, fragOrderTmp;
   DevBuf ocFrag, ocSeq, ocStart, ocEnd;
   DevBuf l2Scratch, l2Best, l2First, l2Last, refStart, idBits, keepFlags, keepOff, mapOut;
   DevBuf l2Ranges[2], l2CodeCount[2], l2CodeOff[2], l2Codes[2], l2SlowFlag[2], l2ClassList[2], l2Order[2], l2LenHist[2];   // two chunk sets (see the L2 loop)
@@ -449,7 +450,8 @@ struct ani_sketch {
   uint64_t n = 0;                          // minimizers over all chunks
   int32_t nContigs = 0, nGenomes = 0;
   uint64_t totalLen = 0;
-  int32_t refIdBase = 0;                   // added to refGenomeId in the CGI rows of the batch entry points (ani_sketch_set_ref_id_base: a shard or block of a larger set)
+  // added to refGenomeId in the CGI rows of the batch entry points (ani_sketch_set_ref_id_base: a shard or block of a larger set)
+  int32_t refIdBase = 0;
   uint64_t nUnique = 0; bool uniqueExact = false;   // distinct hashes over all chunks (computed on demand when there are several)
   std::vector<int32_t> contigLen, genomeContigStart;
   std::vector<std::string> genomeNames;    // optional (ani_sketch_save / _load carry them)
@@ -469,7 +471,8 @@ struct ani_sketch {
 namespace anih {
 
 enum { CNT_POOL = 0, CNT_QPOOL = 1, CNT_CAND = 2, CNT_HITS = 3, CNT_ENTRIES = 4, CNT_STEPS = 5, CNT_ROWS = 6, CNT_UNIQ = 7,
-       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17, CNT_LISTBIG = 18, CNT_ENTRIES_B = 19, CNT_SUMQ_B = 20, CNT_STEPS_B = 21, CNT_TINY = 22, CNT_SMALL = 23, CNT_N = 24 };
+       CNT_MAXS = 8 /* int */, CNT_NEG = 9 /* uint */, CNT_SUMQ = 10, CNT_REASON = 11 /* ..14 */, CNT_CLASSB = 15, CNT_LISTM = 16, CNT_LISTL = 17,
+           CNT_LISTBIG = 18, CNT_ENTRIES_B = 19, CNT_SUMQ_B = 20, CNT_STEPS_B = 21, CNT_TINY = 22, CNT_SMALL = 23, CNT_N = 24 };
 
 
 inline unsigned long long *cnt_ptr(ani_ctx *c, int i) { return c->dCounters.as<unsigned long long>() + i; }

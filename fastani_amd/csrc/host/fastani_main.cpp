@@ -345,7 +345,8 @@ struct FilePipeline {
       // beyond ACGT — nearly every finished genome — hands its byte buffer straight to the next file.
       std::vector<uint8_t> done;
       if (ok && fd.pack()) done = std::move(fd.data);
-      { std::lock_guard<std::mutex> g(mu); slot[i] = std::move(fd); ready[i] = 1; if (!ok) failed = true; if (done.capacity()) spare.push_back(std::move(done)); }
+      { std::lock_guard<std::mutex> g(mu); slot[i] = std::move(fd); ready[i] = 1; if (!ok) failed = true;
+          if (done.capacity()) spare.push_back(std::move(done)); }
       cv.notify_all();
     }
   }
@@ -484,7 +485,8 @@ int main(int argc, char **argv)
     ani_params_t fp_;
     if (ani_sketch_file_info(o.refSketch.c_str(), &fp_, nullptr, nullptr, nullptr)) die("reference sketch file");
     if (fp_.kmerSize != ap.kmerSize || fp_.fragLen != ap.fragLen || fp_.windowSize != ap.windowSize) {
-      std::cerr << "ERROR, the sketch file was built with -k " << fp_.kmerSize << " --fragLen " << fp_.fragLen << ", this run uses -k " << ap.kmerSize << " --fragLen " << ap.fragLen << std::endl; exit(1); }
+      std::cerr << "ERROR, the sketch file was built with -k " << fp_.kmerSize << " --fragLen " << fp_.fragLen << ", this run uses -k " << ap.kmerSize
+          << " --fragLen " << ap.fragLen << std::endl; exit(1); }
   }
 
   // FASTA bytes per slice (the unit that is parsed, packed, uploaded and sketched as one piece, and one mapping call per query
@@ -497,7 +499,8 @@ int main(int argc, char **argv)
   const bool fromFile = !o.refSketch.empty();
   if (fromFile && (o.visualize || o.sanityCheck)) { std::cerr << "ERROR, --refSketch cannot be combined with --visualize or -s" << std::endl; exit(1); }
   if (!o.saveSketch.empty() && (o.visualize
-      || o.sanityCheck)) { std::cerr << "ERROR, --saveSketch cannot be combined with --visualize or -s (those modes sketch per reference split)" << std::endl; exit(1); }
+      || o.sanityCheck)) { std::cerr << "ERROR, --saveSketch cannot be combined with --visualize or -s (those modes sketch per reference split)"
+          << std::endl; exit(1); }
   const bool allVsAll = !fromFile && (o.queries == o.refs) && !o.visualize && !o.sanityCheck;
   if (o.visualize || o.sanityCheck) o.devices.resize(1);            // the per-split / per-mapping paths are single-device
   // before anything is read or sketched
@@ -669,7 +672,8 @@ int main(int argc, char **argv)
       for (auto &t : th) t.join();        // no thread waits for another device's: a failing device cannot stall the others
       { char line[400]; snprintf(line, sizeof line,
           "%s: %zu slices; upload threads waited %.3f s for the readers, %.3f s for the compute threads, entered the slices %.3f s, packed + copied %.3f s, released the host copies %.3f s; compute threads waited %.3f s, worked %.3f s",
-                                 what, slices.size(), stageSecs[0], stageSecs[4], stageSecs[5], stageSecs[1], stageSecs[6], stageSecs[2], stageSecs[3]); trace(line); }
+                                 what, slices.size(), stageSecs[0], stageSecs[4], stageSecs[5], stageSecs[1], stageSecs[6], stageSecs[2], stageSecs[3]);
+                                     trace(line); }
       for (auto &e : errs) if (!e.empty()) { std::cerr << "ERROR, " << what << ": " << e << std::endl; exit(1); }
     };
     auto dev_view = [](const Uploaded &u) {
@@ -718,7 +722,8 @@ int main(int argc, char **argv)
       const uint64_t perDev = (nm * 12 + (uint64_t)nDev - 1) / (uint64_t)nDev;
       nBlocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((perDev + budget - 1) / budget, (uint64_t)std::max(1, nRef / nDev)));
       fileMinimizers = nm;
-      if (nBlocks > 1) std::cerr << "INFO, skch::main, reference sketch of " << nm << " minimizers taken in " << nBlocks << " blocks of genomes per device" << std::endl;
+      if (nBlocks > 1) std::cerr << "INFO, skch::main, reference sketch of " << nm << " minimizers taken in " << nBlocks << " blocks of genomes per device"
+          << std::endl;
     }
     bool streamed = false;
     uint64_t occAll = 0; int32_t chunksAll = 0;
@@ -776,11 +781,13 @@ int main(int argc, char **argv)
         std::cerr << "INFO [thread 0], skch::Sketch::build, minimizers picked from reference = " << (nBlocks > 1 ? fileMinimizers : occ) << std::endl;
         if (nChunks <= 1 && nBlocks == 1) { ani_sketch_stats(shard[0].sk, nullptr, &uniq, nullptr, nullptr, nullptr);
           std::cerr << "INFO [thread 0], skch::Sketch::index, unique minimizers = " << uniq << std::endl; }
-        else if (nBlocks == 1) std::cerr << "INFO [thread 0], skch::Sketch::index, reference set held as " << nChunks << " index chunks on " << nDev << " device(s)" << (streamed ? ", streamed" : "") << std::endl;
+        else if (nBlocks == 1) std::cerr << "INFO [thread 0], skch::Sketch::index, reference set held as " << nChunks << " index chunks on " << nDev
+            << " device(s)" << (streamed ? ", streamed" : "") << std::endl;
         std::cerr << "INFO [thread 0], skch::main, Time spent sketching the reference : " << secs_since(t0) << " sec" << std::endl;
       }
       if (nBlocks > 1)
-        std::cerr << "INFO [thread 0], skch::Sketch::index, reference block " << blk + 1 << " of " << nBlocks << ": " << occ << " minimizers, " << nChunks << " index chunks on " << nDev << " device(s)"
+        std::cerr << "INFO [thread 0], skch::Sketch::index, reference block " << blk + 1 << " of " << nBlocks << ": " << occ << " minimizers, " << nChunks
+            << " index chunks on " << nDev << " device(s)"
                   << (blkStreamed ? ", streamed" : "") << "; loaded at " << secs_since(t0) << " sec" << std::endl;
     }
     };                                               // prepare_block
@@ -799,7 +806,8 @@ int main(int argc, char **argv)
     std::mutex logMu;
     auto log_map = [&](int d, int32_t firstQ, size_t nq, double total, double post) {
       std::lock_guard<std::mutex> lk(logMu);
-      std::cerr << "INFO [thread " << d << "], skch::main, Time spent mapping fragments in query #" << firstQ + 1 << "-#" << firstQ + (int32_t)nq << " : " << std::max(0.0, total - post) << " sec" << std::endl;
+      std::cerr << "INFO [thread " << d << "], skch::main, Time spent mapping fragments in query #" << firstQ + 1 << "-#" << firstQ + (int32_t)nq << " : "
+          << std::max(0.0, total - post) << " sec" << std::endl;
       std::cerr << "INFO [thread " << d << "], skch::main, Time spent post mapping : " << post << " sec" << std::endl;
     };
     const bool collect = allVsAll || nDev > 1 || streamed;
@@ -968,7 +976,8 @@ int main(int argc, char **argv)
         if (ani_map_cgi_batch(ctx, sk, &qb, 0, &rows, &m)) die("ani_map_cgi_batch");
         for (size_t i = 0; i < m; i++) { ani_cgi_t e = rows[i]; e.refGenomeId = refIdx[e.refGenomeId]; finalResults.push_back(e); }
         ani_free(rows);
-        if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #1-#" << nQry << " : " << secs_since(tm) << " sec" << std::endl;
+        if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #1-#" << nQry << " : " << secs_since(tm) << " sec"
+            << std::endl;
       } else if (ok) {
         // per query genome: mappings back to the host for the .visual rows (computeCoreIdentity.hpp:186-261)
         std::vector<int64_t> refOff(rbS.len.size(), 0);
@@ -982,7 +991,8 @@ int main(int argc, char **argv)
           if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Start Map " << qi + 1 << std::endl;
           ani_mapping_t *maps = nullptr; size_t n = 0; uint64_t totalFr = 0;
           if (ani_map_query(ctx, sk, &ob, &maps, &n, &totalFr)) die("ani_map_query");
-          if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #" << qi + 1 << " : " << secs_since(tm) << " sec" << std::endl;
+          if (sp == 0) std::cerr << "INFO [thread 0], skch::main, Time spent mapping fragments in query #" << qi + 1 << " : " << secs_since(tm) << " sec"
+              << std::endl;
           tm = Clock::now();
           ani_cgi_t *rows = nullptr; size_t m = 0;
           if (ani_compute_cgi(ctx, sk, maps, n, totalFr, (int32_t)qi, &rows, &m)) die("ani_compute_cgi");

@@ -214,7 +214,8 @@ __device__ __forceinline__ int32_t lane_value(int32_t x, int l) { return __built
 #else
 __device__ __forceinline__ int32_t lane_value(int32_t x, int l) { return __shfl(x, l); }
 #endif
-__device__ __forceinline__ uint64_t wave_uniform(uint64_t x) { return (uint64_t)wave_uniform((uint32_t)x) | ((uint64_t)wave_uniform((uint32_t)(x >> 32)) << 32); }
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t x) { return (uint64_t)wave_uniform((uint32_t)x) | ((uint64_t)wave_uniform((uint32_t)(x >> 32))
+    << 32); }
 
 // exclusive scan of one int per thread across the workgroup; *total = sum over all threads.
 // `ws` = LDS scratch of at least 8 ints.  Contains barriers: every thread of the block must call it.
@@ -272,7 +273,8 @@ __device__ inline int block_array_excl_scan(int *a, int n, int *ws)
 // Wave-level rendezvous for data exchanged through LDS inside ONE wave: the LDS performs a wave's operations in order, so no
 // counter wait is needed, only that the compiler keeps the order (and, in the CPU stand-in where lanes are fibers, a real rendezvous).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define ANI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define ANI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #else
 #define ANI_WAVE_SYNC() (void)__ballot(1)
 #endif

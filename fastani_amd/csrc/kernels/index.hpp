@@ -325,7 +325,8 @@ static __global__ __launch_bounds__(256) void k_index_window_links(const int32_t
   for (uint32_t x = threadIdx.x; x < span; x += 256) sw[x] = mWpos[(uint32_t)w0 + x];
   block_barrier();
   // (a macro, not a lambda: captured by reference the __shared__ array becomes a generic pointer and every read a flat load)
-#define wpos_at(x_) ([&](int32_t xx_, int32_t staged_) -> int32_t { return (uint32_t)(xx_ - w0) < span ? staged_ : ANI_LOAD_APART(mWpos + xx_); }((x_), sw[(uint32_t)((x_) - w0) < span ? (uint32_t)((x_) - w0) : 0u]))
+#define wpos_at(x_) ([&](int32_t xx_, int32_t staged_) -> int32_t { return (uint32_t)(xx_ - w0) < span ? staged_ : ANI_LOAD_APART(mWpos + xx_); }((x_), \
+    sw[(uint32_t)((x_) - w0) < span ? (uint32_t)((x_) - w0) : 0u]))
   // Four CONSECUTIVE entries per thread (round 5; it was four entries 256 apart): both answers are non-decreasing in j inside a
   // contig — the thresholds grow with wpos[j] and the range bounds with j — so only the thread's first entry (and the first of a
   // contig) runs the two searches; the next ones advance the previous answers by the one or two entries the window has moved

@@ -262,14 +262,16 @@ static __global__ __launch_bounds__(kTPB) void k_l1_probe(L1Args a)
       int m = (s[q] > 0 && s[q] <= a.lutMaxS) ? a.minHitsLUT[s[q]] : 1;
       if (H > 0 && s[q] <= kL1MaxS && H < (m < 1 ? 1 : m)) H = 0;
       a.fragHits[f] = H;
-      { L1FragDesc d; d.f = f; d.sm = (uint32_t)s[q] | ((uint32_t)(m < 0 ? 0 : (m > 0xffff ? 0xffff : m)) << 16); d.H = H; d.off = off[q]; a.fragDesc[i0 + q] = d; }
+      { L1FragDesc d; d.f = f; d.sm = (uint32_t)s[q] | ((uint32_t)(m < 0 ? 0 : (m > 0xffff ? 0xffff : m)) << 16); d.H = H; d.off = off[q];
+        a.fragDesc[i0 + q] = d; }
       if (H64) atomicAdd(stat_slot(a.sumHits), H64);
       if (tooMany) atomicAdd(a.overflowCount, 1u);
       else if (s[q] > 0) {
         // fragments of the larger LDS classes are listed so that their 48 / 96 KiB workgroups are only launched for them
         if (s[q] <= kL1MaxS && H <= a.ldsHitCap) {
           // (a long sketch with a handful of hits: the wave kernel)
-          if (H > kL1HitCapSmall || (s[q] > kL1SmallMaxS && !(H <= 4 * kWave && a.tinyPath))) a.midList[atomicAdd(a.midCount, 1u)] = i0 + q;      // (positions in the processing order: fragDesc)
+          // (positions in the processing order: fragDesc)
+          if (H > kL1HitCapSmall || (s[q] > kL1SmallMaxS && !(H <= 4 * kWave && a.tinyPath))) a.midList[atomicAdd(a.midCount, 1u)] = i0 + q;
           // (striped statistics counters: the host launches k_l1_tiny if there are any,
           else if (H > 0 && H <= 4 * kWave && a.tinyPath) atomicAdd(stat_slot(a.tinyCount), 1ull);
           // and k_l1<0, 2048> over a list instead of over every fragment if there are few)
@@ -468,7 +470,8 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
   // gather (computeMap.hpp:283-299).  (Tried and measured equal: four loads in flight per lane; one lane per hit instead of per
   // sketch hash — again in round 6, with the bisection over the offsets in LDS and a lane's eight loads independent of each other:
   // 27.1 ms against 26.8, although the walk below is 43 % of a workgroup's life by the kernel's own clock, profiles/r06o_l1_phase_clock.txt:
-  // the lines arrive at the memory system's pace for random 128-byte lines, however the requests are issued.)  Measured by compiling the later phases out (1000 x 1000 x 5 Mbp, ms per step of this kernel): gather 13.4,
+  // the lines arrive at the memory system's pace for random 128-byte lines, however the requests are issued.)  Measured by compiling the later phases out
+  // (1000 x 1000 x 5 Mbp, ms per step of this kernel): gather 13.4,
   // noise filter +2.2, sort +10.3 (in registers; the LDS network it replaced: +14.8), candidate emission +4.0.  The gather reads one
   // short run (~5 entries = 40 bytes) per sketch hash from a random place of the hash-ordered payload: ~45 KB of 128-byte lines per
   // fragment for 10 KB of hits, 77 GB per step by the FETCH_SIZE counter — it runs at the memory system's pace for such lines.
@@ -523,7 +526,8 @@ static __global__ __launch_bounds__(kTPB, (HLO == 0 ? 7 : 1)) void k_l1(L1Args a
     }
     block_barrier();
     n = wave_uniform(sKeep);
-    block_barrier();                                 // sKeep lives in the hit array's spare entries, which the sort's padding overwrites: every thread has read it
+    // sKeep lives in the hit array's spare entries, which the sort's padding overwrites: every thread has read it
+    block_barrier();
   }
   block_sort<uint64_t>(hits, n);                    // :320 (starts with a barrier: the gather is complete)
 

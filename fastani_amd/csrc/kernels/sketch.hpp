@@ -552,7 +552,8 @@ static __global__ void k_pack_fragment_pool(const uint32_t *__restrict__ pool, u
 static __global__ void k_fragset_rebase(uint32_t n, const uint32_t *__restrict__ srcOff, const int32_t *__restrict__ srcS,
     const int32_t *__restrict__ srcGenome,
                                         const int32_t *__restrict__ srcQSeq, uint32_t addOff, int32_t addGenome,
-                                        uint32_t *__restrict__ dstOff, int32_t *__restrict__ dstS, int32_t *__restrict__ dstGenome, int32_t *__restrict__ dstQSeq)
+                                        uint32_t *__restrict__ dstOff, int32_t *__restrict__ dstS, int32_t *__restrict__ dstGenome,
+                                            int32_t *__restrict__ dstQSeq)
 {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     dstOff[i] = srcOff[i] + addOff; dstS[i] = srcS[i]; dstGenome[i] = srcGenome[i] + addGenome; dstQSeq[i] = srcQSeq[i];
@@ -562,7 +563,8 @@ static __global__ void k_fragset_rebase(uint32_t n, const uint32_t *__restrict__
 template <bool PACKED>
 __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, int64_t off, int32_t len, const TileDesc td, const FusedInfo fi, int k, int w,
     int fragLen,
-                                                uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
+                                                uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap,
+                                                    unsigned long long *__restrict__ poolCount,
                                                 TileMeta *__restrict__ meta,
                                                 uint32_t *__restrict__ qPool, uint32_t qCap, unsigned long long *__restrict__ qCount,
                                                 uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS, int *__restrict__ maxS,
@@ -629,9 +631,11 @@ __device__ __forceinline__ void fused_tile_body(const void *__restrict__ seq, in
 }
 
 static __global__ __launch_bounds__(kTPB, 3) void k_sketch_fused(const uint32_t *__restrict__ packed, const uint8_t *__restrict__ ascii,
-                                                          const int64_t *__restrict__ contigOff, const int32_t *__restrict__ contigLen, const uint8_t *__restrict__ contigMode,
+                                                          const int64_t *__restrict__ contigOff, const int32_t *__restrict__ contigLen,
+                                                              const uint8_t *__restrict__ contigMode,
                                                           const TileDesc *__restrict__ tiles, const FusedInfo *__restrict__ info, int k, int w, int fragLen,
-                                                          uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap, unsigned long long *__restrict__ poolCount,
+                                                          uint32_t *__restrict__ poolHash, int32_t *__restrict__ poolWpos, uint32_t poolCap,
+                                                              unsigned long long *__restrict__ poolCount,
                                                           TileMeta *__restrict__ meta,
                                                           uint32_t *__restrict__ qPool, uint32_t qCap, unsigned long long *__restrict__ qCount,
                                                           uint32_t *__restrict__ fragOff, int32_t *__restrict__ fragS, int *__restrict__ maxS)
