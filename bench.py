@@ -79,9 +79,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="many-to-many", choices=["many-to-many", "one-to-many", "c4", "c5"])
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
-                    help="N > 1, many-to-many: strong (default) = the fixed 1000 x 1000 job, references sharded, fragment sketches ring-passed; "
-                         "weak = fixed database, 1000 queries per GPU, records all-gathered (also measured beside the strong figure, weak_scaling_leg)")
-    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, many-to-many: skip the weak-scaling measurement beside the strong one")
+                    help="N > 1, many-to-many: weak (default; BASELINE.json north_star's split) = fixed database, 1000 query genomes per GPU, the reference records "
+                         "all-gathered once; strong = the fixed 1000 x 1000 job, references sharded, fragment sketches all-gathered.  The other of the two is measured "
+                         "beside the timed region (strong_scaling_leg / weak_scaling_leg)")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N > 1, many-to-many --scaling strong: skip the weak-scaling measurement beside the strong one")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1, many-to-many: skip the strong-scaling measurement beside the weak one")
     ap.add_argument("--simulate-world", type=int, default=0, help="ONE GPU computes what one rank of a W-GPU strong-scaling (ring) job computes, without the communication: "
                                                                   "the measured per-rank time behind the predicted W-GPU figure (DESIGN.md section 5)")
     ap.add_argument("--simulate-rank", type=int, default=0)
@@ -545,8 +547,10 @@ def dev_sync(R):
 def resolve_mode(R):
     """which step runs in the timed region:
          single    one GPU: sketch + index + map (all-vs-all: every genome hashed once for both roles)
-         ring      N GPUs, STRONG scaling: the references are sharded, the query fragment sketches go round a ring (fastani_amd/multi_gpu.py)
-         gather    N GPUs, WEAK scaling over the query stream: every rank maps its own queries against the full index built from all-gathered records
+         gather    N GPUs, WEAK scaling over the query stream (the default of the headline set at N > 1: north_star's own split, and what the task's
+                   tier rules ask of a path that shards): every rank maps its own queries against the full index built from all-gathered records
+         ring      N GPUs, STRONG scaling (--scaling strong; configs[3] / [4] shapes): the references are sharded, the query fragment sketches are
+                   all-gathered (fastani_amd/multi_gpu.py)
          simulate  one GPU doing the compute of ONE rank of a W-rank ring job (no communication): the measured per-rank time behind the predicted N-GPU figure"""
     a = R.args
     if a.simulate_world > 1:
@@ -555,7 +559,7 @@ def resolve_mode(R):
         return "single"
     if a.config in ("c4", "c5"):
         return "ring"
-    if a.config == "many-to-many" and a.scaling in ("auto", "strong"):
+    if a.config == "many-to-many" and a.scaling == "strong":
         return "ring"
     return "gather"
 
@@ -1013,15 +1017,19 @@ def rows_multiset_hash(rows):
         return int(h.sum(dtype=np.uint64))
 
 
-def rows_multiset(R, rows):
-    """(rows, hash) of the last timed step over ALL ranks: one all-reduce of the count and of the hash in 16-bit limbs"""
+def rows_multiset(R, rows, with_rank0=False):
+    """(rows, hash) of the last timed step over ALL ranks: one all-reduce of the count and of the hash in 16-bit limbs.
+    with_rank0: also rank 0's own (rows, hash) — in the query-sharded job rank 0 maps variant 0 of the set, i.e. the standard job"""
     n, h = len(rows), rows_multiset_hash(rows)
+    n0, h0 = (n, h) if R.rank == 0 else (0, 0)
     if R.dist is not None:
-        t = R.torch.tensor([n] + [(h >> (16 * i)) & 0xffff for i in range(4)], dtype=R.torch.int64, device=R.dev)
+        limbs = lambda x: [(x >> (16 * i)) & 0xffff for i in range(4)]                     # noqa: E731
+        t = R.torch.tensor([n] + limbs(h) + [n0] + limbs(h0), dtype=R.torch.int64, device=R.dev)
         R.dist.all_reduce(t, op=R.dist.ReduceOp.SUM)
         v = [int(x) for x in t.tolist()]
-        n, h = v[0], sum(v[1 + i] << (16 * i) for i in range(4)) & 0xffffffffffffffff
-    return n, h
+        join = lambda w: sum(w[i] << (16 * i) for i in range(4)) & 0xffffffffffffffff      # noqa: E731
+        n, h, n0, h0 = v[0], join(v[1:5]), v[5], join(v[6:10])
+    return (n, h, n0, h0) if with_rank0 else (n, h)
 
 
 def sync(R):
@@ -1149,7 +1157,7 @@ def main():
     rows, dt = res["rows"], res["dt"]
     rank_info = gather_rank_info(R, res, args.steps, mode) if R.dist is not None else None
     # the rows of the last timed step over all ranks as (count, multiset hash); --drop-rows jobs keep no rows and carry their own checksums
-    R.rows_multiset = rows_multiset(R, rows) if not getattr(R, "drop_rows", False) and mode != "simulate" else None
+    R.rows_multiset = rows_multiset(R, rows, with_rank0=True) if not getattr(R, "drop_rows", False) and mode != "simulate" else None
     c = e.counters()
     host_timeline = {k: round(v / args.steps, 2) for k, v in R.timers.items() if v}
     if args.dump_rows:
@@ -1178,6 +1186,30 @@ def main():
             weak_leg = {"scaling": "weak", "error": "%s: %s" % (type(ex).__name__, str(ex)[:400])}
         R.nq_local, R.first_query_id = keep[0], keep[1]
 
+    # N > 1, headline set, default: the timed region above is the WEAK-scaling job (north_star's split).  The strong-scaling figure of the
+    # same kernels — the fixed NR x NR job, references sharded — is measured beside it; its rows over all ranks are the standard job's
+    # rows, so its rows_multiset is held against the stored value: the row check of a multi-rank hardware run.
+    strong_leg = None
+    if mode == "gather" and cfg == "many-to-many" and not args.no_strong_leg and not args.queries:
+        keep = (R.nq_local, R.first_query_id, R.qrys, R.n_queries_total, R.mode)
+        try:
+            R.nq_local, R.qrys, R.first_query_id, R.n_queries_total, R.mode = R.hi - R.lo, R.my_refs, R.lo, NR, "ring"
+            ssteps = max(1, min(args.steps, 3))
+            sres = timed_loop(R, step_ring, ssteps, 1)
+            sinfo = gather_rank_info(R, sres, ssteps, "ring")
+            n_all, h_all = rows_multiset(R, sres["rows"])
+            exp = EXPECTED_ROWS.get((cfg, NR, L, args.cluster_size, args.seed))
+            strong_leg = {"scaling": "strong", "value": round(NR * NR * ssteps / sres["dt"], 1), "unit": "pairs/s", "steps": ssteps, "ms_per_step": round(sres["dt"] / ssteps * 1e3, 2),
+                          "workload": "many-to-many %dx%d: the fixed job on %d GPU(s), references sharded, the ranks' fragment sketches all-gathered" % (NR, NR, world),
+                          "rows_multiset": {"rows": int(n_all), "hash": "%016x" % h_all, "expected": {"rows": exp[0], "hash": exp[1]} if exp else None,
+                                            "ok": (int(n_all) == exp[0] and "%016x" % h_all == exp[1]) if exp else None},
+                          "rows_identical_across_steps": len(set(sres["rows_crc"])) == 1, "ranks": sinfo}
+        except Exception as ex:                              # noqa: BLE001 — any failure of the extra leg is reported, it does not cost the line
+            import traceback
+            traceback.print_exc()
+            strong_leg = {"scaling": "strong", "error": "%s: %s" % (type(ex).__name__, str(ex)[:400])}
+        R.nq_local, R.first_query_id, R.qrys, R.n_queries_total, R.mode = keep
+
     # one-to-many: the latency-shaped number — map the one query against a resident index
     map_only = None
     if cfg == "one-to-many" and rank == 0:
@@ -1194,14 +1226,14 @@ def main():
         map_only = {"ms": round(min(ts), 3), "ms_all": [round(x, 3) for x in ts], "what": "ani_map_cgi_batch of the one query genome (1666 fragments) against the resident 1000-genome index, rows on the host"}
 
     if rank == 0:
-        out = report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only)
+        out = report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only, strong_leg)
         print(json.dumps(out), flush=True)
     e.close()
     if R.dist is not None:
         R.dist.destroy_process_group()
 
 
-def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
+def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only, strong_leg=None):
     """the ONE JSON line of the driver contract (rank 0)"""
     e, p, cfg, mode, NR, L, world = R.e, R.p, args.config, R.mode, R.NR, R.L, R.world
     rows, dt = res["rows"], res["dt"]
@@ -1343,17 +1375,25 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only):
             out["rows_kept"] = {"rows": int(len(rows)), "of_queries": [int(q) for q in R.sample_queries],
                                 "what": "--drop-rows: a step's rows are counted and checksummed block by block (rows_last_step, rows_identical_across_steps); only these queries' rows stay for the oracle check"}
     if getattr(R, "rows_multiset", None) is not None:
-        n_all, h_all = R.rows_multiset
-        exp = EXPECTED_ROWS.get((cfg, NR, L, args.cluster_size, args.seed)) if mode in ("single", "ring") and n_queries_total == NR else None
+        n_all, h_all, n_r0, h_r0 = R.rows_multiset
+        std = EXPECTED_ROWS.get((cfg, NR, L, args.cluster_size, args.seed))
+        exp = std if n_queries_total == NR and (mode in ("single", "ring") or (mode == "gather" and world == 1)) else None
         out["rows_multiset"] = {"rows": int(n_all), "hash": "%016x" % h_all, "ranks": world,
                                 "expected": {"rows": exp[0], "hash": exp[1]} if exp else None,
                                 "ok": (int(n_all) == exp[0] and "%016x" % h_all == exp[1]) if exp else None,
                                 "what": "the rows of the last timed step over all ranks: count and an order- / partition-independent 64-bit hash (bench.py: rows_multiset_hash); "
                                         "expected = the same job's rows on one GPU, which were checked against fastANI_ref and the oracle (parity_timed_rows)"}
+        if mode == "gather" and world > 1 and nq_local == NR and std:
+            # query-sharded: rank 0 maps variant 0 of the set = the references themselves = the standard job, whatever the other ranks map
+            out["rows_multiset"]["rank0"] = {"rows": int(n_r0), "hash": "%016x" % h_r0, "expected": {"rows": std[0], "hash": std[1]},
+                                             "ok": int(n_r0) == std[0] and "%016x" % h_r0 == std[1]}
+            out["rows_multiset"]["ok"] = out["rows_multiset"]["rank0"]["ok"]
     if rank_info:
         out["ranks"] = rank_info
     if weak_leg:
         out["weak_scaling_leg"] = weak_leg
+    if strong_leg:
+        out["strong_scaling_leg"] = strong_leg
     if map_only:
         out["map_only"] = map_only
     if world == 1 and mode == "single" and not R.multi and not (args.no_cpu_baseline and args.no_e2e and args.no_verify):

@@ -147,15 +147,15 @@ def test_sharded_sketch_allgather_matches_single_process(tmp_path, emu_engine, w
     assert np.array_equal(single, np.concatenate(exp))
 
 
-@pytest.mark.parametrize("config,scaling,launcher", [("many-to-many", "auto", True), ("many-to-many", "weak", True), ("c4", "auto", True),
+@pytest.mark.parametrize("config,scaling,launcher", [("many-to-many", "auto", True), ("many-to-many", "strong", True), ("c4", "auto", True),
                                                      ("many-to-many", "auto", False)])
 def test_bench_orchestration_two_ranks(config, scaling, launcher, emu_engine, tmp_path):
     """bench.py's own multi-rank steps launched the way the driver launches it, on the CPU build of the product sources over gloo
     (ANI_BENCH_BACKEND=emu, a test-only switch): 6 genomes of one cluster, every pair related.
-      many-to-many (default at N > 1) = STRONG scaling: the fixed 6 x 6 job, reference-sharded, fragment sets ring-passed; the
-          weak-scaling leg (query-sharded, reference records all-gathered) is measured beside it
-      many-to-many --scaling weak     = the weak leg as the timed region
-      c4                              = the reference-sharded ring again (configs[3] shape)
+      many-to-many (default at N > 1) = WEAK scaling (north_star's split): fixed 6-genome database, 6 queries per rank, query-sharded, reference
+          records all-gathered; the strong-scaling leg (the fixed 6 x 6 job, reference-sharded, fragment sets all-gathered) is measured beside it
+      many-to-many --scaling strong   = the strong job as the timed region, the weak leg beside it
+      c4                              = the reference-sharded job again (configs[3] shape)
     launcher = False: plain `python bench.py --gpus 2` with no WORLD_SIZE around it — bench.py starts its own ranks (self_launch).
     The rows every rank dumps must add up to the single-process rows."""
     import json
@@ -174,7 +174,7 @@ def test_bench_orchestration_two_ranks(config, scaling, launcher, emu_engine, tm
     assert out["n_gpus"] == 2 and "EMULATION" in out["data"] and out["rows_identical_across_steps"]
     ranks = out["ranks"]
     assert ranks["ranks_seen_by_rccl"] == 2 and len(ranks["step_ms"]) == 2
-    strong = not (config == "many-to-many" and scaling == "weak")
+    strong = config == "c4" or scaling == "strong"
     assert out["scaling"] == ("strong" if strong else "weak")
     if strong:
         assert out["config"]["query_genomes"] == 6 and sum(ranks["rows"]) == 36 and "reference-sharded" in ranks["mode"]
@@ -211,6 +211,15 @@ def test_bench_orchestration_two_ranks(config, scaling, launcher, emu_engine, tm
     else:
         # rank 0 maps variant 0 (= the references themselves), rank 1 variant 1 with query ids 6..11
         assert np.array_equal(got[got["qryGenomeId"] < 6], single) and len(got) == 72
+        # the strong-scaling leg beside the weak timed region: the ranks' rows add up to the single-process rows (count and multiset hash)
+        sys.path.insert(0, ROOT)
+        import bench
+        sl = out["strong_scaling_leg"]
+        assert "error" not in sl, sl
+        assert sl["scaling"] == "strong" and sl["value"] > 0 and sl["rows_identical_across_steps"] and sum(sl["ranks"]["rows"]) == 36
+        assert sl["rows_multiset"]["rows"] == len(single) and sl["rows_multiset"]["hash"] == "%016x" % bench.rows_multiset_hash(single)
+        # rank 0 of the weak job maps variant 0 = the references themselves: its rows are the single-process rows (no stored expectation at this size)
+        assert out["rows_multiset"]["rows"] == 72 and "rank0" not in out["rows_multiset"]
 
 
 def test_bench_dry_collectives_two_ranks(tmp_path):

@@ -45,7 +45,7 @@ def _sorted(rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config,scaling", [("many-to-many", "auto"), ("many-to-many", "weak"), ("c4", "auto")])
+@pytest.mark.parametrize("config,scaling", [("many-to-many", "auto"), ("many-to-many", "strong"), ("c4", "auto")])
 def test_bench_over_rccl_one_rank(gpu_engine, tmp_path, config, scaling):
     single = _single_rows(gpu_engine)
     assert len(single) >= 2 * N
@@ -54,7 +54,7 @@ def test_bench_over_rccl_one_rank(gpu_engine, tmp_path, config, scaling):
     ranks = out["ranks"]
     assert ranks["ranks_seen_by_rccl"] == 1 == int(os.environ.get("WORLD_SIZE", "1")) and out["n_gpus"] == 1
     assert out["rows_identical_across_steps"] and out["data"] == "synthetic"
-    strong = not (config == "many-to-many" and scaling == "weak")
+    strong = config == "c4" or scaling == "strong"
     assert out["scaling"] == ("strong" if strong else "weak") and out["config"]["mode"] == ("ring" if strong else "gather")
     assert ("reference-sharded" in ranks["mode"]) == strong
     got = _sorted(np.load(dump + ".rank0.npy"))
@@ -63,6 +63,14 @@ def test_bench_over_rccl_one_rank(gpu_engine, tmp_path, config, scaling):
     if config == "many-to-many" and strong:
         wl = out["weak_scaling_leg"]
         assert wl["ranks"]["ranks_seen_by_rccl"] == 1 and wl["ranks"]["rows"] == [len(single)]
+    elif config == "many-to-many":
+        # the default at N > 1 is the weak job; the strong job is measured beside it and its rows over all ranks are the single-GPU rows
+        sys.path.insert(0, ROOT)
+        import bench
+        sl = out["strong_scaling_leg"]
+        assert "error" not in sl, sl
+        assert sl["ranks"]["ranks_seen_by_rccl"] == 1 and sl["ranks"]["rows"] == [len(single)] and sl["rows_identical_across_steps"]
+        assert sl["rows_multiset"]["hash"] == "%016x" % bench.rows_multiset_hash(single) == out["rows_multiset"]["hash"]
 
 
 @pytest.mark.gpu
