@@ -12,13 +12,15 @@ reference sketch + index build (skch::Sketch), mapping of every query genome (sk
 Workloads (config.workload):
   many-to-many (default) = BASELINE.json configs[2], 1000x1000 synthetic ~5 Mbp genomes, k=16 fragLen=3000.
       N = 1 : 1000 reference genomes x 1000 query genomes (the same set: all-vs-all).
-      N > 1 : STRONG scaling (default, --scaling strong): the SAME 1000 x 1000 job on N GPUs, reference-sharded — rank r hashes
-              genomes [r*1000/N, (r+1)*1000/N) once for both roles, indexes that shard only, and the ranks' packed fragment
-              sketches go round a ring (isend/irecv over RCCL, overlapped with the mapping): nothing is replicated.  value =
-              10^6 pairs / step.  The WEAK-scaling figure is measured beside it (weak_scaling_leg; --scaling weak makes it the
-              timed region): the 1000-genome reference database is fixed, every GPU maps its own 1000 query genomes (rank r
-              maps variant r of the clustered set), each rank sketches 1/N of the references, the 12-byte minimizer records
-              are all-gathered once over RCCL/xGMI and every rank builds the full index.
+      N > 1 : WEAK scaling (default; BASELINE.json north_star's own split, "scaling": "weak"): the 1000-genome reference database is
+              fixed, every GPU maps its own 1000 query genomes (rank r maps variant r of the clustered set; variant 0 is the
+              reference set itself), each rank sketches 1/N of the references, the 12-byte minimizer records are all-gathered
+              once over RCCL/xGMI while the rank sketches its queries' fragments, and every rank builds the full index.
+              value = N x 10^6 pairs / step.  The STRONG-scaling figure is measured beside it (strong_scaling_leg; --scaling strong
+              makes it the timed region and the weak job the leg): the SAME 1000 x 1000 job on N GPUs, reference-sharded — rank r
+              hashes genomes [r*1000/N, (r+1)*1000/N) once for both roles, indexes that shard only, and the ranks' packed fragment
+              sketches are all-gathered (one collective, under the mapping of the rank's own set): nothing is replicated.  The
+              leg's rows over all ranks are the standard job's rows: rows_multiset holds them against the stored value.
       --simulate-world W (one GPU): the compute of ONE rank of the W-GPU strong job, without communication — the measured
               per-rank time behind the predicted W-GPU figure.
   one-to-many = configs[1]: 1 query genome (cluster 0, member 1) against the 1000-genome set; a step still sketches and
