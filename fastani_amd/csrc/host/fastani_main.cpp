@@ -439,7 +439,8 @@ struct RefPart { void *rec = nullptr; uint64_t n = 0; int dev = 0; int32_t g0 = 
 // then _exit.  On other kernels prctl() fails and nothing is done; ANI_CLI_EXIT_THREADS=0 turns it off, =N parks exactly N.
 static void exit_behind_the_caller()
 {
-  auto park = [](int n) { for (int i = 0; i < n; i++) std::thread([]() { for (;;) pause(); }).detach(); };
+  // (a refused thread — process limit of the container, memory — ends the attempt, never the run: the output is on disk)
+  auto park = [](int n) { try { for (int i = 0; i < n; i++) std::thread([]() { for (;;) pause(); }).detach(); } catch (...) {} };
   if (const char *v = getenv("ANI_CLI_EXIT_THREADS")) { park(std::max(0, std::min(atoi(v), 4096))); return; }
   if (prctl(78 /* PR_FUTEX_HASH */, 2 /* PR_FUTEX_HASH_GET_SLOTS */, 0, 0, 0) <= 0) return;      // no private futex hash on this kernel
   park(1);                                                       // (a larger hash that was still waiting for its turn is in place after this clone())
