@@ -64,6 +64,9 @@ sys.path.insert(0, ROOT)
 # codes kernel (L2 stage 86.4 instead of 80.0 ms per 1000 x 1000 step, measured with one rank over RCCL; profiles/r06r_dist_ab.txt).
 # Eight queues restore it.  Must be in the environment before the runtime starts, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process device work (RCCL between the ranks): this host driver only supports dmabuf IPC — without the setting hipIpcGetMemHandle
+# fails with "invalid argument".  The image exports it already; a launcher with a scrubbed environment would not.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # VALU integer ceiling for the MurmurHash3 kernels, from the instruction costs measured on MI355X (tools/ubench/valu.hip,
