@@ -1044,6 +1044,34 @@ def sync(R):
     dev_sync(R)
 
 
+def settle(R, budget_s=5.0, need=5):
+    """Before the warm-up: wait until the device is quiet.  A box may still be busy with what ran before this process — on hosts whose
+    driver wipes freed device memory in the background a step that runs beside it was measured at 327 ms instead of 191
+    (profiles/r08z_bench_first_step_disturbed.json.log: the benchmark started right behind the GPU test suite).  Probe = 1 GiB of
+    read-modify-write (~0.5 ms alone), by HIP events on the current stream; quiet = `need` probes in a row within 1.5 x the fastest one
+    seen.  At most budget_s seconds; nothing of the timed region is touched, and the line says what was seen."""
+    if R.emu:
+        return None
+    torch = R.torch
+    x = torch.zeros(1 << 28, dtype=torch.int32, device=R.dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0, best, run, n, worst = time.perf_counter(), None, 0, 0, 0.0
+    x.add_(1); torch.cuda.synchronize()
+    while time.perf_counter() - t0 < budget_s:
+        ev0.record(); x.add_(1); ev1.record(); ev1.synchronize()
+        ms = ev0.elapsed_time(ev1)
+        n += 1
+        worst = max(worst, ms)
+        best = ms if best is None else min(best, ms)
+        run = run + 1 if ms <= 1.5 * best else 0
+        if run >= need:
+            break
+        time.sleep(0.02)
+    del x
+    return {"probes": n, "waited_s": round(time.perf_counter() - t0, 3), "quiet": run >= need, "probe_ms_best": round(best or 0.0, 3), "probe_ms_worst": round(worst, 3),
+            "what": "before the warm-up steps: 1 GiB read-modify-write probes until %d in a row run within 1.5 x the fastest (a device still busy with an earlier process's leftovers would disturb the first steps)" % need}
+
+
 def timed_loop(R, step, steps, warmup):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronisation; the job's time is the MAX over ranks"""
     import zlib
@@ -1158,6 +1186,7 @@ def main():
         return
     if mode == "simulate":
         prepare_simulation(R)
+    R.settle = settle(R)
     res = timed_loop(R, STEPS[mode], args.steps, args.warmup)
     rows, dt = res["rows"], res["dt"]
     rank_info = gather_rank_info(R, res, args.steps, mode) if R.dist is not None else None
@@ -1421,6 +1450,8 @@ def report(R, args, res, c, rank_info, host_timeline, weak_leg, map_only, strong
         out["value_wall"] = {"value": out["end_to_end"]["pairs_per_s"], "unit": "pairs/s", "seconds": out["end_to_end"]["seconds"],
                              "what": "the same 1000 x 1000 job through the command line: first FASTA byte read -> output file closed (end_to_end)"}
     import resource
+    if getattr(R, "settle", None):
+        out["settle"] = R.settle
     out["host_max_rss_gb"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0, 2)       # this process, checks included
     return out
 
